@@ -1,0 +1,165 @@
+/*
+ * pnec_hip.h -- C ABI of the MI355X-native PNEC pose solver (libpnec_hip.so).
+ *
+ * This is the drop-in boundary for the reference's rel_pose_estimation + optimization hot path.
+ * The reference has no FFI layer; its seams are C++ classes and one pybind module.  Every entry
+ * point below names the reference interface it replaces (paths relative to the reference repo):
+ *
+ *   reference seam                                              replaced by
+ *   ----------------------------------------------------------  ---------------------------------
+ *   PNECCeres::Optimize(bvs1,bvs2,covs,reg,frame)               pnec_hip_problem_create/upload +
+ *     src/optimization/pnec_ceres.cc:70-111                       pnec_hip_solve (mode TARGET/HOST)
+ *   PNECCeres::Optimize(bvs1,bvs2,covs1,covs2,reg)              ... mode SYM
+ *     src/optimization/pnec_ceres.cc:113-168  (pypnec.pyceres, python/pypnec.cpp:50-66)
+ *   NECCeres::Optimize(bvs1,bvs2)                               ... mode NEC
+ *     src/optimization/nec_ceres.cc:73-101    (pypnec.pyceresnec, python/pypnec.cpp:68-82)
+ *   PNECCeres::InitValues(q,t) / Result()                       init_q/init_t in, out_q/out_t out
+ *     src/optimization/pnec_ceres.cc:182-186,201-207
+ *   PNEC::CeresSolver / CeresSolverFull / NECCeresSolver        pnec_hip_solve over a batch of pairs
+ *     src/rel_pose_estimation/pnec.cc:350-411
+ *   ceres::Solver::Options (default-constructed, pnec_ceres.cc:47)   pnec_hip_options
+ *   pnec::common::CostFunction  src/common/common.cc:237-259    pnec_hip_cost_function
+ *
+ * Conventions (same as the reference):
+ *   - bearing vectors: 3 doubles each, unit norm; frame 1 = "host", frame 2 = "target".
+ *   - covariances: 9 doubles each in Eigen column-major order (std::vector<Eigen::Matrix3d>);
+ *     only the symmetric part matters.
+ *   - quaternions: x,y,z,w (Eigen coeffs() order).  R takes frame-2 vectors into frame 1.
+ *   - a batch holds n_pairs independent frame pairs; pair p owns correspondences
+ *     [offsets[p], offsets[p+1]) of the concatenated arrays (ragged sizes allowed).
+ *   - a "solve" is one (pair, hypothesis): s = pair * n_hyp + hypothesis.
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  All functions return 0 on success or a
+ * negative pnec_hip_status; pnec_hip_last_error() gives the message for the calling thread.
+ * A handle (problem) is not thread-safe; distinct handles are independent.
+ */
+#ifndef PNEC_HIP_H_
+#define PNEC_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PNEC_HIP_ABI_VERSION 1
+
+typedef enum pnec_hip_status {
+  PNEC_HIP_OK = 0,
+  PNEC_HIP_ERR_INVALID_ARGUMENT = -1,
+  PNEC_HIP_ERR_HIP_RUNTIME = -2,   /* a hip* call failed (no device, OOM, launch failure ...) */
+  PNEC_HIP_ERR_UNSUPPORTED = -3
+} pnec_hip_status;
+
+/* residual family == which reference functor the device evaluates */
+typedef enum pnec_hip_mode {
+  PNEC_HIP_MODE_NEC = 0,    /* include/optimization/nec_residual.h:51-63   */
+  PNEC_HIP_MODE_TARGET = 1, /* include/optimization/pnec_residual.h:86-104 */
+  PNEC_HIP_MODE_HOST = 2,   /* include/optimization/pnec_residual.h:55-72  */
+  PNEC_HIP_MODE_SYM = 3     /* include/optimization/pnec_residual.h:120-142 */
+} pnec_hip_mode;
+
+/* per-solve termination code (out_status); what ceres::Solver::Summary would have said */
+typedef enum pnec_hip_termination {
+  PNEC_HIP_TERM_FUNCTION_TOL = 0,
+  PNEC_HIP_TERM_PARAMETER_TOL = 1,
+  PNEC_HIP_TERM_GRADIENT_TOL = 2,
+  PNEC_HIP_TERM_MAX_ITERATIONS = 3,
+  PNEC_HIP_TERM_MIN_RADIUS = 4,
+  PNEC_HIP_TERM_INVALID_STEPS = 5,
+  PNEC_HIP_TERM_BAD_INITIAL = 6 /* non-finite cost/Jacobian (e.g. NaN input); last iterate returned */
+} pnec_hip_termination;
+
+typedef enum pnec_hip_memspace {
+  PNEC_HIP_MEM_HOST = 0,  /* pointer arguments are host memory; the call blocks until done */
+  PNEC_HIP_MEM_DEVICE = 1 /* pointer arguments are device memory; the call is asynchronous on `stream` */
+} pnec_hip_memspace;
+
+/* The ceres::Solver::Options fields the reference's default-constructed optimiser relies on
+ * (defaults = Ceres 2.x defaults), plus launch tuning.  Fill with pnec_hip_default_options(). */
+typedef struct pnec_hip_options {
+  int32_t max_num_iterations;                /* 50 */
+  int32_t max_num_consecutive_invalid_steps; /* 5 */
+  int32_t jacobi_scaling;                    /* 1 */
+  int32_t check_convergence;                 /* 1; 0 = exactly max_num_iterations LM iterations */
+  int32_t corr_per_lane;                     /* 0 = auto; launch tuning: correspondences held per lane */
+  int32_t waves_per_pair;                    /* 0 = auto; launch tuning: wavefronts cooperating on one solve */
+  double function_tolerance;                 /* 1e-6 */
+  double gradient_tolerance;                 /* 1e-10 */
+  double parameter_tolerance;                /* 1e-8 */
+  double initial_trust_region_radius;        /* 1e4 */
+  double max_trust_region_radius;            /* 1e16 */
+  double min_trust_region_radius;            /* 1e-32 */
+  double min_relative_decrease;              /* 1e-3 */
+  double min_lm_diagonal;                    /* 1e-6 */
+  double max_lm_diagonal;                    /* 1e32 */
+} pnec_hip_options;
+
+typedef struct pnec_hip_problem pnec_hip_problem; /* opaque: a batch of pairs resident in HBM */
+
+int pnec_hip_abi_version(void);
+const char *pnec_hip_last_error(void);
+int pnec_hip_device_count(int *count);
+void pnec_hip_default_options(pnec_hip_options *opt);
+
+/* Allocate HBM for a batch.  offsets: HOST int64[n_pairs+1], non-decreasing, offsets[0]==0.
+ * mode fixes which arrays the batch carries: NEC bvs only; TARGET/HOST bvs + one covariance
+ * array; SYM bvs + both. */
+int pnec_hip_problem_create(int device, int mode, int64_t n_pairs, const int64_t *offsets,
+                            pnec_hip_problem **out);
+int pnec_hip_problem_destroy(pnec_hip_problem *p);
+
+/* Fill pairs [first_pair, first_pair+n_pairs) from arrays in the REFERENCE layout (AoS: bvs
+ * 3 doubles, covs 9 doubles column-major per correspondence), pointing at the first
+ * correspondence of `first_pair`.  `covs` is the single array of Optimize(bvs1,bvs2,covs,..)
+ * [frame 2 for TARGET, frame 1 for HOST] or covs_2 of the symmetric overload; `covs_host` is
+ * covs_1 of the symmetric overload (NULL otherwise).  space = where those arrays live. */
+int pnec_hip_problem_fill(pnec_hip_problem *p, int64_t first_pair, int64_t n_pairs,
+                          const double *bvs1, const double *bvs2, const double *covs,
+                          const double *covs_host, int space, void *stream);
+
+int64_t pnec_hip_problem_num_pairs(const pnec_hip_problem *p);
+int64_t pnec_hip_problem_num_correspondences(const pnec_hip_problem *p);
+int64_t pnec_hip_problem_max_correspondences(const pnec_hip_problem *p);
+/* bytes of bearing/covariance payload the solver reads per pass over the batch (algorithmic) */
+int64_t pnec_hip_problem_payload_bytes(const pnec_hip_problem *p);
+int pnec_hip_problem_mode(const pnec_hip_problem *p);
+int pnec_hip_problem_device(const pnec_hip_problem *p);
+
+/* Run InitValues + Optimize + Result for every solve of the batch, entirely on the device.
+ *   init_q  [n_pairs,4] xyzw     starting orientation per pair (used as given)
+ *   init_t  [n_pairs,3]          starting translation per pair (any non-zero vector; ignored if hyp_t)
+ *   n_hyp, hyp_t [n_pairs*n_hyp,3]  optional multi-hypothesis starts sharing init_q (hyp_t NULL -> n_hyp=1)
+ *   reg                         regularisation (Options::regularization_, 1e-13 in the reference)
+ *   out_q [S,4] normalised, out_t [S,3] unit, out_cost [S] (= 1/2 sum r^2 at the result),
+ *   out_iterations [S], out_status [S] (pnec_hip_termination); S = n_pairs*n_hyp; any out may be NULL
+ *   space: where init and out arrays live (HOST: blocking; DEVICE: async on stream).  */
+int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init_t, int32_t n_hyp,
+                   const double *hyp_t, double reg, const pnec_hip_options *opt, double *out_q,
+                   double *out_t, double *out_cost, int32_t *out_iterations, int32_t *out_status,
+                   int space, void *stream);
+
+/* For each pair keep the hypothesis with the lowest out_cost (ties: lowest index).
+ * best_index [n_pairs] int32 receives the hypothesis index.  DEVICE or HOST pointers per `space`. */
+int pnec_hip_select_best(int64_t n_pairs, int32_t n_hyp, const double *cost, int32_t *best_index,
+                         int space, int device, void *stream);
+
+/* pnec::common::CostFunction (src/common/common.cc:237-259) for every pair: mean over the
+ * pair's correspondences of n^2 / (g' Sigma g), no regularisation; pose given as q (xyzw,
+ * normalised inside) and t.  Only for TARGET-mode problems.  out [n_pairs]. */
+int pnec_hip_cost_function(pnec_hip_problem *p, const double *q, const double *t, double *out,
+                           int space, void *stream);
+
+/* Name and launch geometry the auto-tuner would pick for this problem (for logs / profiles). */
+int pnec_hip_describe_launch(const pnec_hip_problem *p, const pnec_hip_options *opt,
+                             int32_t *corr_per_lane, int32_t *waves_per_pair,
+                             int32_t *threads_per_block, int32_t *resident);
+
+/* Device-side unit checks of the cross-lane reduction (DPP + v_permlane*_swap), the 5x5 Cholesky
+ * and the reciprocal / reciprocal-square-root refinements.  0 = all good. */
+int pnec_hip_selftest(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNEC_HIP_H_ */

@@ -1,0 +1,146 @@
+/*
+ * pnec_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C99) of the reference's PNEC least-squares hot path.
+ * It exists to CHECK the HIP product path; nothing under pnec_amd/ may include,
+ * link or call it.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it.
+ *
+ * PARITY STATUS: "parity unpinned" for the optimiser trajectory.
+ *   - The objective (residual + propagated-variance weight) IS pinned: it is
+ *     checked against golden vectors produced by importing the reference's
+ *     scripts/pnec/common.py (tests/golden/make_golden.py, tests/test_oracle_golden.py).
+ *   - The Gauss-Newton/LM arithmetic lives in Ceres Solver, which is neither
+ *     vendored under /root/reference nor consistently pinned (Dockerfile:17 says
+ *     1.13.0, src/optimization/pnec_ceres.cc:103 needs the Manifold API, >= 2.1),
+ *     and the reference has no tests for it.  The LM below restates Ceres 2.1's
+ *     published trust-region/Levenberg-Marquardt algorithm.
+ *
+ * Reference files followed (paths relative to /root/reference):
+ *   include/optimization/pnec_residual.h:50-150   residual functors (Host/Target/Symmetrical)
+ *   include/optimization/nec_residual.h:47-68     NEC residual
+ *   src/optimization/pnec_ceres.cc:70-207         problem set-up, parameterisation, Result()
+ *   src/optimization/nec_ceres.cc:73-139          NEC twin
+ *   src/common/common.cc:96-116,210-259           SkewFromVector, AnglesFromVec, metrics
+ *   src/rel_pose_estimation/pnec.cc:350-411       CeresSolver / CeresSolverFull / NECCeresSolver
+ */
+#ifndef PNEC_ORACLE_H_
+#define PNEC_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* residual families (value-compatible with include/pnec_hip.h; a test asserts it) */
+enum {
+  PNEC_ORACLE_MODE_NEC = 0,    /* nec_residual.h:51-63 */
+  PNEC_ORACLE_MODE_TARGET = 1, /* pnec_residual.h:86-104 (default of PNECCeres::Optimize) */
+  PNEC_ORACLE_MODE_HOST = 2,   /* pnec_residual.h:55-72 */
+  PNEC_ORACLE_MODE_SYM = 3     /* pnec_residual.h:120-142 (what pypnec.pyceres runs) */
+};
+
+/* termination codes (value-compatible with include/pnec_hip.h) */
+enum {
+  PNEC_ORACLE_TERM_FUNCTION_TOL = 0,
+  PNEC_ORACLE_TERM_PARAMETER_TOL = 1,
+  PNEC_ORACLE_TERM_GRADIENT_TOL = 2,
+  PNEC_ORACLE_TERM_MAX_ITERATIONS = 3,
+  PNEC_ORACLE_TERM_MIN_RADIUS = 4,
+  PNEC_ORACLE_TERM_INVALID_STEPS = 5,
+  PNEC_ORACLE_TERM_BAD_INITIAL = 6
+};
+
+enum {
+  PNEC_ORACLE_JAC_NUMERIC_CENTRAL = 0, /* what the reference does (pnec_ceres.cc:92-101) */
+  PNEC_ORACLE_JAC_ANALYTIC = 1         /* same LM, closed-form Jacobian (what the HIP path does) */
+};
+
+/* Subset of ceres::Solver::Options that the default-constructed optimiser uses
+ * (pnec_ceres.cc:47, pnec.cc:355).  Defaults = Ceres 2.x defaults [EXT]. */
+typedef struct pnec_oracle_options {
+  int32_t max_num_iterations;                /* 50 */
+  int32_t max_num_consecutive_invalid_steps; /* 5 */
+  int32_t jacobi_scaling;                    /* 1 */
+  int32_t check_convergence;                 /* 1; 0 = run exactly max_num_iterations LM iterations */
+  int32_t jacobian_mode;                     /* PNEC_ORACLE_JAC_* */
+  int32_t reserved;
+  double function_tolerance;                 /* 1e-6 */
+  double gradient_tolerance;                 /* 1e-10 */
+  double parameter_tolerance;                /* 1e-8 */
+  double initial_trust_region_radius;        /* 1e4 */
+  double max_trust_region_radius;            /* 1e16 */
+  double min_trust_region_radius;            /* 1e-32 */
+  double min_relative_decrease;              /* 1e-3 */
+  double min_lm_diagonal;                    /* 1e-6 */
+  double max_lm_diagonal;                    /* 1e32 */
+} pnec_oracle_options;
+
+void pnec_oracle_default_options(pnec_oracle_options *opt);
+
+/* --- small pieces (exported so the tests can pin each one) ------------------------------ */
+
+/* common.cc:103-116 */
+void pnec_oracle_angles_from_vec(const double v[3], double *theta, double *phi);
+/* Eigen::Quaterniond(Matrix3d): rotation matrix (row-major 9) -> quaternion xyzw */
+void pnec_oracle_quat_from_rot(const double R[9], double q[4]);
+/* Eigen::Quaterniond::toRotationMatrix() -- NOT normalising; q = xyzw; R row-major */
+void pnec_oracle_rot_from_quat(const double q[4], double R[9]);
+/* pnec_ceres.cc:192-207: normalised q -> R, (theta,phi) -> unit t */
+void pnec_oracle_result(const double q[4], double theta, double phi, double R[9], double t[3]);
+/* common.cc:210-214, degrees */
+double pnec_oracle_rotational_difference_deg(const double R1[9], const double R2[9]);
+/* common.cc:216-235, degrees */
+double pnec_oracle_translational_difference_deg(const double t1[3], const double t2[3],
+                                                int both_directions);
+/* common.cc:237-259: mean of n^2/(g' Sigma g), NO regularisation; covs AoS col-major 9 */
+double pnec_oracle_cost_function(int64_t n, const double *bvs1, const double *bvs2,
+                                 const double *covs, const double R[9], const double t[3]);
+
+/* One residual, literal form of the functors.  bv = 3 doubles; cov = 9 doubles (Eigen
+ * column-major, as std::vector<Eigen::Matrix3d> stores them); cov1 only for SYM. */
+double pnec_oracle_residual(int mode, const double f1[3], const double f2[3],
+                            const double *cov2, const double *cov1, double reg, double theta,
+                            double phi, const double q[4]);
+
+/* Sum of squared residuals  sum_i r_i^2  (the energy of scripts/pnec/common.py:13-59). */
+double pnec_oracle_energy(int mode, int64_t n, const double *bvs1, const double *bvs2,
+                          const double *covs2, const double *covs1, double reg,
+                          const double R[9], const double t[3]);
+
+/* Residuals r[n], tangent-space Jacobian J[n*5] (row-major; columns theta, phi, delta_xyz of
+ * EigenQuaternionManifold), cost = 1/2 sum r^2 at (theta, phi, q). */
+void pnec_oracle_evaluate(int mode, int jacobian_mode, int64_t n, const double *bvs1,
+                          const double *bvs2, const double *covs2, const double *covs1,
+                          double reg, double theta, double phi, const double q[4], double *r,
+                          double *J, double *cost);
+
+/* --- the solver: PNECCeres::InitValues + Optimize + Result (pnec.cc:350-370) ------------ */
+/* init_q xyzw (not nec. normalised, used as given), init_t any non-zero 3-vector.
+ * out_q xyzw normalised; out_t unit; out_cost = 1/2 sum r^2 at the returned point.
+ * Returns the termination code. */
+int pnec_oracle_solve(int mode, int64_t n, const double *bvs1, const double *bvs2,
+                      const double *covs2, const double *covs1, double reg,
+                      const double init_q[4], const double init_t[3],
+                      const pnec_oracle_options *opt, double out_q[4], double out_t[3],
+                      double *out_theta_phi /* 2, may be NULL */, double *out_cost,
+                      int32_t *out_iterations);
+
+/* Batch driver (OpenMP over solves when compiled with -fopenmp; num_threads<=0 -> all).
+ * offsets[B+1] into the concatenated AoS arrays; solve s = pair*n_hyp + h starts from
+ * (init_q[pair], hyp_t[s]) when hyp_t != NULL, else (init_q[pair], init_t[pair]). */
+void pnec_oracle_solve_batch(int mode, int64_t n_pairs, const int64_t *offsets,
+                             const double *bvs1, const double *bvs2, const double *covs2,
+                             const double *covs1, double reg, const double *init_q,
+                             const double *init_t, int32_t n_hyp, const double *hyp_t,
+                             const pnec_oracle_options *opt, int num_threads, double *out_q,
+                             double *out_t, double *out_cost, int32_t *out_iterations,
+                             int32_t *out_status);
+
+int pnec_oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNEC_ORACLE_H_ */

@@ -1,0 +1,310 @@
+"""ctypes loader for the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(see oracle/pnec_oracle.h).  Nothing under pnec_amd/ does.
+
+Also holds ``energy_numpy``: an independent numpy restatement of the reference's energy
+(scripts/pnec/common.py:13-59 <-> include/optimization/pnec_residual.h:97-102), used to
+cross-check the C restatement against the golden vectors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpnec_oracle.so")
+
+MODE_NEC, MODE_TARGET, MODE_HOST, MODE_SYM = 0, 1, 2, 3
+JAC_NUMERIC_CENTRAL, JAC_ANALYTIC = 0, 1
+TERM_NAMES = {
+    0: "function_tolerance",
+    1: "parameter_tolerance",
+    2: "gradient_tolerance",
+    3: "max_iterations",
+    4: "min_trust_region_radius",
+    5: "invalid_steps",
+    6: "bad_initial_point",
+}
+
+
+class Options(C.Structure):
+    """Mirror of ``pnec_oracle_options`` (ceres::Solver::Options subset, Ceres 2.x defaults)."""
+
+    _fields_ = [
+        ("max_num_iterations", C.c_int32),
+        ("max_num_consecutive_invalid_steps", C.c_int32),
+        ("jacobi_scaling", C.c_int32),
+        ("check_convergence", C.c_int32),
+        ("jacobian_mode", C.c_int32),
+        ("reserved", C.c_int32),
+        ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+        ("initial_trust_region_radius", C.c_double),
+        ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double),
+        ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/libpnec_oracle.so with the committed Makefile."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "pnec_oracle.c"))
+    ):
+        subprocess.run(["make", "-C", _HERE, "-B", "libpnec_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.pnec_oracle_default_options.argtypes = [C.POINTER(Options)]
+        _lib.pnec_oracle_angles_from_vec.argtypes = [_dp, _dp, _dp]
+        _lib.pnec_oracle_quat_from_rot.argtypes = [_dp, _dp]
+        _lib.pnec_oracle_rot_from_quat.argtypes = [_dp, _dp]
+        _lib.pnec_oracle_result.argtypes = [_dp, C.c_double, C.c_double, _dp, _dp]
+        _lib.pnec_oracle_rotational_difference_deg.argtypes = [_dp, _dp]
+        _lib.pnec_oracle_rotational_difference_deg.restype = C.c_double
+        _lib.pnec_oracle_translational_difference_deg.argtypes = [_dp, _dp, C.c_int]
+        _lib.pnec_oracle_translational_difference_deg.restype = C.c_double
+        _lib.pnec_oracle_cost_function.argtypes = [C.c_int64, _dp, _dp, _dp, _dp, _dp]
+        _lib.pnec_oracle_cost_function.restype = C.c_double
+        _lib.pnec_oracle_residual.argtypes = [C.c_int, _dp, _dp, _dp, _dp, C.c_double,
+                                              C.c_double, C.c_double, _dp]
+        _lib.pnec_oracle_residual.restype = C.c_double
+        _lib.pnec_oracle_energy.argtypes = [C.c_int, C.c_int64, _dp, _dp, _dp, _dp, C.c_double,
+                                            _dp, _dp]
+        _lib.pnec_oracle_energy.restype = C.c_double
+        _lib.pnec_oracle_evaluate.argtypes = [C.c_int, C.c_int, C.c_int64, _dp, _dp, _dp, _dp,
+                                              C.c_double, C.c_double, C.c_double, _dp, _dp, _dp,
+                                              _dp]
+        _lib.pnec_oracle_solve.argtypes = [C.c_int, C.c_int64, _dp, _dp, _dp, _dp, C.c_double, _dp,
+                                           _dp, C.POINTER(Options), _dp, _dp, _dp, _dp, _ip]
+        _lib.pnec_oracle_solve.restype = C.c_int
+        _lib.pnec_oracle_solve_batch.argtypes = [C.c_int, C.c_int64, _lp, _dp, _dp, _dp, _dp,
+                                                 C.c_double, _dp, _dp, C.c_int32, _dp,
+                                                 C.POINTER(Options), C.c_int, _dp, _dp, _dp, _ip,
+                                                 _ip]
+        _lib.pnec_oracle_max_threads.restype = C.c_int
+    return _lib
+
+
+def _d(a):
+    """contiguous float64 view + pointer (None -> NULL)"""
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def default_options(**overrides) -> Options:
+    o = Options()
+    lib().pnec_oracle_default_options(C.byref(o))
+    for k, v in overrides.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def covs_to_colmajor9(covs: np.ndarray) -> np.ndarray:
+    """[n,3,3] -> [n,9] in Eigen column-major order (how std::vector<Matrix3d> stores them)."""
+    covs = np.asarray(covs, dtype=np.float64)
+    return np.ascontiguousarray(np.transpose(covs, (0, 2, 1)).reshape(-1, 9))
+
+
+def angles_from_vec(v):
+    v_, vp = _d(v)
+    th, ph = C.c_double(), C.c_double()
+    lib().pnec_oracle_angles_from_vec(vp, C.byref(th), C.byref(ph))
+    return th.value, ph.value
+
+
+def quat_from_rot(R):
+    R_, Rp = _d(np.asarray(R).reshape(9))
+    q = np.zeros(4)
+    lib().pnec_oracle_quat_from_rot(Rp, q.ctypes.data_as(_dp))
+    return q
+
+
+def rot_from_quat(q):
+    q_, qp = _d(q)
+    R = np.zeros(9)
+    lib().pnec_oracle_rot_from_quat(qp, R.ctypes.data_as(_dp))
+    return R.reshape(3, 3)
+
+
+def rotational_difference_deg(R1, R2) -> float:
+    a, ap = _d(np.asarray(R1).reshape(9))
+    b, bp = _d(np.asarray(R2).reshape(9))
+    return lib().pnec_oracle_rotational_difference_deg(ap, bp)
+
+
+def translational_difference_deg(t1, t2, both_directions=True) -> float:
+    a, ap = _d(t1)
+    b, bp = _d(t2)
+    return lib().pnec_oracle_translational_difference_deg(ap, bp, int(both_directions))
+
+
+def cost_function(bvs1, bvs2, covs, R, t) -> float:
+    b1, b1p = _d(bvs1)
+    b2, b2p = _d(bvs2)
+    c, cp = _d(covs_to_colmajor9(covs))
+    R_, Rp = _d(np.asarray(R).reshape(9))
+    t_, tp = _d(t)
+    return lib().pnec_oracle_cost_function(len(b1), b1p, b2p, cp, Rp, tp)
+
+
+def residual(mode, f1, f2, cov2, cov1, reg, theta, phi, q) -> float:
+    f1_, f1p = _d(f1)
+    f2_, f2p = _d(f2)
+    c2, c2p = _d(None if cov2 is None else np.asarray(cov2).T.reshape(9))
+    c1, c1p = _d(None if cov1 is None else np.asarray(cov1).T.reshape(9))
+    q_, qp = _d(q)
+    return lib().pnec_oracle_residual(mode, f1p, f2p, c2p, c1p, reg, theta, phi, qp)
+
+
+def energy(mode, bvs1, bvs2, covs2, covs1, reg, R, t) -> float:
+    """sum_i r_i^2 at an explicit (R, t) -- the quantity scripts/pnec/common.py computes."""
+    b1, b1p = _d(bvs1)
+    b2, b2p = _d(bvs2)
+    c2, c2p = _d(None if covs2 is None else covs_to_colmajor9(covs2))
+    c1, c1p = _d(None if covs1 is None else covs_to_colmajor9(covs1))
+    R_, Rp = _d(np.asarray(R).reshape(9))
+    t_, tp = _d(t)
+    return lib().pnec_oracle_energy(mode, len(b1), b1p, b2p, c2p, c1p, reg, Rp, tp)
+
+
+def evaluate(mode, jacobian_mode, bvs1, bvs2, covs2, covs1, reg, theta, phi, q):
+    """-> (r[n], J[n,5], cost=1/2 sum r^2) in the Ceres tangent space (theta, phi, delta_xyz)."""
+    b1, b1p = _d(bvs1)
+    b2, b2p = _d(bvs2)
+    c2, c2p = _d(None if covs2 is None else covs_to_colmajor9(covs2))
+    c1, c1p = _d(None if covs1 is None else covs_to_colmajor9(covs1))
+    q_, qp = _d(q)
+    n = len(b1)
+    r = np.zeros(n)
+    J = np.zeros((n, 5))
+    cost = C.c_double()
+    lib().pnec_oracle_evaluate(mode, jacobian_mode, n, b1p, b2p, c2p, c1p, reg, theta, phi, qp,
+                               r.ctypes.data_as(_dp), J.ctypes.data_as(_dp), C.byref(cost))
+    return r, J, cost.value
+
+
+@dataclass
+class Solution:
+    q: np.ndarray          # xyzw, normalised
+    t: np.ndarray          # unit
+    R: np.ndarray          # 3x3
+    theta: float
+    phi: float
+    cost: float            # 1/2 sum r^2 at the returned point
+    iterations: int
+    status: int
+
+
+def solve(mode, bvs1, bvs2, covs2, covs1, reg, init_q, init_t, options: Options | None = None
+          ) -> Solution:
+    b1, b1p = _d(bvs1)
+    b2, b2p = _d(bvs2)
+    c2, c2p = _d(None if covs2 is None else covs_to_colmajor9(covs2))
+    c1, c1p = _d(None if covs1 is None else covs_to_colmajor9(covs1))
+    q0, q0p = _d(init_q)
+    t0, t0p = _d(init_t)
+    q = np.zeros(4)
+    t = np.zeros(3)
+    tp = np.zeros(2)
+    cost = C.c_double()
+    it = C.c_int32()
+    st = lib().pnec_oracle_solve(mode, len(b1), b1p, b2p, c2p, c1p, reg, q0p, t0p,
+                                 C.byref(options) if options is not None else None,
+                                 q.ctypes.data_as(_dp), t.ctypes.data_as(_dp),
+                                 tp.ctypes.data_as(_dp), C.byref(cost), C.byref(it))
+    return Solution(q=q, t=t, R=rot_from_quat(q), theta=tp[0], phi=tp[1], cost=cost.value,
+                    iterations=it.value, status=st)
+
+
+def solve_batch(mode, offsets, bvs1, bvs2, covs2_9, covs1_9, reg, init_q, init_t,
+                n_hyp=1, hyp_t=None, options: Options | None = None, num_threads=0):
+    """Batch driver. covs*_9 are [sumN, 9] Eigen column-major (use covs_to_colmajor9)."""
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    B = len(offsets) - 1
+    b1, b1p = _d(bvs1)
+    b2, b2p = _d(bvs2)
+    c2, c2p = _d(covs2_9)
+    c1, c1p = _d(covs1_9)
+    q0, q0p = _d(init_q)
+    t0, t0p = _d(init_t)
+    h, hp = _d(hyp_t)
+    S = B * max(1, n_hyp)
+    out_q = np.zeros((S, 4))
+    out_t = np.zeros((S, 3))
+    out_cost = np.zeros(S)
+    out_it = np.zeros(S, dtype=np.int32)
+    out_st = np.zeros(S, dtype=np.int32)
+    lib().pnec_oracle_solve_batch(mode, B, offsets.ctypes.data_as(_lp), b1p, b2p, c2p, c1p, reg,
+                                  q0p, t0p, n_hyp, hp,
+                                  C.byref(options) if options is not None else None,
+                                  num_threads, out_q.ctypes.data_as(_dp),
+                                  out_t.ctypes.data_as(_dp), out_cost.ctypes.data_as(_dp),
+                                  out_it.ctypes.data_as(_ip), out_st.ctypes.data_as(_ip))
+    return out_q, out_t, out_cost, out_it, out_st
+
+
+def max_threads() -> int:
+    return lib().pnec_oracle_max_threads()
+
+
+# --------------------------------------------------------------------------------------------
+# Independent numpy restatement of the energies (no C involved).
+def skew_numpy(v: np.ndarray) -> np.ndarray:
+    """[...,3] -> [...,3,3]  (src/common/common.cc:96-101)"""
+    v = np.asarray(v, dtype=np.float64)
+    z = np.zeros_like(v[..., 0])
+    return np.stack([
+        np.stack([z, -v[..., 2], v[..., 1]], -1),
+        np.stack([v[..., 2], z, -v[..., 0]], -1),
+        np.stack([-v[..., 1], v[..., 0], z], -1),
+    ], -2)
+
+
+def energy_numpy(mode, bvs1, bvs2, covs2, covs1, reg, R, t) -> float:
+    """sum_i r_i^2 with r_i per pnec_residual.h / nec_residual.h, evaluated in numpy."""
+    f1 = np.asarray(bvs1, dtype=np.float64)
+    f2 = np.asarray(bvs2, dtype=np.float64)
+    R = np.asarray(R, dtype=np.float64)
+    t = np.asarray(t, dtype=np.float64)
+    Rf2 = f2 @ R.T
+    num = np.cross(f1, Rf2) @ t
+    if mode == MODE_NEC:
+        return float(np.sum(num ** 2))
+    den = np.full(len(f1), float(reg))
+    F1 = skew_numpy(f1)
+    if mode in (MODE_TARGET, MODE_SYM):
+        v = np.einsum("i,nij,jk->nk", t, F1, R)
+        den = den + np.einsum("ni,nij,nj->n", v, np.asarray(covs2), v)
+    if mode == MODE_HOST:
+        v = np.einsum("i,nij->nj", t, skew_numpy(f1 @ R.T))
+        den = den + np.einsum("ni,nij,nj->n", v, np.asarray(covs2), v)
+    if mode == MODE_SYM:
+        v = np.einsum("i,nij->nj", t, skew_numpy(Rf2))
+        den = den + np.einsum("ni,nij,nj->n", v, np.asarray(covs1), v)
+    return float(np.sum(num ** 2 / den))

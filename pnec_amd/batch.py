@@ -1,0 +1,227 @@
+"""Batch front-end over the C ABI: a batch of frame pairs resident in HBM and its solves.
+
+numpy arguments go through the HOST memory space of the ABI (blocking, PCIe-inclusive);
+torch CUDA tensors go through the DEVICE space (asynchronous on torch's current stream).
+torch is plumbing here (device memory, streams); all arithmetic is in libpnec_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi
+
+
+def _is_torch(x) -> bool:
+    return x is not None and type(x).__module__.startswith("torch")
+
+
+@dataclass
+class SolveResult:
+    """Per solve (pair-major, hypothesis-minor): what PNECCeres::Result() returns + summary."""
+    q: object           # [S,4] xyzw, normalised
+    t: object           # [S,3] unit
+    cost: object        # [S]   1/2 sum r^2 at the returned point
+    iterations: object  # [S]   int32
+    status: object      # [S]   int32, capi.TERM_NAMES
+
+    def rotation_matrices(self):
+        """[S,3,3] from q (numpy or torch, matching the stored arrays)."""
+        q = self.q
+        x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+        xp = __import__("torch") if _is_torch(q) else np
+        R = xp.stack([
+            xp.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], -1),
+            xp.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], -1),
+            xp.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1),
+        ], -2)
+        return R
+
+
+class Batch:
+    """A batch of independent frame pairs in the solver's SoA layout (``pnec_hip_problem``)."""
+
+    def __init__(self, mode: int, offsets, device: int = 0):
+        self._lib = capi.lib()
+        self.mode = int(mode)
+        self.device = int(device)
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if self.offsets.ndim != 1 or len(self.offsets) < 1:
+            raise ValueError("offsets must be a 1-D array of length n_pairs+1")
+        self.n_pairs = len(self.offsets) - 1
+        h = C.c_void_p()
+        capi.check(self._lib.pnec_hip_problem_create(self.device, self.mode, self.n_pairs,
+                                                     self.offsets.ctypes.data, C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def uniform(cls, mode: int, n_pairs: int, n_corr: int, device: int = 0) -> "Batch":
+        return cls(mode, np.arange(n_pairs + 1, dtype=np.int64) * n_corr, device)
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pnec_hip_problem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- info -------------------------------------------------------------------------------
+    @property
+    def num_correspondences(self) -> int:
+        return self._lib.pnec_hip_problem_num_correspondences(self._h)
+
+    @property
+    def max_correspondences(self) -> int:
+        return self._lib.pnec_hip_problem_max_correspondences(self._h)
+
+    @property
+    def payload_bytes(self) -> int:
+        return self._lib.pnec_hip_problem_payload_bytes(self._h)
+
+    def describe_launch(self, options: capi.Options | None = None) -> dict:
+        cpl, wpp, tpb, res = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        capi.check(self._lib.pnec_hip_describe_launch(
+            self._h, C.byref(options) if options is not None else None, C.byref(cpl),
+            C.byref(wpp), C.byref(tpb), C.byref(res)))
+        return {"corr_per_lane": cpl.value, "waves_per_pair": wpp.value,
+                "threads_per_block": tpb.value, "resident": bool(res.value)}
+
+    # -- ingest -----------------------------------------------------------------------------
+    def fill(self, bvs1, bvs2, covs=None, covs_host=None, first_pair: int = 0,
+             n_pairs: int | None = None):
+        """Fill pairs [first_pair, first_pair+n_pairs) from reference-layout arrays.
+
+        bvs*: [M,3]; covs*: [M,3,3] (symmetric) or [M,9] Eigen column-major; M = the number of
+        correspondences in that pair range.  numpy -> HOST space, torch.cuda -> DEVICE space.
+        """
+        if n_pairs is None:
+            n_pairs = self.n_pairs - first_pair
+        m = int(self.offsets[first_pair + n_pairs] - self.offsets[first_pair])
+        arrays = [bvs1, bvs2, covs, covs_host]
+        on_device = _is_torch(bvs1)
+        ptrs, keep = [], []
+        for i, a in enumerate(arrays):
+            if a is None:
+                ptrs.append(None)
+                continue
+            width = 3 if i < 2 else 9
+            if on_device:
+                import torch
+                if not a.is_cuda:
+                    raise ValueError("torch inputs must be CUDA tensors (or pass numpy)")
+                if a.dim() == 3:  # [M,3,3] symmetric == its own column-major image
+                    a = a.reshape(a.shape[0], 9)
+                a = a.contiguous().to(torch.float64)
+                if a.numel() != m * width:
+                    raise ValueError(f"array {i}: expected {m}x{width} values, got {a.numel()}")
+                keep.append(a)
+                ptrs.append(a.data_ptr())
+            else:
+                a = np.asarray(a, dtype=np.float64)
+                if a.ndim == 3:
+                    a = np.transpose(a, (0, 2, 1)).reshape(a.shape[0], 9)
+                a = np.ascontiguousarray(a)
+                if a.size != m * width:
+                    raise ValueError(f"array {i}: expected {m}x{width} values, got {a.size}")
+                keep.append(a)
+                ptrs.append(a.ctypes.data)
+        stream = None
+        if on_device:
+            import torch
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        capi.check(self._lib.pnec_hip_problem_fill(
+            self._h, first_pair, n_pairs, ptrs[0], ptrs[1], ptrs[2], ptrs[3],
+            capi.MEM_DEVICE if on_device else capi.MEM_HOST, stream))
+        return self
+
+    # -- solve ------------------------------------------------------------------------------
+    def solve(self, init_q, init_t=None, reg: float = 1e-13,
+              options: capi.Options | None = None, hyp_t=None, n_hyp: int = 1,
+              out: SolveResult | None = None) -> SolveResult:
+        """InitValues + Optimize + Result for every (pair, hypothesis) on the device."""
+        on_device = _is_torch(init_q)
+        S = self.n_pairs * (n_hyp if hyp_t is not None else 1)
+        if on_device:
+            import torch
+            dev = init_q.device
+            f64 = dict(dtype=torch.float64, device=dev)
+            init_q = init_q.contiguous()
+            init_t = init_t.contiguous() if init_t is not None else None
+            hyp_t = hyp_t.contiguous() if hyp_t is not None else None
+            if out is None:
+                out = SolveResult(torch.empty((S, 4), **f64), torch.empty((S, 3), **f64),
+                                  torch.empty((S,), **f64),
+                                  torch.empty((S,), dtype=torch.int32, device=dev),
+                                  torch.empty((S,), dtype=torch.int32, device=dev))
+            p = lambda a: None if a is None else a.data_ptr()
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            space = capi.MEM_DEVICE
+        else:
+            init_q = np.ascontiguousarray(init_q, dtype=np.float64)
+            init_t = None if init_t is None else np.ascontiguousarray(init_t, dtype=np.float64)
+            hyp_t = None if hyp_t is None else np.ascontiguousarray(hyp_t, dtype=np.float64)
+            if out is None:
+                out = SolveResult(np.empty((S, 4)), np.empty((S, 3)), np.empty(S),
+                                  np.empty(S, dtype=np.int32), np.empty(S, dtype=np.int32))
+            p = lambda a: None if a is None else a.ctypes.data
+            stream = None
+            space = capi.MEM_HOST
+        if tuple(init_q.shape) != (self.n_pairs, 4):
+            raise ValueError("init_q must be [n_pairs,4] (xyzw)")
+        if init_t is not None and tuple(init_t.shape) != (self.n_pairs, 3):
+            raise ValueError("init_t must be [n_pairs,3]")
+        if hyp_t is not None and tuple(hyp_t.shape) != (S, 3):
+            raise ValueError("hyp_t must be [n_pairs*n_hyp,3]")
+        capi.check(self._lib.pnec_hip_solve(
+            self._h, p(init_q), p(init_t), int(n_hyp), p(hyp_t), float(reg),
+            C.byref(options) if options is not None else None, p(out.q), p(out.t), p(out.cost),
+            p(out.iterations), p(out.status), space, stream))
+        return out
+
+    def cost_function(self, q, t):
+        """pnec::common::CostFunction per pair (TARGET-mode batches)."""
+        if _is_torch(q):
+            import torch
+            out = torch.empty((self.n_pairs,), dtype=torch.float64, device=q.device)
+            capi.check(self._lib.pnec_hip_cost_function(
+                self._h, q.contiguous().data_ptr(), t.contiguous().data_ptr(), out.data_ptr(),
+                capi.MEM_DEVICE, torch.cuda.current_stream(self.device).cuda_stream))
+            return out
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        out = np.empty(self.n_pairs)
+        capi.check(self._lib.pnec_hip_cost_function(self._h, q.ctypes.data, t.ctypes.data,
+                                                    out.ctypes.data, capi.MEM_HOST, None))
+        return out
+
+
+def select_best(cost, n_hyp: int, device: int = 0):
+    """Index of the lowest-cost hypothesis per pair."""
+    L = capi.lib()
+    if _is_torch(cost):
+        import torch
+        n_pairs = cost.numel() // n_hyp
+        best = torch.empty((n_pairs,), dtype=torch.int32, device=cost.device)
+        capi.check(L.pnec_hip_select_best(n_pairs, n_hyp, cost.contiguous().data_ptr(),
+                                          best.data_ptr(), capi.MEM_DEVICE, device,
+                                          torch.cuda.current_stream(device).cuda_stream))
+        return best
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
+    n_pairs = cost.size // n_hyp
+    best = np.empty(n_pairs, dtype=np.int32)
+    capi.check(L.pnec_hip_select_best(n_pairs, n_hyp, cost.ctypes.data, best.ctypes.data,
+                                      capi.MEM_HOST, device, None))
+    return best

@@ -1,0 +1,137 @@
+"""ctypes binding of libpnec_hip.so (the C ABI in include/pnec_hip.h).
+
+This is the only way Python reaches the solver: there is no CPU or PyTorch fallback.  If the
+shared library is missing or cannot be loaded, importing this module's ``lib()`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpnec_hip.so")
+
+MODE_NEC, MODE_TARGET, MODE_HOST, MODE_SYM = 0, 1, 2, 3
+MEM_HOST, MEM_DEVICE = 0, 1
+TERM_NAMES = {
+    0: "function_tolerance",
+    1: "parameter_tolerance",
+    2: "gradient_tolerance",
+    3: "max_iterations",
+    4: "min_trust_region_radius",
+    5: "invalid_steps",
+    6: "bad_initial_point",
+}
+NUM_COMPONENTS = {MODE_NEC: 6, MODE_TARGET: 12, MODE_HOST: 12, MODE_SYM: 18}
+
+# every symbol include/pnec_hip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "pnec_hip_abi_version",
+    "pnec_hip_last_error",
+    "pnec_hip_device_count",
+    "pnec_hip_default_options",
+    "pnec_hip_problem_create",
+    "pnec_hip_problem_destroy",
+    "pnec_hip_problem_fill",
+    "pnec_hip_problem_num_pairs",
+    "pnec_hip_problem_num_correspondences",
+    "pnec_hip_problem_max_correspondences",
+    "pnec_hip_problem_payload_bytes",
+    "pnec_hip_problem_mode",
+    "pnec_hip_problem_device",
+    "pnec_hip_solve",
+    "pnec_hip_select_best",
+    "pnec_hip_cost_function",
+    "pnec_hip_describe_launch",
+    "pnec_hip_selftest",
+]
+
+
+class Options(C.Structure):
+    """``pnec_hip_options``: the ceres::Solver::Options subset + launch tuning."""
+
+    _fields_ = [
+        ("max_num_iterations", C.c_int32),
+        ("max_num_consecutive_invalid_steps", C.c_int32),
+        ("jacobi_scaling", C.c_int32),
+        ("check_convergence", C.c_int32),
+        ("corr_per_lane", C.c_int32),
+        ("waves_per_pair", C.c_int32),
+        ("function_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double),
+        ("initial_trust_region_radius", C.c_double),
+        ("max_trust_region_radius", C.c_double),
+        ("min_trust_region_radius", C.c_double),
+        ("min_relative_decrease", C.c_double),
+        ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double),
+    ]
+
+
+class PnecHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libpnec_hip error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+_vp = C.c_void_p
+
+
+def lib() -> C.CDLL:
+    """Load libpnec_hip.so; raises (loudly) if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C pnec_amd/csrc`. "
+            "There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.pnec_hip_abi_version.restype = C.c_int
+    L.pnec_hip_last_error.restype = C.c_char_p
+    L.pnec_hip_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.pnec_hip_default_options.argtypes = [C.POINTER(Options)]
+    L.pnec_hip_default_options.restype = None
+    L.pnec_hip_problem_create.argtypes = [C.c_int, C.c_int, C.c_int64, _vp, C.POINTER(_vp)]
+    L.pnec_hip_problem_destroy.argtypes = [_vp]
+    L.pnec_hip_problem_fill.argtypes = [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp]
+    for name in ("num_pairs", "num_correspondences", "max_correspondences", "payload_bytes"):
+        f = getattr(L, "pnec_hip_problem_" + name)
+        f.argtypes = [_vp]
+        f.restype = C.c_int64
+    L.pnec_hip_problem_mode.argtypes = [_vp]
+    L.pnec_hip_problem_device.argtypes = [_vp]
+    L.pnec_hip_solve.argtypes = [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.POINTER(Options),
+                                 _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]
+    L.pnec_hip_select_best.argtypes = [C.c_int64, C.c_int32, _vp, _vp, C.c_int, C.c_int, _vp]
+    L.pnec_hip_cost_function.argtypes = [_vp, _vp, _vp, _vp, C.c_int, _vp]
+    L.pnec_hip_describe_launch.argtypes = [_vp, C.POINTER(Options), C.POINTER(C.c_int32),
+                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                           C.POINTER(C.c_int32)]
+    L.pnec_hip_selftest.argtypes = [C.c_int]
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise PnecHipError(rc, (lib().pnec_hip_last_error() or b"").decode())
+
+
+def default_options(**overrides) -> Options:
+    o = Options()
+    lib().pnec_hip_default_options(C.byref(o))
+    for k, v in overrides.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib().pnec_hip_device_count(C.byref(n))
+    return n.value if rc == 0 else 0

@@ -1,0 +1,665 @@
+// pnec_capi.hip -- the C ABI declared in include/pnec_hip.h: batch storage in HBM, ingest
+// (reference AoS -> SoA planes), launch selection, and the small auxiliary kernels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pnec_device.hpp"
+#include "pnec_solve_kernel.hpp"
+
+namespace pnec_hip {
+// one translation unit per residual family (pnec_solve_<family>.hip)
+hipError_t launch_solve_mode_0(int, int, bool, const SolveArgs &, hipStream_t);
+hipError_t launch_solve_mode_1(int, int, bool, const SolveArgs &, hipStream_t);
+hipError_t launch_solve_mode_2(int, int, bool, const SolveArgs &, hipStream_t);
+hipError_t launch_solve_mode_3(int, int, bool, const SolveArgs &, hipStream_t);
+}  // namespace pnec_hip
+
+using namespace pnec_hip;
+
+// ------------------------------------------------------------------------------------------
+// HBM layout of a batch ("problem"):
+//   data:  for pair p, a block of NC planes, each `stride_p = round_up(count_p, 64)` doubles:
+//          f1x f1y f1z | f2x f2y f2z | cov xx xy xz yy yz zz | cov_host xx .. zz (SYM)
+//          block_offset[p] = first double of the block; padding entries are 0.
+//   A wavefront reading plane c touches 64 consecutive doubles (512 B) per load: fully coalesced.
+struct pnec_hip_problem {
+  int device = 0;
+  int mode = 0;
+  int nc = 0;
+  int64_t n_pairs = 0;
+  int64_t n_corr = 0;
+  int32_t n_max = 0;
+  int64_t data_doubles = 0;
+  std::vector<int64_t> offsets;       // host copy, [n_pairs+1]
+  double *d_data = nullptr;           // SoA payload
+  int64_t *d_block_offset = nullptr;  // [n_pairs]
+  int64_t *d_offsets = nullptr;       // [n_pairs+1] AoS offsets (ingest only)
+  int32_t *d_count = nullptr;         // [n_pairs]
+  // staging for host-space solves (grown on demand, reused)
+  double *d_stage = nullptr;
+  int64_t stage_doubles = 0;
+  int32_t *d_stage_i = nullptr;
+  int64_t stage_ints = 0;
+};
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+int fail_hip(hipError_t e, const char *what) {
+  return fail(PNEC_HIP_ERR_HIP_RUNTIME, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define PNEC_HIP_TRY(expr)                               \
+  do {                                                   \
+    hipError_t e_ = (expr);                              \
+    if (e_ != hipSuccess) return fail_hip(e_, #expr);    \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+// ---- ingest: reference AoS (bvs 3, covs 9 column-major) -> SoA planes --------------------
+template <int NC>
+__global__ __launch_bounds__(256) void pack_kernel(double *__restrict__ data,
+                                                   const int64_t *__restrict__ block_offset,
+                                                   const int64_t *__restrict__ offsets,
+                                                   const int32_t *__restrict__ count,
+                                                   int64_t first_pair, int64_t n_pairs,
+                                                   const double *__restrict__ bvs1,
+                                                   const double *__restrict__ bvs2,
+                                                   const double *__restrict__ covs,
+                                                   const double *__restrict__ covs_host) {
+  const int64_t src0 = offsets[first_pair];
+  for (int64_t p = first_pair + blockIdx.y; p < first_pair + n_pairs; p += gridDim.y) {
+    const int n = count[p];
+    const int stride = (n + kWave - 1) & ~(kWave - 1);
+    double *blk = data + block_offset[p];
+    const int64_t src = offsets[p] - src0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < stride; i += gridDim.x * blockDim.x) {
+      const bool in = i < n;
+      const int64_t j = src + i;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        blk[(int64_t)c * stride + i] = in ? bvs1[3 * j + c] : 0.0;
+        blk[(int64_t)(3 + c) * stride + i] = in ? bvs2[3 * j + c] : 0.0;
+      }
+      if constexpr (NC >= 12) {
+        // symmetric part of the column-major 3x3: (r,c) at 3*c + r
+        const double *C = covs + 9 * j;
+        blk[(int64_t)6 * stride + i] = in ? C[0] : 0.0;
+        blk[(int64_t)7 * stride + i] = in ? 0.5 * (C[1] + C[3]) : 0.0;
+        blk[(int64_t)8 * stride + i] = in ? 0.5 * (C[2] + C[6]) : 0.0;
+        blk[(int64_t)9 * stride + i] = in ? C[4] : 0.0;
+        blk[(int64_t)10 * stride + i] = in ? 0.5 * (C[5] + C[7]) : 0.0;
+        blk[(int64_t)11 * stride + i] = in ? C[8] : 0.0;
+      }
+      if constexpr (NC >= 18) {
+        const double *C = covs_host + 9 * j;
+        blk[(int64_t)12 * stride + i] = in ? C[0] : 0.0;
+        blk[(int64_t)13 * stride + i] = in ? 0.5 * (C[1] + C[3]) : 0.0;
+        blk[(int64_t)14 * stride + i] = in ? 0.5 * (C[2] + C[6]) : 0.0;
+        blk[(int64_t)15 * stride + i] = in ? C[4] : 0.0;
+        blk[(int64_t)16 * stride + i] = in ? 0.5 * (C[5] + C[7]) : 0.0;
+        blk[(int64_t)17 * stride + i] = in ? C[8] : 0.0;
+      }
+    }
+  }
+}
+
+// ---- best hypothesis per pair ------------------------------------------------------------
+__global__ void select_best_kernel(int64_t n_pairs, int n_hyp, const double *__restrict__ cost,
+                                   int32_t *__restrict__ best) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  int bi = 0;
+  double bc = cost[p * n_hyp];
+  for (int h = 1; h < n_hyp; ++h) {
+    const double c = cost[p * n_hyp + h];
+    // NaN never wins; first NaN-free minimum wins ties
+    if (c < bc || (bc != bc && c == c)) {
+      bc = c;
+      bi = h;
+    }
+  }
+  best[p] = bi;
+}
+
+// ---- pnec::common::CostFunction (common.cc:237-259), one wavefront per pair ---------------
+__global__ __launch_bounds__(kWave) void cost_function_kernel(const double *__restrict__ data,
+                                                              const int64_t *__restrict__ block_offset,
+                                                              const int32_t *__restrict__ count,
+                                                              const double *__restrict__ qs,
+                                                              const double *__restrict__ ts,
+                                                              double *__restrict__ out) {
+  const int64_t p = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int n = count[p];
+  const int stride = (n + kWave - 1) & ~(kWave - 1);
+  const double *base = data + block_offset[p];
+  double q[4] = {qs[4 * p], qs[4 * p + 1], qs[4 * p + 2], qs[4 * p + 3]};
+  const double qn = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) q[k] *= qn;
+  double R[9];
+  rot_from_quat(q, R);
+  const double tx = ts[3 * p], ty = ts[3 * p + 1], tz = ts[3 * p + 2];
+  double acc = 0.0;
+  for (int i = lane; i < n; i += kWave) {
+    double d[12];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) d[c] = base[(int64_t)c * stride + i];
+    const double mx = ty * d[2] - tz * d[1], my = tz * d[0] - tx * d[2], mz = tx * d[1] - ty * d[0];
+    const double gx = R[0] * mx + R[3] * my + R[6] * mz;
+    const double gy = R[1] * mx + R[4] * my + R[7] * mz;
+    const double gz = R[2] * mx + R[5] * my + R[8] * mz;
+    const double nn = d[3] * gx + d[4] * gy + d[5] * gz;
+    const double sgx = d[6] * gx + d[7] * gy + d[8] * gz;
+    const double sgy = d[7] * gx + d[9] * gy + d[10] * gz;
+    const double sgz = d[8] * gx + d[10] * gy + d[11] * gz;
+    acc += nn * nn / (gx * sgx + gy * sgy + gz * sgz);
+  }
+  acc = wave_allreduce_sum(acc);
+  if (lane == 0) out[p] = acc / (double)n;
+}
+
+// ---- device self-test kernels (cross-lane reduction, 5x5 solve) ---------------------------
+__global__ void selftest_kernel(double *out) {
+  const int lane = threadIdx.x;
+  // sum of (lane+1)^2 over 64 lanes = 89440; every lane must hold it
+  const double v = wave_allreduce_sum((double)((lane + 1) * (lane + 1)));
+  out[lane] = v;
+  if (lane == 0) {
+    // A = M M' + I for a fixed M; solve A y = b and report the residual norm
+    double P[15], b[5], y[5];
+    double M[5][5];
+    for (int i = 0; i < 5; ++i)
+      for (int j = 0; j < 5; ++j) M[i][j] = sin(1.0 + i * 1.7 + j * 0.9);
+    for (int i = 0; i < 5; ++i)
+      for (int j = i; j < 5; ++j) {
+        double sacc = (i == j) ? 1.0 : 0.0;
+        for (int k = 0; k < 5; ++k) sacc += M[i][k] * M[j][k];
+        P[tri(i, j)] = sacc;
+      }
+    for (int i = 0; i < 5; ++i) b[i] = 1.0 + i;
+    const bool ok = chol_solve5(P, b, y);
+    double res = 0.0;
+    for (int i = 0; i < 5; ++i) {
+      double sacc = -b[i];
+      for (int j = 0; j < 5; ++j) sacc += P[sym(i, j)] * y[j];
+      res += sacc * sacc;
+    }
+    out[64] = ok ? sqrt(res) : -1.0;
+    out[65] = fast_rsqrt(2.0) - 0.70710678118654752440;
+    out[66] = fast_rcp(3.0) - 0.33333333333333333333;
+  }
+}
+
+// ---- launch geometry --------------------------------------------------------------------
+struct Geometry {
+  int cpl, wpp;
+  bool resident;
+};
+
+bool geometry_exists(int cpl, int wpp) {
+#define PNEC_GEOMETRY_MATCH(CPL, WPP) \
+  if (cpl == CPL && wpp == WPP) return true;
+  PNEC_FOR_EACH_GEOMETRY(PNEC_GEOMETRY_MATCH)
+#undef PNEC_GEOMETRY_MATCH
+  return false;
+}
+
+// Register-resident whenever the largest pair fits 64*CPL*WPP lanes-slots; one wavefront per
+// solve as long as that wavefront's registers can hold the pair (the serial part of an LM
+// iteration is paid once per wavefront, so fewer, fatter wavefronts win); the SYM family carries
+// 18 doubles per correspondence, so it tops out at 4 per lane.
+int choose_geometry(const pnec_hip_problem *p, const pnec_hip_options *opt, Geometry *g) {
+  const int n = std::max<int32_t>(p->n_max, 1);
+  if (opt && (opt->corr_per_lane > 0 || opt->waves_per_pair > 0)) {
+    const int cpl = opt->corr_per_lane, wpp = opt->waves_per_pair;
+    if (cpl < 0 || wpp < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "negative launch tuning");
+    if (cpl == 0 && wpp > 0) {  // streaming with the fixed 8-wave block
+      *g = {1, kStreamWaves, false};
+      return 0;
+    }
+    if (!geometry_exists(cpl, wpp ? wpp : 1))
+      return fail(PNEC_HIP_ERR_UNSUPPORTED, "launch geometry (corr_per_lane, waves_per_pair) not built");
+    if ((int64_t)kWave * cpl * (wpp ? wpp : 1) < n)
+      return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "launch geometry too small for the largest pair");
+    *g = {cpl, wpp ? wpp : 1, true};
+    return 0;
+  }
+  const int max_cpl_1wave = (p->mode == PNEC_HIP_MODE_SYM) ? 4 : 8;
+  static const int order[][2] = {{1, 1}, {2, 1}, {4, 1}, {8, 1}, {4, 2}, {4, 4}, {4, 8}};
+  for (auto &c : order) {
+    if (c[1] == 1 && c[0] > max_cpl_1wave) continue;
+    if ((int64_t)kWave * c[0] * c[1] >= n) {
+      *g = {c[0], c[1], true};
+      return 0;
+    }
+  }
+  *g = {1, kStreamWaves, false};
+  return 0;
+}
+
+int ensure_stage(pnec_hip_problem *p, int64_t doubles, int64_t ints) {
+  if (doubles > p->stage_doubles) {
+    if (p->d_stage) (void)hipFree(p->d_stage);
+    p->d_stage = nullptr;
+    p->stage_doubles = 0;
+    PNEC_HIP_TRY(hipMalloc(&p->d_stage, sizeof(double) * doubles));
+    p->stage_doubles = doubles;
+  }
+  if (ints > p->stage_ints) {
+    if (p->d_stage_i) (void)hipFree(p->d_stage_i);
+    p->d_stage_i = nullptr;
+    p->stage_ints = 0;
+    PNEC_HIP_TRY(hipMalloc(&p->d_stage_i, sizeof(int32_t) * ints));
+    p->stage_ints = ints;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// ==========================================================================================
+extern "C" {
+
+int pnec_hip_abi_version(void) { return PNEC_HIP_ABI_VERSION; }
+
+const char *pnec_hip_last_error(void) { return g_last_error.c_str(); }
+
+int pnec_hip_device_count(int *count) {
+  if (!count) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "count is NULL");
+  *count = 0;
+  PNEC_HIP_TRY(hipGetDeviceCount(count));
+  return 0;
+}
+
+void pnec_hip_default_options(pnec_hip_options *o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->max_num_iterations = 50;
+  o->max_num_consecutive_invalid_steps = 5;
+  o->jacobi_scaling = 1;
+  o->check_convergence = 1;
+  o->corr_per_lane = 0;
+  o->waves_per_pair = 0;
+  o->function_tolerance = 1e-6;
+  o->gradient_tolerance = 1e-10;
+  o->parameter_tolerance = 1e-8;
+  o->initial_trust_region_radius = 1e4;
+  o->max_trust_region_radius = 1e16;
+  o->min_trust_region_radius = 1e-32;
+  o->min_relative_decrease = 1e-3;
+  o->min_lm_diagonal = 1e-6;
+  o->max_lm_diagonal = 1e32;
+}
+
+int pnec_hip_problem_create(int device, int mode, int64_t n_pairs, const int64_t *offsets,
+                            pnec_hip_problem **out) {
+  if (!out) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  if (mode < PNEC_HIP_MODE_NEC || mode > PNEC_HIP_MODE_SYM)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "unknown mode");
+  if (n_pairs < 0 || !offsets) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad n_pairs/offsets");
+  if (offsets[0] != 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "offsets[0] must be 0");
+  std::vector<int64_t> block_offset((size_t)n_pairs);
+  std::vector<int32_t> count((size_t)n_pairs);
+  const int nc = num_components(mode);
+  int64_t total = 0;
+  int32_t n_max = 0;
+  for (int64_t p = 0; p < n_pairs; ++p) {
+    const int64_t n = offsets[p + 1] - offsets[p];
+    if (n < 0 || n > (int64_t)1 << 30)
+      return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing (pair sizes < 2^30)");
+    const int64_t stride = (n + kWave - 1) & ~(int64_t)(kWave - 1);
+    block_offset[(size_t)p] = total;
+    count[(size_t)p] = (int32_t)n;
+    total += stride * nc;
+    n_max = std::max<int32_t>(n_max, (int32_t)n);
+  }
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "hipSetDevice failed (no such device?)");
+  pnec_hip_problem *p = new (std::nothrow) pnec_hip_problem();
+  if (!p) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "out of host memory");
+  p->device = device;
+  p->mode = mode;
+  p->nc = nc;
+  p->n_pairs = n_pairs;
+  p->n_corr = offsets[n_pairs];
+  p->n_max = n_max;
+  p->data_doubles = total;
+  p->offsets.assign(offsets, offsets + n_pairs + 1);
+  auto cleanup = [&](hipError_t e, const char *what) {
+    pnec_hip_problem_destroy(p);
+    return fail_hip(e, what);
+  };
+  hipError_t e;
+  if ((e = hipMalloc(&p->d_data, sizeof(double) * std::max<int64_t>(total, 1))) != hipSuccess)
+    return cleanup(e, "hipMalloc(data)");
+  if ((e = hipMalloc(&p->d_block_offset, sizeof(int64_t) * std::max<int64_t>(n_pairs, 1))) != hipSuccess)
+    return cleanup(e, "hipMalloc(block_offset)");
+  if ((e = hipMalloc(&p->d_offsets, sizeof(int64_t) * (n_pairs + 1))) != hipSuccess)
+    return cleanup(e, "hipMalloc(offsets)");
+  if ((e = hipMalloc(&p->d_count, sizeof(int32_t) * std::max<int64_t>(n_pairs, 1))) != hipSuccess)
+    return cleanup(e, "hipMalloc(count)");
+  if (n_pairs > 0) {
+    if ((e = hipMemcpy(p->d_block_offset, block_offset.data(), sizeof(int64_t) * n_pairs,
+                       hipMemcpyHostToDevice)) != hipSuccess)
+      return cleanup(e, "hipMemcpy(block_offset)");
+    if ((e = hipMemcpy(p->d_count, count.data(), sizeof(int32_t) * n_pairs,
+                       hipMemcpyHostToDevice)) != hipSuccess)
+      return cleanup(e, "hipMemcpy(count)");
+  }
+  if ((e = hipMemcpy(p->d_offsets, offsets, sizeof(int64_t) * (n_pairs + 1),
+                     hipMemcpyHostToDevice)) != hipSuccess)
+    return cleanup(e, "hipMemcpy(offsets)");
+  *out = p;
+  return 0;
+}
+
+int pnec_hip_problem_destroy(pnec_hip_problem *p) {
+  if (!p) return 0;
+  DeviceGuard guard(p->device);
+  if (p->d_data) (void)hipFree(p->d_data);
+  if (p->d_block_offset) (void)hipFree(p->d_block_offset);
+  if (p->d_offsets) (void)hipFree(p->d_offsets);
+  if (p->d_count) (void)hipFree(p->d_count);
+  if (p->d_stage) (void)hipFree(p->d_stage);
+  if (p->d_stage_i) (void)hipFree(p->d_stage_i);
+  delete p;
+  return 0;
+}
+
+int pnec_hip_problem_fill(pnec_hip_problem *p, int64_t first_pair, int64_t n_pairs,
+                          const double *bvs1, const double *bvs2, const double *covs,
+                          const double *covs_host, int space, void *stream_) {
+  if (!p) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "problem is NULL");
+  if (first_pair < 0 || n_pairs < 0 || first_pair + n_pairs > p->n_pairs)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "pair range out of bounds");
+  if (n_pairs == 0) return 0;
+  const int64_t m = p->offsets[(size_t)(first_pair + n_pairs)] - p->offsets[(size_t)first_pair];
+  if (m > 0 && (!bvs1 || !bvs2)) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bvs1/bvs2 is NULL");
+  if (m > 0 && p->nc >= 12 && !covs)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "covs is NULL for a PNEC-mode problem");
+  if (m > 0 && p->nc >= 18 && !covs_host)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "covs_host is NULL for a SYM-mode problem");
+  DeviceGuard guard(p->device);
+  hipStream_t stream = (hipStream_t)stream_;
+
+  const double *d_b1 = bvs1, *d_b2 = bvs2, *d_c = covs, *d_ch = covs_host;
+  double *tmp = nullptr;
+  if (space == PNEC_HIP_MEM_HOST && m > 0) {
+    const int64_t per = 6 + (p->nc >= 12 ? 9 : 0) + (p->nc >= 18 ? 9 : 0);
+    PNEC_HIP_TRY(hipMalloc(&tmp, sizeof(double) * per * m));
+    double *w = tmp;
+    auto up = [&](const double *src, int64_t k, const double **dst) -> hipError_t {
+      *dst = w;
+      hipError_t e = hipMemcpyAsync(w, src, sizeof(double) * k * m, hipMemcpyHostToDevice, stream);
+      w += k * m;
+      return e;
+    };
+    hipError_t e = up(bvs1, 3, &d_b1);
+    if (e == hipSuccess) e = up(bvs2, 3, &d_b2);
+    if (e == hipSuccess && p->nc >= 12) e = up(covs, 9, &d_c);
+    if (e == hipSuccess && p->nc >= 18) e = up(covs_host, 9, &d_ch);
+    if (e != hipSuccess) {
+      (void)hipFree(tmp);
+      return fail_hip(e, "hipMemcpyAsync(H2D)");
+    }
+  } else if (space != PNEC_HIP_MEM_DEVICE && space != PNEC_HIP_MEM_HOST) {
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad memory space");
+  }
+
+  const int32_t n_max = std::max<int32_t>(p->n_max, 1);
+  const dim3 block(256);
+  const dim3 grid((unsigned)std::min<int64_t>((n_max + 255) / 256, 64),
+                  (unsigned)std::min<int64_t>(n_pairs, 32768));
+  switch (p->nc) {
+    case 6:
+      hipLaunchKernelGGL(pack_kernel<6>, grid, block, 0, stream, p->d_data, p->d_block_offset,
+                         p->d_offsets, p->d_count, first_pair, n_pairs, d_b1, d_b2, d_c, d_ch);
+      break;
+    case 12:
+      hipLaunchKernelGGL(pack_kernel<12>, grid, block, 0, stream, p->d_data, p->d_block_offset,
+                         p->d_offsets, p->d_count, first_pair, n_pairs, d_b1, d_b2, d_c, d_ch);
+      break;
+    default:
+      hipLaunchKernelGGL(pack_kernel<18>, grid, block, 0, stream, p->d_data, p->d_block_offset,
+                         p->d_offsets, p->d_count, first_pair, n_pairs, d_b1, d_b2, d_c, d_ch);
+      break;
+  }
+  hipError_t e = hipGetLastError();
+  if (tmp) {
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(tmp);
+  }
+  if (e != hipSuccess) return fail_hip(e, "pack_kernel");
+  return 0;
+}
+
+int64_t pnec_hip_problem_num_pairs(const pnec_hip_problem *p) { return p ? p->n_pairs : 0; }
+int64_t pnec_hip_problem_num_correspondences(const pnec_hip_problem *p) { return p ? p->n_corr : 0; }
+int64_t pnec_hip_problem_max_correspondences(const pnec_hip_problem *p) { return p ? p->n_max : 0; }
+int64_t pnec_hip_problem_payload_bytes(const pnec_hip_problem *p) {
+  return p ? p->n_corr * p->nc * (int64_t)sizeof(double) : 0;
+}
+int pnec_hip_problem_mode(const pnec_hip_problem *p) { return p ? p->mode : -1; }
+int pnec_hip_problem_device(const pnec_hip_problem *p) { return p ? p->device : -1; }
+
+int pnec_hip_describe_launch(const pnec_hip_problem *p, const pnec_hip_options *opt,
+                             int32_t *corr_per_lane, int32_t *waves_per_pair,
+                             int32_t *threads_per_block, int32_t *resident) {
+  if (!p) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "problem is NULL");
+  Geometry g;
+  if (int rc = choose_geometry(p, opt, &g)) return rc;
+  if (corr_per_lane) *corr_per_lane = g.cpl;
+  if (waves_per_pair) *waves_per_pair = g.wpp;
+  if (threads_per_block) *threads_per_block = kWave * g.wpp;
+  if (resident) *resident = g.resident ? 1 : 0;
+  return 0;
+}
+
+int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init_t, int32_t n_hyp,
+                   const double *hyp_t, double reg, const pnec_hip_options *opt_in, double *out_q,
+                   double *out_t, double *out_cost, int32_t *out_iterations, int32_t *out_status,
+                   int space, void *stream_) {
+  if (!p) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "problem is NULL");
+  if (!init_q) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "init_q is NULL");
+  if (!hyp_t) n_hyp = 1;
+  if (n_hyp < 1) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "n_hyp must be >= 1");
+  if (!hyp_t && !init_t) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "init_t and hyp_t are both NULL");
+  if (space != PNEC_HIP_MEM_DEVICE && space != PNEC_HIP_MEM_HOST)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad memory space");
+  pnec_hip_options opt;
+  if (opt_in)
+    opt = *opt_in;
+  else
+    pnec_hip_default_options(&opt);
+  if (opt.max_num_iterations < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "max_num_iterations < 0");
+  const int64_t S = p->n_pairs * (int64_t)n_hyp;
+  if (S == 0) return 0;
+  if (S > 0x7fffffffLL) return fail(PNEC_HIP_ERR_UNSUPPORTED, "more than 2^31-1 solves in one call");
+  Geometry g;
+  if (int rc = choose_geometry(p, &opt, &g)) return rc;
+
+  DeviceGuard guard(p->device);
+  hipStream_t stream = (hipStream_t)stream_;
+  SolveArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.data = p->d_data;
+  a.block_offset = p->d_block_offset;
+  a.count = p->d_count;
+  a.n_solves = S;
+  a.n_hyp = n_hyp;
+  a.reg = reg;
+  a.opt = opt;
+
+  if (space == PNEC_HIP_MEM_DEVICE) {
+    a.init_q = init_q;
+    a.init_t = init_t;
+    a.hyp_t = hyp_t;
+    a.out_q = out_q;
+    a.out_t = out_t;
+    a.out_cost = out_cost;
+    a.out_iterations = out_iterations;
+    a.out_status = out_status;
+  } else {
+    // stage: [init_q 4P | init_t 3P | hyp_t 3S | out_q 4S | out_t 3S | out_cost S], ints [it S | st S]
+    const int64_t P = p->n_pairs;
+    if (int rc = ensure_stage(p, 7 * P + 11 * S, 2 * S)) return rc;
+    double *w = p->d_stage;
+    double *s_q = w;      w += 4 * P;
+    double *s_t = w;      w += 3 * P;
+    double *s_h = w;      w += 3 * S;
+    double *s_oq = w;     w += 4 * S;
+    double *s_ot = w;     w += 3 * S;
+    double *s_oc = w;
+    PNEC_HIP_TRY(hipMemcpyAsync(s_q, init_q, sizeof(double) * 4 * P, hipMemcpyHostToDevice, stream));
+    if (init_t)
+      PNEC_HIP_TRY(hipMemcpyAsync(s_t, init_t, sizeof(double) * 3 * P, hipMemcpyHostToDevice, stream));
+    if (hyp_t)
+      PNEC_HIP_TRY(hipMemcpyAsync(s_h, hyp_t, sizeof(double) * 3 * S, hipMemcpyHostToDevice, stream));
+    a.init_q = s_q;
+    a.init_t = init_t ? s_t : nullptr;
+    a.hyp_t = hyp_t ? s_h : nullptr;
+    a.out_q = s_oq;
+    a.out_t = s_ot;
+    a.out_cost = s_oc;
+    a.out_iterations = p->d_stage_i;
+    a.out_status = p->d_stage_i + S;
+  }
+
+  hipError_t e;
+  switch (p->mode) {
+    case PNEC_HIP_MODE_NEC: e = launch_solve_mode_0(g.cpl, g.wpp, g.resident, a, stream); break;
+    case PNEC_HIP_MODE_TARGET: e = launch_solve_mode_1(g.cpl, g.wpp, g.resident, a, stream); break;
+    case PNEC_HIP_MODE_HOST: e = launch_solve_mode_2(g.cpl, g.wpp, g.resident, a, stream); break;
+    default: e = launch_solve_mode_3(g.cpl, g.wpp, g.resident, a, stream); break;
+  }
+  if (e != hipSuccess) return fail_hip(e, "lm_solve_kernel launch");
+
+  if (space == PNEC_HIP_MEM_HOST) {
+    if (out_q) PNEC_HIP_TRY(hipMemcpyAsync(out_q, a.out_q, sizeof(double) * 4 * S, hipMemcpyDeviceToHost, stream));
+    if (out_t) PNEC_HIP_TRY(hipMemcpyAsync(out_t, a.out_t, sizeof(double) * 3 * S, hipMemcpyDeviceToHost, stream));
+    if (out_cost) PNEC_HIP_TRY(hipMemcpyAsync(out_cost, a.out_cost, sizeof(double) * S, hipMemcpyDeviceToHost, stream));
+    if (out_iterations)
+      PNEC_HIP_TRY(hipMemcpyAsync(out_iterations, a.out_iterations, sizeof(int32_t) * S, hipMemcpyDeviceToHost, stream));
+    if (out_status)
+      PNEC_HIP_TRY(hipMemcpyAsync(out_status, a.out_status, sizeof(int32_t) * S, hipMemcpyDeviceToHost, stream));
+    PNEC_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  return 0;
+}
+
+int pnec_hip_select_best(int64_t n_pairs, int32_t n_hyp, const double *cost, int32_t *best_index,
+                         int space, int device, void *stream_) {
+  if (n_pairs < 0 || n_hyp < 1 || !cost || !best_index)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad arguments");
+  if (n_pairs == 0) return 0;
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "hipSetDevice failed");
+  hipStream_t stream = (hipStream_t)stream_;
+  const double *d_cost = cost;
+  int32_t *d_best = best_index;
+  double *tmp_c = nullptr;
+  int32_t *tmp_b = nullptr;
+  if (space == PNEC_HIP_MEM_HOST) {
+    PNEC_HIP_TRY(hipMalloc(&tmp_c, sizeof(double) * n_pairs * n_hyp));
+    hipError_t e = hipMalloc(&tmp_b, sizeof(int32_t) * n_pairs);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(tmp_c, cost, sizeof(double) * n_pairs * n_hyp, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) {
+      (void)hipFree(tmp_c);
+      if (tmp_b) (void)hipFree(tmp_b);
+      return fail_hip(e, "select_best staging");
+    }
+    d_cost = tmp_c;
+    d_best = tmp_b;
+  }
+  hipLaunchKernelGGL(select_best_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0,
+                     stream, n_pairs, (int)n_hyp, d_cost, d_best);
+  hipError_t e = hipGetLastError();
+  if (space == PNEC_HIP_MEM_HOST) {
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(best_index, tmp_b, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(tmp_c);
+    (void)hipFree(tmp_b);
+  }
+  if (e != hipSuccess) return fail_hip(e, "select_best_kernel");
+  return 0;
+}
+
+int pnec_hip_cost_function(pnec_hip_problem *p, const double *q, const double *t, double *out,
+                           int space, void *stream_) {
+  if (!p || !q || !t || !out) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (p->mode != PNEC_HIP_MODE_TARGET)
+    return fail(PNEC_HIP_ERR_UNSUPPORTED, "cost_function needs a TARGET-mode problem");
+  if (p->n_pairs == 0) return 0;
+  DeviceGuard guard(p->device);
+  hipStream_t stream = (hipStream_t)stream_;
+  const double *d_q = q, *d_t = t;
+  double *d_out = out;
+  const int64_t P = p->n_pairs;
+  if (space == PNEC_HIP_MEM_HOST) {
+    if (int rc = ensure_stage(p, 8 * P, 0)) return rc;
+    PNEC_HIP_TRY(hipMemcpyAsync(p->d_stage, q, sizeof(double) * 4 * P, hipMemcpyHostToDevice, stream));
+    PNEC_HIP_TRY(hipMemcpyAsync(p->d_stage + 4 * P, t, sizeof(double) * 3 * P, hipMemcpyHostToDevice, stream));
+    d_q = p->d_stage;
+    d_t = p->d_stage + 4 * P;
+    d_out = p->d_stage + 7 * P;
+  }
+  hipLaunchKernelGGL(cost_function_kernel, dim3((unsigned)P), dim3(kWave), 0, stream, p->d_data,
+                     p->d_block_offset, p->d_count, d_q, d_t, d_out);
+  PNEC_HIP_TRY(hipGetLastError());
+  if (space == PNEC_HIP_MEM_HOST) {
+    PNEC_HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(double) * P, hipMemcpyDeviceToHost, stream));
+    PNEC_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  return 0;
+}
+
+int pnec_hip_selftest(int device) {
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "hipSetDevice failed");
+  double *d = nullptr;
+  PNEC_HIP_TRY(hipMalloc(&d, sizeof(double) * 80));
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(kWave), 0, 0, d);
+  double h[80];
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(double) * 67, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail_hip(e, "selftest_kernel");
+  for (int i = 0; i < kWave; ++i)
+    if (h[i] != 89440.0) {
+      char buf[128];
+      std::snprintf(buf, sizeof(buf), "wave_allreduce_sum: lane %d holds %.17g, expected 89440", i, h[i]);
+      return fail(PNEC_HIP_ERR_HIP_RUNTIME, buf);
+    }
+  if (!(h[64] >= 0.0 && h[64] < 1e-12)) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "chol_solve5 residual too large");
+  if (!(std::abs(h[65]) < 1e-15)) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "fast_rsqrt inaccurate");
+  if (!(std::abs(h[66]) < 1e-15)) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "fast_rcp inaccurate");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,292 @@
+// pnec_device.hpp -- device-side building blocks of the MI355X PNEC solver (gfx950 only).
+//
+// Everything here is wave64 code for CDNA4: one wavefront (or a few) owns one solve, keeps the
+// pair's bearings/covariances in registers for the whole Levenberg-Marquardt loop, and reduces the
+// 21 normal-equation sums with DPP / v_permlane*_swap cross-lane moves (plus one LDS hop when
+// several wavefronts share a solve).  No MFMA: the contraction is 5x5.
+//
+// Maths follows the reference functors (include/optimization/pnec_residual.h:50-150,
+// nec_residual.h:47-68) in the factored form of SURVEY.md Appendix A:
+//   m = t x f1,  g = R' m,  n = f2.g,  r = n / sqrt(g' S g + reg)        (TARGET)
+//   J_omega = (R dr/dg) x m,   J_t = f1 x (R dr/dg),   delta = omega / 2 (EigenQuaternionManifold)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pnec_hip.h"
+
+namespace pnec_hip {
+
+constexpr int kWave = 64;
+constexpr int kNumAcc = 21;  // sum r^2 | J'r (5) | upper triangle of J'J (15)
+
+__host__ __device__ constexpr int num_components(int mode) {
+  return mode == PNEC_HIP_MODE_NEC ? 6 : (mode == PNEC_HIP_MODE_SYM ? 18 : 12);
+}
+// packed upper-triangular index of a symmetric 5x5, a <= b
+__host__ __device__ constexpr int tri(int a, int b) { return a * 5 - a * (a - 1) / 2 + (b - a); }
+__host__ __device__ constexpr int sym(int a, int b) { return a <= b ? tri(a, b) : tri(b, a); }
+
+// ------------------------------------------------------------------------------------------
+// scalar helpers
+__device__ __forceinline__ double make_double(int hi, int lo) { return __hiloint2double(hi, lo); }
+
+// Move a wave-uniform double into scalar registers (2 x v_readfirstlane_b32).
+__device__ __forceinline__ double to_sgpr(double x) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+  return make_double(hi, lo);
+}
+__device__ __forceinline__ int to_sgpr(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// 1/sqrt(x): v_rsq_f64 seed (~2^-23 rel.) + one third-order correction -> < 1 ulp-ish.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(-(x * y0), y0, 1.0);
+  return __builtin_fma(y0 * e, __builtin_fma(e, 0.375, 0.5), y0);
+}
+// 1/x: v_rcp_f64 seed + two Newton steps.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-x, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ bool finite_d(double x) { return __builtin_isfinite(x); }
+
+// ------------------------------------------------------------------------------------------
+// cross-lane sum over the 64 lanes of a wavefront; every lane ends with the same bits.
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return make_double(hi, lo);
+}
+// rows {1,3} of one copy <-> rows {0,2} of the other: sum = pairwise row sums in all 4 rows
+__device__ __forceinline__ double row_pair_sum(double x) {
+  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return make_double((int)b[0], (int)a[0]) + make_double((int)b[1], (int)a[1]);
+}
+// lanes 32..63 of one copy <-> lanes 0..31 of the other
+__device__ __forceinline__ double half_pair_sum(double x) {
+  const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return make_double((int)b[0], (int)a[0]) + make_double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double wave_allreduce_sum(double x) {
+  x += dpp_perm<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += dpp_perm<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += dpp_perm<0x141>(x);  // row_half_mirror
+  x += dpp_perm<0x140>(x);  // row_mirror
+  x = row_pair_sum(x);      // v_permlane16_swap (gfx950)
+  x = half_pair_sum(x);     // v_permlane32_swap (gfx950)
+  return x;
+}
+
+// ------------------------------------------------------------------------------------------
+// pose-dependent, correspondence-independent quantities of one pass
+struct PassUniforms {
+  double R[9];    // row-major, Eigen's un-normalised quaternion->matrix formula
+  double t[3];    // (sin th cos ph, sin th sin ph, cos th)
+  double bth[3];  // d t / d theta
+  double bph[3];  // d t / d phi  (z component is 0)
+};
+
+// Eigen::QuaternionBase::toRotationMatrix(), q = xyzw, no normalisation (pnec_residual.h:92-93)
+__device__ __forceinline__ void rot_from_quat(const double (&q)[4], double (&R)[9]) {
+  const double tx = 2.0 * q[0], ty = 2.0 * q[1], tz = 2.0 * q[2];
+  const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+  const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+  const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+  R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+  R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+__device__ __forceinline__ void make_uniforms(double theta, double phi, const double (&q)[4],
+                                              PassUniforms &U) {
+  double R[9];
+  rot_from_quat(q, R);
+  double st, ct, sp, cp;
+  sincos(theta, &st, &ct);
+  sincos(phi, &sp, &cp);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) U.R[i] = to_sgpr(R[i]);
+  U.t[0] = to_sgpr(st * cp);   U.t[1] = to_sgpr(st * sp);   U.t[2] = to_sgpr(ct);
+  U.bth[0] = to_sgpr(ct * cp); U.bth[1] = to_sgpr(ct * sp); U.bth[2] = to_sgpr(-st);
+  U.bph[0] = to_sgpr(-st * sp); U.bph[1] = to_sgpr(st * cp); U.bph[2] = 0.0;
+}
+
+// common.cc:103-116 (AnglesFromVec)
+__device__ __forceinline__ void angles_from_vec(double x, double y, double z, double &theta,
+                                                double &phi) {
+  const double n = sqrt(x * x + y * y + z * z);
+  if (n == 0.0) {
+    theta = 0.0;
+    phi = 0.0;
+    return;
+  }
+  theta = acos(z / n);
+  phi = (fabs(theta) < 1e-10) ? 0.0 : atan2(y / n, x / n);
+}
+
+// ------------------------------------------------------------------------------------------
+// One correspondence: residual r and tangent-space Jacobian (theta, phi, omega_xyz) -- the
+// omega columns are for R <- Exp(omega) R; the caller scales them by 2 (delta = omega/2) once,
+// after the reduction.  d[] = this correspondence's planes:
+//   0..2 f1 | 3..5 f2 | 6..11 cov (xx,xy,xz,yy,yz,zz) | 12..17 cov_host (SYM only)
+template <int MODE>
+__device__ __forceinline__ void eval_corr(const double (&d)[num_components(MODE)], bool valid,
+                                          const PassUniforms &U, double reg, double &r,
+                                          double (&J)[5]) {
+  const double f1x = d[0], f1y = d[1], f1z = d[2];
+  const double f2x = d[3], f2y = d[4], f2z = d[5];
+  const double *R = U.R;
+  // m = t x f1
+  const double mx = U.t[1] * f1z - U.t[2] * f1y;
+  const double my = U.t[2] * f1x - U.t[0] * f1z;
+  const double mz = U.t[0] * f1y - U.t[1] * f1x;
+  // g = R' m
+  const double gx = R[0] * mx + R[3] * my + R[6] * mz;
+  const double gy = R[1] * mx + R[4] * my + R[7] * mz;
+  const double gz = R[2] * mx + R[5] * my + R[8] * mz;
+  const double n = f2x * gx + f2y * gy + f2z * gz;
+
+  double wx, wy, wz;          // dr/dg
+  double ex = 0, ey = 0, ez = 0;  // extra J_omega term (HOST / SYM)
+  double hx = 0, hy = 0, hz = 0;  // extra J_t term
+  if constexpr (MODE == PNEC_HIP_MODE_NEC) {
+    r = n;
+    wx = f2x; wy = f2y; wz = f2z;
+  } else if constexpr (MODE == PNEC_HIP_MODE_TARGET) {
+    const double sgx = d[6] * gx + d[7] * gy + d[8] * gz;
+    const double sgy = d[7] * gx + d[9] * gy + d[10] * gz;
+    const double sgz = d[8] * gx + d[10] * gy + d[11] * gz;
+    const double den = gx * sgx + gy * sgy + gz * sgz + reg;
+    const double y = valid ? fast_rsqrt(den) : 0.0;
+    r = n * y;
+    const double c = r * y;  // n / den
+    wx = y * (f2x - c * sgx);
+    wy = y * (f2y - c * sgy);
+    wz = y * (f2z - c * sgz);
+  } else {
+    // HOST: den = h' S h + reg, h = t x (R f1), S = cov.
+    // SYM : den = g' S2 g + h' S1 h + reg, h = t x (R f2), S2 = cov, S1 = cov_host.
+    constexpr bool kSym = (MODE == PNEC_HIP_MODE_SYM);
+    const double ax = kSym ? f2x : f1x, ay = kSym ? f2y : f1y, az = kSym ? f2z : f1z;
+    const double px = R[0] * ax + R[1] * ay + R[2] * az;
+    const double py = R[3] * ax + R[4] * ay + R[5] * az;
+    const double pz = R[6] * ax + R[7] * ay + R[8] * az;
+    const double qx = U.t[1] * pz - U.t[2] * py;  // h = t x p
+    const double qy = U.t[2] * px - U.t[0] * pz;
+    const double qz = U.t[0] * py - U.t[1] * px;
+    constexpr int o = kSym ? 12 : 6;
+    const double shx = d[o + 0] * qx + d[o + 1] * qy + d[o + 2] * qz;
+    const double shy = d[o + 1] * qx + d[o + 3] * qy + d[o + 4] * qz;
+    const double shz = d[o + 2] * qx + d[o + 4] * qy + d[o + 5] * qz;
+    double den = qx * shx + qy * shy + qz * shz + reg;
+    double sgx = 0, sgy = 0, sgz = 0;
+    if constexpr (kSym) {
+      sgx = d[6] * gx + d[7] * gy + d[8] * gz;
+      sgy = d[7] * gx + d[9] * gy + d[10] * gz;
+      sgz = d[8] * gx + d[10] * gy + d[11] * gz;
+      den += gx * sgx + gy * sgy + gz * sgz;
+    }
+    const double y = valid ? fast_rsqrt(den) : 0.0;
+    r = n * y;
+    const double c = r * y;
+    wx = y * (f2x - c * sgx);
+    wy = y * (f2y - c * sgy);
+    wz = y * (f2z - c * sgz);
+    // wh = dr/dh = -n S h / den^(3/2)
+    const double k = -c * y;
+    const double whx = k * shx, why = k * shy, whz = k * shz;
+    // J_t += p x wh ;  J_omega += p x (wh x t)
+    hx = py * whz - pz * why;
+    hy = pz * whx - px * whz;
+    hz = px * why - py * whx;
+    const double vx = why * U.t[2] - whz * U.t[1];
+    const double vy = whz * U.t[0] - whx * U.t[2];
+    const double vz = whx * U.t[1] - why * U.t[0];
+    ex = py * vz - pz * vy;
+    ey = pz * vx - px * vz;
+    ez = px * vy - py * vx;
+  }
+  // u = R w
+  const double ux = R[0] * wx + R[1] * wy + R[2] * wz;
+  const double uy = R[3] * wx + R[4] * wy + R[5] * wz;
+  const double uz = R[6] * wx + R[7] * wy + R[8] * wz;
+  // J_omega = u x m (+ e)
+  J[2] = uy * mz - uz * my + ex;
+  J[3] = uz * mx - ux * mz + ey;
+  J[4] = ux * my - uy * mx + ez;
+  // J_t = f1 x u (+ h), projected on the (theta, phi) chart
+  const double jx = f1y * uz - f1z * uy + hx;
+  const double jy = f1z * ux - f1x * uz + hy;
+  const double jz = f1x * uy - f1y * ux + hz;
+  J[0] = U.bth[0] * jx + U.bth[1] * jy + U.bth[2] * jz;
+  J[1] = U.bph[0] * jx + U.bph[1] * jy;
+}
+
+__device__ __forceinline__ void accumulate(double r, const double (&J)[5], double (&acc)[kNumAcc]) {
+  acc[0] = __builtin_fma(r, r, acc[0]);
+#pragma unroll
+  for (int a = 0; a < 5; ++a) acc[1 + a] = __builtin_fma(J[a], r, acc[1 + a]);
+#pragma unroll
+  for (int a = 0; a < 5; ++a)
+#pragma unroll
+    for (int b = a; b < 5; ++b) acc[6 + tri(a, b)] = __builtin_fma(J[a], J[b], acc[6 + tri(a, b)]);
+}
+
+// ------------------------------------------------------------------------------------------
+// 5x5 SPD solve A y = b on the packed upper triangle (A(a,b) = P[tri(a,b)]); false if a pivot is
+// not positive or the result is not finite (-> Ceres' LINEAR_SOLVER_FAILURE).
+__device__ __forceinline__ bool chol_solve5(const double (&P)[15], const double (&b)[5],
+                                            double (&y)[5]) {
+  double L[15];  // L(i,j), i >= j, stored at tri(j,i)
+  double inv[5];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    double dj = P[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) dj = __builtin_fma(-L[tri(k, j)], L[tri(k, j)], dj);
+    ok = ok && (dj > 0.0) && finite_d(dj);
+    const double iv = fast_rsqrt(dj);
+    inv[j] = iv;
+    L[tri(j, j)] = dj * iv;
+#pragma unroll
+    for (int i = j + 1; i < 5; ++i) {
+      double s = P[tri(j, i)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s = __builtin_fma(-L[tri(k, i)], L[tri(k, j)], s);
+      L[tri(j, i)] = s * iv;
+    }
+  }
+  double z[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    double s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s = __builtin_fma(-L[tri(k, i)], z[k], s);
+    z[i] = s * inv[i];
+  }
+#pragma unroll
+  for (int i = 4; i >= 0; --i) {
+    double s = z[i];
+#pragma unroll
+    for (int k = i + 1; k < 5; ++k) s = __builtin_fma(-L[tri(i, k)], y[k], s);
+    y[i] = s * inv[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) ok = ok && finite_d(y[i]);
+  return ok;
+}
+
+}  // namespace pnec_hip

@@ -1,0 +1,3 @@
+// residual family target (pnec_hip_mode 1)
+#define PNEC_SOLVE_MODE 1
+#include "pnec_solve_launch.inl"

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the reference's Python modules (this container only).
+
+Run from the repo root:   python tests/golden/make_golden.py
+Needs /root/reference (absent on the GPU box -> the .npz files are committed, this script is
+only their provenance).  Nothing from the reference's source text is stored: the fixtures are
+seeded inputs made here plus the numbers the reference's functions return for them.
+
+Reference functions exercised (scripts/pnec/...):
+  common.pnec_energy_rotations   common.py:13-37   <-> PNECResidualTarget (pnec_residual.h:86-104)
+  common.nec_energy_rotations    common.py:40-59   <-> NECResidual (nec_residual.h:51-63)
+  common.pnec_energy_translations common.py:62-86
+  math.skew, math.unscented_transform (diagonal covariances only: for non-diagonal ones the
+      Python uses ROWS of the Cholesky factor where the C++ uses COLUMNS -- SURVEY.md 8c)
+  scf.fibonacci_sphere            scf.py
+"""
+import os
+import sys
+
+import numpy as np
+
+REF = "/root/reference/scripts"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def random_rotation(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    x, y, z, w = q
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def random_bearings(rng, n):
+    v = rng.normal(size=(n, 3))
+    return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+def random_bearing_covs(rng, f, anisotropic):
+    """rank-2-ish PSD covariances tangent to the bearing, magnitudes like pixel noise / f^2"""
+    n = len(f)
+    out = np.zeros((n, 3, 3))
+    for i in range(n):
+        a = np.cross(f[i], rng.normal(size=3))
+        a /= np.linalg.norm(a)
+        b = np.cross(f[i], a)
+        if anisotropic:
+            s1, s2 = rng.uniform(0.2, 3.0, size=2) * 1.5e-6
+        else:
+            s1 = s2 = 1.5e-6
+        out[i] = s1 * np.outer(a, a) + s2 * np.outer(b, b) + 1e-12 * np.outer(f[i], f[i])
+    return out
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("reference not present: golden vectors can only be regenerated in the build container")
+    sys.path.insert(0, REF)
+    import pnec.common as rc   # noqa: E402  (the reference)
+    import pnec.math as rm     # noqa: E402
+    import pnec.scf as rs      # noqa: E402
+
+    cases = {}
+    idx = 0
+    for seed in (1, 2, 3):
+        for n in (10, 100, 512):
+            for aniso in (False, True):
+                rng = np.random.default_rng(1000 * seed + n + int(aniso))
+                f1 = random_bearings(rng, n)
+                f2 = random_bearings(rng, n)
+                sig = random_bearing_covs(rng, f2, aniso)
+                rots = np.stack([random_rotation(rng) for _ in range(4)]).reshape(2, 2, 3, 3)
+                t = rng.normal(size=3)
+                t /= np.linalg.norm(t)
+                ts = rng.normal(size=(2, 2, 3))
+                ts /= np.linalg.norm(ts, axis=-1, keepdims=True)
+                for reg in (1e-13, 1e-10):
+                    e_p = rc.pnec_energy_rotations(rots, t, f1, f2, sig, reg)
+                    e_n = rc.nec_energy_rotations(rots, t, f1, f2)
+                    e_t = rc.pnec_energy_translations(ts, rots[0, 0], f1, f2, sig, reg)
+                    k = f"case{idx:03d}"
+                    cases[k + "_f1"] = f1
+                    cases[k + "_f2"] = f2
+                    cases[k + "_sigmas"] = sig
+                    cases[k + "_rotations"] = rots
+                    cases[k + "_t"] = t
+                    cases[k + "_ts"] = ts
+                    cases[k + "_reg"] = np.array(reg)
+                    cases[k + "_pnec_energy_rotations"] = e_p
+                    cases[k + "_nec_energy_rotations"] = e_n
+                    cases[k + "_pnec_energy_translations"] = e_t
+                    idx += 1
+    cases["n_cases"] = np.array(idx)
+    np.savez_compressed(os.path.join(HERE, "energy_golden.npz"), **cases)
+
+    # skew + unscented transform (pinhole, diagonal image covariances) + fibonacci sphere
+    rng = np.random.default_rng(77)
+    vs = rng.normal(size=(8, 3))
+    skews = rm.skew(vs)
+    pts = np.stack([rng.uniform(-400, 400, 16), rng.uniform(-300, 300, 16), np.full(16, 800.0)], 1)
+    diag = rng.uniform(0.2, 2.0, size=(16, 2))
+    covs = np.zeros((16, 3, 3))
+    covs[:, 0, 0] = diag[:, 0]
+    covs[:, 1, 1] = diag[:, 1]
+    ut = np.stack([rm.unscented_transform(pts[i], covs[i], False, 1.0) for i in range(16)])
+    fib = np.asarray(rs.fibonacci_sphere(500))
+    np.savez_compressed(os.path.join(HERE, "math_golden.npz"), skew_in=vs, skew_out=skews,
+                        ut_points=pts, ut_covs=covs, ut_out=ut, fibonacci_500=fib)
+    print(f"wrote {idx} energy cases, math goldens")
+
+
+if __name__ == "__main__":
+    main()
