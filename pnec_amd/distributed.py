@@ -1,0 +1,74 @@
+"""Multi-GPU: frame pairs are independent, so the batch shards with no data-path collective.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" on CPU for the
+tests).  Every rank solves a contiguous range of pairs; the only communication is ONE gather of
+fixed-size result records (10 doubles = 80 B per solve) to rank 0 at the end -- a few MB even for
+100k pairs per GPU, latency-bound, nowhere near the per-link xGMI ceiling.
+The partition is a pure function of (sizes, world), so every rank knows every shard's size and no
+size exchange is needed.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+RECORD_WIDTH = 10  # q(4) t(3) cost iterations status
+
+
+def partition(weights, world: int) -> np.ndarray:
+    """Contiguous ranges of items balanced by weight (e.g. correspondences per pair).
+
+    Returns bounds [world+1]; rank r owns items [bounds[r], bounds[r+1]).  Deterministic."""
+    w = np.asarray(weights, dtype=np.float64)
+    n = len(w)
+    bounds = np.zeros(world + 1, dtype=np.int64)
+    if n == 0:
+        return bounds
+    c = np.concatenate([[0.0], np.cumsum(w)])
+    total = c[-1]
+    for r in range(1, world):
+        target = total * r / world
+        bounds[r] = int(np.searchsorted(c, target, side="left"))
+    bounds[world] = n
+    bounds = np.maximum.accumulate(np.minimum(bounds, n))
+    return bounds
+
+
+def partition_uniform(n_items: int, world: int) -> np.ndarray:
+    return partition(np.ones(n_items), world)
+
+
+def pack_records(res) -> torch.Tensor:
+    """SolveResult (torch tensors) -> [S,10] float64 records."""
+    return torch.cat([res.q, res.t, res.cost[:, None], res.iterations.to(torch.float64)[:, None],
+                      res.status.to(torch.float64)[:, None]], dim=1)
+
+
+def unpack_records(rec: torch.Tensor):
+    from .batch import SolveResult
+    return SolveResult(rec[:, 0:4], rec[:, 4:7], rec[:, 7], rec[:, 8].to(torch.int32),
+                       rec[:, 9].to(torch.int32))
+
+
+def gather_records(rec: torch.Tensor, world: int, rank: int, sizes=None, dst: int = 0):
+    """ONE collective: gather every rank's records on `dst` (None elsewhere).
+
+    sizes: records per rank when shards are ragged (known from `partition`); records are padded
+    to the largest shard for the collective and trimmed on arrival."""
+    if world == 1:
+        return rec
+    if sizes is None:
+        sizes = [rec.shape[0]] * world
+    m = int(max(sizes))
+    if rec.shape[0] != sizes[rank]:
+        raise ValueError("record count does not match the partition")
+    if rec.shape[0] < m:
+        pad = torch.zeros((m - rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
+        rec = torch.cat([rec, pad])
+    rec = rec.contiguous()
+    bufs = [torch.empty_like(rec) for _ in range(world)] if rank == dst else None
+    dist.gather(rec, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[: int(s)] for b, s in zip(bufs, sizes)])

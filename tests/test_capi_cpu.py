@@ -1,0 +1,84 @@
+"""CPU suite for the boundary: libpnec_hip.so loads without a GPU, exports every symbol that
+include/pnec_hip.h declares, agrees with the oracle on enum values and option defaults, and the
+product path fails loudly (no CPU fallback) when no device is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from pnec_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = capi.lib()
+    assert L.pnec_hip_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "pnec_hip.h")).read()
+    declared = set(re.findall(r"\b(pnec_hip_[a-z_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(capi.SYMBOLS)
+    for sym in declared:
+        assert getattr(L, sym) is not None
+
+
+def test_no_oracle_or_fallback_in_product_package():
+    """the product package must never import / call the oracle or a CPU fallback"""
+    pkg = os.path.join(ROOT, "pnec_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".inl")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "pnec_oracle" not in text, f
+                assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_option_defaults_match_ceres_defaults_and_oracle(oracle):
+    o = capi.default_options()
+    r = oracle.default_options()
+    for name in ("max_num_iterations", "max_num_consecutive_invalid_steps", "jacobi_scaling",
+                 "check_convergence", "function_tolerance", "gradient_tolerance",
+                 "parameter_tolerance", "initial_trust_region_radius", "max_trust_region_radius",
+                 "min_trust_region_radius", "min_relative_decrease", "min_lm_diagonal",
+                 "max_lm_diagonal"):
+        assert getattr(o, name) == getattr(r, name), name
+    assert (o.max_num_iterations, o.function_tolerance, o.parameter_tolerance) == (50, 1e-6, 1e-8)
+    assert (o.gradient_tolerance, o.initial_trust_region_radius) == (1e-10, 1e4)
+    assert C.sizeof(capi.Options) == 6 * 4 + 9 * 8
+
+
+def test_enum_values_shared_with_oracle(oracle):
+    assert (capi.MODE_NEC, capi.MODE_TARGET, capi.MODE_HOST, capi.MODE_SYM) == \
+           (oracle.MODE_NEC, oracle.MODE_TARGET, oracle.MODE_HOST, oracle.MODE_SYM)
+    assert capi.TERM_NAMES == oracle.TERM_NAMES
+    hdr = open(os.path.join(ROOT, "include", "pnec_hip.h")).read()
+    ohdr = open(os.path.join(ROOT, "oracle", "pnec_oracle.h")).read()
+    for k, v in (("FUNCTION_TOL", 0), ("PARAMETER_TOL", 1), ("GRADIENT_TOL", 2),
+                 ("MAX_ITERATIONS", 3), ("MIN_RADIUS", 4), ("INVALID_STEPS", 5), ("BAD_INITIAL", 6)):
+        assert re.search(rf"PNEC_HIP_TERM_{k} = {v}\b", hdr)
+        assert re.search(rf"PNEC_ORACLE_TERM_{k} = {v}\b", ohdr)
+
+
+def test_argument_validation_without_device():
+    L = capi.lib()
+    h = C.c_void_p()
+    offs = np.array([0, 4, 2], dtype=np.int64)  # decreasing
+    rc = L.pnec_hip_problem_create(0, capi.MODE_TARGET, 2, offs.ctypes.data, C.byref(h))
+    assert rc == -1 and b"non-decreasing" in L.pnec_hip_last_error()
+    offs = np.array([1, 4], dtype=np.int64)
+    assert L.pnec_hip_problem_create(0, capi.MODE_TARGET, 1, offs.ctypes.data, C.byref(h)) == -1
+    offs = np.array([0, 4], dtype=np.int64)
+    assert L.pnec_hip_problem_create(0, 9, 1, offs.ctypes.data, C.byref(h)) == -1
+    assert L.pnec_hip_solve(None, None, None, 1, None, 1e-13, None, None, None, None, None, None, 0, None) == -1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu():
+    """No silent CPU path: creating a batch without a device is an error, not a fallback."""
+    from pnec_amd import Batch
+    with pytest.raises(capi.PnecHipError) as ei:
+        Batch.uniform(capi.MODE_TARGET, 2, 10)
+    assert ei.value.code == -2

@@ -1,0 +1,323 @@
+"""GPU parity suite (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs, against the committed golden vectors, and -- at BASELINE's full size --
+through size-independent properties.
+
+Tolerance (BASELINE.json north_star): rotations within 1e-6 rad of the reference-faithful CPU
+path (central-difference Jacobian + Ceres LM policy).  Against the oracle's analytic-Jacobian
+variant (the same algorithm the kernel runs) the bar is 1e-9 rad.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from pnec_amd import Batch, capi, select_best
+from pnec_amd import simulation as sim
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL_REFERENCE = 1e-6   # rad, vs reference-faithful oracle (north_star)
+ROT_TOL_SAME_ALGO = 1e-9   # rad, vs oracle running the kernel's own algorithm
+
+
+def _rot_err(oracle, Ra, Rb):
+    return math.radians(oracle.rotational_difference_deg(Ra, Rb))
+
+
+def _covs_for(mode, S2):
+    """(covs, covs_host) for a residual family, derived deterministically from S2 [n,3,3]"""
+    if mode == capi.MODE_NEC:
+        return None, None
+    if mode == capi.MODE_SYM:
+        return S2, np.roll(S2, 1, axis=0) * 0.8
+    return S2, None
+
+
+def _oracle_batch(oracle, mode, offsets, f1, f2, c2, c1, reg, q0, t0, opts, **kw):
+    c2_9 = None if c2 is None else oracle.covs_to_colmajor9(c2)
+    c1_9 = None if c1 is None else oracle.covs_to_colmajor9(c1)
+    return oracle.solve_batch(mode, offsets, f1, f2, c2_9, c1_9, reg, q0, t0, options=opts, **kw)
+
+
+def _oracle_opts(oracle, hip_opts, jacobian_mode):
+    o = oracle.default_options(jacobian_mode=jacobian_mode)
+    for name in ("max_num_iterations", "check_convergence", "function_tolerance",
+                 "gradient_tolerance", "parameter_tolerance", "jacobi_scaling"):
+        setattr(o, name, getattr(hip_opts, name))
+    return o
+
+
+def _quat_to_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def test_device_selftest():
+    capi.check(capi.lib().pnec_hip_selftest(0))
+
+
+def test_objective_matches_reference_goldens(golden_dir):
+    """max_num_iterations = 0 returns cost = 1/2 sum r^2 at the start pose: compare the DEVICE's
+    residual evaluation with the numbers scripts/pnec/common.py produced."""
+    z = np.load(f"{golden_dir}/energy_golden.npz")
+    from oracle import pnec_oracle as po
+    opts = capi.default_options(max_num_iterations=0)
+    checked = 0
+    for i in range(int(z["n_cases"])):
+        k = f"case{i:03d}_"
+        f1, f2, S = z[k + "f1"], z[k + "f2"], z[k + "sigmas"]
+        reg = float(z[k + "reg"])
+        rots = z[k + "rotations"].reshape(4, 3, 3)
+        n = len(f1)
+        for mode, key in ((capi.MODE_TARGET, "pnec_energy_rotations"), (capi.MODE_NEC, "nec_energy_rotations")):
+            want = z[k + key].reshape(4)
+            with Batch.uniform(mode, 4, n) as b:
+                b.fill(np.tile(f1, (4, 1)), np.tile(f2, (4, 1)),
+                       None if mode == capi.MODE_NEC else np.tile(S, (4, 1, 1)))
+                q0 = np.stack([po.quat_from_rot(R) for R in rots])
+                t0 = np.tile(z[k + "t"], (4, 1))
+                res = b.solve(q0, t0, reg=reg if mode != capi.MODE_NEC else 0.0, options=opts)
+            np.testing.assert_allclose(2.0 * res.cost, want, rtol=1e-10)
+            assert (res.iterations == 0).all()
+            checked += 4
+    assert checked == 36 * 8
+
+
+@pytest.mark.parametrize("mode", [capi.MODE_NEC, capi.MODE_TARGET, capi.MODE_HOST, capi.MODE_SYM])
+@pytest.mark.parametrize("n_corr", [10, 100, 512])
+def test_lm_parity_with_oracle(oracle, mode, n_corr):
+    B = 24
+    g = sim.generate(B, n_corr, seed=100 + n_corr)
+    f1 = g.bvs1.reshape(-1, 3).numpy()
+    f2 = g.bvs2.reshape(-1, 3).numpy()
+    c2, c1 = _covs_for(mode, g.covs2.reshape(-1, 3, 3).numpy())
+    offsets = np.arange(B + 1, dtype=np.int64) * n_corr
+    reg = 1e-13
+    opts = capi.default_options()
+    with Batch(mode, offsets) as b:
+        b.fill(f1, f2, c2, c1)
+        res = b.solve(g.init_q.numpy(), g.init_t.numpy(), reg=reg, options=opts)
+    for jm, tol in ((oracle.JAC_ANALYTIC, ROT_TOL_SAME_ALGO), (oracle.JAC_NUMERIC_CENTRAL, ROT_TOL_REFERENCE)):
+        q, t, cost, it, st = _oracle_batch(oracle, mode, offsets, f1, f2, c2, c1, reg,
+                                           g.init_q.numpy(), g.init_t.numpy(),
+                                           _oracle_opts(oracle, opts, jm))
+        worst = max(_rot_err(oracle, _quat_to_R(res.q[p]), _quat_to_R(q[p])) for p in range(B))
+        assert worst <= tol, (jm, worst)
+        np.testing.assert_array_equal(res.iterations, it)
+        np.testing.assert_array_equal(res.status, st)
+        np.testing.assert_allclose(res.cost, cost, rtol=1e-9)
+        tdot = np.abs(np.sum(res.t * t, axis=1))
+        assert (tdot > 1 - 1e-10).all()
+    # the optimiser did something and ended near the ground truth
+    gt_err = max(_rot_err(oracle, _quat_to_R(res.q[p]), g.R_gt[p].numpy()) for p in range(B))
+    assert gt_err < 0.02
+
+
+def test_fixed_iteration_mode_matches_oracle(oracle):
+    """the throughput configuration: exactly 10 LM iterations, convergence tests off"""
+    B, N = 16, 512
+    g = sim.generate(B, N, seed=7)
+    f1, f2 = g.bvs1.reshape(-1, 3).numpy(), g.bvs2.reshape(-1, 3).numpy()
+    c2 = g.covs2.reshape(-1, 3, 3).numpy()
+    offsets = np.arange(B + 1, dtype=np.int64) * N
+    opts = capi.default_options(max_num_iterations=10, check_convergence=0)
+    with Batch(capi.MODE_TARGET, offsets) as b:
+        b.fill(f1, f2, c2)
+        res = b.solve(g.init_q.numpy(), g.init_t.numpy(), options=opts)
+    assert (res.iterations == 10).all() and (res.status == 3).all()
+    q, t, cost, it, st = _oracle_batch(oracle, capi.MODE_TARGET, offsets, f1, f2, c2, None, 1e-13,
+                                       g.init_q.numpy(), g.init_t.numpy(),
+                                       _oracle_opts(oracle, opts, oracle.JAC_NUMERIC_CENTRAL))
+    assert (it == 10).all()
+    worst = max(_rot_err(oracle, _quat_to_R(res.q[p]), _quat_to_R(q[p])) for p in range(B))
+    assert worst <= ROT_TOL_REFERENCE
+
+
+def test_ragged_batch_with_empty_and_tiny_pairs(oracle):
+    counts = np.array([0, 1, 5, 63, 64, 65, 127, 300, 512, 700, 1025, 2048, 2500], dtype=np.int64)
+    offsets = np.concatenate([[0], np.cumsum(counts)])
+    B, M = len(counts), int(offsets[-1])
+    g = sim.generate(1, M, seed=31)
+    pose = sim.generate(B, 4, seed=32)
+    f1, f2 = g.bvs1[0].numpy(), g.bvs2[0].numpy()
+    c2 = g.covs2[0].numpy()
+    q0 = np.tile(g.init_q[0].numpy(), (B, 1))
+    t0 = np.tile(g.init_t[0].numpy(), (B, 1))
+    opts = capi.default_options()
+    with Batch(capi.MODE_TARGET, offsets) as b:
+        assert b.max_correspondences == 2500
+        assert b.describe_launch()["resident"] is False  # streams: larger than any resident geometry
+        b.fill(f1, f2, c2)
+        res = b.solve(q0, t0, options=opts)
+    q, t, cost, it, st = _oracle_batch(oracle, capi.MODE_TARGET, offsets, f1, f2, c2, None, 1e-13,
+                                       q0, t0, _oracle_opts(oracle, opts, oracle.JAC_ANALYTIC))
+    for p in range(B):
+        if counts[p] >= 63:   # well-posed pairs (tiny ones are rank-deficient: any LM wanders)
+            assert res.status[p] == st[p] and res.iterations[p] == it[p], counts[p]
+            assert _rot_err(oracle, _quat_to_R(res.q[p]), _quat_to_R(q[p])) <= 1e-8, counts[p]
+    # empty pair: zero cost and gradient -> gradient tolerance at iteration 0, start pose returned
+    assert res.status[0] == st[0] == 2 and res.iterations[0] == 0
+    np.testing.assert_allclose(res.q[0], q0[0] / np.linalg.norm(q0[0]), atol=1e-15)
+    assert np.isfinite(res.q).all() and np.isfinite(res.t).all()
+    del pose
+
+
+@pytest.mark.parametrize("n_corr,geometries", [
+    (512, [(8, 1), (4, 2), (2, 4), (1, 8), (4, 4), (0, 1)]),
+    (100, [(2, 1), (4, 1), (8, 1), (1, 8)]),
+    (2000, [(4, 8), (0, 1)]),
+])
+def test_launch_geometries_agree(n_corr, geometries):
+    """register-resident geometries and the streaming kernel are the same computation"""
+    B = 6
+    g = sim.generate(B, n_corr, seed=n_corr)
+    ref = None
+    with Batch.uniform(capi.MODE_TARGET, B, n_corr) as b:
+        b.fill(g.bvs1.reshape(-1, 3).numpy(), g.bvs2.reshape(-1, 3).numpy(),
+               g.covs2.reshape(-1, 3, 3).numpy())
+        for cpl, wpp in geometries:
+            opts = capi.default_options(corr_per_lane=cpl, waves_per_pair=wpp)
+            d = b.describe_launch(opts)
+            assert d["resident"] == (cpl != 0)
+            res = b.solve(g.init_q.numpy(), g.init_t.numpy(), options=opts)
+            if ref is None:
+                ref = res
+                continue
+            np.testing.assert_array_equal(res.iterations, ref.iterations)
+            np.testing.assert_array_equal(res.status, ref.status)
+            np.testing.assert_allclose(res.q, ref.q, atol=1e-11)
+            np.testing.assert_allclose(res.cost, ref.cost, rtol=1e-10)
+        with pytest.raises(capi.PnecHipError):
+            b.solve(g.init_q.numpy(), g.init_t.numpy(),
+                    options=capi.default_options(corr_per_lane=1, waves_per_pair=1 if n_corr > 64 else 3))
+
+
+def test_multi_hypothesis_shares_payload(oracle):
+    """64 t-hat restarts per pair (BASELINE config 4 shape, small): every hypothesis equals an
+    independent oracle solve from that start; select_best picks the lowest cost."""
+    B, N, H = 3, 1024, 16
+    g = sim.generate(B, N, seed=41)
+    rng = np.random.default_rng(3)
+    hyp = rng.normal(size=(B * H, 3))
+    hyp /= np.linalg.norm(hyp, axis=1, keepdims=True)
+    hyp[::H] = g.init_t.numpy()       # hypothesis 0 = the good start
+    f1, f2 = g.bvs1.reshape(-1, 3).numpy(), g.bvs2.reshape(-1, 3).numpy()
+    c2 = g.covs2.reshape(-1, 3, 3).numpy()
+    offsets = np.arange(B + 1, dtype=np.int64) * N
+    opts = capi.default_options()
+    with Batch(capi.MODE_TARGET, offsets) as b:
+        b.fill(f1, f2, c2)
+        res = b.solve(g.init_q.numpy(), None, options=opts, hyp_t=hyp, n_hyp=H)
+    q, t, cost, it, st = _oracle_batch(oracle, capi.MODE_TARGET, offsets, f1, f2, c2, None, 1e-13,
+                                       g.init_q.numpy(), g.init_t.numpy(),
+                                       _oracle_opts(oracle, opts, oracle.JAC_ANALYTIC),
+                                       n_hyp=H, hyp_t=hyp)
+    np.testing.assert_array_equal(res.iterations, it)
+    np.testing.assert_array_equal(res.status, st)
+    for s in range(B * H):
+        assert _rot_err(oracle, _quat_to_R(res.q[s]), _quat_to_R(q[s])) <= 1e-7
+    best = select_best(res.cost, H)
+    np.testing.assert_array_equal(best, np.argmin(cost.reshape(B, H), axis=1))
+
+
+def test_device_space_equals_host_space():
+    B, N = 10, 256
+    g = sim.generate(B, N, seed=51, device="cuda:0")
+    with Batch.uniform(capi.MODE_TARGET, B, N) as b:
+        b.fill(g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3))
+        dev = b.solve(g.init_q, g.init_t)
+        torch.cuda.synchronize()
+        cf_dev = b.cost_function(dev.q, dev.t)
+        host = b.solve(g.init_q.cpu().numpy(), g.init_t.cpu().numpy())
+        cf_host = b.cost_function(host.q, host.t)
+    np.testing.assert_array_equal(dev.q.cpu().numpy(), host.q)
+    np.testing.assert_array_equal(dev.t.cpu().numpy(), host.t)
+    np.testing.assert_array_equal(dev.iterations.cpu().numpy(), host.iterations)
+    np.testing.assert_array_equal(cf_dev.cpu().numpy(), cf_host)
+
+
+def test_cost_function_metric(oracle):
+    B, N = 4, 77
+    g = sim.generate(B, N, seed=61)
+    with Batch.uniform(capi.MODE_TARGET, B, N) as b:
+        b.fill(g.bvs1.reshape(-1, 3).numpy(), g.bvs2.reshape(-1, 3).numpy(),
+               g.covs2.reshape(-1, 3, 3).numpy())
+        got = b.cost_function(g.init_q.numpy(), g.init_t.numpy())
+    for p in range(B):
+        want = oracle.cost_function(g.bvs1[p].numpy(), g.bvs2[p].numpy(), g.covs2[p].numpy(),
+                                    g.init_R[p].numpy(), g.init_t[p].numpy())
+        assert got[p] == pytest.approx(want, rel=1e-10)
+
+
+def test_nan_input_is_reported_not_hidden():
+    B, N = 3, 64
+    g = sim.generate(B, N, seed=71)
+    f1 = g.bvs1.reshape(-1, 3).numpy().copy()
+    f1[N + 5, 1] = np.nan
+    with Batch.uniform(capi.MODE_TARGET, B, N) as b:
+        b.fill(f1, g.bvs2.reshape(-1, 3).numpy(), g.covs2.reshape(-1, 3, 3).numpy())
+        res = b.solve(g.init_q.numpy(), g.init_t.numpy())
+    assert res.status[1] == 6 and res.iterations[1] == 0
+    assert res.status[0] != 6 and res.status[2] != 6
+    assert np.isfinite(res.q).all()   # the last iterate (= the start) is returned, as the reference would
+
+
+def test_kitti_like_forward_motion_near_chart_singularity(oracle):
+    """t ~ +z is where the (theta,phi) chart degenerates (Appendix C12); parity must hold there."""
+    offsets, f1, f2, c2, R_gt, t_gt, q0, t0 = sim.generate_kitti_like(40, mean_corr=480, seed=5)
+    f1, f2, c2, q0, t0 = (x.numpy() for x in (f1, f2, c2, q0, t0))
+    opts = capi.default_options()
+    with Batch(capi.MODE_TARGET, offsets) as b:
+        b.fill(f1, f2, c2)
+        res = b.solve(q0, t0, options=opts)
+    q, t, cost, it, st = _oracle_batch(oracle, capi.MODE_TARGET, offsets, f1, f2, c2, None, 1e-13,
+                                       q0, t0, _oracle_opts(oracle, opts, oracle.JAC_NUMERIC_CENTRAL))
+    worst = max(_rot_err(oracle, _quat_to_R(res.q[p]), _quat_to_R(q[p])) for p in range(40))
+    assert worst <= ROT_TOL_REFERENCE, worst
+    np.testing.assert_array_equal(res.status, st)
+
+
+def test_full_size_batch_properties(oracle):
+    """BASELINE config 2 (100k pairs x 512 anisotropic correspondences) through properties that
+    do not need a CPU solve of the whole batch: finite results, cost never above the start cost,
+    idempotence (re-solving from the result moves < 1e-6 rad), plus oracle parity on a sample."""
+    B, N = 100_000, 512
+    chunk = 10_000
+    batch = Batch.uniform(capi.MODE_TARGET, B, N)
+    qs, ts, keep = [], [], {}
+    for c in range(B // chunk):
+        g = sim.generate(chunk, N, seed=1000 + c, device="cuda:0")
+        batch.fill(g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3),
+                   first_pair=c * chunk, n_pairs=chunk)
+        qs.append(g.init_q)
+        ts.append(g.init_t)
+        keep[c] = (g.bvs1[:4].cpu().numpy(), g.bvs2[:4].cpu().numpy(), g.covs2[:4].cpu().numpy())
+        del g
+    q0, t0 = torch.cat(qs), torch.cat(ts)
+    start = batch.solve(q0, t0, options=capi.default_options(max_num_iterations=0))
+    res = batch.solve(q0, t0)
+    again = batch.solve(res.q, res.t)
+    torch.cuda.synchronize()
+    assert torch.isfinite(res.q).all() and torch.isfinite(res.cost).all()
+    assert (res.cost <= start.cost * (1 + 1e-12)).all()
+    assert (res.status <= 2).all()                       # every solve converged by a tolerance
+    assert int(res.iterations.max()) <= 50
+    # idempotence
+    dq = (res.q * again.q).sum(-1).abs().clamp(max=1.0)
+    assert float((2 * torch.acos(dq)).max()) < 1e-6 + 2e-8  # acos resolution near 1
+    assert int(again.iterations.max()) <= 2
+    # oracle parity on 4 pairs of every chunk (reference-faithful numeric Jacobian)
+    worst = 0.0
+    rq = res.q.cpu().numpy()
+    for c, (f1, f2, c2) in keep.items():
+        for j in range(4):
+            p = c * chunk + j
+            s = oracle.solve(oracle.MODE_TARGET, f1[j], f2[j], c2[j], None, 1e-13,
+                             q0[p].cpu().numpy(), t0[p].cpu().numpy(), oracle.default_options())
+            worst = max(worst, _rot_err(oracle, _quat_to_R(rq[p]), s.R))
+            assert int(res.iterations[p]) == s.iterations
+    assert worst <= ROT_TOL_REFERENCE, worst
+    batch.close()
