@@ -84,6 +84,9 @@ typedef struct pnec_hip_options {
   int32_t check_convergence;                 /* 1; 0 = exactly max_num_iterations LM iterations */
   int32_t corr_per_lane;                     /* 0 = auto; launch tuning: correspondences held per lane */
   int32_t waves_per_pair;                    /* 0 = auto; launch tuning: wavefronts cooperating on one solve */
+  int32_t lds_corr_per_lane;                 /* launch tuning: how many of corr_per_lane live in LDS */
+  int32_t launch_stagger;                    /* launch tuning: first-round start skew per wavefront slot,
+                                                units of ~4096 clocks; 0 = default (1), -1 = off */
   double function_tolerance;                 /* 1e-6 */
   double gradient_tolerance;                 /* 1e-10 */
   double parameter_tolerance;                /* 1e-8 */
@@ -153,7 +156,8 @@ int pnec_hip_cost_function(pnec_hip_problem *p, const double *q, const double *t
 /* Name and launch geometry the auto-tuner would pick for this problem (for logs / profiles). */
 int pnec_hip_describe_launch(const pnec_hip_problem *p, const pnec_hip_options *opt,
                              int32_t *corr_per_lane, int32_t *waves_per_pair,
-                             int32_t *threads_per_block, int32_t *resident);
+                             int32_t *lds_corr_per_lane, int32_t *threads_per_block,
+                             int32_t *resident);
 
 /* Device-side unit checks of the cross-lane reduction (DPP + v_permlane*_swap), the 5x5 Cholesky
  * and the reciprocal / reciprocal-square-root refinements.  0 = all good. */

@@ -92,12 +92,13 @@ class Batch:
         return self._lib.pnec_hip_problem_payload_bytes(self._h)
 
     def describe_launch(self, options: capi.Options | None = None) -> dict:
-        cpl, wpp, tpb, res = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        cpl, wpp, ldsk, tpb, res = (C.c_int32() for _ in range(5))
         capi.check(self._lib.pnec_hip_describe_launch(
             self._h, C.byref(options) if options is not None else None, C.byref(cpl),
-            C.byref(wpp), C.byref(tpb), C.byref(res)))
+            C.byref(wpp), C.byref(ldsk), C.byref(tpb), C.byref(res)))
         return {"corr_per_lane": cpl.value, "waves_per_pair": wpp.value,
-                "threads_per_block": tpb.value, "resident": bool(res.value)}
+                "lds_corr_per_lane": ldsk.value, "threads_per_block": tpb.value,
+                "resident": bool(res.value)}
 
     # -- ingest -----------------------------------------------------------------------------
     def fill(self, bvs1, bvs2, covs=None, covs_host=None, first_pair: int = 0,

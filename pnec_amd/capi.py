@@ -57,6 +57,8 @@ class Options(C.Structure):
         ("check_convergence", C.c_int32),
         ("corr_per_lane", C.c_int32),
         ("waves_per_pair", C.c_int32),
+        ("lds_corr_per_lane", C.c_int32),
+        ("launch_stagger", C.c_int32),
         ("function_tolerance", C.c_double),
         ("gradient_tolerance", C.c_double),
         ("parameter_tolerance", C.c_double),
@@ -108,9 +110,7 @@ def lib() -> C.CDLL:
                                  _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]
     L.pnec_hip_select_best.argtypes = [C.c_int64, C.c_int32, _vp, _vp, C.c_int, C.c_int, _vp]
     L.pnec_hip_cost_function.argtypes = [_vp, _vp, _vp, _vp, C.c_int, _vp]
-    L.pnec_hip_describe_launch.argtypes = [_vp, C.POINTER(Options), C.POINTER(C.c_int32),
-                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32),
-                                           C.POINTER(C.c_int32)]
+    L.pnec_hip_describe_launch.argtypes = [_vp, C.POINTER(Options)] + [C.POINTER(C.c_int32)] * 5
     L.pnec_hip_selftest.argtypes = [C.c_int]
     _lib = L
     return L

@@ -14,10 +14,10 @@
 
 namespace pnec_hip {
 // one translation unit per residual family (pnec_solve_<family>.hip)
-hipError_t launch_solve_mode_0(int, int, bool, const SolveArgs &, hipStream_t);
-hipError_t launch_solve_mode_1(int, int, bool, const SolveArgs &, hipStream_t);
-hipError_t launch_solve_mode_2(int, int, bool, const SolveArgs &, hipStream_t);
-hipError_t launch_solve_mode_3(int, int, bool, const SolveArgs &, hipStream_t);
+hipError_t launch_solve_mode_0(int, int, int, bool, const SolveArgs &, hipStream_t);
+hipError_t launch_solve_mode_1(int, int, int, bool, const SolveArgs &, hipStream_t);
+hipError_t launch_solve_mode_2(int, int, int, bool, const SolveArgs &, hipStream_t);
+hipError_t launch_solve_mode_3(int, int, int, bool, const SolveArgs &, hipStream_t);
 }  // namespace pnec_hip
 
 using namespace pnec_hip;
@@ -211,52 +211,73 @@ __global__ void selftest_kernel(double *out) {
     out[65] = fast_rsqrt(2.0) - 0.70710678118654752440;
     out[66] = fast_rcp(3.0) - 0.33333333333333333333;
   }
+  // 21-way swap-halving reduction: acc[j] = (lane+1)(j+1) + j  ->  2080 (j+1) + 64 j
+  double acc[kNumAcc], sums[kNumAcc];
+  for (int j = 0; j < kNumAcc; ++j) acc[j] = (double)((lane + 1) * (j + 1) + j);
+  wave_reduce21(acc, sums);
+  if (lane == 0)
+    for (int j = 0; j < kNumAcc; ++j) out[67 + j] = sums[j];
+  // bounded sincos against libm over [-40, 40]
+  double worst = 0.0;
+  for (int k = 0; k < 64; ++k) {
+    const double x = -40.0 + 80.0 * (lane * 64 + k) / 4095.0;
+    double s1, c1, s2, c2;
+    sincos_bounded(x, s1, c1);
+    sincos(x, &s2, &c2);
+    worst = fmax(worst, fmax(fabs(s1 - s2), fabs(c1 - c2)));
+  }
+  out[88 + lane] = worst;
 }
 
 // ---- launch geometry --------------------------------------------------------------------
 struct Geometry {
-  int cpl, wpp;
+  int cpl, wpp, ldsk;
   bool resident;
 };
 
-bool geometry_exists(int cpl, int wpp) {
-#define PNEC_GEOMETRY_MATCH(CPL, WPP) \
-  if (cpl == CPL && wpp == WPP) return true;
+bool geometry_exists(int mode, int cpl, int wpp, int ldsk) {
+#define PNEC_GEOMETRY_MATCH(CPL, WPP, LDSK) \
+  if (cpl == CPL && wpp == WPP && ldsk == LDSK) return geometry_ok(mode, cpl, wpp, ldsk);
   PNEC_FOR_EACH_GEOMETRY(PNEC_GEOMETRY_MATCH)
 #undef PNEC_GEOMETRY_MATCH
   return false;
 }
 
-// Register-resident whenever the largest pair fits 64*CPL*WPP lanes-slots; one wavefront per
-// solve as long as that wavefront's registers can hold the pair (the serial part of an LM
-// iteration is paid once per wavefront, so fewer, fatter wavefronts win); the SYM family carries
-// 18 doubles per correspondence, so it tops out at 4 per lane.
+// On-chip resident whenever the largest pair fits 64*CPL*WPP slots.  Preference: as few
+// wavefronts per solve as possible (the serial part of an LM iteration is paid once per
+// wavefront) at two wavefronts per SIMD; 12-plane payloads use the (8,W,3) family (5 of a
+// lane's 8 correspondences in registers, 3 in LDS), the 18-plane SYM payload the (4,W,0) family.
 int choose_geometry(const pnec_hip_problem *p, const pnec_hip_options *opt, Geometry *g) {
   const int n = std::max<int32_t>(p->n_max, 1);
   if (opt && (opt->corr_per_lane > 0 || opt->waves_per_pair > 0)) {
-    const int cpl = opt->corr_per_lane, wpp = opt->waves_per_pair;
-    if (cpl < 0 || wpp < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "negative launch tuning");
-    if (cpl == 0 && wpp > 0) {  // streaming with the fixed 8-wave block
-      *g = {1, kStreamWaves, false};
+    const int cpl = opt->corr_per_lane, wpp = opt->waves_per_pair ? opt->waves_per_pair : 1;
+    const int ldsk = opt->lds_corr_per_lane;
+    if (cpl < 0 || wpp < 0 || ldsk < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "negative launch tuning");
+    if (cpl == 0) {  // streaming with the fixed block shape
+      *g = {1, kStreamWaves, 0, false};
       return 0;
     }
-    if (!geometry_exists(cpl, wpp ? wpp : 1))
-      return fail(PNEC_HIP_ERR_UNSUPPORTED, "launch geometry (corr_per_lane, waves_per_pair) not built");
-    if ((int64_t)kWave * cpl * (wpp ? wpp : 1) < n)
+    if (!geometry_exists(p->mode, cpl, wpp, ldsk))
+      return fail(PNEC_HIP_ERR_UNSUPPORTED,
+                  "launch geometry (corr_per_lane, waves_per_pair, lds_corr_per_lane) not built");
+    if ((int64_t)kWave * cpl * wpp < n)
       return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "launch geometry too small for the largest pair");
-    *g = {cpl, wpp ? wpp : 1, true};
+    *g = {cpl, wpp, ldsk, true};
     return 0;
   }
-  const int max_cpl_1wave = (p->mode == PNEC_HIP_MODE_SYM) ? 4 : 8;
-  static const int order[][2] = {{1, 1}, {2, 1}, {4, 1}, {8, 1}, {4, 2}, {4, 4}, {4, 8}};
-  for (auto &c : order) {
-    if (c[1] == 1 && c[0] > max_cpl_1wave) continue;
-    if ((int64_t)kWave * c[0] * c[1] >= n) {
-      *g = {c[0], c[1], true};
+  static const int order12[][3] = {{1, 1, 0}, {2, 1, 0}, {4, 1, 0}, {8, 1, 3},
+                                   {8, 2, 3}, {8, 4, 3}, {8, 8, 3}};
+  static const int order18[][3] = {{1, 1, 0}, {2, 1, 0}, {4, 1, 0}, {4, 2, 0}, {4, 4, 0}, {4, 8, 0}};
+  const bool sym = (p->mode == PNEC_HIP_MODE_SYM);
+  const int (*order)[3] = sym ? order18 : order12;
+  const int count = sym ? 6 : 7;
+  for (int i = 0; i < count; ++i) {
+    if ((int64_t)kWave * order[i][0] * order[i][1] >= n) {
+      *g = {order[i][0], order[i][1], order[i][2], true};
       return 0;
     }
   }
-  *g = {1, kStreamWaves, false};
+  *g = {1, kStreamWaves, 0, false};
   return 0;
 }
 
@@ -303,6 +324,8 @@ void pnec_hip_default_options(pnec_hip_options *o) {
   o->check_convergence = 1;
   o->corr_per_lane = 0;
   o->waves_per_pair = 0;
+  o->lds_corr_per_lane = 0;
+  o->launch_stagger = 0;
   o->function_tolerance = 1e-6;
   o->gradient_tolerance = 1e-10;
   o->parameter_tolerance = 1e-8;
@@ -468,12 +491,14 @@ int pnec_hip_problem_device(const pnec_hip_problem *p) { return p ? p->device : 
 
 int pnec_hip_describe_launch(const pnec_hip_problem *p, const pnec_hip_options *opt,
                              int32_t *corr_per_lane, int32_t *waves_per_pair,
-                             int32_t *threads_per_block, int32_t *resident) {
+                             int32_t *lds_corr_per_lane, int32_t *threads_per_block,
+                             int32_t *resident) {
   if (!p) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "problem is NULL");
   Geometry g;
   if (int rc = choose_geometry(p, opt, &g)) return rc;
   if (corr_per_lane) *corr_per_lane = g.cpl;
   if (waves_per_pair) *waves_per_pair = g.wpp;
+  if (lds_corr_per_lane) *lds_corr_per_lane = g.ldsk;
   if (threads_per_block) *threads_per_block = kWave * g.wpp;
   if (resident) *resident = g.resident ? 1 : 0;
   return 0;
@@ -511,6 +536,7 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
   a.count = p->d_count;
   a.n_solves = S;
   a.n_hyp = n_hyp;
+  a.stagger = opt.launch_stagger < 0 ? 0 : (opt.launch_stagger == 0 ? 1 : opt.launch_stagger);
   a.reg = reg;
   a.opt = opt;
 
@@ -551,10 +577,10 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
 
   hipError_t e;
   switch (p->mode) {
-    case PNEC_HIP_MODE_NEC: e = launch_solve_mode_0(g.cpl, g.wpp, g.resident, a, stream); break;
-    case PNEC_HIP_MODE_TARGET: e = launch_solve_mode_1(g.cpl, g.wpp, g.resident, a, stream); break;
-    case PNEC_HIP_MODE_HOST: e = launch_solve_mode_2(g.cpl, g.wpp, g.resident, a, stream); break;
-    default: e = launch_solve_mode_3(g.cpl, g.wpp, g.resident, a, stream); break;
+    case PNEC_HIP_MODE_NEC: e = launch_solve_mode_0(g.cpl, g.wpp, g.ldsk, g.resident, a, stream); break;
+    case PNEC_HIP_MODE_TARGET: e = launch_solve_mode_1(g.cpl, g.wpp, g.ldsk, g.resident, a, stream); break;
+    case PNEC_HIP_MODE_HOST: e = launch_solve_mode_2(g.cpl, g.wpp, g.ldsk, g.resident, a, stream); break;
+    default: e = launch_solve_mode_3(g.cpl, g.wpp, g.ldsk, g.resident, a, stream); break;
   }
   if (e != hipSuccess) return fail_hip(e, "lm_solve_kernel launch");
 
@@ -643,11 +669,11 @@ int pnec_hip_selftest(int device) {
   DeviceGuard guard(device);
   if (!guard.ok) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "hipSetDevice failed");
   double *d = nullptr;
-  PNEC_HIP_TRY(hipMalloc(&d, sizeof(double) * 80));
+  PNEC_HIP_TRY(hipMalloc(&d, sizeof(double) * 160));
   hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(kWave), 0, 0, d);
-  double h[80];
+  double h[160];
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(double) * 67, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(double) * 152, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) return fail_hip(e, "selftest_kernel");
   for (int i = 0; i < kWave; ++i)
@@ -659,6 +685,19 @@ int pnec_hip_selftest(int device) {
   if (!(h[64] >= 0.0 && h[64] < 1e-12)) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "chol_solve5 residual too large");
   if (!(std::abs(h[65]) < 1e-15)) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "fast_rsqrt inaccurate");
   if (!(std::abs(h[66]) < 1e-15)) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "fast_rcp inaccurate");
+  for (int j = 0; j < kNumAcc; ++j)
+    if (h[67 + j] != 2080.0 * (j + 1) + 64.0 * j) {
+      char buf[128];
+      std::snprintf(buf, sizeof(buf), "wave_reduce21: sum %d is %.17g, expected %.17g", j, h[67 + j],
+                    2080.0 * (j + 1) + 64.0 * j);
+      return fail(PNEC_HIP_ERR_HIP_RUNTIME, buf);
+    }
+  for (int i = 0; i < kWave; ++i)
+    if (!(h[88 + i] < 4e-16)) {
+      char buf[128];
+      std::snprintf(buf, sizeof(buf), "sincos_bounded deviates from libm by %.3g", h[88 + i]);
+      return fail(PNEC_HIP_ERR_HIP_RUNTIME, buf);
+    }
   return 0;
 }
 

@@ -55,6 +55,35 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return __builtin_fma(y, e, y);
 }
 __device__ __forceinline__ bool finite_d(double x) { return __builtin_isfinite(x); }
+// sqrt(x) for x >= 0 via the reciprocal square root (0 stays 0)
+__device__ __forceinline__ double fast_sqrt(double x) { return x > 0.0 ? x * fast_rsqrt(x) : 0.0; }
+
+// sin and cos together, for the angles an LM run produces (|x| well below 1e6): two-constant
+// FMA Cody-Waite reduction to [-pi/4, pi/4] + the classic degree-13/14 minimax kernels.
+// ~35 VALU instructions instead of the generic libm path with its Payne-Hanek branch.
+__device__ __forceinline__ void sincos_bounded(double x, double &s, double &c) {
+  const double k = __builtin_rint(x * 0.63661977236758134308);  // 2/pi
+  double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
+  r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
+  const double z = r * r;
+  double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+  ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+  ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+  ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+  const double sr = __builtin_fma(r * z, ps, r);
+  double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+  pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+  pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+  pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+  const double cr = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+  const int q = (int)k & 3;
+  const double a = (q & 1) ? cr : sr;
+  const double b = (q & 1) ? sr : cr;
+  s = (q & 2) ? -a : a;
+  c = ((q + 1) & 2) ? -b : b;
+}
 
 // ------------------------------------------------------------------------------------------
 // cross-lane sum over the 64 lanes of a wavefront; every lane ends with the same bits.
@@ -89,6 +118,65 @@ __device__ __forceinline__ double wave_allreduce_sum(double x) {
   return x;
 }
 
+// Sum each of the 21 accumulators over the 64 lanes and return the sums in scalar registers.
+// v_permlane32_swap / v_permlane16_swap exchange half of one register with the other half of
+// a second one, so one swap + one add reduces TWO accumulators at once with no selects:
+//   swap32(X, Y): X' = [X.lo | Y.lo], Y' = [X.hi | Y.hi]  =>  X' + Y' = [X.lo+X.hi | Y.lo+Y.hi]
+// 21 -> 11 values (lane halves) -> 6 values (rows of 16 lanes); the last four levels run as a
+// DPP butterfly inside each row on those 6 values; v_readlane then picks every sum from the
+// row that owns it.  123 + 42 instructions instead of 378 + 42 for 21 full butterflies.
+__device__ __forceinline__ double swap_add32(double x, double y) {
+  const unsigned xl = (unsigned)__double2loint(x), xh = (unsigned)__double2hiint(x);
+  const unsigned yl = (unsigned)__double2loint(y), yh = (unsigned)__double2hiint(y);
+  const auto a = __builtin_amdgcn_permlane32_swap(xl, yl, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(xh, yh, false, false);
+  return make_double((int)b[0], (int)a[0]) + make_double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double swap_add16(double x, double y) {
+  const unsigned xl = (unsigned)__double2loint(x), xh = (unsigned)__double2hiint(x);
+  const unsigned yl = (unsigned)__double2loint(y), yh = (unsigned)__double2hiint(y);
+  const auto a = __builtin_amdgcn_permlane16_swap(xl, yl, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
+  return make_double((int)b[0], (int)a[0]) + make_double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double row_allreduce_sum(double x) {
+  x += dpp_perm<0xB1>(x);
+  x += dpp_perm<0x4E>(x);
+  x += dpp_perm<0x141>(x);
+  x += dpp_perm<0x140>(x);
+  return x;
+}
+template <int LANE>
+__device__ __forceinline__ double read_lane(double x) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), LANE);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), LANE);
+  return make_double(hi, lo);
+}
+__device__ __forceinline__ void wave_reduce21(const double (&acc)[kNumAcc], double (&sum)[kNumAcc]) {
+  // level 1 (lanes l <-> l+32): b[i] holds acc[i] in lanes 0..31 and acc[i+11] in lanes 32..63
+  double b[11];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) b[i] = swap_add32(acc[i], acc[i + 11]);
+  b[10] = swap_add32(acc[10], 0.0);
+  // level 2 (rows r <-> r^1): c[i] rows {0,2} hold b[i], rows {1,3} hold b[i+6]
+  double c[6];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) c[i] = swap_add16(b[i], b[i + 6]);
+  c[5] = swap_add16(b[5], 0.0);
+  // levels 3..6 inside each row
+#pragma unroll
+  for (int i = 0; i < 6; ++i) c[i] = row_allreduce_sum(c[i]);
+  // row 0: acc[i], row 1: acc[i+6], row 2: acc[i+11], row 3: acc[i+17]
+#pragma unroll
+  for (int i = 0; i < 6; ++i) sum[i] = read_lane<0>(c[i]);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) sum[i + 6] = read_lane<16>(c[i]);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) sum[i + 11] = read_lane<32>(c[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sum[i + 17] = read_lane<48>(c[i]);
+}
+
 // ------------------------------------------------------------------------------------------
 // pose-dependent, correspondence-independent quantities of one pass
 struct PassUniforms {
@@ -114,8 +202,8 @@ __device__ __forceinline__ void make_uniforms(double theta, double phi, const do
   double R[9];
   rot_from_quat(q, R);
   double st, ct, sp, cp;
-  sincos(theta, &st, &ct);
-  sincos(phi, &sp, &cp);
+  sincos_bounded(theta, st, ct);
+  sincos_bounded(phi, sp, cp);
 #pragma unroll
   for (int i = 0; i < 9; ++i) U.R[i] = to_sgpr(R[i]);
   U.t[0] = to_sgpr(st * cp);   U.t[1] = to_sgpr(st * sp);   U.t[2] = to_sgpr(ct);
@@ -169,7 +257,10 @@ __device__ __forceinline__ void eval_corr(const double (&d)[num_components(MODE)
     const double sgy = d[7] * gx + d[9] * gy + d[10] * gz;
     const double sgz = d[8] * gx + d[10] * gy + d[11] * gz;
     const double den = gx * sgx + gy * sgy + gz * sgz + reg;
-    const double y = valid ? fast_rsqrt(den) : 0.0;
+    // padding slots: select AFTER the (unconditional) reciprocal square root -- a conditional
+    // evaluation turns into a branch per correspondence and serialises the unrolled pass
+    const double y_all = fast_rsqrt(den);
+    const double y = valid ? y_all : 0.0;
     r = n * y;
     const double c = r * y;  // n / den
     wx = y * (f2x - c * sgx);
@@ -198,7 +289,8 @@ __device__ __forceinline__ void eval_corr(const double (&d)[num_components(MODE)
       sgz = d[8] * gx + d[10] * gy + d[11] * gz;
       den += gx * sgx + gy * sgy + gz * sgz;
     }
-    const double y = valid ? fast_rsqrt(den) : 0.0;
+    const double y_all = fast_rsqrt(den);
+    const double y = valid ? y_all : 0.0;
     r = n * y;
     const double c = r * y;
     wx = y * (f2x - c * sgx);

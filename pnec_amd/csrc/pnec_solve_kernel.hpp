@@ -12,15 +12,30 @@
 //   * cost, J'J and J'r of the CANDIDATE point are produced by one fused pass, so an accepted step
 //     needs no second evaluation (Ceres evaluates residuals at the candidate, then residuals +
 //     Jacobian again after accepting).  Same numbers, half the passes.
+//
+// Register / LDS plan (what makes one wavefront per 512-correspondence pair viable):
+//   * the pair's payload lives in VGPRs (+ AGPRs when the compiler needs room) for the whole loop;
+//   * the 18 pose uniforms of a pass and the 21 reduced sums live in SGPRs;
+//   * the LM state that must survive a pass (current point, scaled J'J / J'r, trust-region
+//     bookkeeping: ~50 doubles, identical in every lane) is PARKED in a per-wavefront LDS slab
+//     by lane 0 and read back with broadcast ds_reads -- LDS instructions cost no VALU issue,
+//     unlike the v_writelane/v_readlane traffic of SGPR spills.
 #pragma once
 
 #include "pnec_device.hpp"
 
-// (correspondences per lane, wavefronts per solve) geometries that are instantiated for every
-// residual family.  capacity = 64 * CPL * WPP correspondences held in registers.
+// Launch geometries instantiated for every residual family:
+//   (CPL correspondences per lane, WPP wavefronts per solve, LDSK of the CPL kept in LDS)
+// capacity = 64 * CPL * WPP correspondences resident on chip for the whole LM loop.
+// LDSK > 0 moves that many of a lane's correspondences from registers to LDS so that a wavefront
+// fits 256 registers and two wavefronts share a SIMD (latency hiding) while still owning 512
+// correspondences each -- the serial part of an iteration is paid once per wavefront, so fat
+// wavefronts win.  (8,W,3) covers N = 512 W up to 4096 (5 correspondences per lane in registers,
+// 3 in LDS: 18.4 KB per wavefront, 8 wavefronts per CU); (4,W,0) is the family for the 18-plane
+// SYM payload; (8,1,0), (4,2,0) and (1,8,0) also serve the A/B measurements in DESIGN.md.
 #define PNEC_FOR_EACH_GEOMETRY(X) \
-  X(1, 1) X(2, 1) X(4, 1) X(8, 1) \
-  X(4, 2) X(2, 4) X(1, 8) X(4, 4) X(4, 8)
+  X(1, 1, 0) X(2, 1, 0) X(4, 1, 0) X(4, 2, 0) X(4, 4, 0) X(4, 8, 0) \
+  X(8, 1, 3) X(8, 2, 3) X(8, 4, 3) X(8, 8, 3) X(8, 1, 0) X(1, 8, 0)
 constexpr int kStreamWaves = 8;  // block shape of the streaming (non-resident) fallback
 
 namespace pnec_hip {
@@ -39,6 +54,7 @@ struct SolveArgs {
   int32_t *out_status;          // [n_solves] or null
   int64_t n_solves;
   int32_t n_hyp;
+  int32_t stagger;  // first-round start skew, units of s_sleep(64) ~ 4096 clocks per wavefront slot
   double reg;
   pnec_hip_options opt;
 };
@@ -52,9 +68,43 @@ __device__ __forceinline__ int64_t xcd_contiguous_index(int64_t b, int64_t n) {
   return base + (b >> 3);
 }
 
-template <int MODE, int CPL, int WPP, bool RESIDENT>
-__global__ __launch_bounds__(kWave *WPP) void lm_solve_kernel(const SolveArgs a) {
+// slots of the per-wavefront LDS slab (doubles)
+enum : int {
+  kQ = 0,        // 4  current quaternion
+  kTheta = 4,    // 1
+  kPhi = 5,      // 1
+  kCost = 6,     // 1
+  kXNorm = 7,    // 1
+  kRadius = 8,   // 1
+  kInvDec = 9,   // 1  1 / decrease_factor (a power of two)
+  kModel = 10,   // 1  model cost change of the pending step
+  kQc = 11,      // 4  candidate quaternion
+  kThetaC = 15,  // 1
+  kPhiC = 16,    // 1
+  kHs = 17,      // 15 Jacobi-scaled J'J (upper triangle)
+  kGs = 32,      // 5  Jacobi-scaled J'r
+  kDiag = 37,    // 5  clamped LM diagonal
+  kScale = 42,   // 5  Jacobi scale x (2 for the rotation columns)
+  kGmax = 47,    // 1
+  kSlab = 48
+};
+
+// Which (family, geometry) pairs are built: the payload must fit the 160 KB LDS and the
+// register budget of its occupancy target (<= 72 doubles of payload per lane at two wavefronts
+// per SIMD; the (8,W,0) shape runs one wavefront per SIMD with AGPR parking, 12 planes at most).
+__host__ __device__ constexpr bool geometry_ok(int mode, int cpl, int wpp, int ldsk) {
+  const int nc = num_components(mode);
+  const long lds = (long)wpp * (ldsk * nc * kWave * 8 + kSlab * 8) + (wpp > 1 ? 2L * wpp * kNumAcc * 8 : 0);
+  if (lds > 160 * 1024) return false;
+  if (cpl == 8 && ldsk == 0) return nc <= 12;
+  return nc * (cpl - ldsk) <= 72;
+}
+
+template <int MODE, int CPL, int WPP, int LDSK, bool RESIDENT>
+__global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void lm_solve_kernel(
+    const SolveArgs a) {
   constexpr int NC = num_components(MODE);
+  constexpr int REGK = RESIDENT ? CPL - LDSK : 1;  // correspondences per lane kept in registers
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int64_t s = xcd_contiguous_index(blockIdx.x, a.n_solves);
@@ -65,284 +115,346 @@ __global__ __launch_bounds__(kWave *WPP) void lm_solve_kernel(const SolveArgs a)
   const pnec_hip_options &o = a.opt;
   const double reg = a.reg;
 
+  // Equal-length solves keep every wavefront of the chip in lockstep: all of them stream their
+  // payload from HBM at the same moment (a burst at full bandwidth), then all compute (HBM idle).
+  // Skewing the FIRST round by the wavefront's slot on its CU (blocks are dealt round-robin, so
+  // slot ~ blockIdx / 256 CUs) spreads the loads of later rounds under the other slots' compute;
+  // a finished wavefront's successor inherits its phase.  Speed only; results are unaffected.
+  if (a.stagger > 0 && blockIdx.x < 2048) {
+    const int naps = (int)(blockIdx.x >> 8) * a.stagger;
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
+  }
+
+  __shared__ double slab_all[WPP][kSlab];
+  [[maybe_unused]] __shared__ double xw[2][WPP > 1 ? WPP : 1][kNumAcc];
+  [[maybe_unused]] __shared__ double ldata[LDSK > 0 ? WPP : 1][LDSK > 0 ? LDSK : 1][NC][LDSK > 0 ? kWave : 1];
+  double *slab = slab_all[wave];
+  int parity = 0;
+
   // ---- load this lane's correspondences once (coalesced: consecutive lanes, consecutive doubles)
-  double d[RESIDENT ? CPL : 1][NC];
+  double d[REGK][NC];
   unsigned vmask = 0;
   if constexpr (RESIDENT) {
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
       const int idx = (wave * CPL + k) * kWave + lane;
       const bool in = idx < stride;
+      if (k < REGK) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) d[k][c] = in ? base[(int64_t)c * stride + idx] : 0.0;
+        for (int c = 0; c < NC; ++c) d[k < REGK ? k : 0][c] = in ? base[(int64_t)c * stride + idx] : 0.0;
+      } else {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          ldata[wave][k >= REGK ? k - REGK : 0][c][lane] = in ? base[(int64_t)c * stride + idx] : 0.0;
+      }
       vmask |= (idx < n ? 1u : 0u) << k;
     }
   }
 
-  [[maybe_unused]] __shared__ double xw[2][WPP > 1 ? WPP : 1][kNumAcc];
-  int parity = 0;
-
-  // one pass over the pair: all-reduced sums, identical bits in every lane of every wave
-  auto run_pass = [&](const PassUniforms &U, double(&sum)[kNumAcc]) {
-    double acc[kNumAcc];
-#pragma unroll
-    for (int j = 0; j < kNumAcc; ++j) acc[j] = 0.0;
-    if constexpr (RESIDENT) {
-#pragma unroll
-      for (int k = 0; k < CPL; ++k) {
-        double r, J[5];
-        eval_corr<MODE>(d[k], (vmask >> k) & 1u, U, reg, r, J);
-        accumulate(r, J, acc);
-      }
-    } else {
-      for (int idx = threadIdx.x; idx < stride; idx += kWave * WPP) {
-        double e[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) e[c] = base[(int64_t)c * stride + idx];
-        double r, J[5];
-        eval_corr<MODE>(e, idx < n, U, reg, r, J);
-        accumulate(r, J, acc);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < kNumAcc; ++j) acc[j] = wave_allreduce_sum(acc[j]);
-    if constexpr (WPP > 1) {
-      if (lane < kNumAcc) {
-        // lane j publishes sum j (all lanes hold all sums; pick by lane without dynamic indexing)
-        double v = acc[0];
-#pragma unroll
-        for (int j = 1; j < kNumAcc; ++j) v = (lane == j) ? acc[j] : v;
-        xw[parity][wave][lane] = v;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < kNumAcc; ++j) {
-        double t = xw[parity][0][j];
-#pragma unroll
-        for (int w = 1; w < WPP; ++w) t += xw[parity][w][j];
-        acc[j] = t;
-      }
-      parity ^= 1;
-    }
-#pragma unroll
-    for (int j = 0; j < kNumAcc; ++j) sum[j] = to_sgpr(acc[j]);
-  };
-
-  // ---- PNECCeres::InitValues(q, t): pnec_ceres.cc:182-186
-  double q[4], theta, phi;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) q[k] = to_sgpr(a.init_q[pair * 4 + k]);
-  {
+  // ---- PNECCeres::InitValues(q, t): pnec_ceres.cc:182-186.  The start point is the first
+  // "candidate"; the loop's first pass evaluates it (Ceres' iteration zero).
+  if (lane == 0) {
+    double th, ph;
     const double *t0 = a.hyp_t ? a.hyp_t + 3 * s : a.init_t + 3 * pair;
-    angles_from_vec(t0[0], t0[1], t0[2], theta, phi);
-    theta = to_sgpr(theta);
-    phi = to_sgpr(phi);
+    angles_from_vec(t0[0], t0[1], t0[2], th, ph);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) slab[kQc + k] = a.init_q[pair * 4 + k];
+    slab[kThetaC] = th;
+    slab[kPhiC] = ph;
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
-  double cost, Hs[15], gs[5], scale[5], diag[5], gmax;
   int iteration = 0, term = PNEC_HIP_TERM_MAX_ITERATIONS;
+  int first = 1, reuse_diagonal = 0, num_invalid = 0, step_ok = 1;
 
-  // sums -> cost, scaled H and g (delta = omega/2 => omega columns x2)
-  auto unpack = [&](const double(&S)[kNumAcc], double &c, double(&H)[15], double(&g)[5]) {
-    c = 0.5 * S[0];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) g[i] = S[1 + i] * (i >= 2 ? 2.0 : 1.0);
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-      for (int j = i; j < 5; ++j)
-        H[tri(i, j)] = S[6 + tri(i, j)] * ((i >= 2 ? 2.0 : 1.0) * (j >= 2 ? 2.0 : 1.0));
-  };
-  auto all_finite = [&](double c, const double(&H)[15], const double(&g)[5]) {
-    bool ok = finite_d(c);
-#pragma unroll
-    for (int i = 0; i < 5; ++i) ok = ok && finite_d(g[i]);
-#pragma unroll
-    for (int i = 0; i < 15; ++i) ok = ok && finite_d(H[i]);
-    return ok;
-  };
-  auto rescale = [&](const double(&H)[15], const double(&g)[5]) {
-    gmax = 0.0;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      gs[i] = to_sgpr(g[i] * scale[i]);
-      gmax = fmax(gmax, fabs(g[i]));
-    }
-    gmax = to_sgpr(gmax);
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-      for (int j = i; j < 5; ++j) Hs[tri(i, j)] = to_sgpr(H[tri(i, j)] * (scale[i] * scale[j]));
-  };
-
-  {  // ---- iteration zero
-    PassUniforms U;
-    make_uniforms(theta, phi, q, U);
-    double S[kNumAcc], H[15], g[5];
-    run_pass(U, S);
-    unpack(S, cost, H, g);
-    cost = to_sgpr(cost);
-    if (to_sgpr((int)all_finite(cost, H, g)) == 0) {
-      term = PNEC_HIP_TERM_BAD_INITIAL;
-      goto finish;
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-      scale[i] = to_sgpr(o.jacobi_scaling ? 1.0 / (1.0 + sqrt(H[tri(i, i)])) : 1.0);
-    rescale(H, g);
-  }
-
-  {
-    double x_norm = to_sgpr(sqrt(theta * theta + phi * phi + q[0] * q[0] + q[1] * q[1] +
-                                 q[2] * q[2] + q[3] * q[3]));
-    double radius = o.initial_trust_region_radius, decrease_factor = 2.0;
-    int reuse_diagonal = 0, num_invalid = 0, step_ok = 1;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) diag[i] = 0.0;
-
-    for (;;) {
-      // FinalizeIterationAndCheckIfMinimizerCanContinue
+  for (;;) {
+    if (!first) {
+      // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
       if (iteration >= o.max_num_iterations) { term = PNEC_HIP_TERM_MAX_ITERATIONS; break; }
-      if (to_sgpr((int)(o.check_convergence && step_ok && gmax <= o.gradient_tolerance))) {
+      const double radius = slab[kRadius];
+      if (o.check_convergence && step_ok && to_sgpr((int)(slab[kGmax] <= o.gradient_tolerance))) {
         term = PNEC_HIP_TERM_GRADIENT_TOL; break;
       }
-      if (to_sgpr((int)(radius < o.min_trust_region_radius))) {
-        term = PNEC_HIP_TERM_MIN_RADIUS; break;
-      }
+      if (to_sgpr((int)(radius < o.min_trust_region_radius))) { term = PNEC_HIP_TERM_MIN_RADIUS; break; }
       ++iteration;
       step_ok = 0;
 
-      // LevenbergMarquardtStrategy::ComputeStep
+      // ---- LevenbergMarquardtStrategy::ComputeStep on the parked normal equations
+      double Hs[15], gs[5], diag[5], A[15], y[5], step[5];
+#pragma unroll
+      for (int i = 0; i < 15; ++i) Hs[i] = slab[kHs + i];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) gs[i] = slab[kGs + i];
       if (!reuse_diagonal) {
 #pragma unroll
         for (int i = 0; i < 5; ++i)
-          diag[i] = to_sgpr(fmin(fmax(Hs[tri(i, i)], o.min_lm_diagonal), o.max_lm_diagonal));
+          diag[i] = fmin(fmax(Hs[tri(i, i)], o.min_lm_diagonal), o.max_lm_diagonal);
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) slab[kDiag + i] = diag[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) diag[i] = slab[kDiag + i];
       }
-      double A[15], y[5], step[5];
       const double inv_radius = fast_rcp(radius);
 #pragma unroll
       for (int i = 0; i < 15; ++i) A[i] = Hs[i];
 #pragma unroll
       for (int i = 0; i < 5; ++i) A[tri(i, i)] = __builtin_fma(diag[i], inv_radius, A[tri(i, i)]);
       bool valid = chol_solve5(A, gs, y);
-      double model_change = 0.0;
-      {
-        double sg = 0.0, shs = 0.0;
+      double sg = 0.0, shs = 0.0;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) step[i] = -y[i];
+      for (int i = 0; i < 5; ++i) step[i] = -y[i];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-          sg = __builtin_fma(step[i], gs[i], sg);
-          double row = 0.0;
+      for (int i = 0; i < 5; ++i) {
+        sg = __builtin_fma(step[i], gs[i], sg);
+        double row = 0.0;
 #pragma unroll
-          for (int j = 0; j < 5; ++j) row = __builtin_fma(Hs[sym(i, j)], step[j], row);
-          shs = __builtin_fma(step[i], row, shs);
-        }
-        model_change = -(sg + 0.5 * shs);
-        valid = valid && (model_change > 0.0);
+        for (int j = 0; j < 5; ++j) row = __builtin_fma(Hs[sym(i, j)], step[j], row);
+        shs = __builtin_fma(step[i], row, shs);
       }
+      const double model_change = -(sg + 0.5 * shs);  // -(Js)'(r + Js/2)
+      valid = valid && (model_change > 0.0);
       if (to_sgpr((int)valid) == 0) {
         if (++num_invalid >= o.max_num_consecutive_invalid_steps) {
           term = PNEC_HIP_TERM_INVALID_STEPS; break;
         }
-        radius = to_sgpr(radius / decrease_factor);
-        decrease_factor *= 2.0;
+        if (lane == 0) {
+          const double inv_dec = slab[kInvDec];
+          slab[kRadius] = radius * inv_dec;
+          slab[kInvDec] = 0.5 * inv_dec;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         reuse_diagonal = 1;
         continue;
       }
       num_invalid = 0;
 
-      // candidate = Plus(x, step * jacobi_scale): EigenQuaternionManifold::Plus on q
-      double qc[4];
-      const double thc = to_sgpr(theta + step[0] * scale[0]);
-      const double phc = to_sgpr(phi + step[1] * scale[1]);
+      // ---- candidate = Plus(x, step * jacobi_scale): EigenQuaternionManifold::Plus on q.
+      // slab[kScale + i] holds jacobi_scale x (2 for rotation columns): the tangent step in Ceres'
+      // half-angle delta is step * jacobi_scale; the x2 only belongs to J (omega = 2 delta).
+      const double sc0 = slab[kScale + 0], sc1 = slab[kScale + 1];
+      const double dx = step[2] * (0.5 * slab[kScale + 2]);
+      const double dy = step[3] * (0.5 * slab[kScale + 3]);
+      const double dz = step[4] * (0.5 * slab[kScale + 4]);
+      const double q0 = slab[kQ + 0], q1 = slab[kQ + 1], q2 = slab[kQ + 2], q3 = slab[kQ + 3];
+      const double thc = slab[kTheta] + step[0] * sc0;
+      const double phc = slab[kPhi] + step[1] * sc1;
+      const double nd2 = dx * dx + dy * dy + dz * dz;
+      double qc0 = q0, qc1 = q1, qc2 = q2, qc3 = q3;
+      if (nd2 > 0.0) {
+        const double ind = fast_rsqrt(nd2), nd = nd2 * ind;
+        double sn, aw;
+        sincos_bounded(nd, sn, aw);
+        const double sbd = sn * ind;
+        const double ax = sbd * dx, ay = sbd * dy, az = sbd * dz;
+        qc0 = aw * q0 + ax * q3 + ay * q2 - az * q1;
+        qc1 = aw * q1 - ax * q2 + ay * q3 + az * q0;
+        qc2 = aw * q2 + ax * q1 - ay * q0 + az * q3;
+        qc3 = aw * q3 - ax * q0 - ay * q1 - az * q2;
+      }
+      if (lane == 0) {
+        slab[kQc + 0] = qc0; slab[kQc + 1] = qc1; slab[kQc + 2] = qc2; slab[kQc + 3] = qc3;
+        slab[kThetaC] = thc;
+        slab[kPhiC] = phc;
+        slab[kModel] = model_change;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+
+    // ---- one fused pass at the candidate: sum r^2, J'r, J'J ------------------------------
+    double S[kNumAcc];
+    {
+      PassUniforms U;
       {
-        const double dx = step[2] * scale[2], dy = step[3] * scale[3], dz = step[4] * scale[4];
-        const double nd = sqrt(dx * dx + dy * dy + dz * dz);
-        if (nd == 0.0) {
+        const double qc[4] = {slab[kQc + 0], slab[kQc + 1], slab[kQc + 2], slab[kQc + 3]};
+        make_uniforms(slab[kThetaC], slab[kPhiC], qc, U);
+      }
+      double acc[kNumAcc];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) qc[k] = q[k];
-        } else {
-          double sn, aw;
-          sincos(nd, &sn, &aw);
-          const double sbd = sn / nd;
-          const double ax = sbd * dx, ay = sbd * dy, az = sbd * dz;
-          qc[0] = aw * q[0] + ax * q[3] + ay * q[2] - az * q[1];
-          qc[1] = aw * q[1] - ax * q[2] + ay * q[3] + az * q[0];
-          qc[2] = aw * q[2] + ax * q[1] - ay * q[0] + az * q[3];
-          qc[3] = aw * q[3] - ax * q[0] - ay * q[1] - az * q[2];
+      for (int j = 0; j < kNumAcc; ++j) acc[j] = 0.0;
+      if constexpr (RESIDENT) {
+#pragma unroll
+        for (int k = 0; k < REGK; ++k) {
+          double r, J[5];
+          eval_corr<MODE>(d[k], (vmask >> k) & 1u, U, reg, r, J);
+          accumulate(r, J, acc);
+        }
+        // not unrolled: one LDS-resident correspondence live at a time (an unrolled loop lets the
+        // scheduler hoist every slot's 12 loads and blows the 256-register budget)
+#pragma unroll 1
+        for (int k = 0; k < LDSK; ++k) {
+          double e[NC];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) e[c] = ldata[wave][k][c][lane];
+          double r, J[5];
+          eval_corr<MODE>(e, (vmask >> (REGK + k)) & 1u, U, reg, r, J);
+          accumulate(r, J, acc);
+        }
+      } else {
+        for (int idx = threadIdx.x; idx < stride; idx += kWave * WPP) {
+          double e[NC];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) e[c] = base[(int64_t)c * stride + idx];
+          double r, J[5];
+          eval_corr<MODE>(e, idx < n, U, reg, r, J);
+          accumulate(r, J, acc);
         }
       }
-
+      wave_reduce21(acc, S);
+      if constexpr (WPP > 1) {
+        if (lane == 0) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) qc[k] = to_sgpr(qc[k]);
-      model_change = to_sgpr(model_change);
-      // one fused pass at the candidate: cost, J'J, J'r
-      PassUniforms U;
-      make_uniforms(thc, phc, qc, U);
-      double S[kNumAcc], Hc[15], gc[5], cost_c;
-      run_pass(U, S);
-      unpack(S, cost_c, Hc, gc);
-      const bool cand_ok = all_finite(cost_c, Hc, gc);
-      if (!finite_d(cost_c)) cost_c = 1.7976931348623157e308;
-      cost_c = to_sgpr(cost_c);
+          for (int j = 0; j < kNumAcc; ++j) xw[parity][wave][j] = S[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kNumAcc; ++j) {
+          double t = xw[parity][0][j];
+#pragma unroll
+          for (int w = 1; w < WPP; ++w) t += xw[parity][w][j];
+          S[j] = to_sgpr(t);
+        }
+        parity ^= 1;
+      }
+    }
 
+    // ---- sums -> cost; the scaled normal equations are only formed when the point is kept
+    double cost_c = 0.5 * S[0];
+    const bool cost_ok = finite_d(cost_c);
+    bool rest_ok = true;
+#pragma unroll
+    for (int j = 1; j < kNumAcc; ++j) rest_ok = rest_ok && finite_d(S[j]);
+
+    bool accept;
+    double rho = 0.0;
+    if (first) {
+      if (to_sgpr((int)(cost_ok && rest_ok)) == 0) {
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) slab[kQ + k] = slab[kQc + k];
+          slab[kTheta] = slab[kThetaC];
+          slab[kPhi] = slab[kPhiC];
+          slab[kCost] = cost_c;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        term = PNEC_HIP_TERM_BAD_INITIAL;
+        break;
+      }
+      // jacobi_scaling: 1 / (1 + sqrt(diag(J'J))) on the Ceres-tangent Jacobian (rotation
+      // columns = 2 x the omega columns accumulated by the pass); frozen after iteration zero
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          const double f = (i >= 2) ? 2.0 : 1.0;
+          const double hii = S[6 + tri(i, i)] * (f * f);
+          slab[kScale + i] = f * (o.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0);
+        }
+        slab[kRadius] = o.initial_trust_region_radius;
+        slab[kInvDec] = 0.5;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      accept = true;
+    } else {
+      if (!cost_ok) cost_c = 1.7976931348623157e308;
+      const double cost = slab[kCost];
       if (o.check_convergence) {
-        const double dq0 = q[0] - qc[0], dq1 = q[1] - qc[1], dq2 = q[2] - qc[2],
-                     dq3 = q[3] - qc[3];
-        const double step_norm = sqrt((theta - thc) * (theta - thc) + (phi - phc) * (phi - phc) +
-                                      dq0 * dq0 + dq1 * dq1 + dq2 * dq2 + dq3 * dq3);
-        if (to_sgpr((int)(step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)))) {
+        double dn = (slab[kTheta] - slab[kThetaC]) * (slab[kTheta] - slab[kThetaC]) +
+                    (slab[kPhi] - slab[kPhiC]) * (slab[kPhi] - slab[kPhiC]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double dq = slab[kQ + k] - slab[kQc + k];
+          dn = __builtin_fma(dq, dq, dn);
+        }
+        const double step_norm = fast_sqrt(dn);
+        if (to_sgpr((int)(step_norm <= o.parameter_tolerance * (slab[kXNorm] + o.parameter_tolerance)))) {
           term = PNEC_HIP_TERM_PARAMETER_TOL; break;
         }
         if (to_sgpr((int)(fabs(cost - cost_c) <= o.function_tolerance * cost))) {
           term = PNEC_HIP_TERM_FUNCTION_TOL; break;
         }
       }
-      const double rho = (cost - cost_c) / model_change;
-      if (to_sgpr((int)(rho > o.min_relative_decrease))) {
-        if (to_sgpr((int)cand_ok) == 0) {  // finite cost but non-finite Jacobian: Ceres fails here
-          term = PNEC_HIP_TERM_BAD_INITIAL; break;
-        }
-        theta = thc;
-        phi = phc;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) q[k] = qc[k];
-        x_norm = to_sgpr(sqrt(theta * theta + phi * phi + q[0] * q[0] + q[1] * q[1] +
-                              q[2] * q[2] + q[3] * q[3]));
-        cost = cost_c;
-        rescale(Hc, gc);
-        step_ok = 1;
-        const double c1 = 2.0 * rho - 1.0;
-        radius = radius / fmax(1.0 / 3.0, 1.0 - c1 * c1 * c1);
-        radius = to_sgpr(fmin(o.max_trust_region_radius, radius));
-        decrease_factor = 2.0;
-        reuse_diagonal = 0;
-      } else {
-        radius = to_sgpr(radius / decrease_factor);
-        decrease_factor *= 2.0;
-        reuse_diagonal = 1;
+      rho = (cost - cost_c) * fast_rcp(slab[kModel]);
+      accept = to_sgpr((int)(rho > o.min_relative_decrease)) != 0;
+      if (accept && to_sgpr((int)rest_ok) == 0) {  // finite cost, non-finite Jacobian: Ceres fails here
+        term = PNEC_HIP_TERM_BAD_INITIAL; break;
       }
     }
+
+    if (accept) {
+      // x <- candidate; park cost, x_norm and the Jacobi-scaled normal equations
+      double sc[5], gmax = 0.0;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) sc[i] = slab[kScale + i];
+      const double qa0 = slab[kQc + 0], qa1 = slab[kQc + 1], qa2 = slab[kQc + 2], qa3 = slab[kQc + 3];
+      const double tha = slab[kThetaC], pha = slab[kPhiC];
+      const double xn = fast_sqrt(tha * tha + pha * pha + qa0 * qa0 + qa1 * qa1 + qa2 * qa2 + qa3 * qa3);
+      double gsn[5], hsn[15];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        gsn[i] = S[1 + i] * sc[i];
+        gmax = fmax(gmax, fabs(S[1 + i]) * ((i >= 2) ? 2.0 : 1.0));
+      }
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = i; j < 5; ++j) hsn[tri(i, j)] = S[6 + tri(i, j)] * (sc[i] * sc[j]);
+      double new_radius = 0.0;
+      if (!first) {
+        const double c1 = 2.0 * rho - 1.0;
+        new_radius = fmin(o.max_trust_region_radius,
+                          slab[kRadius] * fast_rcp(fmax(1.0 / 3.0, 1.0 - c1 * c1 * c1)));
+      }
+      if (lane == 0) {
+        slab[kQ + 0] = qa0; slab[kQ + 1] = qa1; slab[kQ + 2] = qa2; slab[kQ + 3] = qa3;
+        slab[kTheta] = tha;
+        slab[kPhi] = pha;
+        slab[kCost] = cost_c;
+        slab[kXNorm] = xn;
+        slab[kGmax] = gmax;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) slab[kGs + i] = gsn[i];
+#pragma unroll
+        for (int i = 0; i < 15; ++i) slab[kHs + i] = hsn[i];
+        if (!first) {
+          slab[kRadius] = new_radius;
+          slab[kInvDec] = 0.5;
+        }
+      }
+      step_ok = 1;
+      reuse_diagonal = 0;
+      first = 0;
+    } else {
+      if (lane == 0) {
+        const double inv_dec = slab[kInvDec];
+        slab[kRadius] = slab[kRadius] * inv_dec;
+        slab[kInvDec] = 0.5 * inv_dec;
+      }
+      reuse_diagonal = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   }
 
-finish:
   // ---- PNECCeres::Result(): pnec_ceres.cc:201-207
   if (threadIdx.x == 0) {
-    const double qn = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double q0 = slab[kQ + 0], q1 = slab[kQ + 1], q2 = slab[kQ + 2], q3 = slab[kQ + 3];
+    const double qn = fast_rsqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
     if (a.out_q) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) a.out_q[4 * s + k] = q[k] * qn;
+      a.out_q[4 * s + 0] = q0 * qn;
+      a.out_q[4 * s + 1] = q1 * qn;
+      a.out_q[4 * s + 2] = q2 * qn;
+      a.out_q[4 * s + 3] = q3 * qn;
     }
     if (a.out_t) {
       double st, ct, sp, cp;
-      sincos(theta, &st, &ct);
-      sincos(phi, &sp, &cp);
+      sincos_bounded(slab[kTheta], st, ct);
+      sincos_bounded(slab[kPhi], sp, cp);
       a.out_t[3 * s + 0] = st * cp;
       a.out_t[3 * s + 1] = st * sp;
       a.out_t[3 * s + 2] = ct;
     }
-    if (a.out_cost) a.out_cost[s] = cost;
+    if (a.out_cost) a.out_cost[s] = slab[kCost];
     if (a.out_iterations) a.out_iterations[s] = iteration;
     if (a.out_status) a.out_status[s] = term;
   }

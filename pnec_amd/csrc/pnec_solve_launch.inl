@@ -7,22 +7,26 @@ namespace pnec_hip {
 #define PNEC_CAT_(a, b) a##b
 #define PNEC_CAT(a, b) PNEC_CAT_(a, b)
 
-hipError_t PNEC_CAT(launch_solve_mode_, PNEC_SOLVE_MODE)(int cpl, int wpp, bool resident,
+hipError_t PNEC_CAT(launch_solve_mode_, PNEC_SOLVE_MODE)(int cpl, int wpp, int ldsk, bool resident,
                                                          const SolveArgs &args,
                                                          hipStream_t stream) {
   constexpr int MODE = PNEC_SOLVE_MODE;
   const dim3 grid((unsigned)args.n_solves);
   if (!resident) {
     // streaming fallback for pairs larger than any register-resident geometry
-    hipLaunchKernelGGL((lm_solve_kernel<MODE, 1, kStreamWaves, false>), grid, dim3(kWave * kStreamWaves), 0, stream,
+    hipLaunchKernelGGL((lm_solve_kernel<MODE, 1, kStreamWaves, 0, false>), grid, dim3(kWave * kStreamWaves), 0, stream,
                        args);
     return hipGetLastError();
   }
-#define PNEC_LAUNCH_CASE(CPL, WPP)                                                          \
-  if (cpl == CPL && wpp == WPP) {                                                           \
-    hipLaunchKernelGGL((lm_solve_kernel<MODE, CPL, WPP, true>), grid, dim3(kWave * WPP), 0, \
-                       stream, args);                                                       \
-    return hipGetLastError();                                                               \
+#define PNEC_LAUNCH_CASE(CPL, WPP, LDSK)                                                          \
+  if (cpl == CPL && wpp == WPP && ldsk == LDSK) {                                                   \
+    if constexpr (geometry_ok(MODE, CPL, WPP, LDSK)) {                                              \
+      hipLaunchKernelGGL((lm_solve_kernel<MODE, CPL, WPP, LDSK, true>), grid, dim3(kWave * WPP), 0, \
+                         stream, args);                                                             \
+      return hipGetLastError();                                                                     \
+    } else {                                                                                        \
+      return hipErrorInvalidConfiguration;                                                          \
+    }                                                                                               \
   }
   PNEC_FOR_EACH_GEOMETRY(PNEC_LAUNCH_CASE)
 #undef PNEC_LAUNCH_CASE

@@ -47,7 +47,7 @@ def test_option_defaults_match_ceres_defaults_and_oracle(oracle):
         assert getattr(o, name) == getattr(r, name), name
     assert (o.max_num_iterations, o.function_tolerance, o.parameter_tolerance) == (50, 1e-6, 1e-8)
     assert (o.gradient_tolerance, o.initial_trust_region_radius) == (1e-10, 1e4)
-    assert C.sizeof(capi.Options) == 6 * 4 + 9 * 8
+    assert C.sizeof(capi.Options) == 8 * 4 + 9 * 8
 
 
 def test_enum_values_shared_with_oracle(oracle):
