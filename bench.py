@@ -190,6 +190,16 @@ def main():
         achieved_gbs = payload / (kernel_ms * 1e-3) / 1e9
         flops = FLOP_PER_CORR_PASS * batch.num_correspondences * passes
         valu_tflops = flops / (kernel_ms * 1e-3) / 1e12
+        traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes, if they
+        try:             # were taken on this very workload and geometry
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            w = tj["workload"]
+            if (w["pairs"], w["corr"], w["iters"]) == (args.pairs, args.corr, args.iters) and \
+                    w["geometry"] == [launch["corr_per_lane"], launch["waves_per_pair"], launch["lds_corr_per_lane"]]:
+                traffic = tj["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
+        iters_done = out.iterations.to(torch.float64)
         line = {
             "metric": "PNEC pose solves/sec (512 corr, 10 GN iters)",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
@@ -199,13 +209,16 @@ def main():
             "config": {"workload": "configs[1]: batch of 100k simulated frame pairs x 512 "
                                    "anisotropic-covariance correspondences per GPU",
                        "pairs_per_gpu": args.pairs, "correspondences": args.corr,
-                       "lm_iterations": args.iters, "residual": "PNEC target frame",
+                       "lm_iterations": args.iters,
+                       "lm_iterations_done_min_mean_max": [float(iters_done.min()), float(iters_done.mean()),
+                                                           float(iters_done.max())],
+                       "residual": "PNEC target frame",
                        "sharding": f"independent pairs, {world} rank(s), one RCCL gather of result records",
                        "launch": launch},
             "roofline": {
                 "bound": "hbm", "kernel": "lm_solve_kernel<TARGET>",
                 "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": payload,
                 "note": "register-resident design: the payload (96 B/correspondence) is read from HBM "

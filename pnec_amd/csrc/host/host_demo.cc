@@ -1,0 +1,44 @@
+// host_demo.cc -- compiled into a small executable: run_simulation's call pattern
+// (src/run_simulation.cc:74-86) for one synthetic pair through the C++ facade; used by the GPU
+// tests to exercise the facade without Python.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "pnec_host.h"
+
+int main(int argc, char **argv) {
+  const int n = argc > 1 ? std::atoi(argv[1]) : 100;
+  std::mt19937_64 gen(1);
+  std::uniform_real_distribution<double> U(0.0, 1.0);
+  std::normal_distribution<double> G(0.0, 1.0);
+  // ground truth
+  const pnec::Quaterniond qgt = pnec::Quaterniond(0.97, 0.1, -0.15, 0.12).normalized();
+  const pnec::Matrix3d Rgt = qgt.toRotationMatrix();
+  const pnec::Vector3d tgt = pnec::Vector3d(0.3, -0.2, 0.9);
+  pnec::bearingVectors_t b1(n), b2(n);
+  std::vector<pnec::Matrix3d> covs(n);
+  for (int i = 0; i < n; ++i) {
+    const double d = 2.0 + 3.0 * U(gen);
+    const pnec::Vector3d P((U(gen) - 0.5) * d, (U(gen) - 0.5) * 1.5 * d, d);
+    pnec::Vector3d P2 = Rgt.transpose() * (P - tgt);
+    const double s = 1e-3;
+    P2 = P2 + pnec::Vector3d(s * G(gen), s * G(gen), 0.0) * P2[2];
+    b1[i] = P.normalized();
+    b2[i] = P2.normalized();
+    covs[i] = pnec::Matrix3d::Identity() * (s * s);
+  }
+  pnec::rel_pose_estimation::Options options;
+  options.use_ransac_ = false;
+  options.weighted_iterations_ = 0;
+  pnec::rel_pose_estimation::PNEC pnec_solver(options);
+  const pnec::SE3d init(pnec::Quaterniond(0.975, 0.1, -0.14, 0.115).normalized().toRotationMatrix(),
+                        pnec::Vector3d(0.28, -0.22, 0.92).normalized());
+  const pnec::SE3d sol = pnec_solver.Solve(b1, b2, covs, init);
+  const double e0 = pnec::common::RotationalDifference(init.rotationMatrix(), Rgt);
+  const double e1 = pnec::common::RotationalDifference(sol.rotationMatrix(), Rgt);
+  const double te = pnec::common::TranslationalDifference(sol.translation(), tgt);
+  const double cost = pnec::common::CostFunction(b1, b2, covs, sol);
+  std::printf("n=%d rot_err_init_deg=%.6f rot_err_deg=%.6f t_err_deg=%.6f cost=%.6f\n", n, e0, e1, te, cost);
+  return (e1 < e0 && e1 < 0.1) ? 0 : 1;
+}

@@ -1,0 +1,329 @@
+// pnec_host.cc -- implementation of the host facade over the C ABI.  See pnec_host.h.
+#include "pnec_host.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace pnec {
+namespace {
+
+void Check(int rc) {
+  if (rc != 0) throw HipError(rc, std::string("libpnec_hip: ") + pnec_hip_last_error());
+}
+
+// RAII over pnec_hip_problem
+struct Problem {
+  pnec_hip_problem *p = nullptr;
+  Problem(int device, int mode, const std::vector<int64_t> &offsets) {
+    Check(pnec_hip_problem_create(device, mode, (int64_t)offsets.size() - 1, offsets.data(), &p));
+  }
+  ~Problem() { pnec_hip_problem_destroy(p); }
+  Problem(const Problem &) = delete;
+  Problem &operator=(const Problem &) = delete;
+};
+
+Vector3d TranslationFromAngles(double theta, double phi) {
+  return Vector3d(std::sin(theta) * std::cos(phi), std::sin(theta) * std::sin(phi), std::cos(theta));
+}
+
+// One solve through the ABI: host arrays in the reference's layout in, pose + summary out.
+void SolveOne(int mode, const optimization::SolverOptions &options, const std::vector<Vector3d> &b1,
+              const std::vector<Vector3d> &b2, const std::vector<Matrix3d> *covs,
+              const std::vector<Matrix3d> *covs_host, double reg, Quaterniond &q, double &theta,
+              double &phi, optimization::Summary &summary) {
+  if (b1.size() != b2.size()) throw std::invalid_argument("bvs_1 and bvs_2 differ in size");
+  if (covs && covs->size() != b1.size()) throw std::invalid_argument("covs and bvs differ in size");
+  if (covs_host && covs_host->size() != b1.size()) throw std::invalid_argument("covs_1 and bvs differ in size");
+  const std::vector<int64_t> offsets = {0, (int64_t)b1.size()};
+  Problem prob(options.device, mode, offsets);
+  Check(pnec_hip_problem_fill(prob.p, 0, 1, b1.empty() ? nullptr : b1[0].data(),
+                              b2.empty() ? nullptr : b2[0].data(),
+                              covs && !covs->empty() ? (*covs)[0].data() : nullptr,
+                              covs_host && !covs_host->empty() ? (*covs_host)[0].data() : nullptr,
+                              PNEC_HIP_MEM_HOST, nullptr));
+  const Vector3d t0 = TranslationFromAngles(theta, phi);
+  const pnec_hip_options o = options.ToHip();
+  double out_q[4], out_t[3], cost = 0.0;
+  int32_t it = 0, st = 0;
+  Check(pnec_hip_solve(prob.p, q.coeffs(), t0.data(), 1, nullptr, reg, &o, out_q, out_t, &cost, &it,
+                       &st, PNEC_HIP_MEM_HOST, nullptr));
+  q = Quaterniond(out_q[3], out_q[0], out_q[1], out_q[2]);
+  common::AnglesFromVec(Vector3d(out_t[0], out_t[1], out_t[2]), theta, phi);
+  summary.final_cost = cost;
+  summary.iterations = it;
+  summary.termination = st;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ common
+namespace common {
+
+Matrix3d SkewFromVector(const Vector3d &v) {
+  Matrix3d S;
+  S(0, 1) = -v[2]; S(0, 2) = v[1];
+  S(1, 0) = v[2];  S(1, 2) = -v[0];
+  S(2, 0) = -v[1]; S(2, 1) = v[0];
+  return S;
+}
+
+void AnglesFromVec(const Vector3d &vector, double &theta, double &phi) {
+  const double n = vector.norm();
+  if (n == 0.0) {
+    theta = 0.0;
+    phi = 0.0;
+    return;
+  }
+  theta = std::acos(vector[2] / n);
+  phi = (std::fabs(theta) < 1e-10) ? 0.0 : std::atan2(vector[1] / n, vector[0] / n);
+}
+
+double RotationalDifference(const Matrix3d &rotation_1, const Matrix3d &rotation_2) {
+  const Quaterniond q = Quaterniond(rotation_1.transpose() * rotation_2).normalized();
+  const double n = std::sqrt(q.x() * q.x() + q.y() * q.y() + q.z() * q.z());
+  const double theta = (q.w() < 0.0) ? 2.0 * std::atan2(-n, -q.w()) : 2.0 * std::atan2(n, q.w());
+  return std::fabs(theta) * 180.0 / M_PI;
+}
+
+double TranslationalDifference(const Vector3d &translation_1, const Vector3d &translation_2,
+                               bool both_directions) {
+  const double n1 = translation_1.norm(), n2 = translation_2.norm();
+  if (n1 < 1e-10) return 90.0;  // the reference tests translation_1 twice (common.cc:220)
+  const double c = translation_1.dot(translation_2) / (n1 * n2);
+  double error = std::acos(c);
+  if (both_directions) error = std::min(error, std::acos(-c));
+  return error * 180.0 / M_PI;
+}
+
+double CostFunction(const bearingVectors_t &bvs_1, const bearingVectors_t &bvs_2,
+                    const std::vector<Matrix3d> &covs, const SE3d &camera_pose) {
+  const std::vector<int64_t> offsets = {0, (int64_t)bvs_1.size()};
+  Problem prob(0, PNEC_HIP_MODE_TARGET, offsets);
+  Check(pnec_hip_problem_fill(prob.p, 0, 1, bvs_1[0].data(), bvs_2[0].data(), covs[0].data(), nullptr,
+                              PNEC_HIP_MEM_HOST, nullptr));
+  const Quaterniond q(camera_pose.rotationMatrix());
+  double out = 0.0;
+  Check(pnec_hip_cost_function(prob.p, q.coeffs(), camera_pose.translation().data(), &out,
+                               PNEC_HIP_MEM_HOST, nullptr));
+  return out;
+}
+
+}  // namespace common
+
+// -------------------------------------------------------------------------------- optimization
+namespace optimization {
+
+pnec_hip_options SolverOptions::ToHip() const {
+  pnec_hip_options o;
+  pnec_hip_default_options(&o);
+  o.max_num_iterations = max_num_iterations;
+  o.max_num_consecutive_invalid_steps = max_num_consecutive_invalid_steps;
+  o.jacobi_scaling = jacobi_scaling ? 1 : 0;
+  o.function_tolerance = function_tolerance;
+  o.gradient_tolerance = gradient_tolerance;
+  o.parameter_tolerance = parameter_tolerance;
+  o.initial_trust_region_radius = initial_trust_region_radius;
+  o.max_trust_region_radius = max_trust_region_radius;
+  o.min_trust_region_radius = min_trust_region_radius;
+  o.min_relative_decrease = min_relative_decrease;
+  o.min_lm_diagonal = min_lm_diagonal;
+  o.max_lm_diagonal = max_lm_diagonal;
+  return o;
+}
+
+PNECCeres::PNECCeres() : orientation_(1.0, 0.0, 0.0, 0.0), theta_(0.0), phi_(0.0) {}
+PNECCeres::PNECCeres(const SE3d &init, const SolverOptions &options) : options_(options) {
+  orientation_ = init.unit_quaternion();
+  common::AnglesFromVec(init.translation(), theta_, phi_);
+}
+// (the reference drops `options` in this overload, pnec_ceres.cc:57-59; kept here)
+PNECCeres::PNECCeres(const Quaterniond &orientation, double theta, double phi,
+                     const SolverOptions &options)
+    : orientation_(orientation), theta_(theta), phi_(phi), options_(options) {}
+PNECCeres::PNECCeres(const Quaterniond &orientation, const Vector3d &translation,
+                     const SolverOptions &options)
+    : orientation_(orientation), options_(options) {
+  common::AnglesFromVec(translation, theta_, phi_);
+}
+PNECCeres::~PNECCeres() {}
+
+void PNECCeres::Run(int mode, const std::vector<Vector3d> &b1, const std::vector<Vector3d> &b2,
+                    const std::vector<Matrix3d> *covs, const std::vector<Matrix3d> *covs_host,
+                    double reg) {
+  SolveOne(mode, options_, b1, b2, covs, covs_host, reg, orientation_, theta_, phi_, summary_);
+}
+
+void PNECCeres::Optimize(const std::vector<Vector3d> &bvs_1, const std::vector<Vector3d> &bvs_2,
+                         const std::vector<Matrix3d> &covs, double regularization,
+                         common::NoiseFrame noise_frame) {
+  Run(noise_frame == common::Host ? PNEC_HIP_MODE_HOST : PNEC_HIP_MODE_TARGET, bvs_1, bvs_2, &covs,
+      nullptr, regularization);
+}
+
+void PNECCeres::Optimize(const std::vector<Vector3d> &bvs_1, const std::vector<Vector3d> &bvs_2,
+                         const std::vector<Matrix3d> &covs_1, const std::vector<Matrix3d> &covs_2,
+                         double regularization) {
+  // PNECSymmetrical(bv_1, bv_2, cov_1, cov_2): cov_2 rides with R Sigma R', cov_1 with [R f2]x
+  Run(PNEC_HIP_MODE_SYM, bvs_1, bvs_2, &covs_2, &covs_1, regularization);
+}
+
+void PNECCeres::InitValues(const Quaterniond orientation, double theta, double phi) {
+  orientation_ = orientation;
+  theta_ = theta;
+  phi_ = phi;
+}
+void PNECCeres::InitValues(const SE3d &init) {
+  orientation_ = init.unit_quaternion();
+  common::AnglesFromVec(init.translation(), theta_, phi_);
+}
+void PNECCeres::InitValues(const Quaterniond &orientation, const Vector3d &translation) {
+  orientation_ = orientation;
+  common::AnglesFromVec(translation, theta_, phi_);
+}
+void PNECCeres::SetOptions(const SolverOptions &options) { options_ = options; }
+Matrix3d PNECCeres::Orientation() const { return orientation_.normalized().toRotationMatrix(); }
+Vector3d PNECCeres::Translation() const { return TranslationFromAngles(theta_, phi_); }
+SE3d PNECCeres::Result() const { return SE3d(Orientation(), Translation()); }
+
+NECCeres::NECCeres() : orientation_(1.0, 0.0, 0.0, 0.0), theta_(0.0), phi_(0.0) {}
+NECCeres::NECCeres(const SE3d &init, const SolverOptions &options) : options_(options) {
+  orientation_ = init.unit_quaternion();
+  common::AnglesFromVec(init.translation(), theta_, phi_);
+}
+NECCeres::NECCeres(const Quaterniond &orientation, double theta, double phi, const SolverOptions &options)
+    : orientation_(orientation), theta_(theta), phi_(phi), options_(options) {}
+NECCeres::NECCeres(const Quaterniond &orientation, const Vector3d &translation,
+                   const SolverOptions &options)
+    : orientation_(orientation), options_(options) {
+  common::AnglesFromVec(translation, theta_, phi_);
+}
+NECCeres::~NECCeres() {}
+void NECCeres::Optimize(const std::vector<Vector3d> &bvs_1, const std::vector<Vector3d> &bvs_2) {
+  SolveOne(PNEC_HIP_MODE_NEC, options_, bvs_1, bvs_2, nullptr, nullptr, 0.0, orientation_, theta_,
+           phi_, summary_);
+}
+void NECCeres::InitValues(const Quaterniond orientation, double theta, double phi) {
+  orientation_ = orientation;
+  theta_ = theta;
+  phi_ = phi;
+}
+void NECCeres::InitValues(const SE3d &init) {
+  orientation_ = init.unit_quaternion();
+  common::AnglesFromVec(init.translation(), theta_, phi_);
+}
+void NECCeres::InitValues(const Quaterniond &orientation, const Vector3d &translation) {
+  orientation_ = orientation;
+  common::AnglesFromVec(translation, theta_, phi_);
+}
+void NECCeres::SetOptions(const SolverOptions &options) { options_ = options; }
+Matrix3d NECCeres::Orientation() const { return orientation_.normalized().toRotationMatrix(); }
+Vector3d NECCeres::Translation() const { return TranslationFromAngles(theta_, phi_); }
+SE3d NECCeres::Result() const { return SE3d(Orientation(), Translation()); }
+
+}  // namespace optimization
+
+// -------------------------------------------------------------------------- rel_pose_estimation
+namespace rel_pose_estimation {
+
+PNEC::PNEC(const Options &options) : options_(options) {}
+PNEC::~PNEC() {}
+
+SE3d PNEC::Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                 const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose) {
+  std::vector<int> inliers;
+  return Solve(bvs1, bvs2, projected_covs, initial_pose, inliers);
+}
+
+SE3d PNEC::Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                 const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose,
+                 std::vector<int> &inliers) {
+  // pnec.cc:77-124.  The reference always runs the NEC eigensolver first; its result is only
+  // consumed when use_ransac_, use_nec_ or weighted_iterations_ >= 1 -- those need the eigensolver
+  // stages, which are not built yet.
+  if (options_.use_ransac_ || options_.use_nec_ || options_.weighted_iterations_ >= 1)
+    throw std::logic_error(
+        "PNEC::Solve: this option set needs the NEC eigensolver / RANSAC / weighted eigensolver "
+        "stages (SURVEY.md 8f 'next' rows), which are not built yet; use use_ransac_=false, "
+        "use_nec_=false, weighted_iterations_=0, or call CeresSolver/NECCeresSolver directly");
+  inliers.clear();
+  if (!options_.use_ceres_) return initial_pose;
+  return CeresSolver(bvs1, bvs2, projected_covs, initial_pose);
+}
+
+SE3d PNEC::Eigensolver(const bearingVectors_t &, const bearingVectors_t &, const SE3d &,
+                       std::vector<int> &) {
+  throw std::logic_error("PNEC::Eigensolver: NEC eigensolver + RANSAC not built yet (SURVEY.md 8f rank 2)");
+}
+SE3d PNEC::WeightedEigensolver(const bearingVectors_t &, const bearingVectors_t &,
+                               const std::vector<Matrix3d> &, const SE3d &) {
+  throw std::logic_error("PNEC::WeightedEigensolver: weighted eigensolver + SCF not built yet (SURVEY.md 8f rank 1)");
+}
+
+SE3d PNEC::CeresSolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                       const std::vector<Matrix3d> &projected_covariances, const SE3d &initial_pose) {
+  return CeresSolverFull(bvs1, bvs2, projected_covariances, options_.regularization_, initial_pose);
+}
+
+SE3d PNEC::CeresSolverFull(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                           const std::vector<Matrix3d> &projected_covariances, double regularization,
+                           const SE3d &initial_pose) {
+  // default-constructed optimiser and Target frame, like the reference (pnec.cc:355,366: it ignores
+  // Options::ceres_options_ and noise_frame_)
+  optimization::PNECCeres optimizer;
+  optimizer.InitValues(Quaterniond(initial_pose.rotationMatrix()), initial_pose.translation());
+  optimizer.Optimize(bvs1, bvs2, projected_covariances, regularization);
+  return optimizer.Result();
+}
+
+SE3d PNEC::NECCeresSolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                          const SE3d &initial_pose) {
+  optimization::NECCeres optimizer;
+  optimizer.InitValues(Quaterniond(initial_pose.rotationMatrix()), initial_pose.translation());
+  optimizer.Optimize(bvs1, bvs2);
+  return optimizer.Result();
+}
+
+std::vector<SE3d> PNEC::CeresSolverBatch(const std::vector<FramePair> &pairs,
+                                         std::vector<optimization::Summary> *summaries) {
+  const int64_t B = (int64_t)pairs.size();
+  std::vector<int64_t> offsets(B + 1, 0);
+  for (int64_t p = 0; p < B; ++p) {
+    if (pairs[p].bvs1.size() != pairs[p].bvs2.size() || pairs[p].bvs1.size() != pairs[p].projected_covs.size())
+      throw std::invalid_argument("FramePair arrays differ in size");
+    offsets[p + 1] = offsets[p] + (int64_t)pairs[p].bvs1.size();
+  }
+  std::vector<Vector3d> b1, b2;
+  std::vector<Matrix3d> cv;
+  b1.reserve(offsets[B]); b2.reserve(offsets[B]); cv.reserve(offsets[B]);
+  std::vector<double> q0(4 * B), t0(3 * B);
+  for (int64_t p = 0; p < B; ++p) {
+    b1.insert(b1.end(), pairs[p].bvs1.begin(), pairs[p].bvs1.end());
+    b2.insert(b2.end(), pairs[p].bvs2.begin(), pairs[p].bvs2.end());
+    cv.insert(cv.end(), pairs[p].projected_covs.begin(), pairs[p].projected_covs.end());
+    const Quaterniond q(pairs[p].initial_pose.rotationMatrix());
+    std::memcpy(&q0[4 * p], q.coeffs(), 4 * sizeof(double));
+    std::memcpy(&t0[3 * p], pairs[p].initial_pose.translation().data(), 3 * sizeof(double));
+  }
+  const optimization::SolverOptions so;  // defaults, as CeresSolver does
+  Problem prob(so.device, PNEC_HIP_MODE_TARGET, offsets);
+  if (offsets[B] > 0)
+    Check(pnec_hip_problem_fill(prob.p, 0, B, b1[0].data(), b2[0].data(), cv[0].data(), nullptr,
+                                PNEC_HIP_MEM_HOST, nullptr));
+  std::vector<double> oq(4 * B), ot(3 * B), oc(B);
+  std::vector<int32_t> oi(B), os(B);
+  const pnec_hip_options o = so.ToHip();
+  if (B > 0)
+    Check(pnec_hip_solve(prob.p, q0.data(), t0.data(), 1, nullptr, options_.regularization_, &o, oq.data(),
+                         ot.data(), oc.data(), oi.data(), os.data(), PNEC_HIP_MEM_HOST, nullptr));
+  std::vector<SE3d> out(B);
+  if (summaries) summaries->resize(B);
+  for (int64_t p = 0; p < B; ++p) {
+    out[p] = SE3d(Quaterniond(oq[4 * p + 3], oq[4 * p], oq[4 * p + 1], oq[4 * p + 2]).toRotationMatrix(),
+                  Vector3d(ot[3 * p], ot[3 * p + 1], ot[3 * p + 2]));
+    if (summaries) (*summaries)[p] = {oc[p], oi[p], os[p]};
+  }
+  return out;
+}
+
+}  // namespace rel_pose_estimation
+}  // namespace pnec

@@ -1,0 +1,204 @@
+// pnec_host.h -- host C++ facade: the reference's class / method names for the hot path, on top
+// of the C ABI (include/pnec_hip.h).  No arithmetic of the optimisation lives here: every
+// Optimize()/Solve() is a pnec_hip_* call that runs on the MI355X; there is NO CPU fallback (a
+// missing device or library is a thrown std::runtime_error, loudly).
+//
+// Mirrors (reference file:line):
+//   pnec::common::{NoiseFrame, SkewFromVector, AnglesFromVec, RotationalDifference,
+//                  TranslationalDifference, CostFunction}      include/common/common.h:57-120
+//   pnec::optimization::PNECCeres                               include/optimization/pnec_ceres.h:48-89
+//   pnec::optimization::NECCeres                                include/optimization/nec_ceres.h:46-79
+//   pnec::rel_pose_estimation::{Options, PNEC}                  include/rel_pose_estimation/pnec_config.h:46-65,
+//                                                               include/rel_pose_estimation/pnec.h:48-114
+// Batch entry points (SolveBatch / OptimizeBatch) are additions: the reference solves one pair per
+// call; thousands of pairs per call is what the device is for.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "pnec_hip.h"
+#include "pnec_types.h"
+
+namespace pnec {
+namespace common {
+
+enum NoiseFrame { Host, Target, Both };  // common.h:60
+
+Matrix3d SkewFromVector(const Vector3d &vector);                       // common.cc:96-101
+void AnglesFromVec(const Vector3d &vector, double &theta, double &phi);  // common.cc:103-116
+double RotationalDifference(const Matrix3d &rotation_1, const Matrix3d &rotation_2);  // common.cc:210-214 (deg)
+double TranslationalDifference(const Vector3d &translation_1, const Vector3d &translation_2,
+                               bool both_directions = true);           // common.cc:216-235 (deg)
+// common.cc:237-259, evaluated on the device
+double CostFunction(const bearingVectors_t &bvs_1, const bearingVectors_t &bvs_2,
+                    const std::vector<Matrix3d> &covs, const SE3d &camera_pose);
+
+}  // namespace common
+
+namespace optimization {
+
+// The ceres::Solver::Options fields this path honours (Ceres 2.x defaults).
+struct SolverOptions {
+  int max_num_iterations = 50;
+  double function_tolerance = 1e-6;
+  double gradient_tolerance = 1e-10;
+  double parameter_tolerance = 1e-8;
+  double initial_trust_region_radius = 1e4;
+  double max_trust_region_radius = 1e16;
+  double min_trust_region_radius = 1e-32;
+  double min_relative_decrease = 1e-3;
+  double min_lm_diagonal = 1e-6;
+  double max_lm_diagonal = 1e32;
+  bool jacobi_scaling = true;
+  int max_num_consecutive_invalid_steps = 5;
+  int device = 0;  // which GPU
+  pnec_hip_options ToHip() const;
+};
+
+// What ceres::Solver::Summary would have told (the reference stores it and never reads it).
+struct Summary {
+  double final_cost = 0.0;  // 1/2 sum r^2
+  int iterations = 0;
+  int termination = PNEC_HIP_TERM_MAX_ITERATIONS;  // pnec_hip_termination
+};
+
+class PNECCeres {
+ public:
+  PNECCeres();
+  PNECCeres(const SE3d &init, const SolverOptions &options = SolverOptions());
+  PNECCeres(const Quaterniond &orientation, double theta, double phi,
+            const SolverOptions &options = SolverOptions());
+  PNECCeres(const Quaterniond &orientation, const Vector3d &translation,
+            const SolverOptions &options = SolverOptions());
+  ~PNECCeres();
+
+  void Optimize(const std::vector<Vector3d> &bvs_1, const std::vector<Vector3d> &bvs_2,
+                const std::vector<Matrix3d> &covs, double regularization,
+                common::NoiseFrame noise_frame = common::Target);
+  void Optimize(const std::vector<Vector3d> &bvs_1, const std::vector<Vector3d> &bvs_2,
+                const std::vector<Matrix3d> &covs_1, const std::vector<Matrix3d> &covs_2,
+                double regularization);
+
+  void InitValues(const Quaterniond orientation, double theta, double phi);
+  void InitValues(const SE3d &init);
+  void InitValues(const Quaterniond &orientation, const Vector3d &translation);
+  void SetOptions(const SolverOptions &options);
+
+  Matrix3d Orientation() const;
+  Vector3d Translation() const;
+  SE3d Result() const;
+  const Summary &summary() const { return summary_; }
+
+ private:
+  void Run(int mode, const std::vector<Vector3d> &b1, const std::vector<Vector3d> &b2,
+           const std::vector<Matrix3d> *covs, const std::vector<Matrix3d> *covs_host, double reg);
+  Quaterniond orientation_;
+  double theta_, phi_;
+  SolverOptions options_;
+  Summary summary_;
+};
+
+class NECCeres {
+ public:
+  NECCeres();
+  NECCeres(const SE3d &init, const SolverOptions &options = SolverOptions());
+  NECCeres(const Quaterniond &orientation, double theta, double phi,
+           const SolverOptions &options = SolverOptions());
+  NECCeres(const Quaterniond &orientation, const Vector3d &translation,
+           const SolverOptions &options = SolverOptions());
+  ~NECCeres();
+
+  void Optimize(const std::vector<Vector3d> &bvs_1, const std::vector<Vector3d> &bvs_2);
+  void InitValues(const Quaterniond orientation, double theta, double phi);
+  void InitValues(const SE3d &init);
+  void InitValues(const Quaterniond &orientation, const Vector3d &translation);
+  void SetOptions(const SolverOptions &options);
+  Matrix3d Orientation() const;
+  Vector3d Translation() const;
+  SE3d Result() const;
+  const Summary &summary() const { return summary_; }
+
+ private:
+  Quaterniond orientation_;
+  double theta_, phi_;
+  SolverOptions options_;
+  Summary summary_;
+};
+
+}  // namespace optimization
+
+namespace rel_pose_estimation {
+
+struct Options {  // pnec_config.h:46-65, same names and defaults
+  bool use_nec_ = false;
+  common::NoiseFrame noise_frame_ = common::Target;
+  double regularization_ = 1.0e-13;
+  size_t weighted_iterations_ = 10;
+  bool use_scf_ = true;
+  bool use_ceres_ = true;
+  optimization::SolverOptions ceres_options_ = optimization::SolverOptions();
+  bool use_ransac_ = true;
+  int max_ransac_iterations_ = 5000;
+  int ransac_sample_size_ = 10;
+  int min_matches_ = 30;
+  int min_inliers_ = 10;
+  int min_matches_further_ = 20;
+};
+
+// One frame pair of a batch, in the reference's argument shapes.
+struct FramePair {
+  bearingVectors_t bvs1, bvs2;
+  std::vector<Matrix3d> projected_covs;
+  SE3d initial_pose;
+};
+
+class PNEC {
+ public:
+  PNEC() {}
+  explicit PNEC(const Options &options);
+  ~PNEC();
+
+  // pnec.cc:69-124.  The eigensolver stages (NEC-ES + RANSAC, weighted ES + SCF) are SURVEY 8(f)
+  // "next" rows: option sets that need them throw std::logic_error naming the missing stage;
+  // {use_ransac_=false, use_nec_=false, weighted_iterations_=0} runs initial_pose -> CeresSolver
+  // exactly as the reference does.
+  SE3d Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+             const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose);
+  SE3d Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+             const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose,
+             std::vector<int> &inliers);
+
+  SE3d Eigensolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                   const SE3d &initial_pose, std::vector<int> &inliers);          // pnec.cc:231 (next row)
+  SE3d WeightedEigensolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                           const std::vector<Matrix3d> &projected_covariances,
+                           const SE3d &initial_pose);                            // pnec.cc:283 (next row)
+  SE3d CeresSolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                   const std::vector<Matrix3d> &projected_covariances,
+                   const SE3d &initial_pose);                                    // pnec.cc:350-370
+  SE3d CeresSolverFull(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                       const std::vector<Matrix3d> &projected_covariances, double regularization,
+                       const SE3d &initial_pose);                                // pnec.cc:372-392
+  SE3d NECCeresSolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                      const SE3d &initial_pose);                                 // pnec.cc:394-411
+
+  // Addition: CeresSolver for many pairs in one device launch (ragged sizes allowed).
+  std::vector<SE3d> CeresSolverBatch(const std::vector<FramePair> &pairs,
+                                     std::vector<optimization::Summary> *summaries = nullptr);
+
+ private:
+  Options options_;
+};
+
+}  // namespace rel_pose_estimation
+
+// thrown when the HIP side reports an error (no device, bad argument, launch failure)
+struct HipError : std::runtime_error {
+  int code;
+  HipError(int c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+
+}  // namespace pnec

@@ -1,0 +1,134 @@
+// pypnec.cpp -- the reference's pybind module surface for the hot path (python/pypnec.cpp:50-82,
+// 244-258): pypnec.pyceres / pypnec.pyceresnec with the same call signatures, served by the
+// MI355X solver through the host facade.  The KLT / image toy functions of the reference module
+// are out of scope (image domain, hard-coded author paths at pypnec.cpp:95-99).
+//
+//   pyceres(host_bvs, target_bvs, host_covariances, target_covariances, init_pose, regularization) -> 4x4
+//   pyceresnec(host_bvs, target_bvs, init_pose) -> 4x4
+// host_bvs/target_bvs: sequence of 3-vectors (or an [N,3] array); covariances: sequence of 3x3
+// (or [N,3,3]); init_pose: 4x4.  Addition: ceres_solver_batch over ragged lists of pairs.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <vector>
+
+#include "pnec_host.h"
+
+namespace py = pybind11;
+using arr = py::array_t<double, py::array::c_style | py::array::forcecast>;
+
+namespace {
+
+std::vector<pnec::Vector3d> ToBearings(const arr &a, const char *name) {
+  if (a.ndim() != 2 || a.shape(1) != 3) throw std::invalid_argument(std::string(name) + " must be [N,3]");
+  std::vector<pnec::Vector3d> out((size_t)a.shape(0));
+  auto r = a.unchecked<2>();
+  for (py::ssize_t i = 0; i < a.shape(0); ++i) out[(size_t)i] = pnec::Vector3d(r(i, 0), r(i, 1), r(i, 2));
+  return out;
+}
+
+std::vector<pnec::Matrix3d> ToCovariances(const arr &a, const char *name) {
+  if (a.ndim() != 3 || a.shape(1) != 3 || a.shape(2) != 3)
+    throw std::invalid_argument(std::string(name) + " must be [N,3,3]");
+  std::vector<pnec::Matrix3d> out((size_t)a.shape(0));
+  auto r = a.unchecked<3>();
+  for (py::ssize_t i = 0; i < a.shape(0); ++i)
+    for (int row = 0; row < 3; ++row)
+      for (int col = 0; col < 3; ++col) out[(size_t)i](row, col) = r(i, row, col);
+  return out;
+}
+
+// Sophus::SE3d(Quaterniond(R).normalized().toRotationMatrix(), t)   (pypnec.cpp:56-59)
+pnec::SE3d ToPose(const arr &m) {
+  if (m.ndim() != 2 || m.shape(0) != 4 || m.shape(1) != 4) throw std::invalid_argument("init_pose must be 4x4");
+  auto r = m.unchecked<2>();
+  pnec::Matrix3d R;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R(i, j) = r(i, j);
+  return pnec::SE3d(pnec::Quaterniond(R).normalized().toRotationMatrix(),
+                    pnec::Vector3d(r(0, 3), r(1, 3), r(2, 3)));
+}
+
+arr FromPose(const pnec::SE3d &T) {
+  arr out({4, 4});
+  const pnec::Matrix4d M = T.matrix();
+  auto w = out.mutable_unchecked<2>();
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) w(i, j) = M[4 * i + j];
+  return out;
+}
+
+arr pyceres(arr host_bvs, arr target_bvs, arr host_covariances, arr target_covariances, arr init_pose,
+            double regularization) {
+  const auto b1 = ToBearings(host_bvs, "host_bvs"), b2 = ToBearings(target_bvs, "target_bvs");
+  const auto c1 = ToCovariances(host_covariances, "host_covariances");
+  const auto c2 = ToCovariances(target_covariances, "target_covariances");
+  const pnec::SE3d init = ToPose(init_pose);
+  pnec::SE3d result;
+  {
+    py::gil_scoped_release release;
+    pnec::optimization::PNECCeres optimizer;
+    optimizer.InitValues(pnec::Quaterniond(init.rotationMatrix()), init.translation());
+    optimizer.Optimize(b1, b2, c1, c2, regularization);
+    result = optimizer.Result();
+  }
+  return FromPose(result);
+}
+
+arr pyceresnec(arr host_bvs, arr target_bvs, arr init_pose) {
+  const auto b1 = ToBearings(host_bvs, "host_bvs"), b2 = ToBearings(target_bvs, "target_bvs");
+  const pnec::SE3d init = ToPose(init_pose);
+  pnec::SE3d result;
+  {
+    py::gil_scoped_release release;
+    pnec::optimization::NECCeres optimizer;
+    optimizer.InitValues(pnec::Quaterniond(init.rotationMatrix()), init.translation());
+    optimizer.Optimize(b1, b2);
+    result = optimizer.Result();
+  }
+  return FromPose(result);
+}
+
+// PNEC::CeresSolver (target-frame covariances, pnec.cc:350-370) over a list of pairs, one launch.
+py::list ceres_solver_batch(py::list bvs1, py::list bvs2, py::list covs, py::list init_poses,
+                            double regularization) {
+  const size_t B = bvs1.size();
+  if (bvs2.size() != B || covs.size() != B || init_poses.size() != B)
+    throw std::invalid_argument("all lists must have one entry per frame pair");
+  std::vector<pnec::rel_pose_estimation::FramePair> pairs(B);
+  for (size_t p = 0; p < B; ++p) {
+    pairs[p].bvs1 = ToBearings(bvs1[p].cast<arr>(), "bvs1[i]");
+    pairs[p].bvs2 = ToBearings(bvs2[p].cast<arr>(), "bvs2[i]");
+    pairs[p].projected_covs = ToCovariances(covs[p].cast<arr>(), "covs[i]");
+    pairs[p].initial_pose = ToPose(init_poses[p].cast<arr>());
+  }
+  pnec::rel_pose_estimation::Options options;
+  options.regularization_ = regularization;
+  std::vector<pnec::SE3d> poses;
+  {
+    py::gil_scoped_release release;
+    pnec::rel_pose_estimation::PNEC solver(options);
+    poses = solver.CeresSolverBatch(pairs);
+  }
+  py::list out;
+  for (const auto &T : poses) out.append(FromPose(T));
+  return out;
+}
+
+int add(int i, int j) { return i + j; }  // the reference module's smoke function (pypnec.cpp:34)
+
+}  // namespace
+
+PYBIND11_MODULE(pypnec, m) {
+  m.doc() = "PNEC least-squares refinement on AMD MI355X (drop-in for tum-vision/pnec's pypnec)";
+  m.def("add", &add, "A function that adds two numbers");
+  m.def("pyceres", &pyceres, py::arg("host_bvs"), py::arg("target_bvs"), py::arg("host_covariances"),
+        py::arg("target_covariances"), py::arg("init_pose"), py::arg("regularization"),
+        "Symmetric PNEC refinement (PNECCeres::Optimize with covariances in both frames)");
+  m.def("pyceresnec", &pyceresnec, py::arg("host_bvs"), py::arg("target_bvs"), py::arg("init_pose"),
+        "NEC refinement (NECCeres::Optimize)");
+  m.def("ceres_solver_batch", &ceres_solver_batch, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"),
+        py::arg("init_poses"), py::arg("regularization") = 1e-13,
+        "PNEC::CeresSolver for a list of frame pairs in one device launch (addition)");
+}
