@@ -46,6 +46,16 @@ struct pnec_hip_problem {
   int64_t stage_doubles = 0;
   int32_t *d_stage_i = nullptr;
   int64_t stage_ints = 0;
+  // ragged batches: pairs grouped by the smallest launch geometry that holds them (built lazily)
+  struct Bucket {
+    int cpl, wpp, ldsk;
+    bool resident;
+    int64_t count;
+    int64_t first;  // offset into d_bucket_pairs
+  };
+  std::vector<Bucket> buckets;
+  int32_t *d_bucket_pairs = nullptr;
+  std::vector<int32_t> host_counts;
 };
 
 namespace {
@@ -243,6 +253,16 @@ bool geometry_exists(int mode, int cpl, int wpp, int ldsk) {
   return false;
 }
 
+// The auto-tuner's ladder for a residual family (smallest capacity first).
+int geometry_ladder(int mode, const int (**order)[3]) {
+  static const int order12[][3] = {{1, 1, 0}, {2, 1, 0}, {4, 1, 0}, {8, 1, 3},
+                                   {8, 2, 3}, {8, 4, 3}, {8, 8, 3}};
+  static const int order18[][3] = {{1, 1, 0}, {2, 1, 0}, {4, 1, 0}, {4, 2, 0}, {4, 4, 0}, {4, 8, 0}};
+  const bool sym = (mode == PNEC_HIP_MODE_SYM);
+  *order = sym ? order18 : order12;
+  return sym ? 6 : 7;
+}
+
 // On-chip resident whenever the largest pair fits 64*CPL*WPP slots.  Preference: as few
 // wavefronts per solve as possible (the serial part of an LM iteration is paid once per
 // wavefront) at two wavefronts per SIMD; 12-plane payloads use the (8,W,3) family (5 of a
@@ -265,12 +285,8 @@ int choose_geometry(const pnec_hip_problem *p, const pnec_hip_options *opt, Geom
     *g = {cpl, wpp, ldsk, true};
     return 0;
   }
-  static const int order12[][3] = {{1, 1, 0}, {2, 1, 0}, {4, 1, 0}, {8, 1, 3},
-                                   {8, 2, 3}, {8, 4, 3}, {8, 8, 3}};
-  static const int order18[][3] = {{1, 1, 0}, {2, 1, 0}, {4, 1, 0}, {4, 2, 0}, {4, 4, 0}, {4, 8, 0}};
-  const bool sym = (p->mode == PNEC_HIP_MODE_SYM);
-  const int (*order)[3] = sym ? order18 : order12;
-  const int count = sym ? 6 : 7;
+  const int (*order)[3];
+  const int count = geometry_ladder(p->mode, &order);
   for (int i = 0; i < count; ++i) {
     if ((int64_t)kWave * order[i][0] * order[i][1] >= n) {
       *g = {order[i][0], order[i][1], order[i][2], true};
@@ -278,6 +294,41 @@ int choose_geometry(const pnec_hip_problem *p, const pnec_hip_options *opt, Geom
     }
   }
   *g = {1, kStreamWaves, 0, false};
+  return 0;
+}
+
+// Ragged batches: one launch per geometry actually needed, each over the pairs that fit it, so a
+// few large pairs do not force every small pair into a many-wavefront geometry.
+int ensure_buckets(pnec_hip_problem *p) {
+  if (!p->buckets.empty() || p->n_pairs == 0) return 0;
+  const int (*order)[3];
+  const int count = geometry_ladder(p->mode, &order);
+  std::vector<std::vector<int32_t>> lists((size_t)count + 1);
+  for (int64_t i = 0; i < p->n_pairs; ++i) {
+    const int n = std::max<int32_t>(p->host_counts[(size_t)i], 1);
+    int b = count;  // streaming
+    for (int k = 0; k < count; ++k)
+      if ((int64_t)kWave * order[k][0] * order[k][1] >= n) {
+        b = k;
+        break;
+      }
+    lists[(size_t)b].push_back((int32_t)i);
+  }
+  std::vector<int32_t> flat;
+  flat.reserve((size_t)p->n_pairs);
+  for (int b = 0; b <= count; ++b) {
+    if (lists[(size_t)b].empty()) continue;
+    pnec_hip_problem::Bucket bk;
+    if (b < count) {
+      bk = {order[b][0], order[b][1], order[b][2], true, (int64_t)lists[(size_t)b].size(), (int64_t)flat.size()};
+    } else {
+      bk = {1, kStreamWaves, 0, false, (int64_t)lists[(size_t)b].size(), (int64_t)flat.size()};
+    }
+    p->buckets.push_back(bk);
+    flat.insert(flat.end(), lists[(size_t)b].begin(), lists[(size_t)b].end());
+  }
+  PNEC_HIP_TRY(hipMalloc(&p->d_bucket_pairs, sizeof(int32_t) * flat.size()));
+  PNEC_HIP_TRY(hipMemcpy(p->d_bucket_pairs, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -370,6 +421,7 @@ int pnec_hip_problem_create(int device, int mode, int64_t n_pairs, const int64_t
   p->n_pairs = n_pairs;
   p->n_corr = offsets[n_pairs];
   p->n_max = n_max;
+  p->host_counts = count;
   p->data_doubles = total;
   p->offsets.assign(offsets, offsets + n_pairs + 1);
   auto cleanup = [&](hipError_t e, const char *what) {
@@ -409,6 +461,7 @@ int pnec_hip_problem_destroy(pnec_hip_problem *p) {
   if (p->d_count) (void)hipFree(p->d_count);
   if (p->d_stage) (void)hipFree(p->d_stage);
   if (p->d_stage_i) (void)hipFree(p->d_stage_i);
+  if (p->d_bucket_pairs) (void)hipFree(p->d_bucket_pairs);
   delete p;
   return 0;
 }
@@ -575,12 +628,31 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
     a.out_status = p->d_stage_i + S;
   }
 
-  hipError_t e;
-  switch (p->mode) {
-    case PNEC_HIP_MODE_NEC: e = launch_solve_mode_0(g.cpl, g.wpp, g.ldsk, g.resident, a, stream); break;
-    case PNEC_HIP_MODE_TARGET: e = launch_solve_mode_1(g.cpl, g.wpp, g.ldsk, g.resident, a, stream); break;
-    case PNEC_HIP_MODE_HOST: e = launch_solve_mode_2(g.cpl, g.wpp, g.ldsk, g.resident, a, stream); break;
-    default: e = launch_solve_mode_3(g.cpl, g.wpp, g.ldsk, g.resident, a, stream); break;
+  auto launch = [&](const Geometry &gg, const SolveArgs &aa) -> hipError_t {
+    switch (p->mode) {
+      case PNEC_HIP_MODE_NEC: return launch_solve_mode_0(gg.cpl, gg.wpp, gg.ldsk, gg.resident, aa, stream);
+      case PNEC_HIP_MODE_TARGET: return launch_solve_mode_1(gg.cpl, gg.wpp, gg.ldsk, gg.resident, aa, stream);
+      case PNEC_HIP_MODE_HOST: return launch_solve_mode_2(gg.cpl, gg.wpp, gg.ldsk, gg.resident, aa, stream);
+      default: return launch_solve_mode_3(gg.cpl, gg.wpp, gg.ldsk, gg.resident, aa, stream);
+    }
+  };
+  hipError_t e = hipSuccess;
+  const bool forced = opt.corr_per_lane > 0 || opt.waves_per_pair > 0;
+  if (!forced) {
+    if (int rc = ensure_buckets(p)) return rc;
+  }
+  if (forced || p->buckets.size() <= 1) {
+    e = launch(g, a);
+  } else {
+    // ragged batch: one launch per geometry in use, over the pairs that fit it
+    for (const auto &bk : p->buckets) {
+      SolveArgs ab = a;
+      ab.pair_index = p->d_bucket_pairs + bk.first;
+      ab.n_solves = bk.count * (int64_t)n_hyp;
+      const Geometry gb = {bk.cpl, bk.wpp, bk.ldsk, bk.resident};
+      e = launch(gb, ab);
+      if (e != hipSuccess) break;
+    }
   }
   if (e != hipSuccess) return fail_hip(e, "lm_solve_kernel launch");
 

@@ -44,6 +44,8 @@ struct SolveArgs {
   const double *data;           // SoA payload
   const int64_t *block_offset;  // [n_pairs] first double of the pair's block
   const int32_t *count;         // [n_pairs] correspondences of the pair
+  const int32_t *pair_index;    // null, or the pairs this launch covers (ragged batches: one launch
+                                // per geometry); solve slot i of the launch = pair_index[i / n_hyp]
   const double *init_q;         // [n_pairs,4]
   const double *init_t;         // [n_pairs,3]
   const double *hyp_t;          // [n_solves,3] or null
@@ -107,8 +109,9 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   constexpr int REGK = RESIDENT ? CPL - LDSK : 1;  // correspondences per lane kept in registers
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const int64_t s = xcd_contiguous_index(blockIdx.x, a.n_solves);
-  const int64_t pair = s / a.n_hyp;
+  const int64_t slot = xcd_contiguous_index(blockIdx.x, a.n_solves);
+  const int64_t pair = a.pair_index ? (int64_t)a.pair_index[slot / a.n_hyp] : slot / a.n_hyp;
+  const int64_t s = pair * a.n_hyp + slot % a.n_hyp;
   const double *__restrict__ base = a.data + a.block_offset[pair];
   const int n = a.count[pair];
   const int stride = (n + kWave - 1) & ~(kWave - 1);

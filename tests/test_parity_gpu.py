@@ -167,6 +167,8 @@ def test_ragged_batch_with_empty_and_tiny_pairs(oracle):
     (zero cost, zero gradient) and returns its start pose"""
     launch, res, st, q0 = _ragged_case(
         oracle, [0, 1, 5, 63, 64, 65, 127, 300, 512, 700, 1025, 2048, 2500], seed=31)
+    # describe_launch reports the geometry of the LARGEST pair; smaller pairs of a ragged batch run
+    # in their own, smaller-geometry launches (bucketing) with identical results
     assert launch["resident"] is True and launch["threads_per_block"] == 512
     assert res.status[0] == st[0] == 2 and res.iterations[0] == 0
     np.testing.assert_allclose(res.q[0], q0[0] / np.linalg.norm(q0[0]), atol=1e-15)

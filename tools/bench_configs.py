@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Secondary BASELINE.json configs (parity-test cases, not the bench line): timings + oracle checks.
+Runs on the GPU box; prints one JSON object per config."""
+import json
+import math
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from oracle import pnec_oracle as po
+from pnec_amd import Batch, capi, select_best
+from pnec_amd import simulation as sim
+
+dev = torch.device("cuda:0")
+
+
+def timed(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t)
+    return float(np.median(ts))
+
+
+def quat_angle(a, b):
+    d = np.clip(np.abs(np.sum(a * b, axis=-1)), 0, 1)
+    v = np.linalg.norm(a[..., :3] * b[..., 3:4] - b[..., :3] * a[..., 3:4] - np.cross(a[..., :3], b[..., :3]), axis=-1)
+    return 2 * np.arctan2(v, d)
+
+
+out = []
+
+# ---- config 1: run_simulation plumbing: 1 pair, 100 isotropic correspondences, host-space call
+g = sim.generate(1, 100, noise_type="isotropic_homogeneous", seed=1)
+f1, f2, c2 = g.bvs1[0].numpy(), g.bvs2[0].numpy(), g.covs2[0].numpy()
+def one_pair():
+    with Batch.uniform(capi.MODE_TARGET, 1, 100) as b:
+        b.fill(f1, f2, c2)
+        return b.solve(g.init_q.numpy(), g.init_t.numpy())
+t = timed(one_pair, reps=20)
+r = one_pair()
+s = po.solve(po.MODE_TARGET, f1, f2, c2, None, 1e-13, g.init_q[0].numpy(), g.init_t[0].numpy(), po.default_options())
+t0 = time.perf_counter()
+for _ in range(20):
+    po.solve(po.MODE_TARGET, f1, f2, c2, None, 1e-13, g.init_q[0].numpy(), g.init_t[0].numpy(), po.default_options())
+tc = (time.perf_counter() - t0) / 20
+out.append({"config": "1: run_simulation, 1 pair x 100 isotropic corr (host-space call incl. alloc + PCIe)",
+            "gpu_latency_us": t * 1e6, "cpu_oracle_latency_us": tc * 1e6,
+            "rot_diff_vs_oracle_rad": float(quat_angle(r.q[0], s.q)), "iterations": int(r.iterations[0])})
+
+# ---- config 2 with Ceres-default termination (iterations to converge)
+B, N = 100_000, 512
+batch = Batch.uniform(capi.MODE_TARGET, B, N)
+qs, ts = [], []
+for c in range(10):
+    gg = sim.generate(10_000, N, seed=1 + c, device=dev)
+    batch.fill(gg.bvs1.reshape(-1, 3), gg.bvs2.reshape(-1, 3), gg.covs2.reshape(-1, 3, 3), first_pair=c * 10_000, n_pairs=10_000)
+    qs.append(gg.init_q); ts.append(gg.init_t); del gg
+q0, t0_ = torch.cat(qs), torch.cat(ts)
+res = None
+def conv():
+    global res
+    res = batch.solve(q0, t0_, out=res)
+t = timed(conv)
+it = res.iterations.double()
+out.append({"config": "2b: 100k x 512 anisotropic, Ceres-default termination (not the fixed-10 bench line)",
+            "solves_per_s": B / t, "ms": t * 1e3, "iterations_mean": float(it.mean()), "iterations_max": int(it.max()),
+            "status_hist": torch.bincount(res.status, minlength=7).tolist()})
+batch.close(); del batch, q0, t0_, res
+
+# ---- config 3: KITTI-like stream (SYNTHETIC: no KITTI data here), ~4.5k ragged pairs, forward motion
+offsets, f1, f2, c2, R_gt, t_gt, qi, ti = sim.generate_kitti_like(4541, mean_corr=500, seed=3, device=dev)
+b = Batch(capi.MODE_TARGET, offsets)
+b.fill(f1, f2, c2)
+res = None
+def kitti():
+    global res
+    res = b.solve(qi, ti, out=res)
+t = timed(kitti)
+n_s = 64
+oq, ot, oc, oi, os_ = po.solve_batch(po.MODE_TARGET, offsets[:n_s + 1], f1.cpu().numpy(), f2.cpu().numpy(),
+                                     po.covs_to_colmajor9(c2[: offsets[n_s]].cpu().numpy()), None, 1e-13,
+                                     qi.cpu().numpy(), ti.cpu().numpy(), options=po.default_options())
+ang = quat_angle(res.q[:n_s].cpu().numpy(), oq)
+sizes = np.diff(offsets)
+out.append({"config": "3: KITTI-seq-00-like SYNTHETIC stream (forward motion, fx=718.856), 4541 ragged pairs",
+            "pairs": 4541, "corr_min_mean_max": [int(sizes.min()), float(sizes.mean()), int(sizes.max())],
+            "solves_per_s": 4541 / t, "ms": t * 1e3, "iterations_mean": float(res.iterations.double().mean()),
+            "max_rot_diff_vs_oracle_rad_first64": float(ang.max()),
+            "launch_of_largest_pair": b.describe_launch()})
+b.close()
+
+# ---- config 4: multi-hypothesis, 64 t-hat starts per pair x 4096 correspondences
+Bp, N4, H = 64, 4096, 64
+g4 = sim.generate(Bp, N4, seed=9, device=dev)
+b4 = Batch.uniform(capi.MODE_TARGET, Bp, N4)
+b4.fill(g4.bvs1.reshape(-1, 3), g4.bvs2.reshape(-1, 3), g4.covs2.reshape(-1, 3, 3))
+gen = torch.Generator(device=dev); gen.manual_seed(5)
+hyp = torch.randn(Bp * H, 3, generator=gen, dtype=torch.float64, device=dev)
+hyp = hyp / hyp.norm(dim=1, keepdim=True)
+hyp[::H] = g4.init_t
+opts = capi.default_options(max_num_iterations=10, check_convergence=0)
+res = None
+def multi():
+    global res
+    res = b4.solve(g4.init_q, None, options=opts, hyp_t=hyp, n_hyp=H, out=res)
+t = timed(multi)
+best = select_best(res.cost, H)
+out.append({"config": "4: multi-hypothesis, 64 pairs x 4096 corr x 64 random t-hat starts, 10 LM iterations each",
+            "hypothesis_solves_per_s": Bp * H / t, "pairs_per_s": Bp / t, "ms": t * 1e3,
+            "payload_bytes": b4.payload_bytes, "launch": b4.describe_launch(opts),
+            "best_is_good_start_fraction": float((best == 0).double().mean()),
+            "corr_iterations_per_s": Bp * H * N4 * 11 / t})
+for o in out:
+    print(json.dumps(o), flush=True)
