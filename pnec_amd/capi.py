@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpnec_hip.so")
+# PNEC_HIP_LIB: load an alternative build of the same ABI (kernel A/B experiments only)
+LIB_PATH = os.environ.get("PNEC_HIP_LIB") or os.path.join(_HERE, "libpnec_hip.so")
 
 MODE_NEC, MODE_TARGET, MODE_HOST, MODE_SYM = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1

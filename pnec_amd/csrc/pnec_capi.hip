@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -636,6 +637,15 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
       default: return launch_solve_mode_3(gg.cpl, gg.wpp, gg.ldsk, gg.resident, aa, stream);
     }
   };
+  // PNEC_HIP_TRACE=<file>: per-workgroup phase timestamps of every launch (diagnostics; adds a
+  // device synchronisation, so never set it for timed runs)
+  const char *trace_path = std::getenv("PNEC_HIP_TRACE");
+  unsigned long long *d_trace = nullptr;
+  if (trace_path && *trace_path) {
+    PNEC_HIP_TRY(hipMalloc(&d_trace, sizeof(unsigned long long) * 4 * S));
+    PNEC_HIP_TRY(hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 4 * S, stream));
+    a.trace = d_trace;
+  }
   hipError_t e = hipSuccess;
   const bool forced = opt.corr_per_lane > 0 || opt.waves_per_pair > 0;
   if (!forced) {
@@ -652,6 +662,18 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
       const Geometry gb = {bk.cpl, bk.wpp, bk.ldsk, bk.resident};
       e = launch(gb, ab);
       if (e != hipSuccess) break;
+    }
+  }
+  if (d_trace) {
+    std::vector<unsigned long long> h(4 * (size_t)S);
+    hipError_t te = hipStreamSynchronize(stream);
+    if (te == hipSuccess) te = hipMemcpy(h.data(), d_trace, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+    (void)hipFree(d_trace);
+    if (te == hipSuccess) {
+      if (FILE *f = std::fopen(trace_path, "ab")) {
+        std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+        std::fclose(f);
+      }
     }
   }
   if (e != hipSuccess) return fail_hip(e, "lm_solve_kernel launch");

@@ -22,7 +22,15 @@
 //     unlike the v_writelane/v_readlane traffic of SGPR spills.
 #pragma once
 
+#include <type_traits>
+
 #include "pnec_device.hpp"
+
+#ifdef PNEC_EXP_NOLOAD  // experiment: synthetic payload, no HBM reads (timing only)
+#define PNEC_LOAD_GUARD(in) false
+#else
+#define PNEC_LOAD_GUARD(in) (in)
+#endif
 
 // Launch geometries instantiated for every residual family:
 //   (CPL correspondences per lane, WPP wavefronts per solve, LDSK of the CPL kept in LDS)
@@ -54,6 +62,7 @@ struct SolveArgs {
   double *out_cost;             // [n_solves] or null
   int32_t *out_iterations;      // [n_solves] or null
   int32_t *out_status;          // [n_solves] or null
+  unsigned long long *trace;    // null, or [n_blocks,4]: s_memtime at start / payload on chip / end, hw id
   int64_t n_solves;
   int32_t n_hyp;
   int32_t stagger;  // first-round start skew, units of s_sleep(64) ~ 4096 clocks per wavefront slot
@@ -128,6 +137,9 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
   }
 
+  unsigned long long t_begin = 0, t_loaded = 0;
+  if (a.trace) t_begin = __builtin_amdgcn_s_memtime();
+
   __shared__ double slab_all[WPP][kSlab];
   [[maybe_unused]] __shared__ double xw[2][WPP > 1 ? WPP : 1][kNumAcc];
   [[maybe_unused]] __shared__ double ldata[LDSK > 0 ? WPP : 1][LDSK > 0 ? LDSK : 1][NC][LDSK > 0 ? kWave : 1];
@@ -138,20 +150,50 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   double d[REGK][NC];
   unsigned vmask = 0;
   if constexpr (RESIDENT) {
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-      const int idx = (wave * CPL + k) * kWave + lane;
+    // slot k of a lane is correspondence  wave*CPL*64 + 128*(k/2) + 2*lane + (k&1): two
+    // neighbouring correspondences per 16-byte load (global_load_dwordx4) -- the CU's load path
+    // moves ~2x the bytes per clock of 8-byte loads, which is what bounds the payload fetch.
+    auto put = [&](auto kc, int c, double v) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (k < REGK) d[k][c] = v;
+      else ldata[wave][k - REGK][c][lane] = v;
+    };
+    if constexpr (CPL == 1) {
+      const int idx = wave * kWave + lane;
       const bool in = idx < stride;
-      if (k < REGK) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) d[k < REGK ? k : 0][c] = in ? base[(int64_t)c * stride + idx] : 0.0;
-      } else {
+      for (int c = 0; c < NC; ++c)
+        put(std::integral_constant<int, 0>{}, c, PNEC_LOAD_GUARD(in) ? base[(int64_t)c * stride + idx] : 0.0);
+      vmask = idx < n ? 1u : 0u;
+    } else {
+      static_assert(CPL == 1 || CPL % 2 == 0, "correspondences per lane: 1 or even");
+      using pair_t = __attribute__((ext_vector_type(2))) double;
+      auto load_pair = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int idx = wave * CPL * kWave + 2 * kWave * j + 2 * lane;
+        const bool in = idx < stride;  // stride is a multiple of 64, idx is even: idx+1 < stride too
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
-          ldata[wave][k >= REGK ? k - REGK : 0][c][lane] = in ? base[(int64_t)c * stride + idx] : 0.0;
+        for (int c = 0; c < NC; ++c) {
+          pair_t v = {0.0, 0.0};
+          if (PNEC_LOAD_GUARD(in)) v = *reinterpret_cast<const pair_t *>(base + (int64_t)c * stride + idx);
+          put(std::integral_constant<int, 2 * j>{}, c, v.x);
+          put(std::integral_constant<int, 2 * j + 1>{}, c, v.y);
+        }
+        vmask |= (idx < n ? 1u : 0u) << (2 * j);
+        vmask |= (idx + 1 < n ? 1u : 0u) << (2 * j + 1);
+      };
+      load_pair(std::integral_constant<int, 0>{});
+      if constexpr (CPL >= 4) load_pair(std::integral_constant<int, 1>{});
+      if constexpr (CPL >= 8) {
+        load_pair(std::integral_constant<int, 2>{});
+        load_pair(std::integral_constant<int, 3>{});
       }
-      vmask |= (idx < n ? 1u : 0u) << k;
     }
+  }
+  if (a.trace) {
+    // make "payload on chip" mean what it says: wait for the loads before stamping
+    __builtin_amdgcn_s_waitcnt(0);
+    t_loaded = __builtin_amdgcn_s_memtime();
   }
 
   // ---- PNECCeres::InitValues(q, t): pnec_ceres.cc:182-186.  The start point is the first
@@ -159,7 +201,11 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   if (lane == 0) {
     double th, ph;
     const double *t0 = a.hyp_t ? a.hyp_t + 3 * s : a.init_t + 3 * pair;
+#ifdef PNEC_EXP_NOANGLES
+    th = t0[0]; ph = t0[1];
+#else
     angles_from_vec(t0[0], t0[1], t0[2], th, ph);
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) slab[kQc + k] = a.init_q[pair * 4 + k];
     slab[kThetaC] = th;
@@ -460,6 +506,16 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
     if (a.out_cost) a.out_cost[s] = slab[kCost];
     if (a.out_iterations) a.out_iterations[s] = iteration;
     if (a.out_status) a.out_status[s] = term;
+    if (a.trace) {
+      unsigned hw = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      unsigned xcc = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      a.trace[4 * (size_t)blockIdx.x + 0] = t_begin;
+      a.trace[4 * (size_t)blockIdx.x + 1] = t_loaded;
+      a.trace[4 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+      a.trace[4 * (size_t)blockIdx.x + 3] = ((unsigned long long)xcc << 32) | hw;
+    }
   }
 }
 

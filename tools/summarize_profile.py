@@ -23,6 +23,20 @@ if os.path.exists(stats):
     out.append("(the rest of the trace is the torch kernels of the synthetic-data generator, outside the timed region)")
     out.append("")
 
+# bench.py's own HIP-event timing printed during the traced run (must agree with the trace)
+import json, re
+log = os.path.join(src, "stats.log")
+if os.path.exists(log):
+    for line in open(log):
+        if line.startswith("{") and '"roofline"' in line:
+            d = json.loads(line)
+            out += ["## bench.py line of the traced run (HIP events on the launch stream)", "",
+                    f"* value = {d['value']:.4g} {d['unit']}, ms_per_step = {d['ms_per_step']:.3f}",
+                    f"* roofline.kernel_ms (HIP events, mean of timed steps) = {d['roofline']['kernel_ms']:.3f} ms"
+                    " -- compare with AverageNs above (the trace also includes the warm-up launch; profiled"
+                    " runs clock a few % lower than un-profiled ones, MI355X_MICROARCH.md DVFS note)",
+                    f"* roofline.achieved = {d['roofline']['achieved']:.1f} GB/s ({d['roofline']['frac']:.3f} of 8 TB/s),"
+                    f" FP64 VALU {d['roofline']['valu']['achieved']:.1f} TFLOP/s ({d['roofline']['valu']['frac']:.3f} of 78.6)", ""]
 pmc = defaultdict(list)
 meta = {}
 for sub in sorted(os.listdir(src)):
