@@ -19,6 +19,7 @@
  *     src/rel_pose_estimation/pnec.cc:350-411
  *   ceres::Solver::Options (default-constructed, pnec_ceres.cc:47)   pnec_hip_options
  *   pnec::common::CostFunction  src/common/common.cc:237-259    pnec_hip_cost_function
+ *   pnec::common::UnscentedTransform / Unproject  common.cc:460-525   pnec_hip_unscented_transform
  *
  * Conventions (same as the reference):
  *   - bearing vectors: 3 doubles each, unit norm; frame 1 = "host", frame 2 = "target".
@@ -152,6 +153,18 @@ int pnec_hip_select_best(int64_t n_pairs, int32_t n_hyp, const double *cost, int
  * normalised inside) and t.  Only for TARGET-mode problems.  out [n_pairs]. */
 int pnec_hip_cost_function(pnec_hip_problem *p, const double *q, const double *t, double *out,
                            int space, void *stream);
+
+/* Input side of the path: pnec::common::UnscentedTransform (src/common/common.cc:467-525) and
+ * pnec::common::Unproject (:460-465) for n keypoints at once -- what KeyPoint::Unproject
+ * (src/frames/keypoints.cc:49-62) and the simulator's GetFeatures (src/simulation/sim_common.cc:72-107)
+ * do per point.  mu [n,3] image points (x, y, 1) [or (x, y, f) with K_inv = I], covs [n,9]
+ * column-major 3x3 whose top-left 2x2 is the image-plane covariance (omnidirectional: the
+ * tangent-plane covariance rotated to the bearing), K_inv [9] column-major, kappa (1.0 in the
+ * reference), camera_model 0 = Omnidirectional, 1 = Pinhole (enum CameraModel, common.h:62).
+ * out_covs [n,9] bearing covariances; out_bvs [n,3] unit bearings or NULL. */
+int pnec_hip_unscented_transform(int64_t n, const double *mu, const double *covs, const double *K_inv,
+                                 double kappa, int camera_model, double *out_bvs, double *out_covs,
+                                 int space, int device, void *stream);
 
 /* Name and launch geometry the auto-tuner would pick for this problem (for logs / profiles). */
 int pnec_hip_describe_launch(const pnec_hip_problem *p, const pnec_hip_options *opt,

@@ -205,6 +205,106 @@ double pnec_oracle_cost_function(int64_t n, const double *bvs1, const double *bv
   return cost / (double)n;
 }
 
+/* ------------------------------------------------------------------ covariance propagation */
+/* common.cc:118-124 with point1 = (0,0,1); column-major output */
+static void rotation_from_z(const double v[3], double Rm[9]) {
+  const double z[3] = {0.0, 0.0, 1.0};
+  double c[3], K[9], K2[9];
+  cross3(z, v, c);
+  skew(c, K); /* row-major */
+  const double d = v[2];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0.0;
+      for (int k = 0; k < 3; ++k) a += K[3 * i + k] * K[3 * k + j];
+      K2[3 * i + j] = a;
+    }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      Rm[3 * j + i] = (i == j ? 1.0 : 0.0) + K[3 * i + j] + K2[3 * i + j] / (1.0 + d);
+}
+
+void pnec_oracle_unproject(const double img_pt[2], const double K_inv[9], double out[3]) {
+  const double mu[3] = {img_pt[0], img_pt[1], 1.0};
+  double n = 0.0;
+  for (int r = 0; r < 3; ++r) {
+    out[r] = K_inv[r] * mu[0] + K_inv[3 + r] * mu[1] + K_inv[6 + r] * mu[2];
+    n += out[r] * out[r];
+  }
+  n = sqrt(n);
+  for (int r = 0; r < 3; ++r) out[r] /= n;
+}
+
+void pnec_oracle_unscented_transform(const double mu[3], const double cov[9], const double K_inv[9],
+                                     double kappa, int camera_model, double out[9]) {
+  const int n = 2, m = 5;
+  double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; /* column-major */
+  double Rm[9];
+  double a, b, d;
+  if (camera_model == 0) { /* Omnidirectional */
+    const double nm = sqrt(dot3(mu, mu));
+    const double v[3] = {mu[0] / nm, mu[1] / nm, mu[2] / nm};
+    rotation_from_z(v, Rm);
+    /* local = R' cov R, top-left 2x2 */
+    double T[9], Lc[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < 3; ++k) s += cov[3 * k + i] * Rm[3 * j + k]; /* (cov R)(i,j) */
+        T[3 * j + i] = s;
+      }
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < 3; ++k) s += Rm[3 * i + k] * T[3 * j + k]; /* R'(i,k) = R(k,i) */
+        Lc[3 * j + i] = s;
+      }
+    a = Lc[0]; b = Lc[1]; d = Lc[4];
+  } else {
+    a = cov[0]; b = cov[1]; d = cov[4];
+  }
+  const double l00 = sqrt(a), l10 = b / l00, l11 = sqrt(d - l10 * l10);
+  C[0] = l00; C[1] = l10; C[4] = l11; /* lower factor: (0,0), (1,0), (1,1) */
+  if (camera_model == 0) {
+    double RC[9];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double s = 0.0;
+        for (int k = 0; k < 3; ++k) s += Rm[3 * k + i] * C[3 * j + k];
+        RC[3 * j + i] = s;
+      }
+    memcpy(C, RC, sizeof(C));
+  }
+  double pts[5][3], w[5], tp[5][3], mean[3] = {0, 0, 0};
+  w[0] = kappa / ((double)n + kappa);
+  for (int k = 0; k < 3; ++k) pts[0][k] = mu[k];
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < 3; ++k) {
+      pts[1 + i][k] = mu[k] + C[3 * i + k];
+      pts[1 + n + i][k] = mu[k] - C[3 * i + k];
+    }
+    w[1 + i] = w[1 + n + i] = 0.5 / ((double)n + kappa);
+  }
+  for (int i = 0; i < m; ++i) {
+    double t[3];
+    if (camera_model == 0) {
+      memcpy(t, pts[i], sizeof(t));
+    } else {
+      for (int r = 0; r < 3; ++r)
+        t[r] = K_inv[r] * pts[i][0] + K_inv[3 + r] * pts[i][1] + K_inv[6 + r] * pts[i][2];
+    }
+    const double nt = sqrt(dot3(t, t));
+    for (int k = 0; k < 3; ++k) {
+      tp[i][k] = t[k] / nt;
+      mean[k] += w[i] * tp[i][k];
+    }
+  }
+  memset(out, 0, 9 * sizeof(double));
+  for (int i = 0; i < m; ++i)
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) out[3 * c + r] += w[i] * (tp[i][r] - mean[r]) * (tp[i][c] - mean[c]);
+}
+
 /* ------------------------------------------------------------------ residuals (literal) */
 static double residual_core(int mode, const double f1[3], const double f2[3], const double *cov2,
                             const double *cov1, double reg, const double R[9],

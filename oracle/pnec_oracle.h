@@ -98,6 +98,14 @@ double pnec_oracle_translational_difference_deg(const double t1[3], const double
 double pnec_oracle_cost_function(int64_t n, const double *bvs1, const double *bvs2,
                                  const double *covs, const double R[9], const double t[3]);
 
+/* pnec::common::UnscentedTransform, src/common/common.cc:467-525 (camera_model: 0 = Omnidirectional,
+ * 1 = Pinhole, the order of enum CameraModel at include/common/common.h:62).  mu 3, cov 9 and
+ * K_inv 9 column-major, out 9 column-major. */
+void pnec_oracle_unscented_transform(const double mu[3], const double cov[9], const double K_inv[9],
+                                     double kappa, int camera_model, double out[9]);
+/* pnec::common::Unproject, common.cc:460-465: normalised K_inv (x, y, 1) */
+void pnec_oracle_unproject(const double img_pt[2], const double K_inv[9], double out[3]);
+
 /* One residual, literal form of the functors.  bv = 3 doubles; cov = 9 doubles (Eigen
  * column-major, as std::vector<Eigen::Matrix3d> stores them); cov1 only for SYM. */
 double pnec_oracle_residual(int mode, const double f1[3], const double f2[3],

@@ -104,6 +104,8 @@ def lib() -> C.CDLL:
                                                  C.POINTER(Options), C.c_int, _dp, _dp, _dp, _ip,
                                                  _ip]
         _lib.pnec_oracle_max_threads.restype = C.c_int
+        _lib.pnec_oracle_unscented_transform.argtypes = [_dp, _dp, _dp, C.c_double, C.c_int, _dp]
+        _lib.pnec_oracle_unproject.argtypes = [_dp, _dp, _dp]
     return _lib
 
 
@@ -129,6 +131,29 @@ def covs_to_colmajor9(covs: np.ndarray) -> np.ndarray:
     """[n,3,3] -> [n,9] in Eigen column-major order (how std::vector<Matrix3d> stores them)."""
     covs = np.asarray(covs, dtype=np.float64)
     return np.ascontiguousarray(np.transpose(covs, (0, 2, 1)).reshape(-1, 9))
+
+
+CAMERA_OMNIDIRECTIONAL, CAMERA_PINHOLE = 0, 1
+
+
+def unscented_transform(mu, cov, K_inv=None, kappa=1.0, camera_model=CAMERA_PINHOLE):
+    """common.cc:467-525 for one point; cov / K_inv / result are 3x3 numpy matrices."""
+    K_inv = np.eye(3) if K_inv is None else np.asarray(K_inv, dtype=np.float64)
+    m, mp = _d(mu)
+    c, cp = _d(np.asarray(cov, dtype=np.float64).T.reshape(9))
+    k, kp = _d(K_inv.T.reshape(9))
+    out = np.zeros(9)
+    lib().pnec_oracle_unscented_transform(mp, cp, kp, float(kappa), int(camera_model),
+                                          out.ctypes.data_as(_dp))
+    return out.reshape(3, 3).T
+
+
+def unproject(img_pt, K_inv):
+    p, pp = _d(img_pt)
+    k, kp = _d(np.asarray(K_inv, dtype=np.float64).T.reshape(9))
+    out = np.zeros(3)
+    lib().pnec_oracle_unproject(pp, kp, out.ctypes.data_as(_dp))
+    return out
 
 
 def angles_from_vec(v):

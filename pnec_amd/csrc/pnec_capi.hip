@@ -192,6 +192,90 @@ __global__ __launch_bounds__(kWave) void cost_function_kernel(const double *__re
   if (lane == 0) out[p] = acc / (double)n;
 }
 
+// ---- covariance propagation: pnec::common::UnscentedTransform + Unproject -----------------
+// (src/common/common.cc:460-525; one thread per keypoint, 5 sigma points, kappa-weighted).
+// All matrices column-major like Eigen.  camera_model: 0 omnidirectional, 1 pinhole.
+__global__ __launch_bounds__(256) void unscented_kernel(int64_t n, const double *__restrict__ mu,
+                                                        const double *__restrict__ covs,
+                                                        const double *__restrict__ K_inv_, double kappa,
+                                                        int camera_model, double *__restrict__ out_bvs,
+                                                        double *__restrict__ out_covs) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double K[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) K[k] = K_inv_[k];
+  const double m0 = mu[3 * i], m1 = mu[3 * i + 1], m2 = mu[3 * i + 2];
+  const double *C9 = covs + 9 * i;
+  double c0[3], c1[3];  // the two columns added to / subtracted from mu
+  if (camera_model == 0) {
+    // rotation taking (0,0,1) to the bearing (RotationBetweenPoints, common.cc:118-124)
+    const double nm = fast_rsqrt(m0 * m0 + m1 * m1 + m2 * m2);
+    const double vx = m0 * nm, vy = m1 * nm, vz = m2 * nm;
+    const double cx = -vy, cy = vx;  // (0,0,1) x v = (-vy, vx, 0)
+    double R[9];                     // column-major
+    const double f = 1.0 / (1.0 + vz);
+    // K = skew(c) = [[0,0,cy],[0,0,-cx],[-cy,cx,0]];  R = I + K + K^2 f
+    R[0] = 1.0 - cy * cy * f; R[3] = cx * cy * f;       R[6] = cy;
+    R[1] = cx * cy * f;       R[4] = 1.0 - cx * cx * f; R[7] = -cx;
+    R[2] = -cy;               R[5] = cx;                R[8] = 1.0 - (cx * cx + cy * cy) * f;
+    // local = (R' cov R) top-left 2x2
+    double T[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) T[3 * c + r] = C9[r] * R[3 * c] + C9[3 + r] * R[3 * c + 1] + C9[6 + r] * R[3 * c + 2];
+    const double a = R[0] * T[0] + R[1] * T[1] + R[2] * T[2];
+    const double b = R[3] * T[0] + R[4] * T[1] + R[5] * T[2];
+    const double d = R[3] * T[3] + R[4] * T[4] + R[5] * T[5];
+    const double l00 = sqrt(a), l10 = b / l00, l11 = sqrt(d - l10 * l10);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      c0[r] = R[r] * l00 + R[3 + r] * l10;
+      c1[r] = R[3 + r] * l11;
+    }
+  } else {
+    const double a = C9[0], b = C9[1], d = C9[4];
+    const double l00 = sqrt(a), l10 = b / l00, l11 = sqrt(d - l10 * l10);
+    c0[0] = l00; c0[1] = l10; c0[2] = 0.0;
+    c1[0] = 0.0; c1[1] = l11; c1[2] = 0.0;
+  }
+  const double w0 = kappa / (2.0 + kappa), wi = 0.5 / (2.0 + kappa);
+  double tp[5][3], mean[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    const double sg = (p == 0) ? 0.0 : (p <= 2 ? 1.0 : -1.0);
+    const double *col = (p == 1 || p == 3) ? c0 : c1;
+    const double x = m0 + sg * col[0], y = m1 + sg * col[1], z = m2 + sg * col[2];
+    double tx = x, ty = y, tz = z;
+    if (camera_model != 0) {
+      tx = K[0] * x + K[3] * y + K[6] * z;
+      ty = K[1] * x + K[4] * y + K[7] * z;
+      tz = K[2] * x + K[5] * y + K[8] * z;
+    }
+    const double nn = 1.0 / sqrt(tx * tx + ty * ty + tz * tz);
+    tp[p][0] = tx * nn; tp[p][1] = ty * nn; tp[p][2] = tz * nn;
+    const double w = (p == 0) ? w0 : wi;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mean[k] += w * tp[p][k];
+  }
+  double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    const double w = (p == 0) ? w0 : wi;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) S[3 * c + r] += w * (tp[p][r] - mean[r]) * (tp[p][c] - mean[c]);
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) out_covs[9 * i + k] = S[k];
+  if (out_bvs) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out_bvs[3 * i + k] = tp[0][k];  // normalised (K^-1) mu = Unproject
+  }
+}
+
 // ---- device self-test kernels (cross-lane reduction, 5x5 solve) ---------------------------
 __global__ void selftest_kernel(double *out) {
   const int lane = threadIdx.x;
@@ -756,6 +840,50 @@ int pnec_hip_cost_function(pnec_hip_problem *p, const double *q, const double *t
     PNEC_HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(double) * P, hipMemcpyDeviceToHost, stream));
     PNEC_HIP_TRY(hipStreamSynchronize(stream));
   }
+  return 0;
+}
+
+int pnec_hip_unscented_transform(int64_t n, const double *mu, const double *covs, const double *K_inv,
+                                 double kappa, int camera_model, double *out_bvs, double *out_covs,
+                                 int space, int device, void *stream_) {
+  if (n < 0 || (n > 0 && (!mu || !covs || !out_covs)) || !K_inv)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (camera_model != 0 && camera_model != 1) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "camera_model must be 0 or 1");
+  if (n == 0) return 0;
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "hipSetDevice failed (no such device?)");
+  hipStream_t stream = (hipStream_t)stream_;
+  const double *d_mu = mu, *d_cov = covs, *d_K = K_inv;
+  double *d_ob = out_bvs, *d_oc = out_covs, *tmp = nullptr;
+  if (space == PNEC_HIP_MEM_HOST) {
+    PNEC_HIP_TRY(hipMalloc(&tmp, sizeof(double) * (24 * n + 9)));
+    double *w = tmp;
+    hipError_t e = hipMemcpyAsync(w, mu, sizeof(double) * 3 * n, hipMemcpyHostToDevice, stream);
+    d_mu = w; w += 3 * n;
+    if (e == hipSuccess) e = hipMemcpyAsync(w, covs, sizeof(double) * 9 * n, hipMemcpyHostToDevice, stream);
+    d_cov = w; w += 9 * n;
+    if (e == hipSuccess) e = hipMemcpyAsync(w, K_inv, sizeof(double) * 9, hipMemcpyHostToDevice, stream);
+    d_K = w; w += 9;
+    d_oc = w; w += 9 * n;
+    d_ob = out_bvs ? w : nullptr;
+    if (e != hipSuccess) {
+      (void)hipFree(tmp);
+      return fail_hip(e, "unscented_transform staging");
+    }
+  } else if (space != PNEC_HIP_MEM_DEVICE) {
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad memory space");
+  }
+  hipLaunchKernelGGL(unscented_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, d_mu,
+                     d_cov, d_K, kappa, camera_model, d_ob, d_oc);
+  hipError_t e = hipGetLastError();
+  if (tmp) {
+    if (e == hipSuccess) e = hipMemcpyAsync(out_covs, d_oc, sizeof(double) * 9 * n, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && out_bvs)
+      e = hipMemcpyAsync(out_bvs, d_ob, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(tmp);
+  }
+  if (e != hipSuccess) return fail_hip(e, "unscented_kernel");
   return 0;
 }
 

@@ -1,0 +1,48 @@
+"""Data formats either side of the path: the reference simulator's experiment
+CSVs, run_simulation's result tables and the odometry pose stream."""
+import numpy as np
+
+from pnec_amd import io_formats as io
+from pnec_amd import simulation as sim
+
+
+def test_experiment_folder_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    E, N = 3, 5
+    q = rng.normal(size=(E, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    poses_1 = np.concatenate([np.tile([0, 0, 0, 1.0], (E, 1)), np.zeros((E, 3))], 1)
+    poses_2 = np.concatenate([q, rng.normal(size=(E, 3))], 1)
+    p1 = rng.normal(size=(E, N, 3)) * 100
+    p2 = rng.normal(size=(E, N, 3)) * 100
+    c1 = -np.tile(np.eye(3), (E, N, 1, 1))
+    c2 = np.zeros((E, N, 3, 3)); c2[..., :2, :2] = rng.uniform(0.1, 1, size=(E, N, 1, 1)) * np.eye(2)
+    io.write_experiments(tmp_path, poses_1, poses_2, p1, p2, c1, c2)
+    # literal format: 7 comma-separated values per pose row, trailing comma on point rows, %g
+    first = open(tmp_path / "poses_2.csv").readline().strip().split(",")
+    assert len(first) == 7 and first[0] == "%g" % poses_2[0, 0]
+    assert open(tmp_path / "points_1.csv").readline().rstrip("\n").endswith(",")
+    assert len(open(tmp_path / "covs_2.csv").readline().strip().rstrip(",").split(",")) == 9 * N
+    back = io.read_experiments(tmp_path)
+    np.testing.assert_allclose(back["poses_2"], poses_2, rtol=1e-5)
+    np.testing.assert_allclose(np.stack(back["points_2"]), p2, rtol=1e-5)
+    np.testing.assert_allclose(np.stack(back["covs_2"]), c2, rtol=1e-5, atol=1e-12)
+    R, t = io.relative_poses(back["poses_1"], back["poses_2"])
+    np.testing.assert_allclose(R[1], io.quat_xyzw_to_matrix(poses_2[1, :4]), atol=1e-5)
+    np.testing.assert_allclose(t, poses_2[:, 4:], rtol=1e-5)
+
+
+def test_result_tables_and_pose_stream(tmp_path):
+    res = {"PNEC": {"r_error": [0.01, 0.02], "t_error": [1.5, 2.5], "cost": [3.0, 4.0]},
+           "NEC": {"r_error": [0.03, 0.04], "t_error": [3.5, 4.5], "cost": [5.0, 6.0]}}
+    io.write_result_tables(tmp_path, res)
+    lines = open(tmp_path / "r_error.csv").read().splitlines()
+    assert lines[0] == "index,PNEC,NEC" and lines[1] == "0,0.01,0.03" and lines[2] == "1,0.02,0.04"
+    assert open(tmp_path / "cost.csv").read().splitlines()[2] == "1,4,6"
+    g = sim.generate(2, 4, seed=1)
+    io.write_pose_file(tmp_path / "poses.txt", [0.5, 1.25], g.R_gt.numpy(), g.t_gt.numpy())
+    line = open(tmp_path / "poses.txt").readline().split()
+    assert line[0] == "0.500000" and len(line) == 8 and "e" in line[1] and len(line[1].split("e")[0]) in (10, 11)
+    ts, t, q = io.read_pose_file(tmp_path / "poses.txt")
+    np.testing.assert_allclose(t, g.t_gt.numpy(), rtol=1e-8)
+    np.testing.assert_allclose(io.quat_xyzw_to_matrix(q[0]), g.R_gt[0].numpy(), atol=1e-8)
+    assert io.TIMING_HEADER.split()[:4] == ["ID", "FrameLoading", "FeatureCreation", "NEC-ES"]

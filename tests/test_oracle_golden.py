@@ -255,3 +255,27 @@ def test_batch_driver_matches_single_solves(oracle):
         np.testing.assert_array_equal(q[p], s.q)
         np.testing.assert_array_equal(t[p], s.t)
         assert it[p] == s.iterations and st[p] == s.status
+
+
+def test_unscented_transform_oracle_vs_reference_goldens(oracle, golden_dir):
+    """C restatement of common.cc:467-525 vs scripts/pnec/math.py (pinhole, diagonal covariances:
+    the only case where the reference's Python and C++ agree)."""
+    z = np.load(f"{golden_dir}/math_golden.npz")
+    for i in range(len(z["ut_points"])):
+        got = oracle.unscented_transform(z["ut_points"][i], z["ut_covs"][i], None, 1.0, oracle.CAMERA_PINHOLE)
+        np.testing.assert_allclose(got, z["ut_out"][i], rtol=1e-10, atol=1e-22)
+    # non-diagonal covariance: columns of the Cholesky factor (C++), cross-checked with the harness
+    rng = np.random.default_rng(4)
+    for _ in range(10):
+        A = rng.normal(size=(2, 2))
+        c2 = A @ A.T + 0.1 * np.eye(2)
+        cov = np.zeros((3, 3)); cov[:2, :2] = c2
+        mu = np.array([rng.uniform(-300, 300), rng.uniform(-200, 200), 800.0])
+        got = oracle.unscented_transform(mu, cov)
+        want = sim.unscented_bearing_cov(torch.from_numpy(mu)[None], torch.from_numpy(c2)[None])[0].numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-22)
+        # with intrinsics: K^-1 (x, y, 1)
+        K = np.array([[718.856, 0, 607.19], [0, 718.856, 185.22], [0, 0, 1.0]])
+        b = oracle.unproject(mu[:2], np.linalg.inv(K))
+        p = np.linalg.inv(K) @ np.array([mu[0], mu[1], 1.0])
+        np.testing.assert_allclose(b, p / np.linalg.norm(p), atol=1e-15)

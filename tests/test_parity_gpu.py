@@ -350,3 +350,39 @@ def test_full_size_batch_properties(oracle):
             assert int(res.iterations[p]) == s.iterations
     assert worst <= ROT_TOL_REFERENCE, worst
     batch.close()
+
+
+def test_unscented_transform_device_vs_oracle_and_goldens(oracle, golden_dir):
+    """input-side row: UnscentedTransform + Unproject for a batch of keypoints"""
+    from pnec_amd import frontend
+    z = np.load(f"{golden_dir}/math_golden.npz")
+    bvs, covs = frontend.unscented_transform(z["ut_points"], z["ut_covs"])
+    np.testing.assert_allclose(covs, z["ut_out"], rtol=1e-10, atol=1e-22)
+    np.testing.assert_allclose(bvs, z["ut_points"] / np.linalg.norm(z["ut_points"], axis=1, keepdims=True), atol=1e-15)
+    rng = np.random.default_rng(8)
+    n = 5000
+    K = np.array([[718.856, 0, 607.19], [0, 718.856, 185.22], [0, 0, 1.0]])
+    Kinv = np.linalg.inv(K)
+    pts = np.stack([rng.uniform(0, 1241, n), rng.uniform(0, 376, n), np.ones(n)], 1)
+    A = rng.normal(size=(n, 2, 2)) * 0.3
+    cov = np.zeros((n, 3, 3))
+    cov[:, :2, :2] = A @ np.transpose(A, (0, 2, 1)) + 0.01 * np.eye(2)
+    for model, mu, cv, Ki in ((frontend.CAMERA_PINHOLE, pts, cov, Kinv),
+                              (frontend.CAMERA_OMNIDIRECTIONAL, None, None, None)):
+        if model == frontend.CAMERA_OMNIDIRECTIONAL:
+            v = rng.normal(size=(n, 3))
+            v /= np.linalg.norm(v, axis=1, keepdims=True)
+            v[:, 2] = np.abs(v[:, 2]) * 0.9 + 0.05   # away from the antipode of +z
+            mu = v / np.linalg.norm(v, axis=1, keepdims=True) * 800.0
+            Rb = sim.rotation_between_z_and(torch.from_numpy(mu / 800.0)).numpy()
+            cv = Rb @ cov @ np.transpose(Rb, (0, 2, 1))
+            Ki = np.eye(3)
+        b_dev, c_dev = frontend.unscented_transform(mu, cv, Ki, 1.0, model)
+        for i in range(0, n, 97):
+            want = oracle.unscented_transform(mu[i], cv[i], Ki, 1.0, model)
+            np.testing.assert_allclose(c_dev[i], want, rtol=1e-9, atol=1e-20)
+        # device space == host space
+        bt, ct = frontend.unscented_transform(torch.from_numpy(mu).cuda(), torch.from_numpy(cv).cuda(),
+                                              torch.from_numpy(Ki).cuda(), 1.0, model)
+        np.testing.assert_array_equal(ct.cpu().numpy(), c_dev)
+        np.testing.assert_array_equal(bt.cpu().numpy(), b_dev)
