@@ -20,6 +20,8 @@
  *   ceres::Solver::Options (default-constructed, pnec_ceres.cc:47)   pnec_hip_options
  *   pnec::common::CostFunction  src/common/common.cc:237-259    pnec_hip_cost_function
  *   pnec::common::UnscentedTransform / Unproject  common.cc:460-525   pnec_hip_unscented_transform
+ *   PNEC::Eigensolver (no RANSAC) / WeightedEigensolver  pnec.cc:231-348   pnec_hip_nec_eigensolver /
+ *                                                               pnec_hip_weighted_eigensolver
  *
  * Conventions (same as the reference):
  *   - bearing vectors: 3 doubles each, unit norm; frame 1 = "host", frame 2 = "target".
@@ -153,6 +155,23 @@ int pnec_hip_select_best(int64_t n_pairs, int32_t n_hyp, const double *cost, int
  * normalised inside) and t.  Only for TARGET-mode problems.  out [n_pairs]. */
 int pnec_hip_cost_function(pnec_hip_problem *p, const double *q, const double *t, double *out,
                            int space, void *stream);
+
+/* PNEC::Eigensolver with use_ransac_ = false (src/rel_pose_estimation/pnec.cc:273-278) for every
+ * pair: rotation by opengv-style eigenvalue minimisation (Kneip-Lynen; opengv is not in the
+ * reference tree, so the published algorithm is restated) started at init_q, translation by
+ * TranslationFromM(ComposeM(...)) (src/common/common.cc:127-136,157-181, including ComposeM's
+ * skipped first correspondence).  init_q [n_pairs,4] xyzw -> out_q [n_pairs,4], out_t [n_pairs,3]. */
+int pnec_hip_nec_eigensolver(pnec_hip_problem *p, const double *init_q, double *out_q, double *out_t,
+                             int space, void *stream);
+
+/* PNEC::WeightedEigensolver (src/rel_pose_estimation/pnec.cc:283-348) for every pair of a
+ * TARGET-mode problem: (weighted_iterations - 1) rounds of { weights from the INITIAL pose x 1e-8,
+ * eigensolver on the weighted bearings, 500-direction Fibonacci search of obj_fun
+ * (src/optimization/scf.cc:43-72), 10 scf steps (scf.cc:128-148) }.  Options::weighted_iterations_
+ * is 10 in the reference. */
+int pnec_hip_weighted_eigensolver(pnec_hip_problem *p, const double *init_q, const double *init_t,
+                                  double reg, int32_t weighted_iterations, double *out_q, double *out_t,
+                                  int space, void *stream);
 
 /* Input side of the path: pnec::common::UnscentedTransform (src/common/common.cc:467-525) and
  * pnec::common::Unproject (:460-465) for n keypoints at once -- what KeyPoint::Unproject

@@ -148,6 +148,40 @@ void pnec_oracle_solve_batch(int mode, int64_t n_pairs, const int64_t *offsets,
 
 int pnec_oracle_max_threads(void);
 
+/* --- stages in front of the refinement (pnec_oracle_frontend.c) ----- */
+/* symmetric 3x3 (row-major) -> eigenvalues ascending, eigenvectors in the columns of V (row-major);
+ * each eigenvector's largest-magnitude component is positive */
+void pnec_oracle_sym_eig3(const double A[9], double w[3], double V[9]);
+/* common.cc:127-136 (skip_first = 1 reproduces the loop that starts at i = 1); M row-major */
+void pnec_oracle_compose_m(int64_t n, const double *bvs1, const double *bvs2, const double R[9],
+                           int skip_first, double M[9]);
+/* common.cc:157-181 */
+void pnec_oracle_translation_from_m(const double M[9], double t[3]);
+/* common.cc:183-208; cov column-major */
+double pnec_oracle_weight(const double f1[3], const double f2[3], const double t[3], const double R[9],
+                          const double *cov, double reg, int host_frame);
+void pnec_oracle_cayley_to_rot(const double v[3], double R[9]);
+void pnec_oracle_rot_to_cayley(const double R[9], double v[3]);
+/* opengv::relative_pose::eigensolver restated (Kneip-Lynen eigenvalue minimisation); R row-major */
+int pnec_oracle_eigensolver(int64_t n, const double *bvs1, const double *bvs2, const double R0[9],
+                            double R_out[9], int32_t *iterations);
+/* scf.cc:53-72 (float division quirk), :43-51, :128-148 (with the alt_construct_E slip) */
+void pnec_oracle_fibonacci_sphere(int samples, double *pts);
+double pnec_oracle_obj_fun(const double t[3], int64_t n, const double *Ai, const double *Bi);
+void pnec_oracle_scf(int64_t n, const double *Ai, const double *Bi, const double t0[3], int steps,
+                     double t_out[3]);
+/* pnec.cc:317-328; Ai, Bi row-major 3x3 per correspondence */
+void pnec_oracle_build_ab(int64_t n, const double *bvs1, const double *bvs2, const double *covs,
+                          const double R[9], double reg, double *Ai, double *Bi);
+/* pnec.cc:231-281 without RANSAC: rotation by the eigensolver, translation from ComposeM(i>=1) */
+void pnec_oracle_nec_eigensolver(int64_t n, const double *bvs1, const double *bvs2, const double R0[9],
+                                 double R_out[9], double t_out[3]);
+/* pnec.cc:283-348 */
+void pnec_oracle_weighted_eigensolver(int64_t n, const double *bvs1, const double *bvs2,
+                                      const double *covs, const double R_init[9], const double t_init[3],
+                                      double reg, int weighted_iterations, double R_out[9],
+                                      double t_out[3]);
+
 #ifdef __cplusplus
 }
 #endif

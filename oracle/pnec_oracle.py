@@ -57,7 +57,8 @@ class Options(C.Structure):
 def build(force: bool = False) -> str:
     """Compile oracle/libpnec_oracle.so with the committed Makefile."""
     if force or not os.path.exists(_LIB_PATH) or (
-        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "pnec_oracle.c"))
+        os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                          for f in ("pnec_oracle.c", "pnec_oracle_frontend.c", "pnec_oracle.h"))
     ):
         subprocess.run(["make", "-C", _HERE, "-B", "libpnec_oracle.so"], check=True,
                        stdout=subprocess.DEVNULL)
@@ -106,6 +107,22 @@ def lib() -> C.CDLL:
         _lib.pnec_oracle_max_threads.restype = C.c_int
         _lib.pnec_oracle_unscented_transform.argtypes = [_dp, _dp, _dp, C.c_double, C.c_int, _dp]
         _lib.pnec_oracle_unproject.argtypes = [_dp, _dp, _dp]
+        _lib.pnec_oracle_sym_eig3.argtypes = [_dp, _dp, _dp]
+        _lib.pnec_oracle_compose_m.argtypes = [C.c_int64, _dp, _dp, _dp, C.c_int, _dp]
+        _lib.pnec_oracle_translation_from_m.argtypes = [_dp, _dp]
+        _lib.pnec_oracle_weight.argtypes = [_dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int]
+        _lib.pnec_oracle_weight.restype = C.c_double
+        _lib.pnec_oracle_cayley_to_rot.argtypes = [_dp, _dp]
+        _lib.pnec_oracle_rot_to_cayley.argtypes = [_dp, _dp]
+        _lib.pnec_oracle_eigensolver.argtypes = [C.c_int64, _dp, _dp, _dp, _dp, _ip]
+        _lib.pnec_oracle_fibonacci_sphere.argtypes = [C.c_int, _dp]
+        _lib.pnec_oracle_obj_fun.argtypes = [_dp, C.c_int64, _dp, _dp]
+        _lib.pnec_oracle_obj_fun.restype = C.c_double
+        _lib.pnec_oracle_scf.argtypes = [C.c_int64, _dp, _dp, _dp, C.c_int, _dp]
+        _lib.pnec_oracle_build_ab.argtypes = [C.c_int64, _dp, _dp, _dp, _dp, C.c_double, _dp, _dp]
+        _lib.pnec_oracle_nec_eigensolver.argtypes = [C.c_int64, _dp, _dp, _dp, _dp, _dp]
+        _lib.pnec_oracle_weighted_eigensolver.argtypes = [C.c_int64, _dp, _dp, _dp, _dp, _dp, C.c_double,
+                                                          C.c_int, _dp, _dp]
     return _lib
 
 
@@ -154,6 +171,118 @@ def unproject(img_pt, K_inv):
     out = np.zeros(3)
     lib().pnec_oracle_unproject(pp, kp, out.ctypes.data_as(_dp))
     return out
+
+
+# ---- stages in front of the refinement (pnec_oracle_frontend.c) -------------------------------
+def sym_eig3(A):
+    a, ap = _d(np.asarray(A).reshape(9))
+    w, V = np.zeros(3), np.zeros(9)
+    lib().pnec_oracle_sym_eig3(ap, w.ctypes.data_as(_dp), V.ctypes.data_as(_dp))
+    return w, V.reshape(3, 3)
+
+
+def compose_m(bvs1, bvs2, R, skip_first=True):
+    b1, b1p = _d(bvs1)
+    b2, b2p = _d(bvs2)
+    r, rp = _d(np.asarray(R).reshape(9))
+    M = np.zeros(9)
+    lib().pnec_oracle_compose_m(len(b1), b1p, b2p, rp, int(skip_first), M.ctypes.data_as(_dp))
+    return M.reshape(3, 3)
+
+
+def translation_from_m(M):
+    m, mp = _d(np.asarray(M).reshape(9))
+    t = np.zeros(3)
+    lib().pnec_oracle_translation_from_m(mp, t.ctypes.data_as(_dp))
+    return t
+
+
+def weight(f1, f2, t, R, cov, reg, host_frame=False):
+    a, ap = _d(f1); b, bp = _d(f2); c, cp = _d(t)
+    r, rp = _d(np.asarray(R).reshape(9))
+    s, sp = _d(np.asarray(cov).T.reshape(9))
+    return lib().pnec_oracle_weight(ap, bp, cp, rp, sp, reg, int(host_frame))
+
+
+def cayley_to_rot(v):
+    a, ap = _d(v)
+    R = np.zeros(9)
+    lib().pnec_oracle_cayley_to_rot(ap, R.ctypes.data_as(_dp))
+    return R.reshape(3, 3)
+
+
+def rot_to_cayley(R):
+    r, rp = _d(np.asarray(R).reshape(9))
+    v = np.zeros(3)
+    lib().pnec_oracle_rot_to_cayley(rp, v.ctypes.data_as(_dp))
+    return v
+
+
+def eigensolver(bvs1, bvs2, R0):
+    """rotation minimising the smallest eigenvalue of M(R) (Kneip-Lynen), started at R0"""
+    b1, b1p = _d(bvs1)
+    b2, b2p = _d(bvs2)
+    r, rp = _d(np.asarray(R0).reshape(9))
+    R = np.zeros(9)
+    it = C.c_int32()
+    lib().pnec_oracle_eigensolver(len(b1), b1p, b2p, rp, R.ctypes.data_as(_dp), C.byref(it))
+    return R.reshape(3, 3), it.value
+
+
+def fibonacci_sphere(samples=500):
+    pts = np.zeros((samples, 3))
+    lib().pnec_oracle_fibonacci_sphere(samples, pts.ctypes.data_as(_dp))
+    return pts
+
+
+def obj_fun(t, Ai, Bi):
+    a, ap = _d(t)
+    A, Ap = _d(np.asarray(Ai).reshape(-1, 9))
+    B, Bp = _d(np.asarray(Bi).reshape(-1, 9))
+    return lib().pnec_oracle_obj_fun(ap, len(A), Ap, Bp)
+
+
+def scf(Ai, Bi, t0, steps=10):
+    A, Ap = _d(np.asarray(Ai).reshape(-1, 9))
+    B, Bp = _d(np.asarray(Bi).reshape(-1, 9))
+    a, ap = _d(t0)
+    t = np.zeros(3)
+    lib().pnec_oracle_scf(len(A), Ap, Bp, ap, steps, t.ctypes.data_as(_dp))
+    return t
+
+
+def build_ab(bvs1, bvs2, covs, R, reg):
+    b1, b1p = _d(bvs1)
+    b2, b2p = _d(bvs2)
+    c, cp = _d(covs_to_colmajor9(covs))
+    r, rp = _d(np.asarray(R).reshape(9))
+    n = len(b1)
+    Ai, Bi = np.zeros((n, 3, 3)), np.zeros((n, 3, 3))
+    lib().pnec_oracle_build_ab(n, b1p, b2p, cp, rp, reg, Ai.ctypes.data_as(_dp), Bi.ctypes.data_as(_dp))
+    return Ai, Bi
+
+
+def nec_eigensolver(bvs1, bvs2, R0):
+    """PNEC::Eigensolver without RANSAC (pnec.cc:273-278) -> (R, t)"""
+    b1, b1p = _d(bvs1)
+    b2, b2p = _d(bvs2)
+    r, rp = _d(np.asarray(R0).reshape(9))
+    R, t = np.zeros(9), np.zeros(3)
+    lib().pnec_oracle_nec_eigensolver(len(b1), b1p, b2p, rp, R.ctypes.data_as(_dp), t.ctypes.data_as(_dp))
+    return R.reshape(3, 3), t
+
+
+def weighted_eigensolver(bvs1, bvs2, covs, R_init, t_init, reg=1e-13, weighted_iterations=10):
+    """PNEC::WeightedEigensolver (pnec.cc:283-348) -> (R, t)"""
+    b1, b1p = _d(bvs1)
+    b2, b2p = _d(bvs2)
+    c, cp = _d(covs_to_colmajor9(covs))
+    r, rp = _d(np.asarray(R_init).reshape(9))
+    t0, t0p = _d(t_init)
+    R, t = np.zeros(9), np.zeros(3)
+    lib().pnec_oracle_weighted_eigensolver(len(b1), b1p, b2p, cp, rp, t0p, reg, weighted_iterations,
+                                           R.ctypes.data_as(_dp), t.ctypes.data_as(_dp))
+    return R.reshape(3, 3), t
 
 
 def angles_from_vec(v):

@@ -1,0 +1,436 @@
+/*
+ * pnec_oracle_frontend.c -- TEST INFRASTRUCTURE ONLY (same rules as pnec_oracle.c).
+ *
+ * CPU restatement of the stages in front of the least-squares refinement:
+ *   ComposeM / TranslationFromM / Weight        src/common/common.cc:127-136,157-181,183-208
+ *   fibonacci_sphere / obj_fun / scf            src/optimization/scf.cc:43-72,109-148
+ *   PNEC::Eigensolver (no RANSAC branch)        src/rel_pose_estimation/pnec.cc:231-281
+ *   PNEC::WeightedEigensolver                   src/rel_pose_estimation/pnec.cc:283-348
+ *   PNEC::Solve                                 src/rel_pose_estimation/pnec.cc:77-124
+ *
+ * PARITY STATUS
+ *   pinned   : fibonacci_sphere, obj_fun (goldens from scripts/pnec/scf.py), Weight and the A_i/B_i
+ *              construction (they are the golden-pinned PNEC energy in disguise).
+ *   unpinned : opengv::relative_pose::eigensolver.  opengv is not vendored (basalt master,
+ *              un-pinned) and the reference has no tests.  The minimiser below
+ *              restates the PUBLISHED algorithm (Kneip & Lynen, "Direct optimization of
+ *              frame-to-frame rotation", ICCV 2013): minimise the smallest eigenvalue of
+ *              M(R) = sum_i (f1_i x R f2_i)(f1_i x R f2_i)' over the Cayley parameters of R,
+ *              starting from the supplied rotation.  opengv drives that with MINPACK's lmdif on
+ *              the eigenvalue's Jacobian (ftol 5e-5, <= 100 evaluations); here it is a damped
+ *              Newton iteration run to a tight tolerance -- same minimiser, different path.
+ *              Eigenvector signs (TranslationFromM, scf) are arbitrary in Eigen; here: the
+ *              component of largest magnitude is made positive.
+ *   Reference quirks reproduced: ComposeM skips correspondence 0 (C7); WeightedEigensolver
+ *   recomputes its weights from the INITIAL pose every iteration (C3) and scales them by 1e-8
+ *   (C4); alt_construct_E drops the -frac*B term (C5); fibonacci_sphere divides in float (C6).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pnec_oracle.h"
+
+static inline double dot3(const double a[3], const double b[3]) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+static inline void cross3(const double a[3], const double b[3], double c[3]) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+static inline void mat_vec(const double R[9], const double x[3], double y[3]) {
+  for (int r = 0; r < 3; ++r) y[r] = R[3 * r] * x[0] + R[3 * r + 1] * x[1] + R[3 * r + 2] * x[2];
+}
+static inline void matT_vec(const double R[9], const double x[3], double y[3]) {
+  for (int r = 0; r < 3; ++r) y[r] = R[r] * x[0] + R[3 + r] * x[1] + R[6 + r] * x[2];
+}
+
+/* ---- symmetric 3x3 eigen-decomposition: cyclic Jacobi, eigenvalues ascending ------------- */
+/* A row-major symmetric; w ascending; V row-major with eigenvectors in COLUMNS; each column has its
+ * largest-magnitude component positive. */
+void pnec_oracle_sym_eig3(const double A_in[9], double w[3], double V[9]) {
+  double A[9];
+  memcpy(A, A_in, sizeof(A));
+  for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    const double dg = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+    if (off <= 1e-34 * dg || off == 0.0) break;
+    static const int P[3] = {0, 0, 1}, Q[3] = {1, 2, 2};
+    for (int k = 0; k < 3; ++k) {
+      const int p = P[k], q = Q[k];
+      const double apq = A[3 * p + q];
+      if (apq == 0.0) continue;
+      const double theta = (A[3 * q + q] - A[3 * p + p]) / (2.0 * apq);
+      const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+      /* A <- J' A J */
+      for (int r = 0; r < 3; ++r) {
+        const double arp = A[3 * r + p], arq = A[3 * r + q];
+        A[3 * r + p] = c * arp - s * arq;
+        A[3 * r + q] = s * arp + c * arq;
+      }
+      for (int r = 0; r < 3; ++r) {
+        const double apr = A[3 * p + r], aqr = A[3 * q + r];
+        A[3 * p + r] = c * apr - s * aqr;
+        A[3 * q + r] = s * apr + c * aqr;
+      }
+      for (int r = 0; r < 3; ++r) {
+        const double vrp = V[3 * r + p], vrq = V[3 * r + q];
+        V[3 * r + p] = c * vrp - s * vrq;
+        V[3 * r + q] = s * vrp + c * vrq;
+      }
+    }
+  }
+  double d[3] = {A[0], A[4], A[8]};
+  int idx[3] = {0, 1, 2};
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2 - i; ++j)
+      if (d[idx[j]] > d[idx[j + 1]]) {
+        const int t = idx[j];
+        idx[j] = idx[j + 1];
+        idx[j + 1] = t;
+      }
+  double Vs[9];
+  for (int c = 0; c < 3; ++c) {
+    w[c] = d[idx[c]];
+    int big = 0;
+    for (int r = 1; r < 3; ++r)
+      if (fabs(V[3 * r + idx[c]]) > fabs(V[3 * big + idx[c]])) big = r;
+    const double sg = V[3 * big + idx[c]] < 0.0 ? -1.0 : 1.0;
+    for (int r = 0; r < 3; ++r) Vs[3 * r + c] = sg * V[3 * r + idx[c]];
+  }
+  memcpy(V, Vs, sizeof(Vs));
+}
+
+/* ---- common.cc:127-136 (loop starts at i = 1 when skip_first) ------------------------------ */
+void pnec_oracle_compose_m(int64_t n, const double *bvs1, const double *bvs2, const double R[9],
+                           int skip_first, double M[9]) {
+  memset(M, 0, 9 * sizeof(double));
+  for (int64_t i = skip_first ? 1 : 0; i < n; ++i) {
+    double u[3], nn[3];
+    mat_vec(R, bvs2 + 3 * i, u);
+    cross3(bvs1 + 3 * i, u, nn);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) M[3 * r + c] += nn[r] * nn[c];
+  }
+}
+
+/* ---- common.cc:157-181: unit eigenvector of the smallest eigenvalue ------------------------ */
+void pnec_oracle_translation_from_m(const double M[9], double t[3]) {
+  double w[3], V[9];
+  pnec_oracle_sym_eig3(M, w, V);
+  const double v[3] = {V[0], V[3], V[6]};
+  const double nv = sqrt(dot3(v, v));
+  for (int k = 0; k < 3; ++k) t[k] = v[k] / nv;
+}
+
+/* ---- common.cc:183-208; cov column-major 9 --------------------------------------------------- */
+double pnec_oracle_weight(const double f1[3], const double f2[3], const double t[3], const double R[9],
+                          const double *cov, double reg, int host_frame) {
+  double v[3];
+  if (host_frame) {
+    double p[3];
+    mat_vec(R, f2, p);
+    cross3(t, p, v); /* (t' [R f2]x)' = -(R f2) x t ... sign irrelevant in the quadratic form */
+    double q = 0.0;
+    for (int c = 0; c < 3; ++c)
+      for (int r = 0; r < 3; ++r) q += v[r] * cov[3 * c + r] * v[c];
+    return 1.0 / q;
+  }
+  double m[3];
+  cross3(t, f1, m);
+  matT_vec(R, m, v);
+  double q = 0.0;
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) q += v[r] * cov[3 * c + r] * v[c];
+  return 1.0 / (q + reg);
+}
+
+/* ---- Cayley parameterisation (opengv math/cayley, published formulas) ----------------------- */
+void pnec_oracle_cayley_to_rot(const double v[3], double R[9]) {
+  const double x = v[0], y = v[1], z = v[2];
+  const double s = 1.0 / (1.0 + x * x + y * y + z * z);
+  R[0] = s * (1 + x * x - y * y - z * z); R[1] = s * 2 * (x * y - z); R[2] = s * 2 * (x * z + y);
+  R[3] = s * 2 * (x * y + z); R[4] = s * (1 - x * x + y * y - z * z); R[5] = s * 2 * (y * z - x);
+  R[6] = s * 2 * (x * z - y); R[7] = s * 2 * (y * z + x); R[8] = s * (1 - x * x - y * y + z * z);
+}
+void pnec_oracle_rot_to_cayley(const double R[9], double v[3]) {
+  /* C = (R - I)(R + I)^-1 is skew; v = (-C(1,2), C(0,2), -C(0,1)) */
+  double A[9], B[9];
+  for (int i = 0; i < 9; ++i) {
+    A[i] = R[i] - (i % 4 == 0 ? 1.0 : 0.0);
+    B[i] = R[i] + (i % 4 == 0 ? 1.0 : 0.0);
+  }
+  /* inverse of B by adjugate */
+  const double c00 = B[4] * B[8] - B[5] * B[7], c01 = B[5] * B[6] - B[3] * B[8], c02 = B[3] * B[7] - B[4] * B[6];
+  const double det = B[0] * c00 + B[1] * c01 + B[2] * c02;
+  double Bi[9];
+  Bi[0] = c00 / det; Bi[1] = (B[2] * B[7] - B[1] * B[8]) / det; Bi[2] = (B[1] * B[5] - B[2] * B[4]) / det;
+  Bi[3] = c01 / det; Bi[4] = (B[0] * B[8] - B[2] * B[6]) / det; Bi[5] = (B[2] * B[3] - B[0] * B[5]) / det;
+  Bi[6] = c02 / det; Bi[7] = (B[1] * B[6] - B[0] * B[7]) / det; Bi[8] = (B[0] * B[4] - B[1] * B[3]) / det;
+  double Cm[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) Cm[3 * r + c] = A[3 * r] * Bi[c] + A[3 * r + 1] * Bi[3 + c] + A[3 * r + 2] * Bi[6 + c];
+  v[0] = -Cm[5];
+  v[1] = Cm[2];
+  v[2] = -Cm[1];
+}
+
+/* ---- eigenvalue minimisation ----------------------------------------------------------------- */
+typedef struct {
+  int64_t n;
+  const double *b1, *b2;
+} es_data;
+
+/* lambda_min(M(R(v))), its eigenvector e, and d lambda / d v (analytic: e' dM e) */
+static double g_es_trace; /* trace of the last composed M (noise floor of the line search) */
+#pragma omp threadprivate(g_es_trace)
+static double es_value_grad(const es_data *D, const double v[3], double g[3]) {
+  double R[9], M[9], w[3], V[9];
+  pnec_oracle_cayley_to_rot(v, R);
+  pnec_oracle_compose_m(D->n, D->b1, D->b2, R, 0, M);
+  g_es_trace = M[0] + M[4] + M[8];
+  pnec_oracle_sym_eig3(M, w, V);
+  if (!g) return w[0];
+  const double e[3] = {V[0], V[3], V[6]};
+  /* dR/dv_k = (dN/dv_k - 2 v_k R) / s,  N = (1-|v|^2) I + 2[v]x + 2 v v' */
+  const double s = 1.0 + dot3(v, v);
+  for (int k = 0; k < 3; ++k) {
+    double dN[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; ++i) dN[4 * i] = -2.0 * v[k];
+    /* 2 [e_k]x */
+    const int a = (k + 1) % 3, b = (k + 2) % 3;
+    dN[3 * b + a] += 2.0;
+    dN[3 * a + b] -= 2.0;
+    for (int i = 0; i < 3; ++i) {
+      dN[3 * k + i] += 2.0 * v[i];
+      dN[3 * i + k] += 2.0 * v[i];
+    }
+    double dR[9];
+    for (int i = 0; i < 9; ++i) dR[i] = (dN[i] - 2.0 * v[k] * R[i]) / s;
+    double acc = 0.0;
+    for (int64_t i = 0; i < D->n; ++i) {
+      double u[3], nn[3], du[3], dn[3];
+      mat_vec(R, D->b2 + 3 * i, u);
+      cross3(D->b1 + 3 * i, u, nn);
+      mat_vec(dR, D->b2 + 3 * i, du);
+      cross3(D->b1 + 3 * i, du, dn);
+      acc += 2.0 * dot3(e, nn) * dot3(e, dn);
+    }
+    g[k] = acc;
+  }
+  return w[0];
+}
+
+static int solve3_spd(const double H[9], const double b[3], double x[3]) {
+  /* Cholesky of a symmetric 3x3; 0 if not positive definite */
+  const double l00s = H[0];
+  if (!(l00s > 0.0)) return 0;
+  const double l00 = sqrt(l00s), l10 = H[3] / l00, l20 = H[6] / l00;
+  const double l11s = H[4] - l10 * l10;
+  if (!(l11s > 0.0)) return 0;
+  const double l11 = sqrt(l11s), l21 = (H[7] - l20 * l10) / l11;
+  const double l22s = H[8] - l20 * l20 - l21 * l21;
+  if (!(l22s > 0.0)) return 0;
+  const double l22 = sqrt(l22s);
+  const double z0 = b[0] / l00, z1 = (b[1] - l10 * z0) / l11, z2 = (b[2] - l20 * z0 - l21 * z1) / l22;
+  x[2] = z2 / l22;
+  x[1] = (z1 - l21 * x[2]) / l11;
+  x[0] = (z0 - l10 * x[1] - l20 * x[2]) / l00;
+  return 1;
+}
+
+/* Damped Newton on v (Cayley): Hessian by forward differences of the analytic gradient
+ * (h = 1e-6), Levenberg shift until positive definite and descending, Armijo backtracking.
+ * Stops when |step|_inf < 1e-12, |grad|_inf < 1e-14 * (1 + |lambda|) * n, or after 50 iterations. */
+static int eigensolver_cayley(const es_data *Dp, double v[3]) {
+  const es_data D = *Dp;
+  const int64_t n = D.n;
+  double g[3];
+  double f = es_value_grad(&D, v, g);
+  int it = 0;
+  for (; it < 50; ++it) {
+    const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+    if (gmax <= 1e-14 * (1.0 + fabs(f)) * (double)(n > 0 ? n : 1)) break;
+    double H[9];
+    const double h = 1e-6;
+    for (int k = 0; k < 3; ++k) {
+      double vp[3] = {v[0], v[1], v[2]}, gp[3];
+      vp[k] += h;
+      es_value_grad(&D, vp, gp);
+      for (int r = 0; r < 3; ++r) H[3 * r + k] = (gp[r] - g[r]) / h;
+    }
+    for (int r = 0; r < 3; ++r)
+      for (int c = r + 1; c < 3; ++c) H[3 * r + c] = H[3 * c + r] = 0.5 * (H[3 * r + c] + H[3 * c + r]);
+    double mu = 0.0, d[3];
+    const double tr = fabs(H[0]) + fabs(H[4]) + fabs(H[8]);
+    int ok = 0;
+    for (int tries = 0; tries < 40; ++tries) {
+      double Hm[9];
+      memcpy(Hm, H, sizeof(Hm));
+      Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
+      const double mg[3] = {-g[0], -g[1], -g[2]};
+      if (solve3_spd(Hm, mg, d) && dot3(d, g) < 0.0) { ok = 1; break; }
+      mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * 10.0;
+    }
+    if (!ok) break;
+    double alpha = 1.0, fn = f, vn[3];
+    const double slope = dot3(d, g);
+    int moved = 0;
+    for (int ls = 0; ls < 40; ++ls) {
+      for (int k = 0; k < 3; ++k) vn[k] = v[k] + alpha * d[k];
+      fn = es_value_grad(&D, vn, NULL);
+      /* Armijo with a rounding-noise floor: lambda_min carries ~eps * trace(M) of error */
+      if (fn <= f + 1e-4 * alpha * slope + 4e-16 * g_es_trace) { moved = 1; break; }
+      alpha *= 0.5;
+    }
+    if (!moved) break;
+    const double smax = alpha * fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
+    memcpy(v, vn, sizeof(vn));
+    f = es_value_grad(&D, v, g);
+    if (smax < 1e-12) { ++it; break; }
+  }
+  return it;
+}
+
+int pnec_oracle_eigensolver(int64_t n, const double *bvs1, const double *bvs2, const double R0[9],
+                            double R_out[9], int32_t *iterations) {
+  es_data D = {n, bvs1, bvs2};
+  double v[3];
+  pnec_oracle_rot_to_cayley(R0, v);
+  const int it = eigensolver_cayley(&D, v);
+  pnec_oracle_cayley_to_rot(v, R_out);
+  if (iterations) *iterations = it;
+  return 0;
+}
+
+/* ---- scf.cc --------------------------------------------------------------------------------- */
+void pnec_oracle_fibonacci_sphere(int samples, double *pts /* [samples,3] */) {
+  const double phi = M_PI * (3.0 - sqrt(5.0));
+  for (int i = 0; i < samples; ++i) {
+    const double y = 1.0 - ((float)i / (float)(samples - 1)) * 2.0; /* float division (scf.cc:59) */
+    const double radius = sqrt(1 - y * y);
+    const double theta = phi * (float)i;
+    pts[3 * i] = cos(theta) * radius;
+    pts[3 * i + 1] = y;
+    pts[3 * i + 2] = sin(theta) * radius;
+  }
+}
+
+static double quad9(const double *A /*row-major sym*/, const double t[3]) {
+  double q = 0.0;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) q += t[r] * A[3 * r + c] * t[c];
+  return q;
+}
+
+/* scf.cc:43-51; Ai, Bi arrays of n row-major 3x3 */
+double pnec_oracle_obj_fun(const double t[3], int64_t n, const double *Ai, const double *Bi) {
+  double cost = 0.0;
+  for (int64_t i = 0; i < n; ++i) cost += quad9(Ai + 9 * i, t) / quad9(Bi + 9 * i, t);
+  return cost;
+}
+
+/* scf.cc:128-148 with alt_construct_E's resize/push_back slip (C5): E = sum A_i / (t'B_i t) */
+void pnec_oracle_scf(int64_t n, const double *Ai, const double *Bi, const double t0[3], int steps,
+                     double t_out[3]) {
+  double t[3] = {t0[0], t0[1], t0[2]};
+  for (int s = 0; s < steps; ++s) {
+    double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = 0; i < n; ++i) {
+      const double w = 1.0 / quad9(Bi + 9 * i, t);
+      for (int k = 0; k < 9; ++k) E[k] += w * Ai[9 * i + k];
+    }
+    double w3[3], V[9];
+    pnec_oracle_sym_eig3(E, w3, V);
+    t[0] = V[0]; t[1] = V[3]; t[2] = V[6];
+  }
+  memcpy(t_out, t, sizeof(t));
+}
+
+/* A_i = n n', B_i = f1hat R Sigma R' f1hat' + reg I   (pnec.cc:317-328); row-major outputs */
+void pnec_oracle_build_ab(int64_t n, const double *bvs1, const double *bvs2, const double *covs,
+                          const double R[9], double reg, double *Ai, double *Bi) {
+  for (int64_t i = 0; i < n; ++i) {
+    const double *f1 = bvs1 + 3 * i, *C = covs + 9 * i;
+    double u[3], nn[3];
+    mat_vec(R, bvs2 + 3 * i, u);
+    cross3(f1, u, nn);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) Ai[9 * i + 3 * r + c] = nn[r] * nn[c];
+    /* P = f1hat R (row-major): P(r,c) = sum_k F(r,k) R(k,c) */
+    const double F[9] = {0, -f1[2], f1[1], f1[2], 0, -f1[0], -f1[1], f1[0], 0};
+    double P[9], PS[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) P[3 * r + c] = F[3 * r] * R[c] + F[3 * r + 1] * R[3 + c] + F[3 * r + 2] * R[6 + c];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) /* (P Sigma)(r,c), Sigma column-major: S(k,c) = C[3c+k] */
+        PS[3 * r + c] = P[3 * r] * C[3 * c] + P[3 * r + 1] * C[3 * c + 1] + P[3 * r + 2] * C[3 * c + 2];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        Bi[9 * i + 3 * r + c] = PS[3 * r] * P[3 * c] + PS[3 * r + 1] * P[3 * c + 1] + PS[3 * r + 2] * P[3 * c + 2] +
+                                (r == c ? reg : 0.0);
+  }
+}
+
+/* ---- pnec.cc:231-281, use_ransac_ = false branch -------------------------------------------- */
+void pnec_oracle_nec_eigensolver(int64_t n, const double *bvs1, const double *bvs2, const double R0[9],
+                                 double R_out[9], double t_out[3]) {
+  pnec_oracle_eigensolver(n, bvs1, bvs2, R0, R_out, NULL);
+  double M[9];
+  pnec_oracle_compose_m(n, bvs1, bvs2, R_out, 1, M);
+  pnec_oracle_translation_from_m(M, t_out);
+}
+
+/* ---- pnec.cc:283-348 -------------------------------------------------------------------------- */
+void pnec_oracle_weighted_eigensolver(int64_t n, const double *bvs1, const double *bvs2,
+                                      const double *covs, const double R_init[9], const double t_init[3],
+                                      double reg, int weighted_iterations, double R_out[9],
+                                      double t_out[3]) {
+  double R[9], t[3], v[3];
+  memcpy(R, R_init, sizeof(R));
+  memcpy(t, t_init, sizeof(t));
+  /* the rotation is carried between iterations as its Cayley vector, so an eigensolver call that is
+   * already converged at entry returns bit-identical R (iterations 2.. of the reference only
+   * restart opengv's eigensolver from the previous optimum with unchanged weights, C3) */
+  pnec_oracle_rot_to_cayley(R_init, v);
+  double *w2 = (double *)malloc(sizeof(double) * 3 * (size_t)(n > 0 ? n : 1));
+  double *Ai = (double *)malloc(sizeof(double) * 9 * (size_t)(n > 0 ? n : 1));
+  double *Bi = (double *)malloc(sizeof(double) * 9 * (size_t)(n > 0 ? n : 1));
+  double fib[1500];
+  pnec_oracle_fibonacci_sphere(500, fib);
+  for (int it = 0; it + 1 < weighted_iterations; ++it) {
+    /* weights from the INITIAL pose every iteration (C3), scaled by 1e-8 (C4) */
+    for (int64_t i = 0; i < n; ++i) {
+      const double w = pnec_oracle_weight(bvs1 + 3 * i, bvs2 + 3 * i, t_init, R_init, covs + 9 * i, reg, 0) * 1e-8;
+      const double sw = sqrt(w);
+      for (int k = 0; k < 3; ++k) w2[3 * i + k] = bvs2[3 * i + k] * sw;
+    }
+    double Rn[9];
+    {
+      es_data D = {n, bvs1, w2};
+      eigensolver_cayley(&D, v);
+      pnec_oracle_cayley_to_rot(v, Rn);
+    }
+    pnec_oracle_build_ab(n, bvs1, bvs2, covs, Rn, reg, Ai, Bi);
+    double best[3] = {t[0], t[1], t[2]};
+    double best_cost = pnec_oracle_obj_fun(best, n, Ai, Bi);
+    for (int k = 0; k < 500; ++k) {
+      const double c = pnec_oracle_obj_fun(fib + 3 * k, n, Ai, Bi);
+      if (c < best_cost) {
+        best_cost = c;
+        memcpy(best, fib + 3 * k, sizeof(best));
+      }
+    }
+    pnec_oracle_scf(n, Ai, Bi, best, 10, t);
+    memcpy(R, Rn, sizeof(R));
+  }
+  memcpy(R_out, R, sizeof(R));
+  memcpy(t_out, t, sizeof(t));
+  free(w2);
+  free(Ai);
+  free(Bi);
+}

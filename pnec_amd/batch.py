@@ -192,6 +192,39 @@ class Batch:
             p(out.iterations), p(out.status), space, stream))
         return out
 
+    def _front(self, weighted, init_q, init_t, reg, weighted_iterations):
+        on_device = _is_torch(init_q)
+        if on_device:
+            import torch
+            f64 = dict(dtype=torch.float64, device=init_q.device)
+            oq, ot = torch.empty((self.n_pairs, 4), **f64), torch.empty((self.n_pairs, 3), **f64)
+            p = lambda a: None if a is None else a.contiguous().data_ptr()
+            stream, space = torch.cuda.current_stream(self.device).cuda_stream, capi.MEM_DEVICE
+            keep = [init_q.contiguous(), None if init_t is None else init_t.contiguous()]
+            pq, pt = keep[0].data_ptr(), (None if keep[1] is None else keep[1].data_ptr())
+        else:
+            keep = [np.ascontiguousarray(init_q, dtype=np.float64),
+                    None if init_t is None else np.ascontiguousarray(init_t, dtype=np.float64)]
+            oq, ot = np.empty((self.n_pairs, 4)), np.empty((self.n_pairs, 3))
+            p = lambda a: None if a is None else a.ctypes.data
+            stream, space = None, capi.MEM_HOST
+            pq, pt = keep[0].ctypes.data, (None if keep[1] is None else keep[1].ctypes.data)
+        po, pto = (oq.data_ptr(), ot.data_ptr()) if on_device else (oq.ctypes.data, ot.ctypes.data)
+        if weighted:
+            capi.check(self._lib.pnec_hip_weighted_eigensolver(self._h, pq, pt, float(reg),
+                                                              int(weighted_iterations), po, pto, space, stream))
+        else:
+            capi.check(self._lib.pnec_hip_nec_eigensolver(self._h, pq, po, pto, space, stream))
+        return oq, ot
+
+    def nec_eigensolver(self, init_q):
+        """PNEC::Eigensolver without RANSAC (pnec.cc:273-278): -> (q [P,4], t [P,3])"""
+        return self._front(False, init_q, None, 0.0, 0)
+
+    def weighted_eigensolver(self, init_q, init_t, reg: float = 1e-13, weighted_iterations: int = 10):
+        """PNEC::WeightedEigensolver (pnec.cc:283-348): -> (q [P,4], t [P,3])"""
+        return self._front(True, init_q, init_t, reg, weighted_iterations)
+
     def cost_function(self, q, t):
         """pnec::common::CostFunction per pair (TARGET-mode batches)."""
         if _is_torch(q):

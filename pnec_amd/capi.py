@@ -43,6 +43,8 @@ SYMBOLS = [
     "pnec_hip_solve",
     "pnec_hip_select_best",
     "pnec_hip_cost_function",
+    "pnec_hip_nec_eigensolver",
+    "pnec_hip_weighted_eigensolver",
     "pnec_hip_unscented_transform",
     "pnec_hip_describe_launch",
     "pnec_hip_selftest",
@@ -115,6 +117,8 @@ def lib() -> C.CDLL:
     L.pnec_hip_describe_launch.argtypes = [_vp, C.POINTER(Options)] + [C.POINTER(C.c_int32)] * 5
     L.pnec_hip_unscented_transform.argtypes = [C.c_int64, _vp, _vp, _vp, C.c_double, C.c_int, _vp, _vp,
                                                C.c_int, C.c_int, _vp]
+    L.pnec_hip_nec_eigensolver.argtypes = [_vp, _vp, _vp, _vp, C.c_int, _vp]
+    L.pnec_hip_weighted_eigensolver.argtypes = [_vp, _vp, _vp, C.c_double, C.c_int32, _vp, _vp, C.c_int, _vp]
     L.pnec_hip_selftest.argtypes = [C.c_int]
     _lib = L
     return L

@@ -29,8 +29,8 @@ int main(int argc, char **argv) {
     covs[i] = pnec::Matrix3d::Identity() * (s * s);
   }
   pnec::rel_pose_estimation::Options options;
-  options.use_ransac_ = false;
-  options.weighted_iterations_ = 0;
+  options.use_ransac_ = false;  // everything else at the reference's defaults: NEC-ES -> 9 weighted
+                                // eigensolver rounds + SCF -> Ceres-style refinement
   pnec::rel_pose_estimation::PNEC pnec_solver(options);
   const pnec::SE3d init(pnec::Quaterniond(0.975, 0.1, -0.14, 0.115).normalized().toRotationMatrix(),
                         pnec::Vector3d(0.28, -0.22, 0.92).normalized());

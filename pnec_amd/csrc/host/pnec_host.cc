@@ -234,29 +234,92 @@ SE3d PNEC::Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
   return Solve(bvs1, bvs2, projected_covs, initial_pose, inliers);
 }
 
+namespace {
+// one pair resident on the device, shared by the stages of Solve
+struct PairOnDevice {
+  Problem prob;
+  PairOnDevice(int device, const bearingVectors_t &b1, const bearingVectors_t &b2,
+               const std::vector<Matrix3d> &covs)
+      : prob(device, PNEC_HIP_MODE_TARGET, std::vector<int64_t>{0, (int64_t)b1.size()}) {
+    if (b1.size() != b2.size() || b1.size() != covs.size())
+      throw std::invalid_argument("bvs1, bvs2 and projected_covs differ in size");
+    if (!b1.empty())
+      Check(pnec_hip_problem_fill(prob.p, 0, 1, b1[0].data(), b2[0].data(), covs[0].data(), nullptr,
+                                  PNEC_HIP_MEM_HOST, nullptr));
+  }
+};
+
+SE3d PoseFromQT(const double q[4], const double t[3]) {
+  return SE3d(Quaterniond(q[3], q[0], q[1], q[2]).toRotationMatrix(), Vector3d(t[0], t[1], t[2]));
+}
+}  // namespace
+
 SE3d PNEC::Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
                  const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose,
                  std::vector<int> &inliers) {
-  // pnec.cc:77-124.  The reference always runs the NEC eigensolver first; its result is only
-  // consumed when use_ransac_, use_nec_ or weighted_iterations_ >= 1 -- those need the eigensolver
-  // stages, which are not built yet.
-  if (options_.use_ransac_ || options_.use_nec_ || options_.weighted_iterations_ >= 1)
+  // pnec.cc:77-124, stage by stage on the device.
+  if (options_.use_ransac_)
     throw std::logic_error(
-        "PNEC::Solve: this option set needs the NEC eigensolver / RANSAC / weighted eigensolver "
-        "stages (SURVEY.md 8f 'next' rows), which are not built yet; use use_ransac_=false, "
-        "use_nec_=false, weighted_iterations_=0, or call CeresSolver/NECCeresSolver directly");
+        "PNEC::Solve: Options::use_ransac_ needs the RANSAC stage around the NEC eigensolver "
+        "(SURVEY.md 8f rank 2), which is not built yet; set use_ransac_ = false");
   inliers.clear();
-  if (!options_.use_ceres_) return initial_pose;
-  return CeresSolver(bvs1, bvs2, projected_covs, initial_pose);
+  PairOnDevice dev(optimization::SolverOptions().device, bvs1, bvs2, projected_covs);
+  const Quaterniond q0(initial_pose.rotationMatrix());
+  double q[4], t[3];
+  // ES_solution = Eigensolver(...)
+  Check(pnec_hip_nec_eigensolver(dev.prob.p, q0.coeffs(), q, t, PNEC_HIP_MEM_HOST, nullptr));
+  if (options_.use_nec_) {
+    const SE3d es = PoseFromQT(q, t);
+    return options_.use_ceres_ ? NECCeresSolver(bvs1, bvs2, es) : es;
+  }
+  double qi[4], ti[3];
+  if (options_.weighted_iterations_ > 1) {
+    Check(pnec_hip_weighted_eigensolver(dev.prob.p, q, t, options_.regularization_,
+                                        (int32_t)options_.weighted_iterations_, qi, ti, PNEC_HIP_MEM_HOST,
+                                        nullptr));
+  } else if (options_.weighted_iterations_ == 1) {
+    std::memcpy(qi, q, sizeof(qi));
+    std::memcpy(ti, t, sizeof(ti));
+  } else {
+    std::memcpy(qi, q0.coeffs(), sizeof(qi));
+    std::memcpy(ti, initial_pose.translation().data(), sizeof(ti));
+  }
+  if (!options_.use_ceres_) return PoseFromQT(qi, ti);
+  // CeresSolver: default-constructed optimiser, Target frame (pnec.cc:355,366)
+  const pnec_hip_options o = optimization::SolverOptions().ToHip();
+  double oq[4], ot[3];
+  Check(pnec_hip_solve(dev.prob.p, qi, ti, 1, nullptr, options_.regularization_, &o, oq, ot, nullptr,
+                       nullptr, nullptr, PNEC_HIP_MEM_HOST, nullptr));
+  return PoseFromQT(oq, ot);
 }
 
-SE3d PNEC::Eigensolver(const bearingVectors_t &, const bearingVectors_t &, const SE3d &,
-                       std::vector<int> &) {
-  throw std::logic_error("PNEC::Eigensolver: NEC eigensolver + RANSAC not built yet (SURVEY.md 8f rank 2)");
+SE3d PNEC::Eigensolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                       const SE3d &initial_pose, std::vector<int> &inliers) {
+  if (options_.use_ransac_)
+    throw std::logic_error("PNEC::Eigensolver: the RANSAC branch (pnec.cc:239-272) is not built yet; "
+                           "set use_ransac_ = false");
+  inliers.clear();
+  const std::vector<int64_t> offsets = {0, (int64_t)bvs1.size()};
+  Problem prob(optimization::SolverOptions().device, PNEC_HIP_MODE_NEC, offsets);
+  if (!bvs1.empty())
+    Check(pnec_hip_problem_fill(prob.p, 0, 1, bvs1[0].data(), bvs2[0].data(), nullptr, nullptr,
+                                PNEC_HIP_MEM_HOST, nullptr));
+  const Quaterniond q0(initial_pose.rotationMatrix());
+  double q[4], t[3];
+  Check(pnec_hip_nec_eigensolver(prob.p, q0.coeffs(), q, t, PNEC_HIP_MEM_HOST, nullptr));
+  return PoseFromQT(q, t);
 }
-SE3d PNEC::WeightedEigensolver(const bearingVectors_t &, const bearingVectors_t &,
-                               const std::vector<Matrix3d> &, const SE3d &) {
-  throw std::logic_error("PNEC::WeightedEigensolver: weighted eigensolver + SCF not built yet (SURVEY.md 8f rank 1)");
+
+SE3d PNEC::WeightedEigensolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                               const std::vector<Matrix3d> &projected_covariances,
+                               const SE3d &initial_pose) {
+  PairOnDevice dev(optimization::SolverOptions().device, bvs1, bvs2, projected_covariances);
+  const Quaterniond q0(initial_pose.rotationMatrix());
+  double q[4], t[3];
+  Check(pnec_hip_weighted_eigensolver(dev.prob.p, q0.coeffs(), initial_pose.translation().data(),
+                                      options_.regularization_, (int32_t)options_.weighted_iterations_, q, t,
+                                      PNEC_HIP_MEM_HOST, nullptr));
+  return PoseFromQT(q, t);
 }
 
 SE3d PNEC::CeresSolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,

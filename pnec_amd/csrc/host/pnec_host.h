@@ -161,10 +161,9 @@ class PNEC {
   explicit PNEC(const Options &options);
   ~PNEC();
 
-  // pnec.cc:69-124.  The eigensolver stages (NEC-ES + RANSAC, weighted ES + SCF) are SURVEY 8(f)
-  // "next" rows: option sets that need them throw std::logic_error naming the missing stage;
-  // {use_ransac_=false, use_nec_=false, weighted_iterations_=0} runs initial_pose -> CeresSolver
-  // exactly as the reference does.
+  // pnec.cc:69-124: NEC eigensolver -> (weighted eigensolver + SCF) -> least-squares refinement,
+  // every stage on the device.  Only the RANSAC wrapper around the eigensolver (Options::use_ransac_,
+  // default true in the reference) is still missing: it throws std::logic_error; set it to false.
   SE3d Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
              const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose);
   SE3d Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
@@ -172,10 +171,10 @@ class PNEC {
              std::vector<int> &inliers);
 
   SE3d Eigensolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
-                   const SE3d &initial_pose, std::vector<int> &inliers);          // pnec.cc:231 (next row)
+                   const SE3d &initial_pose, std::vector<int> &inliers);          // pnec.cc:231-281
   SE3d WeightedEigensolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
                            const std::vector<Matrix3d> &projected_covariances,
-                           const SE3d &initial_pose);                            // pnec.cc:283 (next row)
+                           const SE3d &initial_pose);                            // pnec.cc:283-348
   SE3d CeresSolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
                    const std::vector<Matrix3d> &projected_covariances,
                    const SE3d &initial_pose);                                    // pnec.cc:350-370

@@ -19,6 +19,12 @@ hipError_t launch_solve_mode_0(int, int, int, bool, const SolveArgs &, hipStream
 hipError_t launch_solve_mode_1(int, int, int, bool, const SolveArgs &, hipStream_t);
 hipError_t launch_solve_mode_2(int, int, int, bool, const SolveArgs &, hipStream_t);
 hipError_t launch_solve_mode_3(int, int, int, bool, const SolveArgs &, hipStream_t);
+// pnec_frontend.hip
+hipError_t launch_nec_eigensolver(const double *, const int64_t *, const int32_t *, int64_t, const double *,
+                                  double *, double *, int32_t *, hipStream_t);
+hipError_t launch_weighted_eigensolver(int, const double *, const int64_t *, const int32_t *, int64_t,
+                                       const double *, const double *, double, int, double *, double *,
+                                       int32_t *, hipStream_t);
 }  // namespace pnec_hip
 
 using namespace pnec_hip;
@@ -841,6 +847,58 @@ int pnec_hip_cost_function(pnec_hip_problem *p, const double *q, const double *t
     PNEC_HIP_TRY(hipStreamSynchronize(stream));
   }
   return 0;
+}
+
+// shared driver of the two eigensolver stages (host or device pointers)
+static int run_front_stage(pnec_hip_problem *p, bool weighted, const double *init_q, const double *init_t,
+                           double reg, int weighted_iterations, double *out_q, double *out_t, int space,
+                           void *stream_) {
+  if (!p || !init_q || !out_q || !out_t || (weighted && !init_t))
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (weighted && p->mode != PNEC_HIP_MODE_TARGET)
+    return fail(PNEC_HIP_ERR_UNSUPPORTED, "the weighted eigensolver needs a TARGET-mode problem");
+  if (space != PNEC_HIP_MEM_DEVICE && space != PNEC_HIP_MEM_HOST)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad memory space");
+  if (p->n_pairs == 0) return 0;
+  DeviceGuard guard(p->device);
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t P = p->n_pairs;
+  const double *d_q = init_q, *d_t = init_t;
+  double *d_oq = out_q, *d_ot = out_t;
+  if (space == PNEC_HIP_MEM_HOST) {
+    if (int rc = ensure_stage(p, 14 * P, 0)) return rc;
+    double *w = p->d_stage;
+    PNEC_HIP_TRY(hipMemcpyAsync(w, init_q, sizeof(double) * 4 * P, hipMemcpyHostToDevice, stream));
+    d_q = w; w += 4 * P;
+    if (init_t) PNEC_HIP_TRY(hipMemcpyAsync(w, init_t, sizeof(double) * 3 * P, hipMemcpyHostToDevice, stream));
+    d_t = w; w += 3 * P;
+    d_oq = w; w += 4 * P;
+    d_ot = w;
+  }
+  hipError_t e = weighted
+                     ? launch_weighted_eigensolver(p->device, p->d_data, p->d_block_offset, p->d_count, P, d_q,
+                                                   d_t, reg, weighted_iterations, d_oq, d_ot, nullptr, stream)
+                     : launch_nec_eigensolver(p->d_data, p->d_block_offset, p->d_count, P, d_q, d_oq, d_ot,
+                                              nullptr, stream);
+  if (e != hipSuccess) return fail_hip(e, weighted ? "weighted_eigensolver_kernel" : "nec_eigensolver_kernel");
+  if (space == PNEC_HIP_MEM_HOST) {
+    PNEC_HIP_TRY(hipMemcpyAsync(out_q, d_oq, sizeof(double) * 4 * P, hipMemcpyDeviceToHost, stream));
+    PNEC_HIP_TRY(hipMemcpyAsync(out_t, d_ot, sizeof(double) * 3 * P, hipMemcpyDeviceToHost, stream));
+    PNEC_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  return 0;
+}
+
+int pnec_hip_nec_eigensolver(pnec_hip_problem *p, const double *init_q, double *out_q, double *out_t,
+                             int space, void *stream) {
+  return run_front_stage(p, false, init_q, nullptr, 0.0, 0, out_q, out_t, space, stream);
+}
+
+int pnec_hip_weighted_eigensolver(pnec_hip_problem *p, const double *init_q, const double *init_t,
+                                  double reg, int32_t weighted_iterations, double *out_q, double *out_t,
+                                  int space, void *stream) {
+  if (weighted_iterations < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "weighted_iterations < 0");
+  return run_front_stage(p, true, init_q, init_t, reg, weighted_iterations, out_q, out_t, space, stream);
 }
 
 int pnec_hip_unscented_transform(int64_t n, const double *mu, const double *covs, const double *K_inv,

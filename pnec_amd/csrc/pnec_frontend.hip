@@ -1,0 +1,660 @@
+// pnec_frontend.hip -- the stages in front of the least-squares refinement:
+//   PNEC::Eigensolver (use_ransac_ = false branch)   src/rel_pose_estimation/pnec.cc:273-278
+//   PNEC::WeightedEigensolver                         src/rel_pose_estimation/pnec.cc:283-348
+//   ComposeM / TranslationFromM / Weight              src/common/common.cc:127-136,157-181,183-208
+//   fibonacci_sphere / obj_fun / scf                  src/optimization/scf.cc:43-72,109-148
+//
+// One wavefront per frame pair.  The eigensolver (opengv::relative_pose::eigensolver in the
+// reference; opengv is not in the tree, so this is the published Kneip-Lynen algorithm: minimise
+// the smallest eigenvalue of M(R) = sum (f1 x R f2)(f1 x R f2)' over the Cayley parameters of R)
+// needs ONE pass over the payload: the 36 sums  G_kl[a][c] = sum_i w_i f2k f2l f1a f1c  determine
+// M(R) = sum_kl [r_k]x G_kl [r_l]x' for every R (r_k = column k of R), so the damped-Newton
+// iteration on the Cayley vector runs on 36 numbers parked in LDS.  The translation search of the
+// weighted stage (500 Fibonacci directions + 10 SCF steps per iteration) streams the payload from
+// L2: per correspondence n = f1 x R f2 and B = f1hat R Sigma R' f1hat' + reg I are rebuilt per
+// batch of 21 candidate directions, whose 21 partial energies are reduced together
+// (wave_reduce21).  Reference quirks reproduced: C3 (weights from the initial pose in every
+// iteration), C4 (x1e-8), C5 (E = sum A_i / t'B_i t), C6 (float division in fibonacci_sphere),
+// C7 (ComposeM skips correspondence 0).  When an eigensolver call is already converged at entry
+// the rotation is bit-identical to the previous iteration's, and the 500-direction search of that
+// iteration is replayed from the stored minimum instead of recomputed (identical result).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "pnec_device.hpp"
+
+namespace pnec_hip {
+
+// ------------------------------------------------------------------------------------------
+// symmetric 3x3 eigen-decomposition, cyclic Jacobi; eigenvalues ascending, eigenvectors in the
+// columns of V (row-major), largest-magnitude component of each made positive
+__device__ void sym_eig3(const double (&A_in)[9], double (&w)[3], double (&V)[9]) {
+  double A[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    A[i] = A_in[i];
+    V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  }
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    const double dg = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+    if (off <= 1e-34 * dg || off == 0.0) break;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int p = (k == 2) ? 1 : 0, q = (k == 0) ? 1 : 2;
+      const double apq = A[3 * p + q];
+      if (apq == 0.0) continue;
+      const double theta = (A[3 * q + q] - A[3 * p + p]) / (2.0 * apq);
+      const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double arp = A[3 * r + p], arq = A[3 * r + q];
+        A[3 * r + p] = c * arp - s * arq;
+        A[3 * r + q] = s * arp + c * arq;
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double apr = A[3 * p + r], aqr = A[3 * q + r];
+        A[3 * p + r] = c * apr - s * aqr;
+        A[3 * q + r] = s * apr + c * aqr;
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double vrp = V[3 * r + p], vrq = V[3 * r + q];
+        V[3 * r + p] = c * vrp - s * vrq;
+        V[3 * r + q] = s * vrp + c * vrq;
+      }
+    }
+  }
+  const double d[3] = {A[0], A[4], A[8]};
+  int i0 = 0, i1 = 1, i2 = 2;
+  if (d[i0] > d[i1]) { const int t = i0; i0 = i1; i1 = t; }
+  if (d[i1] > d[i2]) { const int t = i1; i1 = i2; i2 = t; }
+  if (d[i0] > d[i1]) { const int t = i0; i0 = i1; i1 = t; }
+  const int idx[3] = {i0, i1, i2};
+  double Vs[9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int j = idx[c];
+    const double v0 = (j == 0) ? V[0] : (j == 1 ? V[1] : V[2]);
+    const double v1 = (j == 0) ? V[3] : (j == 1 ? V[4] : V[5]);
+    const double v2 = (j == 0) ? V[6] : (j == 1 ? V[7] : V[8]);
+    w[c] = (j == 0) ? d[0] : (j == 1 ? d[1] : d[2]);
+    double big = v0;
+    if (fabs(v1) > fabs(big)) big = v1;
+    if (fabs(v2) > fabs(big)) big = v2;
+    const double sg = big < 0.0 ? -1.0 : 1.0;
+    Vs[c] = sg * v0;
+    Vs[3 + c] = sg * v1;
+    Vs[6 + c] = sg * v2;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) V[i] = Vs[i];
+}
+
+__device__ void cayley_to_rot(const double (&v)[3], double (&R)[9]) {
+  const double x = v[0], y = v[1], z = v[2];
+  const double s = 1.0 / (1.0 + x * x + y * y + z * z);
+  R[0] = s * (1 + x * x - y * y - z * z); R[1] = s * 2 * (x * y - z); R[2] = s * 2 * (x * z + y);
+  R[3] = s * 2 * (x * y + z); R[4] = s * (1 - x * x + y * y - z * z); R[5] = s * 2 * (y * z - x);
+  R[6] = s * 2 * (x * z - y); R[7] = s * 2 * (y * z + x); R[8] = s * (1 - x * x - y * y + z * z);
+}
+
+__device__ void rot_to_cayley(const double (&R)[9], double (&v)[3]) {
+  double A[9], B[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    A[i] = R[i] - (i % 4 == 0 ? 1.0 : 0.0);
+    B[i] = R[i] + (i % 4 == 0 ? 1.0 : 0.0);
+  }
+  const double c00 = B[4] * B[8] - B[5] * B[7], c01 = B[5] * B[6] - B[3] * B[8], c02 = B[3] * B[7] - B[4] * B[6];
+  const double det = B[0] * c00 + B[1] * c01 + B[2] * c02;
+  double Bi[9];
+  Bi[0] = c00 / det; Bi[1] = (B[2] * B[7] - B[1] * B[8]) / det; Bi[2] = (B[1] * B[5] - B[2] * B[4]) / det;
+  Bi[3] = c01 / det; Bi[4] = (B[0] * B[8] - B[2] * B[6]) / det; Bi[5] = (B[2] * B[3] - B[0] * B[5]) / det;
+  Bi[6] = c02 / det; Bi[7] = (B[1] * B[6] - B[0] * B[7]) / det; Bi[8] = (B[0] * B[4] - B[1] * B[3]) / det;
+  // C = A B^-1; v = (-C(1,2), C(0,2), -C(0,1))
+  v[0] = -(A[3] * Bi[2] + A[4] * Bi[5] + A[5] * Bi[8]);
+  v[1] = A[0] * Bi[2] + A[1] * Bi[5] + A[2] * Bi[8];
+  v[2] = -(A[0] * Bi[1] + A[1] * Bi[4] + A[2] * Bi[7]);
+}
+
+__device__ __forceinline__ void skew9(double x, double y, double z, double (&S)[9]) {
+  S[0] = 0.0; S[1] = -z; S[2] = y;
+  S[3] = z; S[4] = 0.0; S[5] = -x;
+  S[6] = -y; S[7] = x; S[8] = 0.0;
+}
+__device__ __forceinline__ void mul33(const double (&A)[9], const double (&B)[9], double (&C)[9]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+}
+// C = A B'
+__device__ __forceinline__ void mul33t(const double (&A)[9], const double (&B)[9], double (&C)[9]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) C[3 * r + c] = A[3 * r] * B[3 * c] + A[3 * r + 1] * B[3 * c + 1] + A[3 * r + 2] * B[3 * c + 2];
+}
+// packed symmetric index of (a,c) in a 3x3: 00 01 02 11 12 22
+__device__ __forceinline__ constexpr int s3(int a, int c) {
+  return a <= c ? (a * 3 - a * (a - 1) / 2 + (c - a)) : (c * 3 - c * (c - 1) / 2 + (a - c));
+}
+__device__ __forceinline__ void load_g(const double *G, int kl, double (&M)[9]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) M[3 * a + c] = G[6 * kl + s3(a, c)];
+}
+
+// lambda_min(M(R(v))) from the 36 sums, optionally its gradient w.r.t. the Cayley vector (e' dM e).
+// M_out (row-major) is the composed matrix.
+__device__ double es_value_grad(const double *G, const double (&v)[3], double *g, double *M_out) {
+  double R[9];
+  cayley_to_rot(v, R);
+  double M[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) M[i] = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    double Sk[9];
+    skew9(R[k], R[3 + k], R[6 + k], Sk);
+    for (int l = 0; l < 3; ++l) {
+      double Sl[9], Gm[9], T[9], X[9];
+      skew9(R[l], R[3 + l], R[6 + l], Sl);
+      load_g(G, s3(k, l), Gm);
+      mul33(Sk, Gm, T);
+      mul33t(T, Sl, X);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) M[i] += X[i];
+    }
+  }
+  // symmetrise (rounding)
+  M[1] = M[3] = 0.5 * (M[1] + M[3]);
+  M[2] = M[6] = 0.5 * (M[2] + M[6]);
+  M[5] = M[7] = 0.5 * (M[5] + M[7]);
+  if (M_out) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) M_out[i] = M[i];
+  }
+  double w[3], V[9];
+  sym_eig3(M, w, V);
+  if (!g) return w[0];
+  double Se[9];
+  skew9(V[0], V[3], V[6], Se);
+  // q_k = sum_l C_kl r_l with C_kl = [e]x' G_kl [e]x
+  double q[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) q[k][0] = q[k][1] = q[k][2] = 0.0;
+  for (int k = 0; k < 3; ++k)
+    for (int l = 0; l < 3; ++l) {
+      double Gm[9], T[9];
+      load_g(G, s3(k, l), Gm);
+      // y = [e]x r_l ; z = G y ; q_k += [e]x' z
+      const double rl[3] = {R[l], R[3 + l], R[6 + l]};
+      double y[3], z[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) y[r] = Se[3 * r] * rl[0] + Se[3 * r + 1] * rl[1] + Se[3 * r + 2] * rl[2];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) z[r] = Gm[3 * r] * y[0] + Gm[3 * r + 1] * y[1] + Gm[3 * r + 2] * y[2];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) q[k][r] += Se[r] * z[0] + Se[3 + r] * z[1] + Se[6 + r] * z[2];
+      (void)T;
+    }
+  const double s = 1.0 + v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  for (int j = 0; j < 3; ++j) {
+    double dN[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dN[i] = 0.0;
+    dN[0] = dN[4] = dN[8] = -2.0 * v[j];
+    const int a = (j + 1) % 3, b = (j + 2) % 3;
+    dN[3 * b + a] += 2.0;
+    dN[3 * a + b] -= 2.0;
+    for (int i = 0; i < 3; ++i) {
+      dN[3 * j + i] += 2.0 * v[i];
+      dN[3 * i + j] += 2.0 * v[i];
+    }
+    double acc = 0.0;
+    for (int k = 0; k < 3; ++k)
+      for (int r = 0; r < 3; ++r) {
+        const double drk = (dN[3 * r + k] - 2.0 * v[j] * R[3 * r + k]) / s;  // d r_k[r] / d v_j
+        acc += drk * q[k][r];
+      }
+    g[j] = 2.0 * acc;
+  }
+  return w[0];
+}
+
+__device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&x)[3]) {
+  if (!(H[0] > 0.0)) return false;
+  const double l00 = sqrt(H[0]), l10 = H[3] / l00, l20 = H[6] / l00;
+  const double l11s = H[4] - l10 * l10;
+  if (!(l11s > 0.0)) return false;
+  const double l11 = sqrt(l11s), l21 = (H[7] - l20 * l10) / l11;
+  const double l22s = H[8] - l20 * l20 - l21 * l21;
+  if (!(l22s > 0.0)) return false;
+  const double l22 = sqrt(l22s);
+  const double z0 = b[0] / l00, z1 = (b[1] - l10 * z0) / l11, z2 = (b[2] - l20 * z0 - l21 * z1) / l22;
+  x[2] = z2 / l22;
+  x[1] = (z1 - l21 * x[2]) / l11;
+  x[0] = (z0 - l10 * x[1] - l20 * x[2]) / l00;
+  return true;
+}
+
+// damped Newton on the Cayley vector; returns the number of iterations taken (0 = already converged)
+__device__ int es_minimise(const double *G, double (&v)[3], double n_scale) {
+  double g[3];
+  double f = es_value_grad(G, v, g, nullptr);
+  int it = 0;
+  for (; it < 50; ++it) {
+    const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+    if (gmax <= 1e-14 * (1.0 + fabs(f)) * n_scale) break;
+    double H[9];
+    const double h = 1e-6;
+    for (int k = 0; k < 3; ++k) {
+      double vp[3] = {v[0], v[1], v[2]}, gp[3];
+      vp[k] += h;
+      es_value_grad(G, vp, gp, nullptr);
+      for (int r = 0; r < 3; ++r) H[3 * r + k] = (gp[r] - g[r]) / h;
+    }
+    H[1] = H[3] = 0.5 * (H[1] + H[3]);
+    H[2] = H[6] = 0.5 * (H[2] + H[6]);
+    H[5] = H[7] = 0.5 * (H[5] + H[7]);
+    double mu = 0.0, d[3] = {0.0, 0.0, 0.0};
+    const double tr = fabs(H[0]) + fabs(H[4]) + fabs(H[8]);
+    bool ok = false;
+    for (int tries = 0; tries < 40; ++tries) {
+      double Hm[9];
+      for (int i = 0; i < 9; ++i) Hm[i] = H[i];
+      Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
+      const double mg[3] = {-g[0], -g[1], -g[2]};
+      if (solve3_spd(Hm, mg, d) && (d[0] * g[0] + d[1] * g[1] + d[2] * g[2]) < 0.0) { ok = true; break; }
+      mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * 10.0;
+    }
+    if (!ok) break;
+    double alpha = 1.0, vn[3] = {v[0], v[1], v[2]};
+    const double slope = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];
+    bool moved = false;
+    for (int ls = 0; ls < 40; ++ls) {
+      for (int k = 0; k < 3; ++k) vn[k] = v[k] + alpha * d[k];
+      double Mn[9];
+      const double fn = es_value_grad(G, vn, nullptr, Mn);
+      // Armijo with a rounding-noise floor: lambda_min carries ~eps * trace(M) of error
+      if (fn <= f + 1e-4 * alpha * slope + 4e-16 * (Mn[0] + Mn[4] + Mn[8])) { moved = true; break; }
+      alpha *= 0.5;
+    }
+    if (!moved) break;
+    const double smax = alpha * fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
+    for (int k = 0; k < 3; ++k) v[k] = vn[k];
+    f = es_value_grad(G, v, g, nullptr);
+    if (smax < 1e-12) { ++it; break; }
+  }
+  return it;
+}
+
+// ------------------------------------------------------------------------------------------
+struct FrontArgs {
+  const double *data;           // SoA payload (12 planes for the weighted stage, >= 6 for NEC)
+  const int64_t *block_offset;
+  const int32_t *count;
+  const double *init_q;  // [n_pairs,4] xyzw
+  const double *init_t;  // [n_pairs,3] (weighted stage)
+  const double *fib;     // [500,3] Fibonacci directions
+  double *out_q;         // [n_pairs,4]
+  double *out_t;         // [n_pairs,3]
+  int32_t *out_iterations;  // [n_pairs] Newton iterations of the (first) eigensolver call, or null
+  double reg;
+  int weighted_iterations;
+};
+
+__device__ __forceinline__ void quat_from_rot_dev(const double (&R)[9], double (&q)[4]) {
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0.0) {
+    double t = sqrt(tr + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[7] - R[5]) * t;
+    q[1] = (R[2] - R[6]) * t;
+    q[2] = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > (i == 0 ? R[0] : R[4])) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+    double qq[4];
+    qq[i] = 0.5 * t;
+    t = 0.5 / t;
+    qq[3] = (R[3 * k + j] - R[3 * j + k]) * t;
+    qq[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+    qq[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+    q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
+  }
+}
+
+// 36 sums G_kl[a][c] over the pair; WEIGHTED multiplies by Weight(init pose) * 1e-8 (C3, C4)
+template <bool WEIGHTED>
+__device__ void pass_sums36(const double *base, int n, int stride, const double (&R0)[9],
+                            const double (&t0)[3], double reg, int lane, double *G /* LDS, 36 */) {
+  double acc[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+  for (int idx = lane; idx < stride; idx += kWave) {
+    const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
+    const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
+                          base[(int64_t)5 * stride + idx]};
+    double w = 1.0;
+    if constexpr (WEIGHTED) {
+      const double mx = t0[1] * f1[2] - t0[2] * f1[1], my = t0[2] * f1[0] - t0[0] * f1[2],
+                   mz = t0[0] * f1[1] - t0[1] * f1[0];
+      const double gx = R0[0] * mx + R0[3] * my + R0[6] * mz, gy = R0[1] * mx + R0[4] * my + R0[7] * mz,
+                   gz = R0[2] * mx + R0[5] * my + R0[8] * mz;
+      const double sxx = base[(int64_t)6 * stride + idx], sxy = base[(int64_t)7 * stride + idx],
+                   sxz = base[(int64_t)8 * stride + idx], syy = base[(int64_t)9 * stride + idx],
+                   syz = base[(int64_t)10 * stride + idx], szz = base[(int64_t)11 * stride + idx];
+      const double q = gx * (sxx * gx + sxy * gy + sxz * gz) + gy * (sxy * gx + syy * gy + syz * gz) +
+                       gz * (sxz * gx + syz * gy + szz * gz);
+      w = (idx < n) ? (1.0 / (q + reg)) * 1.0e-8 : 0.0;
+    }
+    double p[6], qq[6];
+    p[0] = w * f2[0] * f2[0]; p[1] = w * f2[0] * f2[1]; p[2] = w * f2[0] * f2[2];
+    p[3] = w * f2[1] * f2[1]; p[4] = w * f2[1] * f2[2]; p[5] = w * f2[2] * f2[2];
+    qq[0] = f1[0] * f1[0]; qq[1] = f1[0] * f1[1]; qq[2] = f1[0] * f1[2];
+    qq[3] = f1[1] * f1[1]; qq[4] = f1[1] * f1[2]; qq[5] = f1[2] * f1[2];
+#pragma unroll
+    for (int kl = 0; kl < 6; ++kl)
+#pragma unroll
+      for (int ac = 0; ac < 6; ++ac) acc[6 * kl + ac] = __builtin_fma(p[kl], qq[ac], acc[6 * kl + ac]);
+  }
+#pragma unroll
+  for (int i = 0; i < 36; ++i) {
+    const double s = wave_allreduce_sum(acc[i]);
+    if (lane == 0) G[i] = s;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+}
+
+// ---- PNEC::Eigensolver, no RANSAC: rotation by eigenvalue minimisation, translation from
+// ComposeM (correspondences 1..n-1) -> TranslationFromM
+__global__ __launch_bounds__(kWave) void nec_eigensolver_kernel(const FrontArgs a) {
+  const int64_t pair = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int n = a.count[pair];
+  const int stride = (n + kWave - 1) & ~(kWave - 1);
+  const double *base = a.data + a.block_offset[pair];
+  __shared__ double G[36];
+  double q0[4] = {a.init_q[4 * pair], a.init_q[4 * pair + 1], a.init_q[4 * pair + 2], a.init_q[4 * pair + 3]};
+  {
+    const double qn = 1.0 / sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
+    for (int k = 0; k < 4; ++k) q0[k] *= qn;
+  }
+  double R[9];
+  rot_from_quat(q0, R);
+  const double t_dummy[3] = {0.0, 0.0, 1.0};
+  pass_sums36<false>(base, n, stride, R, t_dummy, 0.0, lane, G);
+  double v[3];
+  rot_to_cayley(R, v);
+  const int it = es_minimise(G, v, (double)(n > 0 ? n : 1));
+  double M[9];
+  es_value_grad(G, v, nullptr, M);
+  cayley_to_rot(v, R);
+  if (n > 0) {  // ComposeM starts at i = 1 (C7): remove correspondence 0
+    const double f1[3] = {base[0], base[stride], base[2 * (int64_t)stride]};
+    const double f2[3] = {base[3 * (int64_t)stride], base[4 * (int64_t)stride], base[5 * (int64_t)stride]};
+    const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
+                         R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
+    const double nn[3] = {f1[1] * u[2] - f1[2] * u[1], f1[2] * u[0] - f1[0] * u[2], f1[0] * u[1] - f1[1] * u[0]};
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) M[3 * r + c] -= nn[r] * nn[c];
+  }
+  double w[3], V[9];
+  sym_eig3(M, w, V);
+  if (lane == 0) {
+    double qo[4];
+    quat_from_rot_dev(R, qo);
+    const double qn = 1.0 / sqrt(qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3]);
+    for (int k = 0; k < 4; ++k) a.out_q[4 * pair + k] = qo[k] * qn;
+    const double tn = 1.0 / sqrt(V[0] * V[0] + V[3] * V[3] + V[6] * V[6]);
+    a.out_t[3 * pair + 0] = V[0] * tn;
+    a.out_t[3 * pair + 1] = V[3] * tn;
+    a.out_t[3 * pair + 2] = V[6] * tn;
+    if (a.out_iterations) a.out_iterations[pair] = it;
+  }
+}
+
+// per-correspondence n = f1 x R f2 and B = f1hat R Sigma R' f1hat' + reg I (packed symmetric)
+__device__ __forceinline__ void corr_nb(const double *base, int stride, int idx, const double (&R)[9],
+                                        double reg, double (&nn)[3], double (&B)[6]) {
+  const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
+  const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
+                        base[(int64_t)5 * stride + idx]};
+  const double S[6] = {base[(int64_t)6 * stride + idx], base[(int64_t)7 * stride + idx],
+                       base[(int64_t)8 * stride + idx], base[(int64_t)9 * stride + idx],
+                       base[(int64_t)10 * stride + idx], base[(int64_t)11 * stride + idx]};
+  const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
+                       R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
+  nn[0] = f1[1] * u[2] - f1[2] * u[1];
+  nn[1] = f1[2] * u[0] - f1[0] * u[2];
+  nn[2] = f1[0] * u[1] - f1[1] * u[0];
+  // P = f1hat R: column c of P = f1 x (column c of R)
+  double P[9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const double rx = R[c], ry = R[3 + c], rz = R[6 + c];
+    P[c] = f1[1] * rz - f1[2] * ry;
+    P[3 + c] = f1[2] * rx - f1[0] * rz;
+    P[6 + c] = f1[0] * ry - f1[1] * rx;
+  }
+  double PS[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    PS[3 * r + 0] = P[3 * r] * S[0] + P[3 * r + 1] * S[1] + P[3 * r + 2] * S[2];
+    PS[3 * r + 1] = P[3 * r] * S[1] + P[3 * r + 1] * S[3] + P[3 * r + 2] * S[4];
+    PS[3 * r + 2] = P[3 * r] * S[2] + P[3 * r + 1] * S[4] + P[3 * r + 2] * S[5];
+  }
+  B[0] = PS[0] * P[0] + PS[1] * P[1] + PS[2] * P[2] + reg;
+  B[1] = PS[0] * P[3] + PS[1] * P[4] + PS[2] * P[5];
+  B[2] = PS[0] * P[6] + PS[1] * P[7] + PS[2] * P[8];
+  B[3] = PS[3] * P[3] + PS[4] * P[4] + PS[5] * P[5] + reg;
+  B[4] = PS[3] * P[6] + PS[4] * P[7] + PS[5] * P[8];
+  B[5] = PS[6] * P[6] + PS[7] * P[7] + PS[8] * P[8] + reg;
+}
+
+// obj_fun for one direction over the whole pair (scf.cc:43-51), all lanes get the sum
+__device__ double obj_fun_pair(const double *base, int n, int stride, const double (&R)[9], double reg,
+                               const double (&t)[3], int lane) {
+  double acc = 0.0;
+  for (int idx = lane; idx < n; idx += kWave) {
+    double nn[3], B[6];
+    corr_nb(base, stride, idx, R, reg, nn, B);
+    const double a = t[0] * nn[0] + t[1] * nn[1] + t[2] * nn[2];
+    const double d = t[0] * (B[0] * t[0] + B[1] * t[1] + B[2] * t[2]) + t[1] * (B[1] * t[0] + B[3] * t[1] + B[4] * t[2]) +
+                     t[2] * (B[2] * t[0] + B[4] * t[1] + B[5] * t[2]);
+    acc += a * a / d;
+  }
+  return wave_allreduce_sum(acc);
+}
+
+// ---- PNEC::WeightedEigensolver ---------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const FrontArgs a) {
+  const int64_t pair = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int n = a.count[pair];
+  const int stride = (n + kWave - 1) & ~(kWave - 1);
+  const double *base = a.data + a.block_offset[pair];
+  __shared__ double G[36];
+  __shared__ double cand[21][3];
+  double q0[4] = {a.init_q[4 * pair], a.init_q[4 * pair + 1], a.init_q[4 * pair + 2], a.init_q[4 * pair + 3]};
+  {
+    const double qn = 1.0 / sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
+    for (int k = 0; k < 4; ++k) q0[k] *= qn;
+  }
+  double R0[9];
+  rot_from_quat(q0, R0);
+  const double t0[3] = {a.init_t[3 * pair], a.init_t[3 * pair + 1], a.init_t[3 * pair + 2]};
+  double R[9], t[3] = {t0[0], t0[1], t0[2]}, v[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = R0[i];
+  rot_to_cayley(R0, v);
+  // weights come from the INITIAL pose in every iteration (C3): the 36 weighted sums never change
+  pass_sums36<true>(base, n, stride, R0, t0, a.reg, lane, G);
+
+  double fib_min_cost = 0.0;
+  int fib_min_idx = -1;  // -1: no stored search yet
+  int first_iterations = 0;
+  for (int it = 0; it + 1 < a.weighted_iterations; ++it) {
+    const int newton = es_minimise(G, v, (double)(n > 0 ? n : 1));
+    if (it == 0) first_iterations = newton;
+    const bool same_rotation = (it > 0 && newton == 0 && fib_min_idx >= 0);
+    if (!same_rotation) {
+      cayley_to_rot(v, R);
+      // 500 Fibonacci directions, 21 at a time: per correspondence n, B once per batch
+      fib_min_idx = -1;
+      for (int b0 = 0; b0 < 500; b0 += 21) {
+        const int nb = (500 - b0 < 21) ? 500 - b0 : 21;
+        if (lane < nb * 3) cand[lane / 3][lane % 3] = a.fib[3 * b0 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        double acc[kNumAcc];
+#pragma unroll
+        for (int c = 0; c < kNumAcc; ++c) acc[c] = 0.0;
+        for (int idx = lane; idx < n; idx += kWave) {
+          double nn[3], B[6];
+          corr_nb(base, stride, idx, R, a.reg, nn, B);
+#pragma unroll
+          for (int c = 0; c < kNumAcc; ++c) {
+            const double tx = cand[c][0], ty = cand[c][1], tz = cand[c][2];
+            const double aa = tx * nn[0] + ty * nn[1] + tz * nn[2];
+            const double d = tx * (B[0] * tx + B[1] * ty + B[2] * tz) + ty * (B[1] * tx + B[3] * ty + B[4] * tz) +
+                             tz * (B[2] * tx + B[4] * ty + B[5] * tz);
+            acc[c] += aa * aa / d;
+          }
+        }
+        double sums[kNumAcc];
+        wave_reduce21(acc, sums);
+#pragma unroll
+        for (int c = 0; c < kNumAcc; ++c) {
+          if (c < nb && (fib_min_idx < 0 || sums[c] < fib_min_cost)) {
+            fib_min_cost = sums[c];
+            fib_min_idx = b0 + c;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      }
+    }
+    // best_point = current translation unless a Fibonacci direction is strictly better
+    const double cur_cost = obj_fun_pair(base, n, stride, R, a.reg, t, lane);
+    if (fib_min_idx >= 0 && fib_min_cost < cur_cost) {
+      t[0] = a.fib[3 * fib_min_idx];
+      t[1] = a.fib[3 * fib_min_idx + 1];
+      t[2] = a.fib[3 * fib_min_idx + 2];
+    }
+    // scf: 10 steps of  t <- eigenvector of the smallest eigenvalue of sum A_i / (t' B_i t)
+    for (int step = 0; step < 10; ++step) {
+      double e[6] = {0, 0, 0, 0, 0, 0};
+      for (int idx = lane; idx < n; idx += kWave) {
+        double nn[3], B[6];
+        corr_nb(base, stride, idx, R, a.reg, nn, B);
+        const double d = t[0] * (B[0] * t[0] + B[1] * t[1] + B[2] * t[2]) + t[1] * (B[1] * t[0] + B[3] * t[1] + B[4] * t[2]) +
+                         t[2] * (B[2] * t[0] + B[4] * t[1] + B[5] * t[2]);
+        const double w = 1.0 / d;
+        e[0] += w * nn[0] * nn[0]; e[1] += w * nn[0] * nn[1]; e[2] += w * nn[0] * nn[2];
+        e[3] += w * nn[1] * nn[1]; e[4] += w * nn[1] * nn[2]; e[5] += w * nn[2] * nn[2];
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) e[k] = wave_allreduce_sum(e[k]);
+      const double E[9] = {e[0], e[1], e[2], e[1], e[3], e[4], e[2], e[4], e[5]};
+      double w3[3], V[9];
+      sym_eig3(E, w3, V);
+      t[0] = V[0]; t[1] = V[3]; t[2] = V[6];
+    }
+  }
+  if (lane == 0) {
+    double qo[4];
+    quat_from_rot_dev(R, qo);
+    const double qn = 1.0 / sqrt(qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3]);
+    for (int k = 0; k < 4; ++k) a.out_q[4 * pair + k] = qo[k] * qn;
+    for (int k = 0; k < 3; ++k) a.out_t[3 * pair + k] = t[k];
+    if (a.out_iterations) a.out_iterations[pair] = first_iterations;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: launchers called from pnec_capi.hip
+static std::mutex g_fib_mutex;
+static double *g_fib_dev[64] = {nullptr};
+
+// scf.cc:53-72, including the float division (C6); computed on the host with libm, once per device
+hipError_t fibonacci_table(int device, const double **out) {
+  std::lock_guard<std::mutex> lock(g_fib_mutex);
+  if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+  if (!g_fib_dev[device]) {
+    std::vector<double> pts(1500);
+    const int samples = 500;
+    const double phi = M_PI * (3.0 - std::sqrt(5.0));
+    for (int i = 0; i < samples; ++i) {
+      const double y = 1.0 - ((float)i / (float)(samples - 1)) * 2.0;
+      const double radius = std::sqrt(1 - y * y);
+      const double theta = phi * (float)i;
+      pts[3 * i] = std::cos(theta) * radius;
+      pts[3 * i + 1] = y;
+      pts[3 * i + 2] = std::sin(theta) * radius;
+    }
+    double *d = nullptr;
+    hipError_t e = hipMalloc(&d, sizeof(double) * 1500);
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(d, pts.data(), sizeof(double) * 1500, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(d);
+      return e;
+    }
+    g_fib_dev[device] = d;
+  }
+  *out = g_fib_dev[device];
+  return hipSuccess;
+}
+
+hipError_t launch_nec_eigensolver(const double *data, const int64_t *block_offset, const int32_t *count,
+                                  int64_t n_pairs, const double *init_q, double *out_q, double *out_t,
+                                  int32_t *out_iterations, hipStream_t stream) {
+  FrontArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.data = data;
+  a.block_offset = block_offset;
+  a.count = count;
+  a.init_q = init_q;
+  a.out_q = out_q;
+  a.out_t = out_t;
+  a.out_iterations = out_iterations;
+  hipLaunchKernelGGL(nec_eigensolver_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_weighted_eigensolver(int device, const double *data, const int64_t *block_offset,
+                                       const int32_t *count, int64_t n_pairs, const double *init_q,
+                                       const double *init_t, double reg, int weighted_iterations,
+                                       double *out_q, double *out_t, int32_t *out_iterations,
+                                       hipStream_t stream) {
+  FrontArgs a;
+  std::memset(&a, 0, sizeof(a));
+  hipError_t e = fibonacci_table(device, &a.fib);
+  if (e != hipSuccess) return e;
+  a.data = data;
+  a.block_offset = block_offset;
+  a.count = count;
+  a.init_q = init_q;
+  a.init_t = init_t;
+  a.out_q = out_q;
+  a.out_t = out_t;
+  a.out_iterations = out_iterations;
+  a.reg = reg;
+  a.weighted_iterations = weighted_iterations;
+  hipLaunchKernelGGL(weighted_eigensolver_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace pnec_hip

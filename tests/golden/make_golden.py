@@ -12,7 +12,7 @@ Reference functions exercised (scripts/pnec/...):
   common.pnec_energy_translations common.py:62-86
   math.skew, math.unscented_transform (diagonal covariances only: for non-diagonal ones the
       Python uses ROWS of the Cholesky factor where the C++ uses COLUMNS -- SURVEY.md 8c)
-  scf.fibonacci_sphere            scf.py
+  scf.fibonacci_sphere, scf.obj_fun   scf.py
 """
 import os
 import sys
@@ -106,8 +106,17 @@ def main():
     covs[:, 1, 1] = diag[:, 1]
     ut = np.stack([rm.unscented_transform(pts[i], covs[i], False, 1.0) for i in range(16)])
     fib = np.asarray(rs.fibonacci_sphere(500))
+    # scf.obj_fun (hard-wired to k = 10 matrices): sum_i x'A_i x / x'B_i x
+    nvec = rng.normal(size=(10, 3))
+    Ai = nvec[:, :, None] * nvec[:, None, :]
+    Lb = rng.normal(size=(10, 3, 3)) * 1e-3
+    Bi = Lb @ np.transpose(Lb, (0, 2, 1)) + 1e-9 * np.eye(3)
+    X = rng.normal(size=(6, 3))
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    obj = rs.obj_fun(X, Ai, Bi)
     np.savez_compressed(os.path.join(HERE, "math_golden.npz"), skew_in=vs, skew_out=skews,
-                        ut_points=pts, ut_covs=covs, ut_out=ut, fibonacci_500=fib)
+                        ut_points=pts, ut_covs=covs, ut_out=ut, fibonacci_500=fib,
+                        obj_Ai=Ai, obj_Bi=Bi, obj_X=X, obj_out=obj)
     print(f"wrote {idx} energy cases, math goldens")
 
 

@@ -386,3 +386,51 @@ def test_unscented_transform_device_vs_oracle_and_goldens(oracle, golden_dir):
                                               torch.from_numpy(Ki).cuda(), 1.0, model)
         np.testing.assert_array_equal(ct.cpu().numpy(), c_dev)
         np.testing.assert_array_equal(bt.cpu().numpy(), b_dev)
+
+
+def test_nec_eigensolver_device_vs_oracle(oracle):
+    """SURVEY 8f row 2 (without RANSAC): PNEC::Eigensolver = eigenvalue minimisation + TranslationFromM"""
+    counts = np.array([64, 100, 256, 512, 700, 37], dtype=np.int64)
+    offsets = np.concatenate([[0], np.cumsum(counts)])
+    g = sim.generate(1, int(offsets[-1]), seed=91)
+    poses = sim.generate(len(counts), 4, seed=92)
+    f1, f2 = g.bvs1[0].numpy(), g.bvs2[0].numpy()
+    q0 = np.tile(g.init_q[0].numpy(), (len(counts), 1))
+    with Batch(capi.MODE_NEC, offsets) as b:
+        b.fill(f1, f2)
+        q, t = b.nec_eigensolver(q0)
+    R0 = g.init_R[0].numpy()
+    for p, n in enumerate(counts):
+        sl = slice(offsets[p], offsets[p + 1])
+        Ro, to = oracle.nec_eigensolver(f1[sl], f2[sl], R0)
+        assert _rot_err(oracle, _quat_to_R(q[p]), Ro) <= 1e-8, n
+        assert abs(abs(t[p] @ to) - 1) < 1e-9, n
+        assert t[p][np.argmax(np.abs(t[p]))] > 0            # deterministic eigenvector sign
+    del poses
+
+
+def test_weighted_eigensolver_device_vs_oracle(oracle):
+    """SURVEY 8f row 1: PNEC::WeightedEigensolver (weights, eigensolver, Fibonacci search, scf)"""
+    B, N = 6, 512
+    g = sim.generate(B, N, seed=93)
+    f1, f2 = g.bvs1.reshape(-1, 3).numpy(), g.bvs2.reshape(-1, 3).numpy()
+    c2 = g.covs2.reshape(-1, 3, 3).numpy()
+    with Batch.uniform(capi.MODE_TARGET, B, N) as b:
+        b.fill(f1, f2, c2)
+        qn, tn = b.nec_eigensolver(g.init_q.numpy())
+        for iters in (10, 2, 1):
+            qw, tw = b.weighted_eigensolver(qn, tn, 1e-13, iters)
+            for p in range(B):
+                sl = slice(p * N, (p + 1) * N)
+                Rn = _quat_to_R(qn[p])
+                Ro, to = oracle.weighted_eigensolver(f1[sl], f2[sl], c2[sl], Rn, tn[p], 1e-13, iters)
+                assert _rot_err(oracle, _quat_to_R(qw[p]), Ro) <= 1e-8, (iters, p)
+                assert abs(abs(tw[p] @ to) - 1) < 1e-8, (iters, p)
+        # device space, and the whole PNEC::Solve chain (no RANSAC): ES -> weighted ES -> refinement
+        qd, td = b.weighted_eigensolver(torch.from_numpy(qn).cuda(), torch.from_numpy(tn).cuda(), 1e-13, 10)
+        res = b.solve(qd, td)
+        torch.cuda.synchronize()
+        qw10, tw10 = b.weighted_eigensolver(qn, tn, 1e-13, 10)
+        np.testing.assert_allclose(qd.cpu().numpy(), qw10, atol=1e-14)
+    for p in range(B):
+        assert _rot_err(oracle, _quat_to_R(res.q[p].cpu().numpy()), g.R_gt[p].numpy()) < 0.01
