@@ -164,6 +164,26 @@ int pnec_hip_cost_function(pnec_hip_problem *p, const double *q, const double *t
 int pnec_hip_nec_eigensolver(pnec_hip_problem *p, const double *init_q, double *out_q, double *out_t,
                              int space, void *stream);
 
+/* PNEC::Eigensolver with use_ransac_ = true (src/rel_pose_estimation/pnec.cc:239-272): RANSAC over
+ * eigensolver hypotheses from `sample_size` random correspondences (Options::ransac_sample_size_ = 10),
+ * at most `max_iterations` (Options::max_ransac_iterations_ = 5000) with the adaptive bound for 99 %
+ * confidence, inlier threshold on the midpoint-triangulation reprojection score (1e-6 in the
+ * reference, pnec.cc:248), eigensolver re-run on the inliers, translation by
+ * TranslationFromM(ComposeM(inliers)).  opengv::sac::Ransac is restated (opengv is not in the tree);
+ * its rand() draws are replaced by a counter-based hash of (seed, pair, hypothesis, draw).
+ * out_inlier_mask [sum N] (1 = inlier, in the caller's correspondence order), out_inlier_count
+ * [n_pairs], out_ransac_iterations [n_pairs] may each be NULL.  Pairs with fewer than sample_size
+ * correspondences fall back to the plain eigensolver with every correspondence an inlier. */
+int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint64_t seed,
+                                int32_t max_iterations, int32_t sample_size, double threshold, double *out_q,
+                                double *out_t, uint8_t *out_inlier_mask, int32_t *out_inlier_count,
+                                int32_t *out_ransac_iterations, int space, void *stream);
+
+/* PNEC::InlierExtraction (src/rel_pose_estimation/pnec.cc:210-229): a new batch holding, pair by pair
+ * and in order, the correspondences whose mask byte is non-zero.  Blocks until done. */
+int pnec_hip_problem_select(pnec_hip_problem *src, const uint8_t *mask, int space, void *stream,
+                            pnec_hip_problem **out);
+
 /* PNEC::WeightedEigensolver (src/rel_pose_estimation/pnec.cc:283-348) for every pair of a
  * TARGET-mode problem: (weighted_iterations - 1) rounds of { weights from the INITIAL pose x 1e-8,
  * eigensolver on the weighted bearings, 500-direction Fibonacci search of obj_fun

@@ -176,6 +176,14 @@ void pnec_oracle_build_ab(int64_t n, const double *bvs1, const double *bvs2, con
 /* pnec.cc:231-281 without RANSAC: rotation by the eigensolver, translation from ComposeM(i>=1) */
 void pnec_oracle_nec_eigensolver(int64_t n, const double *bvs1, const double *bvs2, const double R0[9],
                                  double R_out[9], double t_out[3]);
+/* pnec.cc:239-272: RANSAC around the eigensolver (opengv restated; counter-based RNG) */
+double pnec_oracle_rng_uniform(uint64_t seed, uint64_t pair, uint64_t hyp, uint64_t draw);
+double pnec_oracle_reprojection_score(const double f1[3], const double f2[3], const double R[9],
+                                      const double t[3]);
+int pnec_oracle_ransac_eigensolver(int64_t n, const double *bvs1, const double *bvs2, const double R0[9],
+                                   uint64_t seed, uint64_t pair_id, int max_iterations, int sample_size,
+                                   double threshold, double R_out[9], double t_out[3], uint8_t *inlier_mask,
+                                   int32_t *n_inliers, int32_t *iterations);
 /* pnec.cc:283-348 */
 void pnec_oracle_weighted_eigensolver(int64_t n, const double *bvs1, const double *bvs2,
                                       const double *covs, const double R_init[9], const double t_init[3],

@@ -121,6 +121,12 @@ def lib() -> C.CDLL:
         _lib.pnec_oracle_scf.argtypes = [C.c_int64, _dp, _dp, _dp, C.c_int, _dp]
         _lib.pnec_oracle_build_ab.argtypes = [C.c_int64, _dp, _dp, _dp, _dp, C.c_double, _dp, _dp]
         _lib.pnec_oracle_nec_eigensolver.argtypes = [C.c_int64, _dp, _dp, _dp, _dp, _dp]
+        _lib.pnec_oracle_rng_uniform.argtypes = [C.c_uint64] * 4
+        _lib.pnec_oracle_rng_uniform.restype = C.c_double
+        _lib.pnec_oracle_reprojection_score.argtypes = [_dp, _dp, _dp, _dp]
+        _lib.pnec_oracle_reprojection_score.restype = C.c_double
+        _lib.pnec_oracle_ransac_eigensolver.argtypes = [C.c_int64, _dp, _dp, _dp, C.c_uint64, C.c_uint64, C.c_int,
+                                                        C.c_int, C.c_double, _dp, _dp, C.POINTER(C.c_uint8), _ip, _ip]
         _lib.pnec_oracle_weighted_eigensolver.argtypes = [C.c_int64, _dp, _dp, _dp, _dp, _dp, C.c_double,
                                                           C.c_int, _dp, _dp]
     return _lib
@@ -270,6 +276,26 @@ def nec_eigensolver(bvs1, bvs2, R0):
     R, t = np.zeros(9), np.zeros(3)
     lib().pnec_oracle_nec_eigensolver(len(b1), b1p, b2p, rp, R.ctypes.data_as(_dp), t.ctypes.data_as(_dp))
     return R.reshape(3, 3), t
+
+
+def ransac_eigensolver(bvs1, bvs2, R0, seed=1, pair_id=0, max_iterations=5000, sample_size=10, threshold=1e-6):
+    """PNEC::Eigensolver with use_ransac_ (pnec.cc:239-272) -> (R, t, inlier_mask, ransac_iterations)"""
+    b1, b1p = _d(bvs1)
+    b2, b2p = _d(bvs2)
+    r, rp = _d(np.asarray(R0).reshape(9))
+    n = len(b1)
+    R, t = np.zeros(9), np.zeros(3)
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    cnt, it = C.c_int32(), C.c_int32()
+    lib().pnec_oracle_ransac_eigensolver(n, b1p, b2p, rp, seed, pair_id, max_iterations, sample_size, threshold,
+                                         R.ctypes.data_as(_dp), t.ctypes.data_as(_dp),
+                                         mask.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(cnt), C.byref(it))
+    return R.reshape(3, 3), t, mask[:n].astype(bool), it.value
+
+
+def reprojection_score(f1, f2, R, t):
+    a, ap = _d(f1); b, bp = _d(f2); r, rp = _d(np.asarray(R).reshape(9)); c, cp = _d(t)
+    return lib().pnec_oracle_reprojection_score(ap, bp, rp, cp)
 
 
 def weighted_eigensolver(bvs1, bvs2, covs, R_init, t_init, reg=1e-13, weighted_iterations=10):

@@ -434,3 +434,138 @@ void pnec_oracle_weighted_eigensolver(int64_t n, const double *bvs1, const doubl
   free(Ai);
   free(Bi);
 }
+
+/* ---- RANSAC around the eigensolver: pnec.cc:239-272 -------------------------------------------
+ * opengv::sac::Ransac<EigensolverSacProblem> restated from its published behaviour (opengv is not
+ * in the tree): hypotheses from `sample_size` random correspondences with the start rotation
+ * jittered by +-0.01 in Cayley space, eigensolver on the sample, translation = eigenvector of the
+ * smallest eigenvalue signed by the directional evidence sum t.(f1 - R f2), score per
+ * correspondence = (1 - f1.reproj1) + (1 - f2.reproj2) of the midpoint triangulation, inlier if
+ * score < threshold (1e-6 in the reference), adaptive iteration bound k = log(1-p)/log(1-w^s) with
+ * p = 0.99, then the eigensolver re-run on the inliers (optimizeModelCoefficients) and the
+ * reference's own TranslationFromM(ComposeM(inliers)).  opengv draws from rand(); here every draw
+ * is a counter-based hash of (seed, pair, hypothesis, draw), so CPU oracle and device agree. */
+static uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+double pnec_oracle_rng_uniform(uint64_t seed, uint64_t pair, uint64_t hyp, uint64_t draw) {
+  const uint64_t h = splitmix64(splitmix64(splitmix64(seed ^ 0xD1B54A32D192ED03ull) + pair) + (hyp << 20) + draw);
+  return (double)(h >> 11) * (1.0 / 9007199254740992.0); /* [0,1) */
+}
+
+/* reprojection score of one correspondence under (R, t) -- opengv midpoint triangulation */
+double pnec_oracle_reprojection_score(const double f1[3], const double f2[3], const double R[9],
+                                      const double t[3]) {
+  double f2u[3];
+  mat_vec(R, f2, f2u);
+  const double b0 = dot3(t, f1), b1 = dot3(t, f2u);
+  const double a00 = dot3(f1, f1), a10 = dot3(f1, f2u), a01 = -a10, a11 = -dot3(f2u, f2u);
+  const double det = a00 * a11 - a01 * a10;
+  const double l0 = (a11 * b0 - a01 * b1) / det, l1 = (-a10 * b0 + a00 * b1) / det;
+  double p[3], p2[3], d[3];
+  for (int k = 0; k < 3; ++k) p[k] = 0.5 * (l0 * f1[k] + t[k] + l1 * f2u[k]);
+  for (int k = 0; k < 3; ++k) d[k] = p[k] - t[k];
+  matT_vec(R, d, p2); /* R' (p - t) */
+  const double n1 = sqrt(dot3(p, p)), n2 = sqrt(dot3(p2, p2));
+  return (1.0 - dot3(f1, p) / n1) + (1.0 - dot3(f2, p2) / n2);
+}
+
+static void es_model_translation(int64_t m, const double *b1, const double *b2, const double R[9], double t[3]) {
+  double M[9], w[3], V[9];
+  pnec_oracle_compose_m(m, b1, b2, R, 0, M);
+  pnec_oracle_sym_eig3(M, w, V);
+  t[0] = V[0]; t[1] = V[3]; t[2] = V[6];
+  double ev = 0.0; /* directional evidence */
+  for (int64_t i = 0; i < m; ++i) {
+    double u[3];
+    mat_vec(R, b2 + 3 * i, u);
+    for (int k = 0; k < 3; ++k) ev += t[k] * (b1[3 * i + k] - u[k]);
+  }
+  if (ev < 0.0)
+    for (int k = 0; k < 3; ++k) t[k] = -t[k];
+}
+
+int pnec_oracle_ransac_eigensolver(int64_t n, const double *bvs1, const double *bvs2, const double R0[9],
+                                   uint64_t seed, uint64_t pair_id, int max_iterations, int sample_size,
+                                   double threshold, double R_out[9], double t_out[3], uint8_t *inlier_mask,
+                                   int32_t *n_inliers, int32_t *iterations) {
+  if (sample_size > 16) sample_size = 16;
+  if (n < sample_size || sample_size < 1) { /* cannot sample: plain eigensolver, everything an inlier */
+    pnec_oracle_nec_eigensolver(n, bvs1, bvs2, R0, R_out, t_out);
+    for (int64_t i = 0; i < n; ++i) inlier_mask[i] = 1;
+    *n_inliers = (int32_t)n;
+    if (iterations) *iterations = 0;
+    return 0;
+  }
+  double v0[3];
+  pnec_oracle_rot_to_cayley(R0, v0);
+  double best_R[9], best_t[3] = {0, 0, 1};
+  memcpy(best_R, R0, sizeof(best_R));
+  int best_count = -1, it = 0;
+  double k = 1.0;
+  while (it < k) {
+    int sel[16], m = 0;
+    uint64_t draw = 0;
+    while (m < sample_size) {
+      int64_t idx = (int64_t)(pnec_oracle_rng_uniform(seed, pair_id, (uint64_t)it, draw++) * (double)n);
+      if (idx >= n) idx = n - 1;
+      int dup = 0;
+      for (int j = 0; j < m; ++j) dup |= (sel[j] == idx);
+      if (!dup) sel[m++] = (int)idx;
+    }
+    double s1[48], s2[48], v[3], R[9], t[3];
+    for (int j = 0; j < sample_size; ++j) {
+      memcpy(s1 + 3 * j, bvs1 + 3 * sel[j], 3 * sizeof(double));
+      memcpy(s2 + 3 * j, bvs2 + 3 * sel[j], 3 * sizeof(double));
+    }
+    for (int c = 0; c < 3; ++c)
+      v[c] = v0[c] + (pnec_oracle_rng_uniform(seed, pair_id, (uint64_t)it, 1000 + c) - 0.5) * 2.0 * 0.01;
+    es_data D = {sample_size, s1, s2};
+    eigensolver_cayley(&D, v);
+    pnec_oracle_cayley_to_rot(v, R);
+    es_model_translation(sample_size, s1, s2, R, t);
+    int count = 0;
+    for (int64_t i = 0; i < n; ++i)
+      count += pnec_oracle_reprojection_score(bvs1 + 3 * i, bvs2 + 3 * i, R, t) < threshold;
+    if (count > best_count) {
+      best_count = count;
+      memcpy(best_R, R, sizeof(R));
+      memcpy(best_t, t, sizeof(t));
+      const double w = (double)count / (double)n;
+      double p_no = 1.0 - pow(w, (double)sample_size);
+      p_no = fmax(2.220446049250313e-16, p_no);
+      p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
+      k = log(1.0 - 0.99) / log(p_no);
+    }
+    ++it;
+    if (it > max_iterations) break;
+  }
+  /* inliers of the best model, then optimizeModelCoefficients on them */
+  int32_t cnt = 0;
+  double *i1 = (double *)malloc(sizeof(double) * 3 * (size_t)n), *i2 = (double *)malloc(sizeof(double) * 3 * (size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    const int in = pnec_oracle_reprojection_score(bvs1 + 3 * i, bvs2 + 3 * i, best_R, best_t) < threshold;
+    inlier_mask[i] = (uint8_t)in;
+    if (in) {
+      memcpy(i1 + 3 * cnt, bvs1 + 3 * i, 3 * sizeof(double));
+      memcpy(i2 + 3 * cnt, bvs2 + 3 * i, 3 * sizeof(double));
+      ++cnt;
+    }
+  }
+  double v[3];
+  pnec_oracle_rot_to_cayley(best_R, v);
+  es_data D = {cnt, i1, i2};
+  eigensolver_cayley(&D, v);
+  pnec_oracle_cayley_to_rot(v, R_out);
+  double M[9];
+  pnec_oracle_compose_m(cnt, i1, i2, R_out, 1, M); /* the reference's ComposeM on the inliers (C7) */
+  pnec_oracle_translation_from_m(M, t_out);
+  free(i1);
+  free(i2);
+  *n_inliers = cnt;
+  if (iterations) *iterations = it;
+  return 0;
+}

@@ -217,6 +217,54 @@ class Batch:
             capi.check(self._lib.pnec_hip_nec_eigensolver(self._h, pq, po, pto, space, stream))
         return oq, ot
 
+    def ransac_eigensolver(self, init_q, seed: int = 1, max_iterations: int = 5000, sample_size: int = 10,
+                           threshold: float = 1e-6):
+        """PNEC::Eigensolver with RANSAC (pnec.cc:239-272): -> (q, t, inlier_mask [sumN] uint8,
+        inlier_count [P], ransac_iterations [P])"""
+        M, P = self.num_correspondences, self.n_pairs
+        if _is_torch(init_q):
+            import torch
+            dev = init_q.device
+            q = torch.empty((P, 4), dtype=torch.float64, device=dev)
+            t = torch.empty((P, 3), dtype=torch.float64, device=dev)
+            mask = torch.empty((max(M, 1),), dtype=torch.uint8, device=dev)
+            cnt = torch.empty((P,), dtype=torch.int32, device=dev)
+            its = torch.empty((P,), dtype=torch.int32, device=dev)
+            iq = init_q.contiguous()
+            capi.check(self._lib.pnec_hip_ransac_eigensolver(
+                self._h, iq.data_ptr(), int(seed), int(max_iterations), int(sample_size), float(threshold),
+                q.data_ptr(), t.data_ptr(), mask.data_ptr(), cnt.data_ptr(), its.data_ptr(), capi.MEM_DEVICE,
+                torch.cuda.current_stream(self.device).cuda_stream))
+            return q, t, mask[:M], cnt, its
+        iq = np.ascontiguousarray(init_q, dtype=np.float64)
+        q, t = np.empty((P, 4)), np.empty((P, 3))
+        mask = np.zeros(max(M, 1), dtype=np.uint8)
+        cnt, its = np.zeros(P, dtype=np.int32), np.zeros(P, dtype=np.int32)
+        capi.check(self._lib.pnec_hip_ransac_eigensolver(
+            self._h, iq.ctypes.data, int(seed), int(max_iterations), int(sample_size), float(threshold),
+            q.ctypes.data, t.ctypes.data, mask.ctypes.data, cnt.ctypes.data, its.ctypes.data, capi.MEM_HOST, None))
+        return q, t, mask[:M], cnt, its
+
+    def select(self, mask) -> "Batch":
+        """PNEC::InlierExtraction (pnec.cc:210-229): new Batch with the masked correspondences."""
+        h = C.c_void_p()
+        if _is_torch(mask):
+            import torch
+            m = mask.contiguous().to(torch.uint8)
+            capi.check(self._lib.pnec_hip_problem_select(self._h, m.data_ptr(), capi.MEM_DEVICE,
+                                                         torch.cuda.current_stream(self.device).cuda_stream,
+                                                         C.byref(h)))
+            counts = None
+        else:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            capi.check(self._lib.pnec_hip_problem_select(self._h, m.ctypes.data, capi.MEM_HOST, None, C.byref(h)))
+        out = Batch.__new__(Batch)
+        out._lib, out.mode, out.device, out._h = self._lib, self.mode, self.device, h
+        out.n_pairs = self.n_pairs
+        # offsets of the new batch are known to the library; rebuild them from its pair sizes lazily
+        out.offsets = None
+        return out
+
     def nec_eigensolver(self, init_q):
         """PNEC::Eigensolver without RANSAC (pnec.cc:273-278): -> (q [P,4], t [P,3])"""
         return self._front(False, init_q, None, 0.0, 0)

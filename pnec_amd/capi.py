@@ -44,6 +44,8 @@ SYMBOLS = [
     "pnec_hip_select_best",
     "pnec_hip_cost_function",
     "pnec_hip_nec_eigensolver",
+    "pnec_hip_ransac_eigensolver",
+    "pnec_hip_problem_select",
     "pnec_hip_weighted_eigensolver",
     "pnec_hip_unscented_transform",
     "pnec_hip_describe_launch",
@@ -118,6 +120,9 @@ def lib() -> C.CDLL:
     L.pnec_hip_unscented_transform.argtypes = [C.c_int64, _vp, _vp, _vp, C.c_double, C.c_int, _vp, _vp,
                                                C.c_int, C.c_int, _vp]
     L.pnec_hip_nec_eigensolver.argtypes = [_vp, _vp, _vp, _vp, C.c_int, _vp]
+    L.pnec_hip_ransac_eigensolver.argtypes = [_vp, _vp, C.c_uint64, C.c_int32, C.c_int32, C.c_double, _vp, _vp,
+                                              _vp, _vp, _vp, C.c_int, _vp]
+    L.pnec_hip_problem_select.argtypes = [_vp, _vp, C.c_int, _vp, C.POINTER(_vp)]
     L.pnec_hip_weighted_eigensolver.argtypes = [_vp, _vp, _vp, C.c_double, C.c_int32, _vp, _vp, C.c_int, _vp]
     L.pnec_hip_selftest.argtypes = [C.c_int]
     _lib = L

@@ -28,17 +28,19 @@ int main(int argc, char **argv) {
     b2[i] = P2.normalized();
     covs[i] = pnec::Matrix3d::Identity() * (s * s);
   }
+  // the reference's default Options: RANSAC eigensolver -> inliers -> 9 weighted eigensolver rounds +
+  // SCF -> Ceres-style refinement (run_simulation.cc:74-86 calls it exactly like this)
   pnec::rel_pose_estimation::Options options;
-  options.use_ransac_ = false;  // everything else at the reference's defaults: NEC-ES -> 9 weighted
-                                // eigensolver rounds + SCF -> Ceres-style refinement
   pnec::rel_pose_estimation::PNEC pnec_solver(options);
   const pnec::SE3d init(pnec::Quaterniond(0.975, 0.1, -0.14, 0.115).normalized().toRotationMatrix(),
                         pnec::Vector3d(0.28, -0.22, 0.92).normalized());
-  const pnec::SE3d sol = pnec_solver.Solve(b1, b2, covs, init);
+  std::vector<int> inliers;
+  const pnec::SE3d sol = pnec_solver.Solve(b1, b2, covs, init, inliers);
   const double e0 = pnec::common::RotationalDifference(init.rotationMatrix(), Rgt);
   const double e1 = pnec::common::RotationalDifference(sol.rotationMatrix(), Rgt);
   const double te = pnec::common::TranslationalDifference(sol.translation(), tgt);
   const double cost = pnec::common::CostFunction(b1, b2, covs, sol);
-  std::printf("n=%d rot_err_init_deg=%.6f rot_err_deg=%.6f t_err_deg=%.6f cost=%.6f\n", n, e0, e1, te, cost);
+  std::printf("n=%d inliers=%zu rot_err_init_deg=%.6f rot_err_deg=%.6f t_err_deg=%.6f cost=%.6f\n", n,
+              inliers.size(), e0, e1, te, cost);
   return (e1 < e0 && e1 < 0.1) ? 0 : 1;
 }

@@ -258,23 +258,47 @@ SE3d PNEC::Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
                  const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose,
                  std::vector<int> &inliers) {
   // pnec.cc:77-124, stage by stage on the device.
-  if (options_.use_ransac_)
-    throw std::logic_error(
-        "PNEC::Solve: Options::use_ransac_ needs the RANSAC stage around the NEC eigensolver "
-        "(SURVEY.md 8f rank 2), which is not built yet; set use_ransac_ = false");
-  inliers.clear();
   PairOnDevice dev(optimization::SolverOptions().device, bvs1, bvs2, projected_covs);
   const Quaterniond q0(initial_pose.rotationMatrix());
   double q[4], t[3];
-  // ES_solution = Eigensolver(...)
-  Check(pnec_hip_nec_eigensolver(dev.prob.p, q0.coeffs(), q, t, PNEC_HIP_MEM_HOST, nullptr));
+  pnec_hip_problem *stage = dev.prob.p;   // the batch the later stages run on (inliers under RANSAC)
+  pnec_hip_problem *selected = nullptr;
+  struct Guard {
+    pnec_hip_problem *&p;
+    ~Guard() { if (p) pnec_hip_problem_destroy(p); }
+  } guard{selected};
+  // ES_solution = Eigensolver(bvs1, bvs2, initial_pose, inliers)
+  inliers.clear();
+  if (options_.use_ransac_) {
+    std::vector<uint8_t> mask(bvs1.size() ? bvs1.size() : 1);
+    Check(pnec_hip_ransac_eigensolver(dev.prob.p, q0.coeffs(), /*seed*/ 1, options_.max_ransac_iterations_,
+                                      options_.ransac_sample_size_, /*threshold pnec.cc:248*/ 1.0e-6, q, t,
+                                      mask.data(), nullptr, nullptr, PNEC_HIP_MEM_HOST, nullptr));
+    for (size_t i = 0; i < bvs1.size(); ++i)
+      if (mask[i]) inliers.push_back((int)i);
+    // InlierExtraction (pnec.cc:210-229)
+    Check(pnec_hip_problem_select(dev.prob.p, mask.data(), PNEC_HIP_MEM_HOST, nullptr, &selected));
+    stage = selected;
+  } else {
+    Check(pnec_hip_nec_eigensolver(dev.prob.p, q0.coeffs(), q, t, PNEC_HIP_MEM_HOST, nullptr));
+  }
+  const pnec_hip_options o = optimization::SolverOptions().ToHip();
+  double oq[4], ot[3];
   if (options_.use_nec_) {
-    const SE3d es = PoseFromQT(q, t);
-    return options_.use_ceres_ ? NECCeresSolver(bvs1, bvs2, es) : es;
+    if (!options_.use_ceres_) return PoseFromQT(q, t);
+    // NECCeresSolver on the (inlier) bearings: the NEC residual ignores the covariance planes, but
+    // the kernel family is fixed by the batch, so the inlier bearings go into a NEC batch
+    std::vector<Vector3d> b1, b2;
+    if (options_.use_ransac_) {
+      for (int i : inliers) { b1.push_back(bvs1[(size_t)i]); b2.push_back(bvs2[(size_t)i]); }
+    } else {
+      b1 = bvs1; b2 = bvs2;
+    }
+    return NECCeresSolver(b1, b2, PoseFromQT(q, t));
   }
   double qi[4], ti[3];
   if (options_.weighted_iterations_ > 1) {
-    Check(pnec_hip_weighted_eigensolver(dev.prob.p, q, t, options_.regularization_,
+    Check(pnec_hip_weighted_eigensolver(stage, q, t, options_.regularization_,
                                         (int32_t)options_.weighted_iterations_, qi, ti, PNEC_HIP_MEM_HOST,
                                         nullptr));
   } else if (options_.weighted_iterations_ == 1) {
@@ -286,18 +310,13 @@ SE3d PNEC::Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
   }
   if (!options_.use_ceres_) return PoseFromQT(qi, ti);
   // CeresSolver: default-constructed optimiser, Target frame (pnec.cc:355,366)
-  const pnec_hip_options o = optimization::SolverOptions().ToHip();
-  double oq[4], ot[3];
-  Check(pnec_hip_solve(dev.prob.p, qi, ti, 1, nullptr, options_.regularization_, &o, oq, ot, nullptr,
-                       nullptr, nullptr, PNEC_HIP_MEM_HOST, nullptr));
+  Check(pnec_hip_solve(stage, qi, ti, 1, nullptr, options_.regularization_, &o, oq, ot, nullptr, nullptr,
+                       nullptr, PNEC_HIP_MEM_HOST, nullptr));
   return PoseFromQT(oq, ot);
 }
 
 SE3d PNEC::Eigensolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
                        const SE3d &initial_pose, std::vector<int> &inliers) {
-  if (options_.use_ransac_)
-    throw std::logic_error("PNEC::Eigensolver: the RANSAC branch (pnec.cc:239-272) is not built yet; "
-                           "set use_ransac_ = false");
   inliers.clear();
   const std::vector<int64_t> offsets = {0, (int64_t)bvs1.size()};
   Problem prob(optimization::SolverOptions().device, PNEC_HIP_MODE_NEC, offsets);
@@ -306,7 +325,16 @@ SE3d PNEC::Eigensolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs
                                 PNEC_HIP_MEM_HOST, nullptr));
   const Quaterniond q0(initial_pose.rotationMatrix());
   double q[4], t[3];
-  Check(pnec_hip_nec_eigensolver(prob.p, q0.coeffs(), q, t, PNEC_HIP_MEM_HOST, nullptr));
+  if (options_.use_ransac_) {
+    std::vector<uint8_t> mask(bvs1.size() ? bvs1.size() : 1);
+    Check(pnec_hip_ransac_eigensolver(prob.p, q0.coeffs(), 1, options_.max_ransac_iterations_,
+                                      options_.ransac_sample_size_, 1.0e-6, q, t, mask.data(), nullptr, nullptr,
+                                      PNEC_HIP_MEM_HOST, nullptr));
+    for (size_t i = 0; i < bvs1.size(); ++i)
+      if (mask[i]) inliers.push_back((int)i);
+  } else {
+    Check(pnec_hip_nec_eigensolver(prob.p, q0.coeffs(), q, t, PNEC_HIP_MEM_HOST, nullptr));
+  }
   return PoseFromQT(q, t);
 }
 

@@ -161,9 +161,9 @@ class PNEC {
   explicit PNEC(const Options &options);
   ~PNEC();
 
-  // pnec.cc:69-124: NEC eigensolver -> (weighted eigensolver + SCF) -> least-squares refinement,
-  // every stage on the device.  Only the RANSAC wrapper around the eigensolver (Options::use_ransac_,
-  // default true in the reference) is still missing: it throws std::logic_error; set it to false.
+  // pnec.cc:69-124: NEC eigensolver (+ RANSAC, inlier extraction) -> weighted eigensolver + SCF ->
+  // least-squares refinement, every stage on the device, driven by the same Options fields the
+  // reference reads.  RANSAC draws come from a counter-based hash (seed 1), not rand().
   SE3d Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
              const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose);
   SE3d Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,

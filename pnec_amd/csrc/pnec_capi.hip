@@ -20,6 +20,11 @@ hipError_t launch_solve_mode_1(int, int, int, bool, const SolveArgs &, hipStream
 hipError_t launch_solve_mode_2(int, int, int, bool, const SolveArgs &, hipStream_t);
 hipError_t launch_solve_mode_3(int, int, int, bool, const SolveArgs &, hipStream_t);
 // pnec_frontend.hip
+hipError_t launch_ransac_eigensolver(const double *, const int64_t *, const int64_t *, const int32_t *, int64_t,
+                                     const double *, unsigned long long, int, int, double, double *, double *,
+                                     uint8_t *, int32_t *, int32_t *, hipStream_t);
+hipError_t launch_select(int, const double *, const int64_t *, const int64_t *, const int32_t *, const uint8_t *,
+                         double *, const int64_t *, const int32_t *, int64_t, hipStream_t);
 hipError_t launch_nec_eigensolver(const double *, const int64_t *, const int32_t *, int64_t, const double *,
                                   double *, double *, int32_t *, hipStream_t);
 hipError_t launch_weighted_eigensolver(int, const double *, const int64_t *, const int32_t *, int64_t,
@@ -280,6 +285,19 @@ __global__ __launch_bounds__(256) void unscented_kernel(int64_t n, const double 
 #pragma unroll
     for (int k = 0; k < 3; ++k) out_bvs[3 * i + k] = tp[0][k];  // normalised (K^-1) mu = Unproject
   }
+}
+
+// ---- inliers per pair from a correspondence mask ----------------------------------------------
+__global__ __launch_bounds__(kWave) void mask_count_kernel(const uint8_t *__restrict__ mask,
+                                                           const int64_t *__restrict__ offsets,
+                                                           const int32_t *__restrict__ count,
+                                                           int32_t *__restrict__ out) {
+  const int64_t p = blockIdx.x;
+  const int n = count[p];
+  int c = 0;
+  for (int i = threadIdx.x; i < n; i += kWave) c += mask[offsets[p] + i] != 0;
+  c = (int)wave_allreduce_sum((double)c);
+  if (threadIdx.x == 0) out[p] = c;
 }
 
 // ---- device self-test kernels (cross-lane reduction, 5x5 solve) ---------------------------
@@ -899,6 +917,109 @@ int pnec_hip_weighted_eigensolver(pnec_hip_problem *p, const double *init_q, con
                                   int space, void *stream) {
   if (weighted_iterations < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "weighted_iterations < 0");
   return run_front_stage(p, true, init_q, init_t, reg, weighted_iterations, out_q, out_t, space, stream);
+}
+
+int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint64_t seed,
+                                int32_t max_iterations, int32_t sample_size, double threshold, double *out_q,
+                                double *out_t, uint8_t *out_inlier_mask, int32_t *out_inlier_count,
+                                int32_t *out_ransac_iterations, int space, void *stream_) {
+  if (!p || !init_q || !out_q || !out_t) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (max_iterations < 0 || sample_size < 1) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad RANSAC parameters");
+  if (space != PNEC_HIP_MEM_DEVICE && space != PNEC_HIP_MEM_HOST)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad memory space");
+  if (p->n_pairs == 0) return 0;
+  DeviceGuard guard(p->device);
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t P = p->n_pairs, M = p->n_corr;
+  const double *d_q = init_q;
+  double *d_oq = out_q, *d_ot = out_t;
+  uint8_t *d_mask = out_inlier_mask;
+  int32_t *d_cnt = out_inlier_count, *d_it = out_ransac_iterations;
+  uint8_t *tmp_mask = nullptr;
+  if (space == PNEC_HIP_MEM_HOST) {
+    if (int rc = ensure_stage(p, 11 * P, 2 * P)) return rc;
+    double *w = p->d_stage;
+    PNEC_HIP_TRY(hipMemcpyAsync(w, init_q, sizeof(double) * 4 * P, hipMemcpyHostToDevice, stream));
+    d_q = w; w += 4 * P;
+    d_oq = w; w += 4 * P;
+    d_ot = w;
+    d_cnt = p->d_stage_i;
+    d_it = p->d_stage_i + P;
+    if (out_inlier_mask) {
+      PNEC_HIP_TRY(hipMalloc(&tmp_mask, (size_t)std::max<int64_t>(M, 1)));
+      d_mask = tmp_mask;
+    }
+  }
+  hipError_t e = launch_ransac_eigensolver(p->d_data, p->d_block_offset, p->d_offsets, p->d_count, P, d_q, seed,
+                                           max_iterations, sample_size, threshold, d_oq, d_ot, d_mask, d_cnt, d_it,
+                                           stream);
+  if (e == hipSuccess && space == PNEC_HIP_MEM_HOST) {
+    e = hipMemcpyAsync(out_q, d_oq, sizeof(double) * 4 * P, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_t, d_ot, sizeof(double) * 3 * P, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && out_inlier_mask && M > 0)
+      e = hipMemcpyAsync(out_inlier_mask, d_mask, (size_t)M, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && out_inlier_count)
+      e = hipMemcpyAsync(out_inlier_count, d_cnt, sizeof(int32_t) * P, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && out_ransac_iterations)
+      e = hipMemcpyAsync(out_ransac_iterations, d_it, sizeof(int32_t) * P, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  }
+  if (tmp_mask) (void)hipFree(tmp_mask);
+  if (e != hipSuccess) return fail_hip(e, "ransac_eigensolver_kernel");
+  return 0;
+}
+
+int pnec_hip_problem_select(pnec_hip_problem *src, const uint8_t *mask, int space, void *stream_,
+                            pnec_hip_problem **out) {
+  if (!src || !mask || !out) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (space != PNEC_HIP_MEM_DEVICE && space != PNEC_HIP_MEM_HOST)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad memory space");
+  *out = nullptr;
+  DeviceGuard guard(src->device);
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t P = src->n_pairs, M = src->n_corr;
+  const uint8_t *d_mask = mask;
+  uint8_t *tmp_mask = nullptr;
+  int32_t *d_cnt = nullptr;
+  std::vector<int32_t> counts((size_t)P);
+  auto cleanup = [&]() {
+    if (tmp_mask) (void)hipFree(tmp_mask);
+    if (d_cnt) (void)hipFree(d_cnt);
+  };
+  if (space == PNEC_HIP_MEM_HOST && M > 0) {
+    PNEC_HIP_TRY(hipMalloc(&tmp_mask, (size_t)M));
+    hipError_t e = hipMemcpyAsync(tmp_mask, mask, (size_t)M, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) { cleanup(); return fail_hip(e, "mask upload"); }
+    d_mask = tmp_mask;
+  }
+  if (P > 0) {
+    hipError_t e = hipMalloc(&d_cnt, sizeof(int32_t) * P);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)P), dim3(kWave), 0, stream, d_mask, src->d_offsets,
+                         src->d_count, d_cnt);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_cnt, sizeof(int32_t) * P, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { cleanup(); return fail_hip(e, "mask_count_kernel"); }
+  }
+  std::vector<int64_t> offsets((size_t)P + 1, 0);
+  for (int64_t i = 0; i < P; ++i) offsets[(size_t)i + 1] = offsets[(size_t)i] + counts[(size_t)i];
+  pnec_hip_problem *dst = nullptr;
+  if (int rc = pnec_hip_problem_create(src->device, src->mode, P, offsets.data(), &dst)) { cleanup(); return rc; }
+  if (P > 0) {
+    hipError_t e = launch_select(src->nc, src->d_data, src->d_block_offset, src->d_offsets, src->d_count, d_mask,
+                                 dst->d_data, dst->d_block_offset, dst->d_count, P, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+      cleanup();
+      pnec_hip_problem_destroy(dst);
+      return fail_hip(e, "select_kernel");
+    }
+  }
+  cleanup();
+  *out = dst;
+  return 0;
 }
 
 int pnec_hip_unscented_transform(int64_t n, const double *mu, const double *covs, const double *K_inv,

@@ -583,6 +583,308 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
   }
 }
 
+// ---- RANSAC around the eigensolver (pnec.cc:239-272; opengv::sac::Ransac<EigensolverSacProblem>
+// restated, see oracle/pnec_oracle_frontend.c for the definition both sides follow) -----------
+// One wavefront per pair, ONE LANE PER HYPOTHESIS: a round evaluates 64 hypotheses at once (sample,
+// 36 sums of the sample, damped Newton, translation, inlier count over all correspondences with
+// broadcast payload reads), then the lanes are scanned in hypothesis order with the sequential
+// rule (strictly better count wins, adaptive bound k) so the outcome equals the sequential loop.
+struct RansacArgs {
+  const double *data;
+  const int64_t *block_offset;
+  const int64_t *offsets;  // AoS offsets (inlier mask is written in the caller's correspondence order)
+  const int32_t *count;
+  const double *init_q;
+  double *out_q, *out_t;
+  uint8_t *out_mask;
+  int32_t *out_count, *out_iterations;
+  unsigned long long seed;
+  int max_iterations, sample_size;
+  double threshold;
+};
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ double rng_uniform(unsigned long long seed, unsigned long long pair,
+                                              unsigned long long hyp, unsigned long long draw) {
+  const unsigned long long h =
+      splitmix64(splitmix64(splitmix64(seed ^ 0xD1B54A32D192ED03ull) + pair) + (hyp << 20) + draw);
+  return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+__device__ __forceinline__ double reprojection_score(const double (&f1)[3], const double (&f2)[3],
+                                                     const double (&R)[9], const double (&t)[3]) {
+  const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
+                       R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
+  const double b0 = t[0] * f1[0] + t[1] * f1[1] + t[2] * f1[2], b1 = t[0] * u[0] + t[1] * u[1] + t[2] * u[2];
+  const double a00 = f1[0] * f1[0] + f1[1] * f1[1] + f1[2] * f1[2];
+  const double a10 = f1[0] * u[0] + f1[1] * u[1] + f1[2] * u[2];
+  const double a01 = -a10, a11 = -(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+  const double det = a00 * a11 - a01 * a10;
+  const double l0 = (a11 * b0 - a01 * b1) / det, l1 = (-a10 * b0 + a00 * b1) / det;
+  double p[3], d[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    p[k] = 0.5 * (l0 * f1[k] + t[k] + l1 * u[k]);
+    d[k] = p[k] - t[k];
+  }
+  const double p2[3] = {R[0] * d[0] + R[3] * d[1] + R[6] * d[2], R[1] * d[0] + R[4] * d[1] + R[7] * d[2],
+                        R[2] * d[0] + R[5] * d[1] + R[8] * d[2]};
+  const double n1 = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+  const double n2 = sqrt(p2[0] * p2[0] + p2[1] * p2[1] + p2[2] * p2[2]);
+  return (1.0 - (f1[0] * p[0] + f1[1] * p[1] + f1[2] * p[2]) / n1) +
+         (1.0 - (f2[0] * p2[0] + f2[1] * p2[1] + f2[2] * p2[2]) / n2);
+}
+
+__global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacArgs a) {
+  const int64_t pair = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int n = a.count[pair];
+  const int stride = (n + kWave - 1) & ~(kWave - 1);
+  const double *base = a.data + a.block_offset[pair];
+  __shared__ double G[36];
+  __shared__ double best_model[12];  // R (9) + t (3)
+  double q0[4] = {a.init_q[4 * pair], a.init_q[4 * pair + 1], a.init_q[4 * pair + 2], a.init_q[4 * pair + 3]};
+  {
+    const double qn = 1.0 / sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
+    for (int k = 0; k < 4; ++k) q0[k] *= qn;
+  }
+  double R0[9], v0[3];
+  rot_from_quat(q0, R0);
+  rot_to_cayley(R0, v0);
+  const int ss = a.sample_size > 16 ? 16 : a.sample_size;
+  const bool can_sample = (n >= ss && ss >= 1);
+  int it = 0;
+  double bR[9], bt[3] = {0.0, 0.0, 1.0};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) bR[i] = R0[i];
+
+  if (can_sample) {
+    int best_count = -1;
+    double k = 1.0;
+    bool stop = false;
+    while (!stop && (double)it < k) {
+      const unsigned long long h = (unsigned long long)(it + lane);
+      // ---- this lane's hypothesis: sample, sums, minimise, translation
+      int sel[16];
+      int m = 0;
+      unsigned long long draw = 0;
+      while (m < ss) {
+        long long idx = (long long)(rng_uniform(a.seed, (unsigned long long)pair, h, draw++) * (double)n);
+        if (idx >= n) idx = n - 1;
+        bool dup = false;
+        for (int j = 0; j < m; ++j) dup = dup || (sel[j] == (int)idx);
+        if (!dup) sel[m++] = (int)idx;
+      }
+      double Gl[36];
+      for (int i = 0; i < 36; ++i) Gl[i] = 0.0;
+      double ev1[3] = {0, 0, 0};  // sum f1 (for the directional evidence)
+      for (int j = 0; j < ss; ++j) {
+        const int idx = sel[j];
+        const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
+        const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
+                              base[(int64_t)5 * stride + idx]};
+        const double p[6] = {f2[0] * f2[0], f2[0] * f2[1], f2[0] * f2[2], f2[1] * f2[1], f2[1] * f2[2], f2[2] * f2[2]};
+        const double qq[6] = {f1[0] * f1[0], f1[0] * f1[1], f1[0] * f1[2], f1[1] * f1[1], f1[1] * f1[2], f1[2] * f1[2]};
+        for (int kl = 0; kl < 6; ++kl)
+          for (int ac = 0; ac < 6; ++ac) Gl[6 * kl + ac] += p[kl] * qq[ac];
+        for (int c = 0; c < 3; ++c) ev1[c] += f1[c];
+      }
+      double v[3], R[9], t[3], M[9];
+      for (int c = 0; c < 3; ++c)
+        v[c] = v0[c] + (rng_uniform(a.seed, (unsigned long long)pair, h, 1000 + c) - 0.5) * 2.0 * 0.01;
+      es_minimise(Gl, v, (double)ss);
+      es_value_grad(Gl, v, nullptr, M);
+      cayley_to_rot(v, R);
+      {
+        double w[3], V[9];
+        sym_eig3(M, w, V);
+        t[0] = V[0]; t[1] = V[3]; t[2] = V[6];
+        // directional evidence sum t.(f1 - R f2) over the sample
+        double ev = t[0] * ev1[0] + t[1] * ev1[1] + t[2] * ev1[2];
+        for (int j = 0; j < ss; ++j) {
+          const int idx = sel[j];
+          const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
+                                base[(int64_t)5 * stride + idx]};
+          const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
+                               R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
+          ev -= t[0] * u[0] + t[1] * u[1] + t[2] * u[2];
+        }
+        if (ev < 0.0) { t[0] = -t[0]; t[1] = -t[1]; t[2] = -t[2]; }
+      }
+      // ---- inlier count of this hypothesis over the whole pair (payload reads are wave-uniform)
+      int cnt = 0;
+      for (int i = 0; i < n; ++i) {
+        const double f1[3] = {base[i], base[(int64_t)stride + i], base[(int64_t)2 * stride + i]};
+        const double f2[3] = {base[(int64_t)3 * stride + i], base[(int64_t)4 * stride + i],
+                              base[(int64_t)5 * stride + i]};
+        cnt += reprojection_score(f1, f2, R, t) < a.threshold ? 1 : 0;
+      }
+      // ---- consume the 64 hypotheses in order with the sequential rule
+      int winner = -1;
+      for (int j = 0; j < kWave; ++j) {
+        if (!((double)it < k)) { stop = true; break; }
+        const int cj = __builtin_amdgcn_readlane(cnt, j);
+        if (cj > best_count) {
+          best_count = cj;
+          winner = j;
+          const double w = (double)cj / (double)n;
+          double p_no = 1.0 - pow(w, (double)ss);
+          p_no = fmax(2.220446049250313e-16, p_no);
+          p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
+          k = log(1.0 - 0.99) / log(p_no);
+        }
+        ++it;
+        if (it > a.max_iterations) { stop = true; break; }
+      }
+      if (winner >= 0 && lane == winner) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) best_model[i] = R[i];
+        best_model[9] = t[0]; best_model[10] = t[1]; best_model[11] = t[2];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) bR[i] = best_model[i];
+    bt[0] = best_model[9]; bt[1] = best_model[10]; bt[2] = best_model[11];
+  }
+
+  // ---- inliers of the best model (all correspondences when sampling is impossible), their 36 sums,
+  // the first inlier (ComposeM on the inlier list starts at its second entry, C7)
+  double acc[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+  int my_count = 0, my_first = 0x7fffffff;
+  const int64_t aos0 = a.offsets[pair];
+  for (int idx = lane; idx < stride; idx += kWave) {
+    const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
+    const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
+                          base[(int64_t)5 * stride + idx]};
+    bool in = idx < n;
+    if (in && can_sample) in = reprojection_score(f1, f2, bR, bt) < a.threshold;
+    if (idx < n && a.out_mask) a.out_mask[aos0 + idx] = in ? 1 : 0;
+    if (in) {
+      ++my_count;
+      if (idx < my_first) my_first = idx;
+      const double p[6] = {f2[0] * f2[0], f2[0] * f2[1], f2[0] * f2[2], f2[1] * f2[1], f2[1] * f2[2], f2[2] * f2[2]};
+      const double qq[6] = {f1[0] * f1[0], f1[0] * f1[1], f1[0] * f1[2], f1[1] * f1[1], f1[1] * f1[2], f1[2] * f1[2]};
+#pragma unroll
+      for (int kl = 0; kl < 6; ++kl)
+#pragma unroll
+        for (int ac = 0; ac < 6; ++ac) acc[6 * kl + ac] = __builtin_fma(p[kl], qq[ac], acc[6 * kl + ac]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 36; ++i) {
+    const double sres = wave_allreduce_sum(acc[i]);
+    if (lane == 0) G[i] = sres;
+  }
+  const int total = (int)wave_allreduce_sum((double)my_count);
+  int first = my_first;
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(first, off);
+    first = o < first ? o : first;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+  // optimizeModelCoefficients: eigensolver on the inliers from the best model's rotation
+  double v[3], R[9], M[9];
+  rot_to_cayley(bR, v);
+  es_minimise(G, v, (double)(total > 0 ? total : 1));
+  es_value_grad(G, v, nullptr, M);
+  cayley_to_rot(v, R);
+  if (total > 0) {
+    const int idx = first;
+    const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
+    const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
+                          base[(int64_t)5 * stride + idx]};
+    const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
+                         R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
+    const double nn[3] = {f1[1] * u[2] - f1[2] * u[1], f1[2] * u[0] - f1[0] * u[2], f1[0] * u[1] - f1[1] * u[0]};
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) M[3 * r + c] -= nn[r] * nn[c];
+  }
+  double w3[3], V[9];
+  sym_eig3(M, w3, V);
+  if (lane == 0) {
+    double qo[4];
+    quat_from_rot_dev(R, qo);
+    const double qn = 1.0 / sqrt(qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3]);
+    for (int k = 0; k < 4; ++k) a.out_q[4 * pair + k] = qo[k] * qn;
+    const double tn = 1.0 / sqrt(V[0] * V[0] + V[3] * V[3] + V[6] * V[6]);
+    a.out_t[3 * pair + 0] = V[0] * tn;
+    a.out_t[3 * pair + 1] = V[3] * tn;
+    a.out_t[3 * pair + 2] = V[6] * tn;
+    if (a.out_count) a.out_count[pair] = total;
+    if (a.out_iterations) a.out_iterations[pair] = it;
+  }
+}
+
+// ---- InlierExtraction (pnec.cc:210-229): compact the masked correspondences of every pair into a
+// new batch, order preserved.  One wavefront per pair; positions by ballot prefix counts.
+__global__ __launch_bounds__(kWave) void select_kernel(int nc, const double *src, const int64_t *src_block,
+                                                       const int64_t *src_offsets, const int32_t *src_count,
+                                                       const uint8_t *mask, double *dst,
+                                                       const int64_t *dst_block, const int32_t *dst_count) {
+  const int64_t pair = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int n = src_count[pair], m = dst_count[pair];
+  const int sstride = (n + kWave - 1) & ~(kWave - 1), dstride = (m + kWave - 1) & ~(kWave - 1);
+  const double *sb = src + src_block[pair];
+  double *db = dst + dst_block[pair];
+  const uint8_t *mk = mask + src_offsets[pair];
+  int written = 0;
+  for (int c0 = 0; c0 < sstride; c0 += kWave) {
+    const int idx = c0 + lane;
+    const bool in = idx < n && mk[idx] != 0;
+    const unsigned long long b = __ballot(in);
+    const int pos = written + __popcll(b & ((1ull << lane) - 1ull));
+    if (in)
+      for (int c = 0; c < nc; ++c) db[(int64_t)c * dstride + pos] = sb[(int64_t)c * sstride + idx];
+    written += __popcll(b);
+  }
+  for (int idx = m + lane; idx < dstride; idx += kWave)  // zero padding of the last 64-chunk
+    for (int c = 0; c < nc; ++c) db[(int64_t)c * dstride + idx] = 0.0;
+}
+
+hipError_t launch_select(int nc, const double *src, const int64_t *src_block, const int64_t *src_offsets,
+                         const int32_t *src_count, const uint8_t *mask, double *dst, const int64_t *dst_block,
+                         const int32_t *dst_count, int64_t n_pairs, hipStream_t stream) {
+  hipLaunchKernelGGL(select_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, nc, src, src_block,
+                     src_offsets, src_count, mask, dst, dst_block, dst_count);
+  return hipGetLastError();
+}
+
+hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_offset, const int64_t *offsets,
+                                     const int32_t *count, int64_t n_pairs, const double *init_q,
+                                     unsigned long long seed, int max_iterations, int sample_size,
+                                     double threshold, double *out_q, double *out_t, uint8_t *out_mask,
+                                     int32_t *out_count, int32_t *out_iterations, hipStream_t stream) {
+  RansacArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.data = data;
+  a.block_offset = block_offset;
+  a.offsets = offsets;
+  a.count = count;
+  a.init_q = init_q;
+  a.out_q = out_q;
+  a.out_t = out_t;
+  a.out_mask = out_mask;
+  a.out_count = out_count;
+  a.out_iterations = out_iterations;
+  a.seed = seed;
+  a.max_iterations = max_iterations;
+  a.sample_size = sample_size;
+  a.threshold = threshold;
+  hipLaunchKernelGGL(ransac_eigensolver_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // host side: launchers called from pnec_capi.hip
 static std::mutex g_fib_mutex;

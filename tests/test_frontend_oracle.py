@@ -128,3 +128,40 @@ def test_weighted_eigensolver_and_full_pipeline(oracle):
         R1, t1 = oracle.weighted_eigensolver(f1, f2, S, Rn, tn, 1e-13, 1)
         np.testing.assert_array_equal(R1, Rn)
         np.testing.assert_array_equal(t1, tn)
+
+
+def _with_outliers(g, p, frac, rng):
+    f1, f2 = g.bvs1[p].numpy().copy(), g.bvs2[p].numpy().copy()
+    n = len(f1)
+    out = rng.choice(n, int(frac * n), replace=False)
+    v = rng.normal(size=(len(out), 3))
+    f2[out] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    return f1, f2, out
+
+
+def test_ransac_eigensolver_rejects_outliers_and_is_deterministic(oracle):
+    """pnec.cc:239-272 restated: RANSAC over eigensolver hypotheses, reprojection-score inliers"""
+    g = sim.generate(3, 300, seed=14)
+    rng = np.random.default_rng(1)
+    for p in range(3):
+        f1, f2, out = _with_outliers(g, p, 0.25, rng)
+        R, t, mask, it = oracle.ransac_eigensolver(f1, f2, g.init_R[p].numpy(), seed=7, pair_id=p)
+        assert mask[out].sum() <= 1 and mask.sum() > 150        # gross outliers are gone
+        assert 1 <= it <= 5000
+        assert oracle.rotational_difference_deg(R, g.R_gt[p].numpy()) < 0.1
+        Rp, _ = oracle.nec_eigensolver(f1, f2, g.init_R[p].numpy())
+        assert oracle.rotational_difference_deg(Rp, g.R_gt[p].numpy()) > 1.0   # plain ES is thrown off
+        R2, t2, mask2, it2 = oracle.ransac_eigensolver(f1, f2, g.init_R[p].numpy(), seed=7, pair_id=p)
+        np.testing.assert_array_equal(R, R2)
+        np.testing.assert_array_equal(mask, mask2)
+        # result = eigensolver on the inliers + ComposeM/TranslationFromM on the inliers
+        Ri, ti = oracle.nec_eigensolver(f1[mask], f2[mask], R)
+        assert math.radians(oracle.rotational_difference_deg(Ri, R)) < 1e-9 and abs(abs(ti @ t) - 1) < 1e-9
+    # fewer correspondences than the sample size: plain eigensolver, everything an inlier
+    R, t, mask, it = oracle.ransac_eigensolver(g.bvs1[0].numpy()[:8], g.bvs2[0].numpy()[:8], g.init_R[0].numpy())
+    assert mask.all() and it == 0
+    # the score is the midpoint-triangulation reprojection error: ~0 for exact geometry
+    f1, f2, Rg, tg = _exact_pair(g, 1, 20)
+    assert max(oracle.reprojection_score(f1[i], f2[i], Rg, tg) for i in range(20)) < 1e-15
+    u = [oracle.lib().pnec_oracle_rng_uniform(1, 2, 3, d) for d in range(1000)]
+    assert 0 <= min(u) and max(u) < 1 and 0.45 < np.mean(u) < 0.55

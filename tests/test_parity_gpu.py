@@ -434,3 +434,48 @@ def test_weighted_eigensolver_device_vs_oracle(oracle):
         np.testing.assert_allclose(qd.cpu().numpy(), qw10, atol=1e-14)
     for p in range(B):
         assert _rot_err(oracle, _quat_to_R(res.q[p].cpu().numpy()), g.R_gt[p].numpy()) < 0.01
+
+
+def test_ransac_eigensolver_and_inlier_selection_device_vs_oracle(oracle):
+    """SURVEY 8f row 2 with RANSAC (pnec.cc:239-272) + InlierExtraction (pnec.cc:210-229): same
+    counter-based draws on both sides -> same inlier sets, same rotations"""
+    counts = np.array([300, 512, 128, 8, 40], dtype=np.int64)
+    offsets = np.concatenate([[0], np.cumsum(counts)])
+    B = len(counts)
+    g = sim.generate(B, 512, seed=95)
+    rng = np.random.default_rng(2)
+    f1 = np.concatenate([g.bvs1[p].numpy()[:n] for p, n in enumerate(counts)])
+    f2 = np.concatenate([g.bvs2[p].numpy()[:n] for p, n in enumerate(counts)])
+    c2 = np.concatenate([g.covs2[p].numpy()[:n] for p, n in enumerate(counts)])
+    for p in range(B):                       # 20 % gross outliers in every pair
+        sl = np.arange(offsets[p], offsets[p + 1])
+        bad = rng.choice(sl, len(sl) // 5, replace=False)
+        v = rng.normal(size=(len(bad), 3))
+        f2[bad] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    with Batch(capi.MODE_TARGET, offsets) as b:
+        b.fill(f1, f2, c2)
+        q, t, mask, cnt, its = b.ransac_eigensolver(g.init_q.numpy(), seed=11, max_iterations=5000,
+                                                    sample_size=10, threshold=1e-6)
+        for p in range(B):
+            sl = slice(offsets[p], offsets[p + 1])
+            Ro, to, mo, ito = oracle.ransac_eigensolver(f1[sl], f2[sl], g.init_R[p].numpy(), seed=11, pair_id=p)
+            assert its[p] == ito, (p, its[p], ito)
+            np.testing.assert_array_equal(mask[sl].astype(bool), mo)
+            assert cnt[p] == mo.sum()
+            assert _rot_err(oracle, _quat_to_R(q[p]), Ro) <= 1e-8
+            assert abs(abs(t[p] @ to) - 1) < 1e-8
+        # InlierExtraction: the selected batch holds exactly the inliers, in order
+        sel = b.select(mask)
+        assert sel.num_correspondences == int(mask.sum())
+        qs, ts = sel.nec_eigensolver(q)
+        for p in range(B):
+            sl = slice(offsets[p], offsets[p + 1])
+            m = mask[sl].astype(bool)
+            Ro, to = oracle.nec_eigensolver(f1[sl][m], f2[sl][m], _quat_to_R(q[p]))
+            assert _rot_err(oracle, _quat_to_R(qs[p]), Ro) <= 1e-8
+        # the reference's whole default pipeline on the inliers: weighted ES + SCF, then refinement
+        qw, tw = sel.weighted_eigensolver(q, t, 1e-13, 10)
+        res = sel.solve(qw, tw)
+        for p in (0, 1, 2):
+            assert _rot_err(oracle, _quat_to_R(res.q[p]), g.R_gt[p].numpy()) < 0.01
+        sel.close()
