@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Stage timings of the full PNEC::Solve pipeline (the reference's FrameTiming columns NEC-ES, IT-ES,
+CERES: include/common/timing.h:52-66) on one GPU, with the CPU oracle's time for the same stages on a
+sample.  Prints one JSON object."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from oracle import pnec_oracle as po
+from pnec_amd import Batch, capi
+from pnec_amd import simulation as sim
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+N = 512
+dev = torch.device("cuda:0")
+batch = Batch.uniform(capi.MODE_TARGET, B, N)
+qs, ts, first = [], [], None
+for c in range(0, B, 5000):
+    m = min(5000, B - c)
+    g = sim.generate(m, N, seed=1 + c, device=dev)
+    # 10 % gross outliers so that RANSAC has something to do
+    bad = torch.rand(m, N, device=dev, generator=torch.Generator(device=dev).manual_seed(c)) < 0.10
+    rnd = torch.randn(m, N, 3, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(c + 1))
+    rnd = rnd / rnd.norm(dim=-1, keepdim=True)
+    g.bvs2 = torch.where(bad[..., None], rnd, g.bvs2)
+    batch.fill(g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3), first_pair=c, n_pairs=m)
+    qs.append(g.init_q); ts.append(g.init_t)
+    if first is None:
+        first = g
+q0, t0 = torch.cat(qs), torch.cat(ts)
+
+
+def timed(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    out = []
+    for _ in range(reps):
+        t = time.perf_counter(); r = fn(); torch.cuda.synchronize(); out.append(time.perf_counter() - t)
+    return float(np.median(out)), r
+
+
+t_nec, (qn, tn) = timed(lambda: batch.nec_eigensolver(q0))
+t_ran, (qr, tr, mask, cnt, its) = timed(lambda: batch.ransac_eigensolver(q0, seed=1))
+t_sel, sel = timed(lambda: batch.select(mask), reps=1)
+t_wes, (qw, tw) = timed(lambda: sel.weighted_eigensolver(qr, tr, 1e-13, 10))
+t_ls, res = timed(lambda: sel.solve(qw, tw))
+Rg = torch.cat([sim.generate(min(5000, B - c), N, seed=1 + c, device=dev).R_gt for c in range(0, min(B, 5000), 5000)])
+dq = res.rotation_matrices()[: Rg.shape[0]]
+err = torch.acos(((dq.transpose(-1, -2) @ Rg).diagonal(dim1=-2, dim2=-1).sum(-1).clamp(-1, 3) - 1).clamp(-2, 2) / 2).mul(180 / np.pi)
+
+# CPU oracle, same stages, 16 pairs, single thread
+n_s = 16
+f1 = first.bvs1[:n_s].cpu().numpy(); f2 = first.bvs2[:n_s].cpu().numpy(); c2 = first.covs2[:n_s].cpu().numpy()
+R0 = first.init_R[:n_s].cpu().numpy()
+tc = {"nec_es": 0.0, "ransac_es": 0.0, "weighted_es": 0.0, "ls": 0.0}
+worst = 0.0
+for p in range(n_s):
+    t = time.perf_counter(); po.nec_eigensolver(f1[p], f2[p], R0[p]); tc["nec_es"] += time.perf_counter() - t
+    t = time.perf_counter(); Rr, trr, m, it = po.ransac_eigensolver(f1[p], f2[p], R0[p], seed=1, pair_id=p); tc["ransac_es"] += time.perf_counter() - t
+    t = time.perf_counter(); Rw, tww = po.weighted_eigensolver(f1[p][m], f2[p][m], c2[p][m], Rr, trr); tc["weighted_es"] += time.perf_counter() - t
+    t = time.perf_counter(); s = po.solve(po.MODE_TARGET, f1[p][m], f2[p][m], c2[p][m], None, 1e-13, po.quat_from_rot(Rw), tww, po.default_options()); tc["ls"] += time.perf_counter() - t
+    gq = res.q[p].cpu().numpy()
+    worst = max(worst, np.radians(po.rotational_difference_deg(s.R, po.rot_from_quat(gq))))
+print(json.dumps({
+    "workload": f"{B} pairs x {N} corr, 10 % gross outliers, reference-default Options (RANSAC eigensolver, 10 weighted iterations, LS with Ceres-default termination)",
+    "gpu_ms": {"nec_es (no ransac)": t_nec * 1e3, "ransac_es": t_ran * 1e3, "inlier_extraction": t_sel * 1e3,
+               "weighted_es+scf": t_wes * 1e3, "ls_refinement": t_ls * 1e3},
+    "gpu_pairs_per_s_full_pipeline": B / (t_ran + t_sel + t_wes + t_ls),
+    "mean_inliers": float(cnt.double().mean()), "mean_ransac_iterations": float(its.double().mean()),
+    "median_rot_err_deg_vs_ground_truth": float(err.median()),
+    "cpu_oracle_ms_per_pair_1_thread": {k: v / n_s * 1e3 for k, v in tc.items()},
+    "max_rot_diff_gpu_vs_oracle_pipeline_rad_16_pairs": worst}))
