@@ -475,7 +475,7 @@ __device__ double obj_fun_pair(const double *base, int n, int stride, const doub
     const double a = t[0] * nn[0] + t[1] * nn[1] + t[2] * nn[2];
     const double d = t[0] * (B[0] * t[0] + B[1] * t[1] + B[2] * t[2]) + t[1] * (B[1] * t[0] + B[3] * t[1] + B[4] * t[2]) +
                      t[2] * (B[2] * t[0] + B[4] * t[1] + B[5] * t[2]);
-    acc += a * a / d;
+    acc = __builtin_fma(a * a, fast_rcp(d), acc);
   }
   return wave_allreduce_sum(acc);
 }
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
             const double aa = tx * nn[0] + ty * nn[1] + tz * nn[2];
             const double d = tx * (B[0] * tx + B[1] * ty + B[2] * tz) + ty * (B[1] * tx + B[3] * ty + B[4] * tz) +
                              tz * (B[2] * tx + B[4] * ty + B[5] * tz);
-            acc[c] += aa * aa / d;
+            acc[c] = __builtin_fma(aa * aa, fast_rcp(d), acc[c]);
           }
         }
         double sums[kNumAcc];
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
         corr_nb(base, stride, idx, R, a.reg, nn, B);
         const double d = t[0] * (B[0] * t[0] + B[1] * t[1] + B[2] * t[2]) + t[1] * (B[1] * t[0] + B[3] * t[1] + B[4] * t[2]) +
                          t[2] * (B[2] * t[0] + B[4] * t[1] + B[5] * t[2]);
-        const double w = 1.0 / d;
+        const double w = fast_rcp(d);
         e[0] += w * nn[0] * nn[0]; e[1] += w * nn[0] * nn[1]; e[2] += w * nn[0] * nn[2];
         e[3] += w * nn[1] * nn[1]; e[4] += w * nn[1] * nn[2]; e[5] += w * nn[2] * nn[2];
       }
