@@ -26,11 +26,6 @@
 
 #include "pnec_device.hpp"
 
-#ifdef PNEC_EXP_NOLOAD  // experiment: synthetic payload, no HBM reads (timing only)
-#define PNEC_LOAD_GUARD(in) false
-#else
-#define PNEC_LOAD_GUARD(in) (in)
-#endif
 
 // Launch geometries instantiated for every residual family:
 //   (CPL correspondences per lane, WPP wavefronts per solve, LDSK of the CPL kept in LDS)
@@ -163,7 +158,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
       const bool in = idx < stride;
 #pragma unroll
       for (int c = 0; c < NC; ++c)
-        put(std::integral_constant<int, 0>{}, c, PNEC_LOAD_GUARD(in) ? base[(int64_t)c * stride + idx] : 0.0);
+        put(std::integral_constant<int, 0>{}, c, in ? base[(int64_t)c * stride + idx] : 0.0);
       vmask = idx < n ? 1u : 0u;
     } else {
       static_assert(CPL == 1 || CPL % 2 == 0, "correspondences per lane: 1 or even");
@@ -175,7 +170,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
           pair_t v = {0.0, 0.0};
-          if (PNEC_LOAD_GUARD(in)) v = *reinterpret_cast<const pair_t *>(base + (int64_t)c * stride + idx);
+          if (in) v = *reinterpret_cast<const pair_t *>(base + (int64_t)c * stride + idx);
           put(std::integral_constant<int, 2 * j>{}, c, v.x);
           put(std::integral_constant<int, 2 * j + 1>{}, c, v.y);
         }
@@ -201,11 +196,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   if (lane == 0) {
     double th, ph;
     const double *t0 = a.hyp_t ? a.hyp_t + 3 * s : a.init_t + 3 * pair;
-#ifdef PNEC_EXP_NOANGLES
-    th = t0[0]; ph = t0[1];
-#else
     angles_from_vec(t0[0], t0[1], t0[2], th, ph);
-#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) slab[kQc + k] = a.init_q[pair * 4 + k];
     slab[kThetaC] = th;
