@@ -584,7 +584,11 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
 }
 
 // ---- RANSAC around the eigensolver (pnec.cc:239-272; opengv::sac::Ransac<EigensolverSacProblem>
-// restated, see oracle/pnec_oracle_frontend.c for the definition both sides follow) -----------
+// restated from its published behaviour: hypotheses from `sample_size` random correspondences with
+// the start rotation jittered by +-0.01 in Cayley space, score = (1 - f1.reproj1) + (1 - f2.reproj2)
+// of the midpoint triangulation, inlier if score < threshold, adaptive bound
+// k = log(1 - 0.99) / log(1 - w^s), eigensolver re-run on the inliers; rand() replaced by a
+// counter-based hash of (seed, pair, hypothesis, draw)) ------------------------------------------
 // One wavefront per pair, ONE LANE PER HYPOTHESIS: a round evaluates 64 hypotheses at once (sample,
 // 36 sums of the sample, damped Newton, translation, inlier count over all correspondences with
 // broadcast payload reads), then the lanes are scanned in hypothesis order with the sequential
