@@ -27,7 +27,7 @@ hipError_t launch_select(int, const double *, const int64_t *, const int64_t *, 
                          double *, const int64_t *, const int32_t *, int64_t, hipStream_t);
 hipError_t launch_nec_eigensolver(const double *, const int64_t *, const int32_t *, int64_t, const double *,
                                   double *, double *, int32_t *, hipStream_t);
-hipError_t launch_weighted_eigensolver(int, const double *, const int64_t *, const int32_t *, int64_t,
+hipError_t launch_weighted_eigensolver(int, const double *, const int64_t *, const int32_t *, int64_t, int,
                                        const double *, const double *, double, int, double *, double *,
                                        int32_t *, hipStream_t);
 }  // namespace pnec_hip
@@ -894,7 +894,7 @@ static int run_front_stage(pnec_hip_problem *p, bool weighted, const double *ini
     d_ot = w;
   }
   hipError_t e = weighted
-                     ? launch_weighted_eigensolver(p->device, p->d_data, p->d_block_offset, p->d_count, P, d_q,
+                     ? launch_weighted_eigensolver(p->device, p->d_data, p->d_block_offset, p->d_count, P, p->n_max, d_q,
                                                    d_t, reg, weighted_iterations, d_oq, d_ot, nullptr, stream)
                      : launch_nec_eigensolver(p->d_data, p->d_block_offset, p->d_count, P, d_q, d_oq, d_ot,
                                               nullptr, stream);

@@ -247,7 +247,7 @@ __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&
 }
 
 // damped Newton on the Cayley vector; returns the number of iterations taken (0 = already converged)
-__device__ int es_minimise(const double *G, double (&v)[3], double n_scale) {
+__device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double n_scale) {
   double g[3];
   double f = es_value_grad(G, v, g, nullptr);
   int it = 0;
@@ -481,6 +481,10 @@ __device__ double obj_fun_pair(const double *base, int n, int stride, const doub
 }
 
 // ---- PNEC::WeightedEigensolver ---------------------------------------------------------------
+// RES: the pair has <= 512 correspondences, so each lane keeps n and B of its (<= 8)
+// correspondences in registers for the 24 search batches and the SCF steps of a round instead of
+// re-reading the payload and rebuilding them every time (they only change with the rotation).
+template <bool RES>
 __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const FrontArgs a) {
   const int64_t pair = blockIdx.x;
   const int lane = threadIdx.x;
@@ -504,6 +508,22 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
   // weights come from the INITIAL pose in every iteration (C3): the 36 weighted sums never change
   pass_sums36<true>(base, n, stride, R0, t0, a.reg, lane, G);
 
+  constexpr int KR = RES ? 8 : 1;
+  double rn[KR][3], rB[KR][6];
+  // visit every correspondence of the lane with its (n, B): from registers or by streaming
+  auto for_each_corr = [&](auto &&body) {
+    if constexpr (RES) {
+#pragma unroll
+      for (int k = 0; k < KR; ++k) body(rn[k], rB[k]);
+    } else {
+      for (int idx = lane; idx < n; idx += kWave) {
+        double nn[3], B[6];
+        corr_nb(base, stride, idx, R, a.reg, nn, B);
+        body(nn, B);
+      }
+    }
+  };
+
   double fib_min_cost = 0.0;
   int fib_min_idx = -1;  // -1: no stored search yet
   int first_iterations = 0;
@@ -511,43 +531,79 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
     const int newton = es_minimise(G, v, (double)(n > 0 ? n : 1));
     if (it == 0) first_iterations = newton;
     const bool same_rotation = (it > 0 && newton == 0 && fib_min_idx >= 0);
-    if (!same_rotation) {
-      cayley_to_rot(v, R);
-      // 500 Fibonacci directions, 21 at a time: per correspondence n, B once per batch
-      fib_min_idx = -1;
-      for (int b0 = 0; b0 < 500; b0 += 21) {
-        const int nb = (500 - b0 < 21) ? 500 - b0 : 21;
-        if (lane < nb * 3) cand[lane / 3][lane % 3] = a.fib[3 * b0 + lane];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        double acc[kNumAcc];
+    cayley_to_rot(v, R);  // bit-identical to the previous round's when the Newton iteration did not move
+    if constexpr (RES) {
+      // rebuilt every round (cheap) so that the arrays are dead across es_minimise: the Newton
+      // iteration and 144 resident registers do not fit a wavefront's register file together
 #pragma unroll
-        for (int c = 0; c < kNumAcc; ++c) acc[c] = 0.0;
-        for (int idx = lane; idx < n; idx += kWave) {
-          double nn[3], B[6];
-          corr_nb(base, stride, idx, R, a.reg, nn, B);
+      for (int k = 0; k < KR; ++k) {
+        const int idx = lane + kWave * k;
+        if (idx < n) {
+          corr_nb(base, stride, idx, R, a.reg, rn[k], rB[k]);
+        } else {  // padding: contributes exactly 0 to every sum (n = 0, B = I)
+          rn[k][0] = rn[k][1] = rn[k][2] = 0.0;
+          rB[k][0] = rB[k][3] = rB[k][5] = 1.0;
+          rB[k][1] = rB[k][2] = rB[k][4] = 0.0;
+        }
+      }
+    }
+    if (!same_rotation) {
+      auto energy_term = [](double tx, double ty, double tz, const double(&nn)[3], const double(&B)[6]) {
+        const double aa = tx * nn[0] + ty * nn[1] + tz * nn[2];
+        const double d = tx * (B[0] * tx + B[1] * ty + B[2] * tz) + ty * (B[1] * tx + B[3] * ty + B[4] * tz) +
+                         tz * (B[2] * tx + B[4] * ty + B[5] * tz);
+        return aa * aa * fast_rcp(d);
+      };
+      fib_min_idx = -1;
+      if constexpr (RES) {
+        // 500 Fibonacci directions against the resident (n, B): one direction at a time
+#pragma unroll 2
+        for (int c = 0; c < 500; ++c) {
+          const double tx = a.fib[3 * c], ty = a.fib[3 * c + 1], tz = a.fib[3 * c + 2];
+          double sacc = 0.0;
+#pragma unroll
+          for (int k = 0; k < KR; ++k) sacc += energy_term(tx, ty, tz, rn[k], rB[k]);
+          const double sum = wave_allreduce_sum(sacc);
+          if (fib_min_idx < 0 || sum < fib_min_cost) {
+            fib_min_cost = sum;
+            fib_min_idx = c;
+          }
+        }
+      } else {
+        // streaming: 21 directions at a time, per correspondence n, B rebuilt once per batch
+        for (int b0 = 0; b0 < 500; b0 += 21) {
+          const int nb = (500 - b0 < 21) ? 500 - b0 : 21;
+          if (lane < nb * 3) cand[lane / 3][lane % 3] = a.fib[3 * b0 + lane];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          double acc[kNumAcc];
+#pragma unroll
+          for (int c = 0; c < kNumAcc; ++c) acc[c] = 0.0;
+          for_each_corr([&](const double(&nn)[3], const double(&B)[6]) {
+#pragma unroll
+            for (int c = 0; c < kNumAcc; ++c) acc[c] += energy_term(cand[c][0], cand[c][1], cand[c][2], nn, B);
+          });
+          double sums[kNumAcc];
+          wave_reduce21(acc, sums);
 #pragma unroll
           for (int c = 0; c < kNumAcc; ++c) {
-            const double tx = cand[c][0], ty = cand[c][1], tz = cand[c][2];
-            const double aa = tx * nn[0] + ty * nn[1] + tz * nn[2];
-            const double d = tx * (B[0] * tx + B[1] * ty + B[2] * tz) + ty * (B[1] * tx + B[3] * ty + B[4] * tz) +
-                             tz * (B[2] * tx + B[4] * ty + B[5] * tz);
-            acc[c] = __builtin_fma(aa * aa, fast_rcp(d), acc[c]);
+            if (c < nb && (fib_min_idx < 0 || sums[c] < fib_min_cost)) {
+              fib_min_cost = sums[c];
+              fib_min_idx = b0 + c;
+            }
           }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
-        double sums[kNumAcc];
-        wave_reduce21(acc, sums);
-#pragma unroll
-        for (int c = 0; c < kNumAcc; ++c) {
-          if (c < nb && (fib_min_idx < 0 || sums[c] < fib_min_cost)) {
-            fib_min_cost = sums[c];
-            fib_min_idx = b0 + c;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       }
     }
     // best_point = current translation unless a Fibonacci direction is strictly better
-    const double cur_cost = obj_fun_pair(base, n, stride, R, a.reg, t, lane);
+    double cur_cost = 0.0;
+    for_each_corr([&](const double(&nn)[3], const double(&B)[6]) {
+      const double aa = t[0] * nn[0] + t[1] * nn[1] + t[2] * nn[2];
+      const double d = t[0] * (B[0] * t[0] + B[1] * t[1] + B[2] * t[2]) + t[1] * (B[1] * t[0] + B[3] * t[1] + B[4] * t[2]) +
+                       t[2] * (B[2] * t[0] + B[4] * t[1] + B[5] * t[2]);
+      cur_cost = __builtin_fma(aa * aa, fast_rcp(d), cur_cost);
+    });
+    cur_cost = wave_allreduce_sum(cur_cost);
     if (fib_min_idx >= 0 && fib_min_cost < cur_cost) {
       t[0] = a.fib[3 * fib_min_idx];
       t[1] = a.fib[3 * fib_min_idx + 1];
@@ -556,15 +612,13 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
     // scf: 10 steps of  t <- eigenvector of the smallest eigenvalue of sum A_i / (t' B_i t)
     for (int step = 0; step < 10; ++step) {
       double e[6] = {0, 0, 0, 0, 0, 0};
-      for (int idx = lane; idx < n; idx += kWave) {
-        double nn[3], B[6];
-        corr_nb(base, stride, idx, R, a.reg, nn, B);
+      for_each_corr([&](const double(&nn)[3], const double(&B)[6]) {
         const double d = t[0] * (B[0] * t[0] + B[1] * t[1] + B[2] * t[2]) + t[1] * (B[1] * t[0] + B[3] * t[1] + B[4] * t[2]) +
                          t[2] * (B[2] * t[0] + B[4] * t[1] + B[5] * t[2]);
         const double w = fast_rcp(d);
         e[0] += w * nn[0] * nn[0]; e[1] += w * nn[0] * nn[1]; e[2] += w * nn[0] * nn[2];
         e[3] += w * nn[1] * nn[1]; e[4] += w * nn[1] * nn[2]; e[5] += w * nn[2] * nn[2];
-      }
+      });
 #pragma unroll
       for (int k = 0; k < 6; ++k) e[k] = wave_allreduce_sum(e[k]);
       const double E[9] = {e[0], e[1], e[2], e[1], e[3], e[4], e[2], e[4], e[5]};
@@ -941,7 +995,7 @@ hipError_t launch_nec_eigensolver(const double *data, const int64_t *block_offse
 }
 
 hipError_t launch_weighted_eigensolver(int device, const double *data, const int64_t *block_offset,
-                                       const int32_t *count, int64_t n_pairs, const double *init_q,
+                                       const int32_t *count, int64_t n_pairs, int n_max, const double *init_q,
                                        const double *init_t, double reg, int weighted_iterations,
                                        double *out_q, double *out_t, int32_t *out_iterations,
                                        hipStream_t stream) {
@@ -959,7 +1013,10 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
   a.out_iterations = out_iterations;
   a.reg = reg;
   a.weighted_iterations = weighted_iterations;
-  hipLaunchKernelGGL(weighted_eigensolver_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
+  if (n_max <= 8 * kWave)
+    hipLaunchKernelGGL(weighted_eigensolver_kernel<true>, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
+  else
+    hipLaunchKernelGGL(weighted_eigensolver_kernel<false>, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
   return hipGetLastError();
 }
 
