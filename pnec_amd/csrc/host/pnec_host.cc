@@ -1,6 +1,7 @@
 // pnec_host.cc -- implementation of the host facade over the C ABI.  See pnec_host.h.
 #include "pnec_host.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -93,6 +94,87 @@ double TranslationalDifference(const Vector3d &translation_1, const Vector3d &tr
   double error = std::acos(c);
   if (both_directions) error = std::min(error, std::acos(-c));
   return error * 180.0 / M_PI;
+}
+
+Matrix3d ComposeM(const bearingVectors_t &bvs_1, const bearingVectors_t &bvs_2, const Matrix3d &rotation) {
+  Matrix3d M;
+  for (size_t i = 1; i < bvs_1.size(); ++i) {  // sic: the reference's loop starts at 1
+    const Vector3d n = bvs_1[i].cross(rotation * bvs_2[i]);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) M(r, c) += n[r] * n[c];
+  }
+  return M;
+}
+
+// unit eigenvector of the smallest eigenvalue (cyclic Jacobi); largest-magnitude component positive
+Vector3d TranslationFromM(const Matrix3d &M) {
+  double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) A[r][c] = 0.5 * (M(r, c) + M(c, r));
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+    const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+    if (off <= 1e-34 * dg || off == 0.0) break;
+    const int P[3] = {0, 0, 1}, Q[3] = {1, 2, 2};
+    for (int k = 0; k < 3; ++k) {
+      const int p = P[k], q = Q[k];
+      if (A[p][q] == 0.0) continue;
+      const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+      const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+      const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+      for (int r = 0; r < 3; ++r) {
+        const double arp = A[r][p], arq = A[r][q];
+        A[r][p] = c * arp - s * arq;
+        A[r][q] = s * arp + c * arq;
+      }
+      for (int r = 0; r < 3; ++r) {
+        const double apr = A[p][r], aqr = A[q][r];
+        A[p][r] = c * apr - s * aqr;
+        A[q][r] = s * apr + c * aqr;
+      }
+      for (int r = 0; r < 3; ++r) {
+        const double vrp = V[r][p], vrq = V[r][q];
+        V[r][p] = c * vrp - s * vrq;
+        V[r][q] = s * vrp + c * vrq;
+      }
+    }
+  }
+  int j = 0;
+  if (A[1][1] < A[j][j]) j = 1;
+  if (A[2][2] < A[j][j]) j = 2;
+  Vector3d v(V[0][j], V[1][j], V[2][j]);
+  int big = 0;
+  for (int r = 1; r < 3; ++r)
+    if (std::fabs(v[r]) > std::fabs(v[big])) big = r;
+  if (v[big] < 0.0) v = -v;
+  return v.normalized();
+}
+
+double Weight(const Vector3d &f1, const Vector3d &f2, const Vector3d &translation, const Matrix3d &rotation,
+              const Matrix3d &covariance, double regularization, bool host_frame) {
+  const Vector3d v = host_frame ? translation.cross(rotation * f2) : rotation.transpose() * translation.cross(f1);
+  const double q = v.dot(covariance * v);
+  return host_frame ? 1.0 / q : 1.0 / (q + regularization);
+}
+
+Vector3d Unproject(const double img_pt[2], const Matrix3d &K_inv) {
+  return (K_inv * Vector3d(img_pt[0], img_pt[1], 1.0)).normalized();
+}
+
+std::vector<Matrix3d> UnscentedTransform(const std::vector<Vector3d> &mus, const std::vector<Matrix3d> &covs,
+                                         const Matrix3d &K_inv, double kappa, CameraModel camera_model) {
+  if (mus.size() != covs.size()) return covs;  // the reference warns and returns the input (common.cc:532-537)
+  std::vector<Matrix3d> out(mus.size());
+  if (!mus.empty())
+    Check(pnec_hip_unscented_transform((int64_t)mus.size(), mus[0].data(), covs[0].data(), K_inv.data(), kappa,
+                                       camera_model == Pinhole ? 1 : 0, nullptr, out[0].data(),
+                                       PNEC_HIP_MEM_HOST, 0, nullptr));
+  return out;
+}
+
+Matrix3d UnscentedTransform(const Vector3d &mu, const Matrix3d &cov, const Matrix3d &K_inv, double kappa,
+                            CameraModel camera_model) {
+  return UnscentedTransform(std::vector<Vector3d>{mu}, std::vector<Matrix3d>{cov}, K_inv, kappa, camera_model)[0];
 }
 
 double CostFunction(const bearingVectors_t &bvs_1, const bearingVectors_t &bvs_2,
@@ -257,7 +339,29 @@ SE3d PoseFromQT(const double q[4], const double t[3]) {
 SE3d PNEC::Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
                  const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose,
                  std::vector<int> &inliers) {
-  // pnec.cc:77-124, stage by stage on the device.
+  return SolveImpl(bvs1, bvs2, projected_covs, initial_pose, inliers, nullptr);
+}
+SE3d PNEC::Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                 const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose,
+                 common::FrameTiming &timing) {
+  std::vector<int> inliers;
+  return SolveImpl(bvs1, bvs2, projected_covs, initial_pose, inliers, &timing);
+}
+SE3d PNEC::Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                 const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose,
+                 std::vector<int> &inliers, common::FrameTiming &timing) {
+  return SolveImpl(bvs1, bvs2, projected_covs, initial_pose, inliers, &timing);
+}
+
+SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                     const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose,
+                     std::vector<int> &inliers, common::FrameTiming *timing) {
+  // pnec.cc:77-124 (timed twin :135-208), stage by stage on the device.
+  using clock = std::chrono::high_resolution_clock;
+  auto ms_since = [](clock::time_point t0) {
+    return (long)std::chrono::duration_cast<std::chrono::milliseconds>(clock::now() - t0).count();
+  };
+  auto tic = clock::now();
   PairOnDevice dev(optimization::SolverOptions().device, bvs1, bvs2, projected_covs);
   const Quaterniond q0(initial_pose.rotationMatrix());
   double q[4], t[3];
@@ -282,10 +386,13 @@ SE3d PNEC::Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
   } else {
     Check(pnec_hip_nec_eigensolver(dev.prob.p, q0.coeffs(), q, t, PNEC_HIP_MEM_HOST, nullptr));
   }
+  if (timing) timing->nec_es_ = ms_since(tic);
   const pnec_hip_options o = optimization::SolverOptions().ToHip();
   double oq[4], ot[3];
   if (options_.use_nec_) {
+    if (timing) timing->ceres_ = 0;
     if (!options_.use_ceres_) return PoseFromQT(q, t);
+    tic = clock::now();
     // NECCeresSolver on the (inlier) bearings: the NEC residual ignores the covariance planes, but
     // the kernel family is fixed by the batch, so the inlier bearings go into a NEC batch
     std::vector<Vector3d> b1, b2;
@@ -294,13 +401,21 @@ SE3d PNEC::Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
     } else {
       b1 = bvs1; b2 = bvs2;
     }
-    return NECCeresSolver(b1, b2, PoseFromQT(q, t));
+    const SE3d nec = NECCeresSolver(b1, b2, PoseFromQT(q, t));
+    if (timing) timing->ceres_ = ms_since(tic);
+    return nec;
   }
   double qi[4], ti[3];
+  if (timing) timing->it_es_ = timing->avg_it_es_ = 0;
   if (options_.weighted_iterations_ > 1) {
+    tic = clock::now();
     Check(pnec_hip_weighted_eigensolver(stage, q, t, options_.regularization_,
                                         (int32_t)options_.weighted_iterations_, qi, ti, PNEC_HIP_MEM_HOST,
                                         nullptr));
+    if (timing) {
+      timing->it_es_ = ms_since(tic);
+      timing->avg_it_es_ = timing->it_es_ / (long)options_.weighted_iterations_;
+    }
   } else if (options_.weighted_iterations_ == 1) {
     std::memcpy(qi, q, sizeof(qi));
     std::memcpy(ti, t, sizeof(ti));
@@ -308,10 +423,13 @@ SE3d PNEC::Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
     std::memcpy(qi, q0.coeffs(), sizeof(qi));
     std::memcpy(ti, initial_pose.translation().data(), sizeof(ti));
   }
+  if (timing) timing->ceres_ = 0;
   if (!options_.use_ceres_) return PoseFromQT(qi, ti);
   // CeresSolver: default-constructed optimiser, Target frame (pnec.cc:355,366)
+  tic = clock::now();
   Check(pnec_hip_solve(stage, qi, ti, 1, nullptr, options_.regularization_, &o, oq, ot, nullptr, nullptr,
                        nullptr, PNEC_HIP_MEM_HOST, nullptr));
+  if (timing) timing->ceres_ = ms_since(tic);
   return PoseFromQT(oq, ot);
 }
 

@@ -32,6 +32,31 @@ void AnglesFromVec(const Vector3d &vector, double &theta, double &phi);  // comm
 double RotationalDifference(const Matrix3d &rotation_1, const Matrix3d &rotation_2);  // common.cc:210-214 (deg)
 double TranslationalDifference(const Vector3d &translation_1, const Vector3d &translation_2,
                                bool both_directions = true);           // common.cc:216-235 (deg)
+// common.cc:127-136 (the loop starts at i = 1, as in the reference), :157-181, :183-208
+Matrix3d ComposeM(const bearingVectors_t &bvs_1, const bearingVectors_t &bvs_2, const Matrix3d &rotation);
+Vector3d TranslationFromM(const Matrix3d &M);
+double Weight(const Vector3d &bearing_vector_1, const Vector3d &bearing_vector_2, const Vector3d &translation,
+              const Matrix3d &rotation, const Matrix3d &covariance, double regularization, bool host_frame);
+// common.cc:460-525, evaluated on the device (batch overload :527-550)
+enum CameraModel { Omnidirectional, Pinhole };  // common.h:62
+Vector3d Unproject(const double img_pt[2], const Matrix3d &K_inv);
+Matrix3d UnscentedTransform(const Vector3d &mu, const Matrix3d &cov, const Matrix3d &K_inv, double kappa,
+                            CameraModel camera_model);
+std::vector<Matrix3d> UnscentedTransform(const std::vector<Vector3d> &mus, const std::vector<Matrix3d> &covs,
+                                         const Matrix3d &K_inv, double kappa, CameraModel camera_model);
+
+// include/common/timing.h:48-67: per-frame stage timers in milliseconds
+struct FrameTiming {
+  explicit FrameTiming(int id) : id_(id) {}
+  static std::string TimingHeader() {
+    return "ID FrameLoading FeatureCreation NEC-ES IT-ES AVG-IT-ES CERES OPTIMIZATION TOTAL";
+  }
+  int OptimizationTime() const { return (int)(nec_es_ + it_es_ + ceres_); }
+  int TotalTime() const { return (int)(frame_loading_ + feature_creation_) + OptimizationTime(); }
+  int id_;
+  long frame_loading_ = 0, feature_creation_ = 0, nec_es_ = 0, it_es_ = 0, avg_it_es_ = 0, ceres_ = 0;  // ms
+};
+
 // common.cc:237-259, evaluated on the device
 double CostFunction(const bearingVectors_t &bvs_1, const bearingVectors_t &bvs_2,
                     const std::vector<Matrix3d> &covs, const SE3d &camera_pose);
@@ -169,6 +194,13 @@ class PNEC {
   SE3d Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
              const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose,
              std::vector<int> &inliers);
+  // the timed twins (pnec.cc:126-208): same result, stage times filled in
+  SE3d Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+             const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose,
+             common::FrameTiming &timing);
+  SE3d Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+             const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose,
+             std::vector<int> &inliers, common::FrameTiming &timing);
 
   SE3d Eigensolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
                    const SE3d &initial_pose, std::vector<int> &inliers);          // pnec.cc:231-281
@@ -189,6 +221,9 @@ class PNEC {
                                      std::vector<optimization::Summary> *summaries = nullptr);
 
  private:
+  SE3d SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
+                 const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose,
+                 std::vector<int> &inliers, common::FrameTiming *timing);
   Options options_;
 };
 

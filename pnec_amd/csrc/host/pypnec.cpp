@@ -116,6 +116,32 @@ py::list ceres_solver_batch(py::list bvs1, py::list bvs2, py::list covs, py::lis
   return out;
 }
 
+// additions used by the tests: the small pnec::common helpers of the facade
+arr compose_m(arr bvs1, arr bvs2, arr rotation) {
+  const auto b1 = ToBearings(bvs1, "bvs1"), b2 = ToBearings(bvs2, "bvs2");
+  auto r = rotation.unchecked<2>();
+  pnec::Matrix3d R;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R(i, j) = r(i, j);
+  const pnec::Matrix3d M = pnec::common::ComposeM(b1, b2, R);
+  arr out({3, 3});
+  auto w = out.mutable_unchecked<2>();
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) w(i, j) = M(i, j);
+  return out;
+}
+arr translation_from_m(arr M) {
+  auto r = M.unchecked<2>();
+  pnec::Matrix3d Mm;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Mm(i, j) = r(i, j);
+  const pnec::Vector3d t = pnec::common::TranslationFromM(Mm);
+  arr out({3});
+  auto w = out.mutable_unchecked<1>();
+  for (int i = 0; i < 3; ++i) w(i) = t[i];
+  return out;
+}
+
 int add(int i, int j) { return i + j; }  // the reference module's smoke function (pypnec.cpp:34)
 
 }  // namespace
@@ -128,6 +154,8 @@ PYBIND11_MODULE(pypnec, m) {
         "Symmetric PNEC refinement (PNECCeres::Optimize with covariances in both frames)");
   m.def("pyceresnec", &pyceresnec, py::arg("host_bvs"), py::arg("target_bvs"), py::arg("init_pose"),
         "NEC refinement (NECCeres::Optimize)");
+  m.def("compose_m", &compose_m, "pnec::common::ComposeM (loop from i = 1, like the reference)");
+  m.def("translation_from_m", &translation_from_m, "pnec::common::TranslationFromM");
   m.def("ceres_solver_batch", &ceres_solver_batch, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"),
         py::arg("init_poses"), py::arg("regularization") = 1e-13,
         "PNEC::CeresSolver for a list of frame pairs in one device launch (addition)");

@@ -86,3 +86,13 @@ def test_cpp_facade_demo_runs_run_simulation_call_pattern():
     r = subprocess.run([exe, "100"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rot_err_deg" in r.stdout
+
+
+def test_common_helpers_of_the_facade_match_oracle(oracle):
+    """pnec::common::ComposeM (loop from i = 1) and TranslationFromM in the C++ facade"""
+    import pypnec
+    g = sim.generate(1, 60, seed=3)
+    f1, f2, R = g.bvs1[0].numpy(), g.bvs2[0].numpy(), g.R_gt[0].numpy()
+    M = pypnec.compose_m(f1, f2, R)
+    np.testing.assert_allclose(M, oracle.compose_m(f1, f2, R, skip_first=True), atol=1e-14)
+    np.testing.assert_allclose(pypnec.translation_from_m(M), oracle.translation_from_m(M), atol=1e-13)
