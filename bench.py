@@ -233,7 +233,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             from oracle import pnec_oracle as po
             cores = po.max_threads()
-            n_sample = args.cpu_sample or int(min(sample.bvs1.shape[0], 4096, max(64, 256 * cores)))
+            n_sample = args.cpu_sample or int(min(sample.bvs1.shape[0], max(64, 64 * cores)))
             base, parity = cpu_baseline(sample, n_sample, opts, out.q)
             line["cpu_baseline"] = base
             line["parity"] = parity
