@@ -90,8 +90,24 @@ __device__ __forceinline__ void sincos_bounded(double x, double &s, double &c) {
 template <int CTRL>
 __device__ __forceinline__ double dpp_perm(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
+#ifdef PNEC_DPP_OLD
   lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
   hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+#else
+  // every lane is written (full masks, in-row permutations): no "old" value to preserve, so the
+  // compiler need not copy the source first
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+#endif
+  return make_double(hi, lo);
+}
+// lane ^ XOR inside a group of 32 through the LDS crossbar (ds_swizzle_b32, bit-mask mode): the
+// exchange runs on the LDS pipe, not the VALU the solver is bound by
+template <int XOR>
+__device__ __forceinline__ double swizzle_xor(double x) {
+  constexpr int pattern = (XOR << 10) | 0x1F;
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), pattern);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), pattern);
   return make_double(hi, lo);
 }
 // rows {1,3} of one copy <-> rows {0,2} of the other: sum = pairwise row sums in all 4 rows
@@ -123,8 +139,8 @@ __device__ __forceinline__ double wave_allreduce_sum(double x) {
 // a second one, so one swap + one add reduces TWO accumulators at once with no selects:
 //   swap32(X, Y): X' = [X.lo | Y.lo], Y' = [X.hi | Y.hi]  =>  X' + Y' = [X.lo+X.hi | Y.lo+Y.hi]
 // 21 -> 11 values (lane halves) -> 6 values (rows of 16 lanes); the last four levels run as a
-// DPP butterfly inside each row on those 6 values; v_readlane then picks every sum from the
-// row that owns it.  123 + 42 instructions instead of 378 + 42 for 21 full butterflies.
+// butterfly inside each row on those 6 values (exchanges on the LDS crossbar); the four row
+// leaders then store their sums to LDS, from where every lane reads all 21 back (broadcast).
 __device__ __forceinline__ double swap_add32(double x, double y) {
   const unsigned xl = (unsigned)__double2loint(x), xh = (unsigned)__double2hiint(x);
   const unsigned yl = (unsigned)__double2loint(y), yh = (unsigned)__double2hiint(y);
@@ -140,10 +156,17 @@ __device__ __forceinline__ double swap_add16(double x, double y) {
   return make_double((int)b[0], (int)a[0]) + make_double((int)b[1], (int)a[1]);
 }
 __device__ __forceinline__ double row_allreduce_sum(double x) {
+#ifdef PNEC_ROW_DPP
   x += dpp_perm<0xB1>(x);
   x += dpp_perm<0x4E>(x);
   x += dpp_perm<0x141>(x);
   x += dpp_perm<0x140>(x);
+#else
+  x += swizzle_xor<1>(x);
+  x += swizzle_xor<2>(x);
+  x += swizzle_xor<4>(x);
+  x += swizzle_xor<8>(x);
+#endif
   return x;
 }
 template <int LANE>
@@ -152,21 +175,32 @@ __device__ __forceinline__ double read_lane(double x) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(x), LANE);
   return make_double(hi, lo);
 }
-__device__ __forceinline__ void wave_reduce21(const double (&acc)[kNumAcc], double (&sum)[kNumAcc]) {
+// Where sum j lands in the 24-slot table the row leaders write (row r owns slots 6r .. 6r+5):
+// row 0: acc[0..5], row 1: acc[6..10], row 2: acc[11..16], row 3: acc[17..20].
+constexpr int kSumSlots = 24;
+__host__ __device__ constexpr int sum_slot(int j) {
+  return j < 6 ? j : (j < 11 ? 6 + (j - 6) : (j < 17 ? 12 + (j - 11) : 18 + (j - 17)));
+}
+// 21 accumulators -> 6 registers whose 16-lane rows each hold the complete sums that row owns
+// (every lane of the row has the same bits).
+__device__ __forceinline__ void wave_reduce21_rows(const double (&acc)[kNumAcc], double (&c)[6]) {
   // level 1 (lanes l <-> l+32): b[i] holds acc[i] in lanes 0..31 and acc[i+11] in lanes 32..63
   double b[11];
 #pragma unroll
   for (int i = 0; i < 10; ++i) b[i] = swap_add32(acc[i], acc[i + 11]);
   b[10] = swap_add32(acc[10], 0.0);
   // level 2 (rows r <-> r^1): c[i] rows {0,2} hold b[i], rows {1,3} hold b[i+6]
-  double c[6];
 #pragma unroll
   for (int i = 0; i < 5; ++i) c[i] = swap_add16(b[i], b[i + 6]);
   c[5] = swap_add16(b[5], 0.0);
   // levels 3..6 inside each row
 #pragma unroll
   for (int i = 0; i < 6; ++i) c[i] = row_allreduce_sum(c[i]);
-  // row 0: acc[i], row 1: acc[i+6], row 2: acc[i+11], row 3: acc[i+17]
+}
+// the same sums as wave-uniform values, picked from the owning rows with v_readlane
+__device__ __forceinline__ void wave_reduce21(const double (&acc)[kNumAcc], double (&sum)[kNumAcc]) {
+  double c[6];
+  wave_reduce21_rows(acc, c);
 #pragma unroll
   for (int i = 0; i < 6; ++i) sum[i] = read_lane<0>(c[i]);
 #pragma unroll
@@ -175,6 +209,13 @@ __device__ __forceinline__ void wave_reduce21(const double (&acc)[kNumAcc], doub
   for (int i = 0; i < 6; ++i) sum[i + 11] = read_lane<32>(c[i]);
 #pragma unroll
   for (int i = 0; i < 4; ++i) sum[i + 17] = read_lane<48>(c[i]);
+}
+// true when no lane of the wavefront holds an Inf/NaN in any of the six registers
+__device__ __forceinline__ bool rows_all_finite(const double (&c)[6]) {
+  double z = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) z = __builtin_fma(c[i], 0.0, z);  // 0 for finite, NaN otherwise
+  return __builtin_amdgcn_ballot_w64(!(z == 0.0)) == 0ull;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -87,12 +87,14 @@ enum : int {
   kQc = 11,      // 4  candidate quaternion
   kThetaC = 15,  // 1
   kPhiC = 16,    // 1
-  kHs = 17,      // 15 Jacobi-scaled J'J (upper triangle)
-  kGs = 32,      // 5  Jacobi-scaled J'r
-  kDiag = 37,    // 5  clamped LM diagonal
-  kScale = 42,   // 5  Jacobi scale x (2 for the rotation columns)
+  kHs = 17,      // 15 J'J at the current point (upper triangle), as the pass accumulates it
+  kGs = 32,      // 5  J'r
+  kDiag = 37,    // 5  LM diagonal, mapped to the pass's parameter scale (see the step below)
+  kScaleSq = 42, // 5  (Jacobi scale x (2 for the rotation columns))^2
   kGmax = 47,    // 1
-  kSlab = 48
+  kSums = 48,    // 24 the pass's 21 sums, as the row leaders store them (sum_slot)
+  kInvScaleSq = 72,  // 5
+  kSlab = 78
 };
 
 // Which (family, geometry) pairs are built: the payload must fit the 160 KB LDS and the
@@ -100,11 +102,18 @@ enum : int {
 // per SIMD; the (8,W,0) shape runs one wavefront per SIMD with AGPR parking, 12 planes at most).
 __host__ __device__ constexpr bool geometry_ok(int mode, int cpl, int wpp, int ldsk) {
   const int nc = num_components(mode);
-  const long lds = (long)wpp * (ldsk * nc * kWave * 8 + kSlab * 8) + (wpp > 1 ? 2L * wpp * kNumAcc * 8 : 0);
+  const long lds = (long)wpp * (ldsk * nc * kWave * 8 + kSlab * 8) + (wpp > 1 ? 2L * wpp * kSumSlots * 8 : 0);
   if (lds > 160 * 1024) return false;
   if (cpl == 8 && ldsk == 0) return nc <= 12;
   return nc * (cpl - ldsk) <= 72;
 }
+
+// region markers for tools/isa_mix.py --regions (assembly comments; compiled in only on request)
+#ifdef PNEC_ISA_MARKS
+#define PNEC_MARK(name) asm volatile("; PNEC_MARK " name)
+#else
+#define PNEC_MARK(name)
+#endif
 
 template <int MODE, int CPL, int WPP, int LDSK, bool RESIDENT>
 __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void lm_solve_kernel(
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   if (a.trace) t_begin = __builtin_amdgcn_s_memtime();
 
   __shared__ double slab_all[WPP][kSlab];
-  [[maybe_unused]] __shared__ double xw[2][WPP > 1 ? WPP : 1][kNumAcc];
+  [[maybe_unused]] __shared__ double xw[2][WPP > 1 ? WPP : 1][kSumSlots];
   [[maybe_unused]] __shared__ double ldata[LDSK > 0 ? WPP : 1][LDSK > 0 ? LDSK : 1][NC][LDSK > 0 ? kWave : 1];
   double *slab = slab_all[wave];
   int parity = 0;
@@ -185,6 +194,13 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
       }
     }
   }
+  // validity of slot k as a 64-lane mask in scalar registers: the pass's selects then take the
+  // mask operand directly instead of re-deriving a per-lane predicate for every correspondence
+  [[maybe_unused]] unsigned long long lanes_valid[RESIDENT ? CPL : 1];
+  if constexpr (RESIDENT) {
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) lanes_valid[k] = __builtin_amdgcn_ballot_w64(((vmask >> k) & 1u) != 0u);
+  }
   if (a.trace) {
     // make "payload on chip" mean what it says: wait for the loads before stamping
     __builtin_amdgcn_s_waitcnt(0);
@@ -219,16 +235,23 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
       ++iteration;
       step_ok = 0;
 
-      // ---- LevenbergMarquardtStrategy::ComputeStep on the parked normal equations
-      double Hs[15], gs[5], diag[5], A[15], y[5], step[5];
+      PNEC_MARK("lm_step");
+      // ---- LevenbergMarquardtStrategy::ComputeStep on the parked normal equations.
+      // Ceres solves (S H S + D/radius) y = -S g with the Jacobi scaling S frozen at iteration
+      // zero, D = clamp(diag(S H S)), and steps by S y.  With p = S y that is
+      //   (H + S^-1 D S^-1 / radius) p = -g,
+      // so the scaling only enters through the diagonal D' = clamp(s_i^2 H_ii) / s_i^2 and p is
+      // the parameter step itself (theta, phi, omega; the quaternion's half-angle delta = omega/2).
+      double H[15], g[5], diag[5], dr[5], A[15], y[5], step[5];
 #pragma unroll
-      for (int i = 0; i < 15; ++i) Hs[i] = slab[kHs + i];
+      for (int i = 0; i < 15; ++i) H[i] = slab[kHs + i];
 #pragma unroll
-      for (int i = 0; i < 5; ++i) gs[i] = slab[kGs + i];
+      for (int i = 0; i < 5; ++i) g[i] = slab[kGs + i];
       if (!reuse_diagonal) {
 #pragma unroll
         for (int i = 0; i < 5; ++i)
-          diag[i] = fmin(fmax(Hs[tri(i, i)], o.min_lm_diagonal), o.max_lm_diagonal);
+          diag[i] = fmin(fmax(H[tri(i, i)] * slab[kScaleSq + i], o.min_lm_diagonal), o.max_lm_diagonal) *
+                    slab[kInvScaleSq + i];
         if (lane == 0) {
 #pragma unroll
           for (int i = 0; i < 5; ++i) slab[kDiag + i] = diag[i];
@@ -239,22 +262,23 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
       }
       const double inv_radius = fast_rcp(radius);
 #pragma unroll
-      for (int i = 0; i < 15; ++i) A[i] = Hs[i];
-#pragma unroll
-      for (int i = 0; i < 5; ++i) A[tri(i, i)] = __builtin_fma(diag[i], inv_radius, A[tri(i, i)]);
-      bool valid = chol_solve5(A, gs, y);
-      double sg = 0.0, shs = 0.0;
-#pragma unroll
-      for (int i = 0; i < 5; ++i) step[i] = -y[i];
+      for (int i = 0; i < 15; ++i) A[i] = H[i];
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
-        sg = __builtin_fma(step[i], gs[i], sg);
-        double row = 0.0;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) row = __builtin_fma(Hs[sym(i, j)], step[j], row);
-        shs = __builtin_fma(step[i], row, shs);
+        dr[i] = diag[i] * inv_radius;
+        A[tri(i, i)] += dr[i];
       }
-      const double model_change = -(sg + 0.5 * shs);  // -(Js)'(r + Js/2)
+      bool valid = chol_solve5(A, g, y);
+      // model cost change -(Jp)'(r + Jp/2) = -(g'p + p'Hp/2); with (H + D'/radius) p = -g this is
+      // (-g'p + p'(D'/radius)p) / 2 -- two non-negative terms, no cancellation
+      double sg = 0.0, sd = 0.0;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        step[i] = -y[i];
+        sg = __builtin_fma(step[i], g[i], sg);
+        sd = __builtin_fma(dr[i] * step[i], step[i], sd);
+      }
+      const double model_change = 0.5 * (sd - sg);
       valid = valid && (model_change > 0.0);
       if (to_sgpr((int)valid) == 0) {
         if (++num_invalid >= o.max_num_consecutive_invalid_steps) {
@@ -271,16 +295,12 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
       }
       num_invalid = 0;
 
-      // ---- candidate = Plus(x, step * jacobi_scale): EigenQuaternionManifold::Plus on q.
-      // slab[kScale + i] holds jacobi_scale x (2 for rotation columns): the tangent step in Ceres'
-      // half-angle delta is step * jacobi_scale; the x2 only belongs to J (omega = 2 delta).
-      const double sc0 = slab[kScale + 0], sc1 = slab[kScale + 1];
-      const double dx = step[2] * (0.5 * slab[kScale + 2]);
-      const double dy = step[3] * (0.5 * slab[kScale + 3]);
-      const double dz = step[4] * (0.5 * slab[kScale + 4]);
+      PNEC_MARK("plus");
+      // ---- candidate = Plus(x, p): EigenQuaternionManifold::Plus on q with delta = omega / 2
+      const double dx = 0.5 * step[2], dy = 0.5 * step[3], dz = 0.5 * step[4];
       const double q0 = slab[kQ + 0], q1 = slab[kQ + 1], q2 = slab[kQ + 2], q3 = slab[kQ + 3];
-      const double thc = slab[kTheta] + step[0] * sc0;
-      const double phc = slab[kPhi] + step[1] * sc1;
+      const double thc = slab[kTheta] + step[0];
+      const double phc = slab[kPhi] + step[1];
       const double nd2 = dx * dx + dy * dy + dz * dz;
       double qc0 = q0, qc1 = q1, qc2 = q2, qc3 = q3;
       if (nd2 > 0.0) {
@@ -304,7 +324,9 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
     }
 
     // ---- one fused pass at the candidate: sum r^2, J'r, J'J ------------------------------
+    PNEC_MARK("uniforms");
     double S[kNumAcc];
+    bool sums_finite = true;  // cost AND Jacobian sums
     {
       PassUniforms U;
       {
@@ -314,11 +336,12 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
       double acc[kNumAcc];
 #pragma unroll
       for (int j = 0; j < kNumAcc; ++j) acc[j] = 0.0;
+      PNEC_MARK("pass");
       if constexpr (RESIDENT) {
 #pragma unroll
         for (int k = 0; k < REGK; ++k) {
           double r, J[5];
-          eval_corr<MODE>(d[k], (vmask >> k) & 1u, U, reg, r, J);
+          eval_corr<MODE>(d[k], __builtin_amdgcn_inverse_ballot_w64(lanes_valid[k]), U, reg, r, J);
           accumulate(r, J, acc);
         }
         // not unrolled: one LDS-resident correspondence live at a time (an unrolled loop lets the
@@ -329,7 +352,10 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
 #pragma unroll
           for (int c = 0; c < NC; ++c) e[c] = ldata[wave][k][c][lane];
           double r, J[5];
-          eval_corr<MODE>(e, (vmask >> (REGK + k)) & 1u, U, reg, r, J);
+          unsigned long long m = lanes_valid[REGK];
+#pragma unroll
+          for (int i = 1; i < LDSK; ++i) m = (k == i) ? lanes_valid[REGK + i] : m;
+          eval_corr<MODE>(e, __builtin_amdgcn_inverse_ballot_w64(m), U, reg, r, J);
           accumulate(r, J, acc);
         }
       } else {
@@ -342,30 +368,43 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
           accumulate(r, J, acc);
         }
       }
-      wave_reduce21(acc, S);
-      if constexpr (WPP > 1) {
-        if (lane == 0) {
+      PNEC_MARK("reduce");
+      double c[6];
+      wave_reduce21_rows(acc, c);
+      if constexpr (WPP == 1) sums_finite = rows_all_finite(c);
+      // the four row leaders store the sums they own; every lane reads all 21 back (broadcast)
+      double *dst = WPP > 1 ? &xw[parity][wave][0] : &slab[kSums];
+      if ((lane & 15) == 0) {
 #pragma unroll
-          for (int j = 0; j < kNumAcc; ++j) xw[parity][wave][j] = S[j];
-        }
+        for (int i = 0; i < 6; ++i) dst[(lane >> 4) * 6 + i] = c[i];
+      }
+      if constexpr (WPP > 1) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < kNumAcc; ++j) {
-          double t = xw[parity][0][j];
+          double t = xw[parity][0][sum_slot(j)];
 #pragma unroll
-          for (int w = 1; w < WPP; ++w) t += xw[parity][w][j];
-          S[j] = to_sgpr(t);
+          for (int w = 1; w < WPP; ++w) t += xw[parity][w][sum_slot(j)];
+          S[j] = t;
         }
         parity ^= 1;
+        double z = 0.0;
+#pragma unroll
+        for (int j = 0; j < kNumAcc; ++j) z = __builtin_fma(S[j], 0.0, z);
+        sums_finite = (z == 0.0);
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < kNumAcc; ++j) S[j] = slab[kSums + sum_slot(j)];
       }
     }
 
+    PNEC_MARK("evaluate");
     // ---- sums -> cost; the scaled normal equations are only formed when the point is kept
     double cost_c = 0.5 * S[0];
     const bool cost_ok = finite_d(cost_c);
-    bool rest_ok = true;
-#pragma unroll
-    for (int j = 1; j < kNumAcc; ++j) rest_ok = rest_ok && finite_d(S[j]);
+    // only consulted when the cost is finite, so the cost's own term in it is harmless
+    const bool rest_ok = sums_finite;
 
     bool accept;
     double rho = 0.0;
@@ -382,14 +421,17 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
         term = PNEC_HIP_TERM_BAD_INITIAL;
         break;
       }
-      // jacobi_scaling: 1 / (1 + sqrt(diag(J'J))) on the Ceres-tangent Jacobian (rotation
-      // columns = 2 x the omega columns accumulated by the pass); frozen after iteration zero
+      // jacobi_scaling: s = 1 / (1 + sqrt(diag(J'J))) on the Ceres-tangent Jacobian (rotation
+      // columns = 2 x the omega columns accumulated by the pass); frozen after iteration zero.
+      // Parked: (f s)^2 and its inverse, f = 2 for the rotation columns.
       if (lane == 0) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
           const double f = (i >= 2) ? 2.0 : 1.0;
           const double hii = S[6 + tri(i, i)] * (f * f);
-          slab[kScale + i] = f * (o.jacobi_scaling ? 1.0 / (1.0 + sqrt(hii)) : 1.0);
+          const double a = (o.jacobi_scaling ? 1.0 + sqrt(hii) : 1.0) / f;  // 1 / (f s)
+          slab[kInvScaleSq + i] = a * a;
+          slab[kScaleSq + i] = 1.0 / (a * a);
         }
         slab[kRadius] = o.initial_trust_region_radius;
         slab[kInvDec] = 0.5;
@@ -422,24 +464,15 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
       }
     }
 
+    PNEC_MARK("accept");
     if (accept) {
-      // x <- candidate; park cost, x_norm and the Jacobi-scaled normal equations
-      double sc[5], gmax = 0.0;
-#pragma unroll
-      for (int i = 0; i < 5; ++i) sc[i] = slab[kScale + i];
+      // x <- candidate; park cost, x_norm and the normal equations
+      double gmax = 0.0;
       const double qa0 = slab[kQc + 0], qa1 = slab[kQc + 1], qa2 = slab[kQc + 2], qa3 = slab[kQc + 3];
       const double tha = slab[kThetaC], pha = slab[kPhiC];
       const double xn = fast_sqrt(tha * tha + pha * pha + qa0 * qa0 + qa1 * qa1 + qa2 * qa2 + qa3 * qa3);
-      double gsn[5], hsn[15];
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        gsn[i] = S[1 + i] * sc[i];
-        gmax = fmax(gmax, fabs(S[1 + i]) * ((i >= 2) ? 2.0 : 1.0));
-      }
-#pragma unroll
-      for (int i = 0; i < 5; ++i)
-#pragma unroll
-        for (int j = i; j < 5; ++j) hsn[tri(i, j)] = S[6 + tri(i, j)] * (sc[i] * sc[j]);
+      for (int i = 0; i < 5; ++i) gmax = fmax(gmax, fabs(S[1 + i]) * ((i >= 2) ? 2.0 : 1.0));
       double new_radius = 0.0;
       if (!first) {
         const double c1 = 2.0 * rho - 1.0;
@@ -454,9 +487,9 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
         slab[kXNorm] = xn;
         slab[kGmax] = gmax;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) slab[kGs + i] = gsn[i];
+        for (int i = 0; i < 5; ++i) slab[kGs + i] = S[1 + i];
 #pragma unroll
-        for (int i = 0; i < 15; ++i) slab[kHs + i] = hsn[i];
+        for (int i = 0; i < 15; ++i) slab[kHs + i] = S[6 + i];
         if (!first) {
           slab[kRadius] = new_radius;
           slab[kInvDec] = 0.5;
@@ -476,6 +509,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   }
 
+  PNEC_MARK("result");
   // ---- PNECCeres::Result(): pnec_ceres.cc:201-207
   if (threadIdx.x == 0) {
     const double q0 = slab[kQ + 0], q1 = slab[kQ + 1], q2 = slab[kQ + 2], q3 = slab[kQ + 3];
