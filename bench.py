@@ -36,8 +36,8 @@ FLOP_PER_CORR_PASS = 2 * 91
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps; ~20 of these 3.5 ms steps bring the GPU to its steady clocks")
     ap.add_argument("--pairs", type=int, default=100_000, help="frame pairs per GPU")
     ap.add_argument("--corr", type=int, default=512, help="correspondences per pair")
     ap.add_argument("--iters", type=int, default=10, help="LM iterations per solve (fixed count)")
