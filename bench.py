@@ -44,7 +44,6 @@ def parse_args():
     ap.add_argument("--cpl", type=int, default=0, help="launch tuning: correspondences per lane")
     ap.add_argument("--wpp", type=int, default=0, help="launch tuning: wavefronts per solve")
     ap.add_argument("--ldsk", type=int, default=0, help="launch tuning: correspondences per lane kept in LDS")
-    ap.add_argument("--stagger", type=int, default=0, help="launch tuning: first-round skew (0 default, -1 off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
@@ -143,7 +142,7 @@ def main():
     batch, q0, t0, sample = build_shard(args.pairs, args.corr, rank, device)
     opts = capi.default_options(max_num_iterations=args.iters, check_convergence=0,
                                 corr_per_lane=args.cpl, waves_per_pair=args.wpp,
-                                lds_corr_per_lane=args.ldsk, launch_stagger=args.stagger)
+                                lds_corr_per_lane=args.ldsk)
     launch = batch.describe_launch(opts)
     out = None
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]

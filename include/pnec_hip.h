@@ -88,8 +88,7 @@ typedef struct pnec_hip_options {
   int32_t corr_per_lane;                     /* 0 = auto; launch tuning: correspondences held per lane */
   int32_t waves_per_pair;                    /* 0 = auto; launch tuning: wavefronts cooperating on one solve */
   int32_t lds_corr_per_lane;                 /* launch tuning: how many of corr_per_lane live in LDS */
-  int32_t launch_stagger;                    /* launch tuning: first-round start skew per wavefront slot,
-                                                units of ~4096 clocks; 0 = default (1), -1 = off */
+  int32_t reserved;                          /* must be 0 */
   double function_tolerance;                 /* 1e-6 */
   double gradient_tolerance;                 /* 1e-10 */
   double parameter_tolerance;                /* 1e-8 */

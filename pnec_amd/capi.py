@@ -64,7 +64,7 @@ class Options(C.Structure):
         ("corr_per_lane", C.c_int32),
         ("waves_per_pair", C.c_int32),
         ("lds_corr_per_lane", C.c_int32),
-        ("launch_stagger", C.c_int32),
+        ("reserved", C.c_int32),
         ("function_tolerance", C.c_double),
         ("gradient_tolerance", C.c_double),
         ("parameter_tolerance", C.c_double),

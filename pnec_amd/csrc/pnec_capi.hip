@@ -19,6 +19,7 @@ hipError_t launch_solve_mode_0(int, int, int, bool, const SolveArgs &, hipStream
 hipError_t launch_solve_mode_1(int, int, int, bool, const SolveArgs &, hipStream_t);
 hipError_t launch_solve_mode_2(int, int, int, bool, const SolveArgs &, hipStream_t);
 hipError_t launch_solve_mode_3(int, int, int, bool, const SolveArgs &, hipStream_t);
+
 // pnec_frontend.hip
 hipError_t launch_ransac_eigensolver(const double *, const int64_t *, const int64_t *, const int32_t *, int64_t,
                                      const double *, unsigned long long, int, int, double, double *, double *,
@@ -354,6 +355,7 @@ struct Geometry {
   bool resident;
 };
 
+
 bool geometry_exists(int mode, int cpl, int wpp, int ldsk) {
 #define PNEC_GEOMETRY_MATCH(CPL, WPP, LDSK) \
   if (cpl == CPL && wpp == WPP && ldsk == LDSK) return geometry_ok(mode, cpl, wpp, ldsk);
@@ -485,7 +487,7 @@ void pnec_hip_default_options(pnec_hip_options *o) {
   o->corr_per_lane = 0;
   o->waves_per_pair = 0;
   o->lds_corr_per_lane = 0;
-  o->launch_stagger = 0;
+  o->reserved = 0;
   o->function_tolerance = 1e-6;
   o->gradient_tolerance = 1e-10;
   o->parameter_tolerance = 1e-8;
@@ -698,7 +700,6 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
   a.count = p->d_count;
   a.n_solves = S;
   a.n_hyp = n_hyp;
-  a.stagger = opt.launch_stagger < 0 ? 0 : (opt.launch_stagger == 0 ? 1 : opt.launch_stagger);
   a.reg = reg;
   a.opt = opt;
 

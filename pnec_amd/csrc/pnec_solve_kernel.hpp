@@ -14,12 +14,16 @@
 //     Jacobian again after accepting).  Same numbers, half the passes.
 //
 // Register / LDS plan (what makes one wavefront per 512-correspondence pair viable):
-//   * the pair's payload lives in VGPRs (+ AGPRs when the compiler needs room) for the whole loop;
-//   * the 18 pose uniforms of a pass and the 21 reduced sums live in SGPRs;
-//   * the LM state that must survive a pass (current point, scaled J'J / J'r, trust-region
-//     bookkeeping: ~50 doubles, identical in every lane) is PARKED in a per-wavefront LDS slab
-//     by lane 0 and read back with broadcast ds_reads -- LDS instructions cost no VALU issue,
-//     unlike the v_writelane/v_readlane traffic of SGPR spills.
+//   * the pair's payload lives in VGPRs (+ LDS slots, + AGPRs when the compiler needs room) for
+//     the whole loop; the 17 pose uniforms of a pass live in SGPRs;
+//   * a pass ends with the 21 sums in a per-wavefront LDS slab (swap-halving + LDS-crossbar
+//     reduction, pnec_device.hpp);
+//   * everything that is one value per solve -- accept/reject, trust region, the 5x5 solve, the
+//     manifold update, the next pose's uniforms (lm_advance) -- runs in lane 0 on LDS-resident
+//     state (~80 doubles per wavefront): a ~500-instruction latency chain that the SIMD's other
+//     wavefront hides under its pass.  (Measured dead ends, DESIGN.md section 6: narrowing EXEC
+//     does not shorten the issue time of that chain, and sharing one chain between the
+//     wavefronts of a workgroup trades its issue slots for barrier stalls -- no gain.)
 #pragma once
 
 #include <type_traits>
@@ -60,7 +64,7 @@ struct SolveArgs {
   unsigned long long *trace;    // null, or [n_blocks,4]: s_memtime at start / payload on chip / end, hw id
   int64_t n_solves;
   int32_t n_hyp;
-  int32_t stagger;  // first-round start skew, units of s_sleep(64) ~ 4096 clocks per wavefront slot
+  int32_t pad_;
   double reg;
   pnec_hip_options opt;
 };
@@ -94,18 +98,381 @@ enum : int {
   kGmax = 47,    // 1
   kSums = 48,    // 24 the pass's 21 sums, as the row leaders store them (sum_slot)
   kInvScaleSq = 72,  // 5
-  kSlab = 78
+  kSumsFinite = 78,  // 1  1.0 when all 21 sums are finite
+  kSlab = 80
 };
+constexpr int kUnif = 18;   // pass uniforms of the candidate: R[9] | t[3] | dt/dtheta[3] | dt/dphi[2] | pad
+// per-solve integer state (LDS)
+enum : int { kIIter = 0, kIFirst, kIReuseDiag, kINumInvalid, kIStepOk, kINumI = 6 };
 
 // Which (family, geometry) pairs are built: the payload must fit the 160 KB LDS and the
 // register budget of its occupancy target (<= 72 doubles of payload per lane at two wavefronts
 // per SIMD; the (8,W,0) shape runs one wavefront per SIMD with AGPR parking, 12 planes at most).
 __host__ __device__ constexpr bool geometry_ok(int mode, int cpl, int wpp, int ldsk) {
   const int nc = num_components(mode);
-  const long lds = (long)wpp * (ldsk * nc * kWave * 8 + kSlab * 8) + (wpp > 1 ? 2L * wpp * kSumSlots * 8 : 0);
+  const long lds = (long)wpp * (ldsk * nc * kWave * 8 + (kSlab + kUnif) * 8 + kINumI * 4) + (wpp > 1 ? 2L * wpp * kSumSlots * 8 : 0);
   if (lds > 160 * 1024) return false;
   if (cpl == 8 && ldsk == 0) return nc <= 12;
   return nc * (cpl - ldsk) <= 72;
+}
+
+
+// ---- shared by the solve kernels -------------------------------------------------------------
+// Load one wavefront's share of a pair (CPL correspondences per lane starting at first_corr) into
+// REGK register slots + (CPL - REGK) LDS slots; returns the lane's validity bits.
+// Slot k of a lane is correspondence  first_corr + 128*(k/2) + 2*lane + (k&1): two neighbouring
+// correspondences per 16-byte load (global_load_dwordx4) -- the CU's load path moves ~2x the
+// bytes per clock of 8-byte loads, which is what bounds the payload fetch.
+template <int NC, int CPL, int REGK>
+__device__ __forceinline__ unsigned load_resident(const double *__restrict__ base, int n, int stride,
+                                                  int first_corr, int lane, double (&d)[REGK][NC],
+                                                  double *lds /* [CPL-REGK][NC][64] */) {
+  unsigned vmask = 0;
+  auto put = [&](auto kc, int c, double v) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k < REGK) d[k][c] = v;
+    else lds[((k - REGK) * NC + c) * kWave + lane] = v;
+  };
+  if constexpr (CPL == 1) {
+    const int idx = first_corr + lane;
+    const bool in = idx < stride;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      put(std::integral_constant<int, 0>{}, c, in ? base[(int64_t)c * stride + idx] : 0.0);
+    vmask = idx < n ? 1u : 0u;
+  } else {
+    static_assert(CPL == 1 || CPL % 2 == 0, "correspondences per lane: 1 or even");
+    using pair_t = __attribute__((ext_vector_type(2))) double;
+    auto load_pair = [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const int idx = first_corr + 2 * kWave * j + 2 * lane;
+      const bool in = idx < stride;  // stride is a multiple of 64, idx is even: idx+1 < stride too
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        pair_t v = {0.0, 0.0};
+        if (in) v = *reinterpret_cast<const pair_t *>(base + (int64_t)c * stride + idx);
+        put(std::integral_constant<int, 2 * j>{}, c, v.x);
+        put(std::integral_constant<int, 2 * j + 1>{}, c, v.y);
+      }
+      vmask |= (idx < n ? 1u : 0u) << (2 * j);
+      vmask |= (idx + 1 < n ? 1u : 0u) << (2 * j + 1);
+    };
+    load_pair(std::integral_constant<int, 0>{});
+    if constexpr (CPL >= 4) load_pair(std::integral_constant<int, 1>{});
+    if constexpr (CPL >= 8) {
+      load_pair(std::integral_constant<int, 2>{});
+      load_pair(std::integral_constant<int, 3>{});
+    }
+  }
+  return vmask;
+}
+
+// One fused pass of a wavefront over its resident correspondences: acc = this lane's partial
+// sums of r^2, J'r and J'J at the pose in U.
+template <int MODE, int REGK, int LDSK>
+__device__ __forceinline__ void pass_resident(const double (&d)[REGK][num_components(MODE)],
+                                              const double *lds /* [LDSK][NC][64] */,
+                                              const unsigned long long (&lanes_valid)[REGK + LDSK],
+                                              int lane, const PassUniforms &U, double reg,
+                                              double (&acc)[kNumAcc]) {
+  constexpr int NC = num_components(MODE);
+  // The first two slots are always evaluated (their masks zero the padding).  The rest of
+  // the register slots, and each LDS slot, are skipped by a wave-uniform branch when no
+  // lane holds a correspondence there -- the tail of a ragged pair -- so a short pair does
+  // not pay for what the geometry could hold.  (Measured: < 0.5 % on full-size pairs,
+  // +8 % solves/s on pairs of 513..600 correspondences.)
+  auto eval_slot = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    double r, J[5];
+    eval_corr<MODE>(d[k], __builtin_amdgcn_inverse_ballot_w64(lanes_valid[k]), U, reg, r, J);
+    accumulate(r, J, acc);
+  };
+  eval_slot(std::integral_constant<int, 0>{});
+  if constexpr (REGK > 1) eval_slot(std::integral_constant<int, 1>{});
+  if constexpr (REGK > 2) {
+    if (lanes_valid[2] != 0ull) {
+      eval_slot(std::integral_constant<int, 2>{});
+      if constexpr (REGK > 3) eval_slot(std::integral_constant<int, 3>{});
+      if constexpr (REGK > 4) eval_slot(std::integral_constant<int, 4>{});
+      if constexpr (REGK > 5) eval_slot(std::integral_constant<int, 5>{});
+      if constexpr (REGK > 6) eval_slot(std::integral_constant<int, 6>{});
+      if constexpr (REGK > 7) eval_slot(std::integral_constant<int, 7>{});
+    }
+  }
+  // not unrolled: one LDS-resident correspondence live at a time (an unrolled loop lets the
+  // scheduler hoist every slot's 12 loads and blows the 256-register budget)
+#pragma unroll 1
+  for (int k = 0; k < LDSK; ++k) {
+    unsigned long long m = lanes_valid[REGK];
+#pragma unroll
+    for (int i = 1; i < LDSK; ++i) m = (k == i) ? lanes_valid[REGK + i] : m;
+    if (m == 0ull) continue;
+    double e[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) e[c] = lds[(k * NC + c) * kWave + lane];
+    double r, J[5];
+    eval_corr<MODE>(e, __builtin_amdgcn_inverse_ballot_w64(m), U, reg, r, J);
+    accumulate(r, J, acc);
+  }
+}
+
+// pose -> the correspondence-independent quantities of a pass, as plain doubles
+__device__ __forceinline__ void pose_uniforms(double theta, double phi, const double (&q)[4], double *u) {
+  double R[9];
+  rot_from_quat(q, R);
+  double st, ct, sp, cp;
+  sincos_bounded(theta, st, ct);
+  sincos_bounded(phi, sp, cp);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) u[i] = R[i];
+  u[9] = st * cp;   u[10] = st * sp;  u[11] = ct;
+  u[12] = ct * cp;  u[13] = ct * sp;  u[14] = -st;
+  u[15] = -st * sp; u[16] = st * cp;
+}
+
+// PNECCeres::Result(): pnec_ceres.cc:201-207
+__device__ __forceinline__ void write_result(const SolveArgs &a, int64_t s, const double *slab, int iteration,
+                                             int term) {
+  const double q0 = slab[kQ + 0], q1 = slab[kQ + 1], q2 = slab[kQ + 2], q3 = slab[kQ + 3];
+  const double qn = fast_rsqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+  if (a.out_q) {
+    a.out_q[4 * s + 0] = q0 * qn;
+    a.out_q[4 * s + 1] = q1 * qn;
+    a.out_q[4 * s + 2] = q2 * qn;
+    a.out_q[4 * s + 3] = q3 * qn;
+  }
+  if (a.out_t) {
+    double st, ct, sp, cp;
+    sincos_bounded(slab[kTheta], st, ct);
+    sincos_bounded(slab[kPhi], sp, cp);
+    a.out_t[3 * s + 0] = st * cp;
+    a.out_t[3 * s + 1] = st * sp;
+    a.out_t[3 * s + 2] = ct;
+  }
+  if (a.out_cost) a.out_cost[s] = slab[kCost];
+  if (a.out_iterations) a.out_iterations[s] = iteration;
+  if (a.out_status) a.out_status[s] = term;
+}
+
+// Advance ONE solve (the calling lane's): consume the sums of the pass at the candidate, run
+// Ceres' accept/reject + trust-region logic (TrustRegionMinimizer + LevenbergMarquardtStrategy,
+// SURVEY.md Appendix B), and either publish the next candidate (slab + pass uniforms) or
+// terminate.  Returns the termination code, or -1 while the solve goes on.
+//
+// This is a latency chain (~500 dependent FP64 instructions) executed by one lane while the other
+// wavefront of the SIMD runs its pass, so it is written to keep LDS round trips off the chain:
+// everything is loaded in one batch up front, values are forwarded in registers (an accepted
+// point's J'J / J'r are the pass's sums themselves), and the stores trail.
+__device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, const pnec_hip_options &o) {
+  int iteration = ist[kIIter], reuse_diagonal = ist[kIReuseDiag];
+  int num_invalid = ist[kINumInvalid], step_ok = ist[kIStepOk];
+  const int first = ist[kIFirst];
+  int term = -1;
+
+  // ---- one batch of loads
+  double S[kNumAcc];
+#pragma unroll
+  for (int j = 0; j < kNumAcc; ++j) S[j] = slab[kSums + sum_slot(j)];
+  const bool rest_ok = slab[kSumsFinite] != 0.0;
+  const double qc0 = slab[kQc + 0], qc1 = slab[kQc + 1], qc2 = slab[kQc + 2], qc3 = slab[kQc + 3];
+  const double thc0 = slab[kThetaC], phc0 = slab[kPhiC];
+  const double cost = slab[kCost], model = slab[kModel], xnorm = slab[kXNorm];
+  double radius = slab[kRadius], inv_dec = slab[kInvDec], gmax = slab[kGmax];
+  double x[6];
+
+  double cost_c = 0.5 * S[0];
+  const bool cost_ok = finite_d(cost_c);
+  bool accept = false;
+  double rho = 0.0;
+  if (first) {
+    if (!(cost_ok && rest_ok)) {
+      slab[kQ + 0] = qc0; slab[kQ + 1] = qc1; slab[kQ + 2] = qc2; slab[kQ + 3] = qc3;
+      slab[kTheta] = thc0;
+      slab[kPhi] = phc0;
+      slab[kCost] = cost_c;
+      term = PNEC_HIP_TERM_BAD_INITIAL;
+    } else {
+      // jacobi_scaling: s = 1 / (1 + sqrt(diag(J'J))) on the Ceres-tangent Jacobian (rotation
+      // columns = 2 x the omega columns accumulated by the pass); frozen after iteration zero.
+      // Parked: (f s)^2 and its inverse, f = 2 for the rotation columns.
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const double f = (i >= 2) ? 2.0 : 1.0;
+        const double hii = S[6 + tri(i, i)] * (f * f);
+        const double a = (o.jacobi_scaling ? 1.0 + sqrt(hii) : 1.0) / f;  // 1 / (f s)
+        slab[kInvScaleSq + i] = a * a;
+        slab[kScaleSq + i] = 1.0 / (a * a);
+      }
+      accept = true;
+    }
+  } else {
+    if (!cost_ok) cost_c = 1.7976931348623157e308;
+    if (o.check_convergence) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = slab[kQ + k];
+      x[4] = slab[kTheta];
+      x[5] = slab[kPhi];
+      double dn = (x[4] - thc0) * (x[4] - thc0) + (x[5] - phc0) * (x[5] - phc0);
+      dn = __builtin_fma(x[0] - qc0, x[0] - qc0, dn);
+      dn = __builtin_fma(x[1] - qc1, x[1] - qc1, dn);
+      dn = __builtin_fma(x[2] - qc2, x[2] - qc2, dn);
+      dn = __builtin_fma(x[3] - qc3, x[3] - qc3, dn);
+      const double step_norm = fast_sqrt(dn);
+      if (step_norm <= o.parameter_tolerance * (xnorm + o.parameter_tolerance))
+        term = PNEC_HIP_TERM_PARAMETER_TOL;
+      else if (fabs(cost - cost_c) <= o.function_tolerance * cost)
+        term = PNEC_HIP_TERM_FUNCTION_TOL;
+    }
+    if (term < 0) {
+      rho = (cost - cost_c) * fast_rcp(model);
+      accept = rho > o.min_relative_decrease;
+      if (accept && !rest_ok) term = PNEC_HIP_TERM_BAD_INITIAL;  // finite cost, non-finite Jacobian: Ceres fails here
+    }
+  }
+
+  if (term < 0) {
+    double H[15], g[5], diag[5];
+    if (accept) {
+      // x <- candidate; its normal equations are the sums of the pass just made
+      x[0] = qc0; x[1] = qc1; x[2] = qc2; x[3] = qc3; x[4] = thc0; x[5] = phc0;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) g[i] = S[1 + i];
+#pragma unroll
+      for (int i = 0; i < 15; ++i) H[i] = S[6 + i];
+      gmax = 0.0;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) gmax = fmax(gmax, fabs(g[i]) * ((i >= 2) ? 2.0 : 1.0));
+      if (first) {
+        radius = o.initial_trust_region_radius;
+      } else {
+        const double c1 = 2.0 * rho - 1.0;
+        radius = fmin(o.max_trust_region_radius, radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - c1 * c1 * c1)));
+      }
+      inv_dec = 0.5;
+      step_ok = 1;
+      reuse_diagonal = 0;
+      // park (stores only; nothing below reads them back)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) slab[kQ + k] = x[k];
+      slab[kTheta] = x[4];
+      slab[kPhi] = x[5];
+      slab[kCost] = cost_c;
+      slab[kXNorm] = fast_sqrt(x[4] * x[4] + x[5] * x[5] + x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+      slab[kGmax] = gmax;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) slab[kGs + i] = g[i];
+#pragma unroll
+      for (int i = 0; i < 15; ++i) slab[kHs + i] = H[i];
+    } else {
+      // rejected: back to the parked point, smaller region
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = slab[kQ + k];
+      x[4] = slab[kTheta];
+      x[5] = slab[kPhi];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) g[i] = slab[kGs + i];
+#pragma unroll
+      for (int i = 0; i < 15; ++i) H[i] = slab[kHs + i];
+      radius = radius * inv_dec;
+      inv_dec = 0.5 * inv_dec;
+      reuse_diagonal = 1;
+    }
+    if (reuse_diagonal) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) diag[i] = slab[kDiag + i];
+    }
+
+    // ---- FinalizeIterationAndCheckIfMinimizerCanContinue + the next trust-region step
+    for (bool retry = false;; retry = true) {
+      if (iteration >= o.max_num_iterations) { term = PNEC_HIP_TERM_MAX_ITERATIONS; break; }
+      if (retry) {
+        // (rare) the previous attempt consumed H in place: fetch the parked copy again
+#pragma unroll
+        for (int i = 0; i < 15; ++i) H[i] = slab[kHs + i];
+      }
+      if (o.check_convergence && step_ok && gmax <= o.gradient_tolerance) {
+        term = PNEC_HIP_TERM_GRADIENT_TOL; break;
+      }
+      if (radius < o.min_trust_region_radius) { term = PNEC_HIP_TERM_MIN_RADIUS; break; }
+      ++iteration;
+      step_ok = 0;
+
+      // LevenbergMarquardtStrategy::ComputeStep.  Ceres solves (S H S + D/radius) y = -S g with the
+      // Jacobi scaling S frozen at iteration zero, D = clamp(diag(S H S)), and steps by S y.  With
+      // p = S y that is (H + S^-1 D S^-1 / radius) p = -g: the scaling only enters through the
+      // diagonal D' = clamp(s_i^2 H_ii) / s_i^2, and p is the parameter step itself
+      // (theta, phi, omega; the quaternion's half-angle delta = omega / 2).
+      if (!reuse_diagonal) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          diag[i] = fmin(fmax(H[tri(i, i)] * slab[kScaleSq + i], o.min_lm_diagonal), o.max_lm_diagonal) *
+                    slab[kInvScaleSq + i];
+          slab[kDiag + i] = diag[i];
+        }
+      }
+      const double inv_radius = fast_rcp(radius);
+      double dr[5], y[5], step[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        dr[i] = diag[i] * inv_radius;
+        H[tri(i, i)] += dr[i];
+      }
+      bool valid = chol_solve5(H, g, y);
+      // model cost change -(Jp)'(r + Jp/2) = -(g'p + p'Hp/2); with (H + D'/radius) p = -g this is
+      // (-g'p + p'(D'/radius)p) / 2 -- two non-negative terms, no cancellation
+      double sg = 0.0, sd = 0.0;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        step[i] = -y[i];
+        sg = __builtin_fma(step[i], g[i], sg);
+        sd = __builtin_fma(dr[i] * step[i], step[i], sd);
+      }
+      const double model_change = 0.5 * (sd - sg);
+      valid = valid && (model_change > 0.0);
+      if (!valid) {
+        if (++num_invalid >= o.max_num_consecutive_invalid_steps) { term = PNEC_HIP_TERM_INVALID_STEPS; break; }
+        radius = radius * inv_dec;
+        inv_dec = 0.5 * inv_dec;
+        reuse_diagonal = 1;
+        continue;
+      }
+      num_invalid = 0;
+
+      // candidate = Plus(x, p): EigenQuaternionManifold::Plus on q with delta = omega / 2
+      const double dx = 0.5 * step[2], dy = 0.5 * step[3], dz = 0.5 * step[4];
+      const double thc = x[4] + step[0];
+      const double phc = x[5] + step[1];
+      const double nd2 = dx * dx + dy * dy + dz * dz;
+      double qc[4] = {x[0], x[1], x[2], x[3]};
+      if (nd2 > 0.0) {
+        const double ind = fast_rsqrt(nd2), nd = nd2 * ind;
+        double sn, aw;
+        sincos_bounded(nd, sn, aw);
+        const double sbd = sn * ind;
+        const double ax = sbd * dx, ay = sbd * dy, az = sbd * dz;
+        qc[0] = aw * x[0] + ax * x[3] + ay * x[2] - az * x[1];
+        qc[1] = aw * x[1] - ax * x[2] + ay * x[3] + az * x[0];
+        qc[2] = aw * x[2] + ax * x[1] - ay * x[0] + az * x[3];
+        qc[3] = aw * x[3] - ax * x[0] - ay * x[1] - az * x[2];
+      }
+      pose_uniforms(thc, phc, qc, unif);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) slab[kQc + k] = qc[k];
+      slab[kThetaC] = thc;
+      slab[kPhiC] = phc;
+      slab[kModel] = model_change;
+      break;
+    }
+    slab[kRadius] = radius;
+    slab[kInvDec] = inv_dec;
+  }
+
+  ist[kIIter] = iteration;
+  ist[kIFirst] = (term < 0 || !first) ? 0 : 1;
+  ist[kIReuseDiag] = reuse_diagonal;
+  ist[kINumInvalid] = num_invalid;
+  ist[kIStepOk] = step_ok;
+  return term;
 }
 
 // region markers for tools/isa_mix.py --regions (assembly comments; compiled in only on request)
@@ -131,72 +498,28 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   const pnec_hip_options &o = a.opt;
   const double reg = a.reg;
 
-  // Equal-length solves keep every wavefront of the chip in lockstep: all of them stream their
-  // payload from HBM at the same moment (a burst at full bandwidth), then all compute (HBM idle).
-  // Skewing the FIRST round by the wavefront's slot on its CU (blocks are dealt round-robin, so
-  // slot ~ blockIdx / 256 CUs) spreads the loads of later rounds under the other slots' compute;
-  // a finished wavefront's successor inherits its phase.  Speed only; results are unaffected.
-  if (a.stagger > 0 && blockIdx.x < 2048) {
-    const int naps = (int)(blockIdx.x >> 8) * a.stagger;
-    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
-  }
-
   unsigned long long t_begin = 0, t_loaded = 0;
   if (a.trace) t_begin = __builtin_amdgcn_s_memtime();
 
+  // every wavefront of the solve keeps its own copy of the LM state and advances it identically
   __shared__ double slab_all[WPP][kSlab];
+  __shared__ double unif_all[WPP][kUnif];
+  __shared__ int ist_all[WPP][kINumI];
   [[maybe_unused]] __shared__ double xw[2][WPP > 1 ? WPP : 1][kSumSlots];
   [[maybe_unused]] __shared__ double ldata[LDSK > 0 ? WPP : 1][LDSK > 0 ? LDSK : 1][NC][LDSK > 0 ? kWave : 1];
   double *slab = slab_all[wave];
-  int parity = 0;
+  double *unif = unif_all[wave];
+  int *ist = ist_all[wave];
+  [[maybe_unused]] int parity = 0;
 
   // ---- load this lane's correspondences once (coalesced: consecutive lanes, consecutive doubles)
   double d[REGK][NC];
   unsigned vmask = 0;
-  if constexpr (RESIDENT) {
-    // slot k of a lane is correspondence  wave*CPL*64 + 128*(k/2) + 2*lane + (k&1): two
-    // neighbouring correspondences per 16-byte load (global_load_dwordx4) -- the CU's load path
-    // moves ~2x the bytes per clock of 8-byte loads, which is what bounds the payload fetch.
-    auto put = [&](auto kc, int c, double v) {
-      constexpr int k = decltype(kc)::value;
-      if constexpr (k < REGK) d[k][c] = v;
-      else ldata[wave][k - REGK][c][lane] = v;
-    };
-    if constexpr (CPL == 1) {
-      const int idx = wave * kWave + lane;
-      const bool in = idx < stride;
-#pragma unroll
-      for (int c = 0; c < NC; ++c)
-        put(std::integral_constant<int, 0>{}, c, in ? base[(int64_t)c * stride + idx] : 0.0);
-      vmask = idx < n ? 1u : 0u;
-    } else {
-      static_assert(CPL == 1 || CPL % 2 == 0, "correspondences per lane: 1 or even");
-      using pair_t = __attribute__((ext_vector_type(2))) double;
-      auto load_pair = [&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const int idx = wave * CPL * kWave + 2 * kWave * j + 2 * lane;
-        const bool in = idx < stride;  // stride is a multiple of 64, idx is even: idx+1 < stride too
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          pair_t v = {0.0, 0.0};
-          if (in) v = *reinterpret_cast<const pair_t *>(base + (int64_t)c * stride + idx);
-          put(std::integral_constant<int, 2 * j>{}, c, v.x);
-          put(std::integral_constant<int, 2 * j + 1>{}, c, v.y);
-        }
-        vmask |= (idx < n ? 1u : 0u) << (2 * j);
-        vmask |= (idx + 1 < n ? 1u : 0u) << (2 * j + 1);
-      };
-      load_pair(std::integral_constant<int, 0>{});
-      if constexpr (CPL >= 4) load_pair(std::integral_constant<int, 1>{});
-      if constexpr (CPL >= 8) {
-        load_pair(std::integral_constant<int, 2>{});
-        load_pair(std::integral_constant<int, 3>{});
-      }
-    }
-  }
+  if constexpr (RESIDENT)
+    vmask = load_resident<NC, CPL, REGK>(base, n, stride, wave * CPL * kWave, lane, d, &ldata[LDSK > 0 ? wave : 0][0][0][0]);
   // validity of slot k as a 64-lane mask in scalar registers: the pass's selects then take the
   // mask operand directly instead of re-deriving a per-lane predicate for every correspondence
-  [[maybe_unused]] unsigned long long lanes_valid[RESIDENT ? CPL : 1];
+  [[maybe_unused]] unsigned long long lanes_valid[REGK + LDSK];
   if constexpr (RESIDENT) {
 #pragma unroll
     for (int k = 0; k < CPL; ++k) lanes_valid[k] = __builtin_amdgcn_ballot_w64(((vmask >> k) & 1u) != 0u);
@@ -209,173 +532,51 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
 
   // ---- PNECCeres::InitValues(q, t): pnec_ceres.cc:182-186.  The start point is the first
   // "candidate"; the loop's first pass evaluates it (Ceres' iteration zero).
+  // Everything that is one value per solve -- here and in lm_advance below -- runs in lane 0
+  // only: a wavefront instruction with one live 16-lane quarter issues in a quarter of the time.
   if (lane == 0) {
     double th, ph;
     const double *t0 = a.hyp_t ? a.hyp_t + 3 * s : a.init_t + 3 * pair;
     angles_from_vec(t0[0], t0[1], t0[2], th, ph);
+    double q[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) slab[kQc + k] = a.init_q[pair * 4 + k];
+    for (int k = 0; k < 4; ++k) {
+      q[k] = a.init_q[pair * 4 + k];
+      slab[kQc + k] = q[k];
+    }
     slab[kThetaC] = th;
     slab[kPhiC] = ph;
+    pose_uniforms(th, ph, q, unif);
+    ist[kIIter] = 0;
+    ist[kIFirst] = 1;
+    ist[kIReuseDiag] = 0;
+    ist[kINumInvalid] = 0;
+    ist[kIStepOk] = 1;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
-  int iteration = 0, term = PNEC_HIP_TERM_MAX_ITERATIONS;
-  int first = 1, reuse_diagonal = 0, num_invalid = 0, step_ok = 1;
-
+  int term;
   for (;;) {
-    if (!first) {
-      // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
-      if (iteration >= o.max_num_iterations) { term = PNEC_HIP_TERM_MAX_ITERATIONS; break; }
-      const double radius = slab[kRadius];
-      if (o.check_convergence && step_ok && to_sgpr((int)(slab[kGmax] <= o.gradient_tolerance))) {
-        term = PNEC_HIP_TERM_GRADIENT_TOL; break;
-      }
-      if (to_sgpr((int)(radius < o.min_trust_region_radius))) { term = PNEC_HIP_TERM_MIN_RADIUS; break; }
-      ++iteration;
-      step_ok = 0;
-
-      PNEC_MARK("lm_step");
-      // ---- LevenbergMarquardtStrategy::ComputeStep on the parked normal equations.
-      // Ceres solves (S H S + D/radius) y = -S g with the Jacobi scaling S frozen at iteration
-      // zero, D = clamp(diag(S H S)), and steps by S y.  With p = S y that is
-      //   (H + S^-1 D S^-1 / radius) p = -g,
-      // so the scaling only enters through the diagonal D' = clamp(s_i^2 H_ii) / s_i^2 and p is
-      // the parameter step itself (theta, phi, omega; the quaternion's half-angle delta = omega/2).
-      double H[15], g[5], diag[5], dr[5], A[15], y[5], step[5];
-#pragma unroll
-      for (int i = 0; i < 15; ++i) H[i] = slab[kHs + i];
-#pragma unroll
-      for (int i = 0; i < 5; ++i) g[i] = slab[kGs + i];
-      if (!reuse_diagonal) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-          diag[i] = fmin(fmax(H[tri(i, i)] * slab[kScaleSq + i], o.min_lm_diagonal), o.max_lm_diagonal) *
-                    slab[kInvScaleSq + i];
-        if (lane == 0) {
-#pragma unroll
-          for (int i = 0; i < 5; ++i) slab[kDiag + i] = diag[i];
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 5; ++i) diag[i] = slab[kDiag + i];
-      }
-      const double inv_radius = fast_rcp(radius);
-#pragma unroll
-      for (int i = 0; i < 15; ++i) A[i] = H[i];
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        dr[i] = diag[i] * inv_radius;
-        A[tri(i, i)] += dr[i];
-      }
-      bool valid = chol_solve5(A, g, y);
-      // model cost change -(Jp)'(r + Jp/2) = -(g'p + p'Hp/2); with (H + D'/radius) p = -g this is
-      // (-g'p + p'(D'/radius)p) / 2 -- two non-negative terms, no cancellation
-      double sg = 0.0, sd = 0.0;
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        step[i] = -y[i];
-        sg = __builtin_fma(step[i], g[i], sg);
-        sd = __builtin_fma(dr[i] * step[i], step[i], sd);
-      }
-      const double model_change = 0.5 * (sd - sg);
-      valid = valid && (model_change > 0.0);
-      if (to_sgpr((int)valid) == 0) {
-        if (++num_invalid >= o.max_num_consecutive_invalid_steps) {
-          term = PNEC_HIP_TERM_INVALID_STEPS; break;
-        }
-        if (lane == 0) {
-          const double inv_dec = slab[kInvDec];
-          slab[kRadius] = radius * inv_dec;
-          slab[kInvDec] = 0.5 * inv_dec;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        reuse_diagonal = 1;
-        continue;
-      }
-      num_invalid = 0;
-
-      PNEC_MARK("plus");
-      // ---- candidate = Plus(x, p): EigenQuaternionManifold::Plus on q with delta = omega / 2
-      const double dx = 0.5 * step[2], dy = 0.5 * step[3], dz = 0.5 * step[4];
-      const double q0 = slab[kQ + 0], q1 = slab[kQ + 1], q2 = slab[kQ + 2], q3 = slab[kQ + 3];
-      const double thc = slab[kTheta] + step[0];
-      const double phc = slab[kPhi] + step[1];
-      const double nd2 = dx * dx + dy * dy + dz * dz;
-      double qc0 = q0, qc1 = q1, qc2 = q2, qc3 = q3;
-      if (nd2 > 0.0) {
-        const double ind = fast_rsqrt(nd2), nd = nd2 * ind;
-        double sn, aw;
-        sincos_bounded(nd, sn, aw);
-        const double sbd = sn * ind;
-        const double ax = sbd * dx, ay = sbd * dy, az = sbd * dz;
-        qc0 = aw * q0 + ax * q3 + ay * q2 - az * q1;
-        qc1 = aw * q1 - ax * q2 + ay * q3 + az * q0;
-        qc2 = aw * q2 + ax * q1 - ay * q0 + az * q3;
-        qc3 = aw * q3 - ax * q0 - ay * q1 - az * q2;
-      }
-      if (lane == 0) {
-        slab[kQc + 0] = qc0; slab[kQc + 1] = qc1; slab[kQc + 2] = qc2; slab[kQc + 3] = qc3;
-        slab[kThetaC] = thc;
-        slab[kPhiC] = phc;
-        slab[kModel] = model_change;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    }
-
     // ---- one fused pass at the candidate: sum r^2, J'r, J'J ------------------------------
     PNEC_MARK("uniforms");
-    double S[kNumAcc];
-    bool sums_finite = true;  // cost AND Jacobian sums
     {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       PassUniforms U;
-      {
-        const double qc[4] = {slab[kQc + 0], slab[kQc + 1], slab[kQc + 2], slab[kQc + 3]};
-        make_uniforms(slab[kThetaC], slab[kPhiC], qc, U);
-      }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) U.R[i] = to_sgpr(unif[i]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) U.t[i] = to_sgpr(unif[9 + i]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) U.bth[i] = to_sgpr(unif[12 + i]);
+      U.bph[0] = to_sgpr(unif[15]);
+      U.bph[1] = to_sgpr(unif[16]);
+      U.bph[2] = 0.0;
       double acc[kNumAcc];
 #pragma unroll
       for (int j = 0; j < kNumAcc; ++j) acc[j] = 0.0;
       PNEC_MARK("pass");
       if constexpr (RESIDENT) {
-        // The first two slots are always evaluated (their masks zero the padding).  The rest of
-        // the register slots, and each LDS slot, are skipped by a wave-uniform branch when no
-        // lane holds a correspondence there -- the tail of a ragged pair -- so a short pair does
-        // not pay for what the geometry could hold.  (Measured: < 0.5 % on full-size pairs,
-        // +8 % solves/s on pairs of 513..600 correspondences.)
-        auto eval_slot = [&](auto kc) {
-          constexpr int k = decltype(kc)::value;
-          double r, J[5];
-          eval_corr<MODE>(d[k], __builtin_amdgcn_inverse_ballot_w64(lanes_valid[k]), U, reg, r, J);
-          accumulate(r, J, acc);
-        };
-        eval_slot(std::integral_constant<int, 0>{});
-        if constexpr (REGK > 1) eval_slot(std::integral_constant<int, 1>{});
-        if constexpr (REGK > 2) {
-          if (lanes_valid[2] != 0ull) {
-            eval_slot(std::integral_constant<int, 2>{});
-            if constexpr (REGK > 3) eval_slot(std::integral_constant<int, 3>{});
-            if constexpr (REGK > 4) eval_slot(std::integral_constant<int, 4>{});
-            if constexpr (REGK > 5) eval_slot(std::integral_constant<int, 5>{});
-            if constexpr (REGK > 6) eval_slot(std::integral_constant<int, 6>{});
-            if constexpr (REGK > 7) eval_slot(std::integral_constant<int, 7>{});
-          }
-        }
-        // not unrolled: one LDS-resident correspondence live at a time (an unrolled loop lets the
-        // scheduler hoist every slot's 12 loads and blows the 256-register budget)
-#pragma unroll 1
-        for (int k = 0; k < LDSK; ++k) {
-          unsigned long long m = lanes_valid[REGK];
-#pragma unroll
-          for (int i = 1; i < LDSK; ++i) m = (k == i) ? lanes_valid[REGK + i] : m;
-          if (m == 0ull) continue;
-          double e[NC];
-#pragma unroll
-          for (int c = 0; c < NC; ++c) e[c] = ldata[wave][k][c][lane];
-          double r, J[5];
-          eval_corr<MODE>(e, __builtin_amdgcn_inverse_ballot_w64(m), U, reg, r, J);
-          accumulate(r, J, acc);
-        }
+        pass_resident<MODE, REGK, LDSK>(d, &ldata[LDSK > 0 ? wave : 0][0][0][0], lanes_valid, lane, U, reg, acc);
       } else {
         for (int idx = threadIdx.x; idx < stride; idx += kWave * WPP) {
           double e[NC];
@@ -389,166 +590,53 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
       PNEC_MARK("reduce");
       double c[6];
       wave_reduce21_rows(acc, c);
-      if constexpr (WPP == 1) sums_finite = rows_all_finite(c);
-      // the four row leaders store the sums they own; every lane reads all 21 back (broadcast)
-      double *dst = WPP > 1 ? &xw[parity][wave][0] : &slab[kSums];
-      if ((lane & 15) == 0) {
+      // the four row leaders store the sums they own (sum_slot layout)
+      if constexpr (WPP == 1) {
+        const bool fin = rows_all_finite(c);
+        if ((lane & 15) == 0) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) dst[(lane >> 4) * 6 + i] = c[i];
-      }
-      if constexpr (WPP > 1) {
+          for (int i = 0; i < 6; ++i) slab[kSums + (lane >> 4) * 6 + i] = c[i];
+          if (lane == 0) slab[kSumsFinite] = fin ? 1.0 : 0.0;
+        }
+      } else {
+        if ((lane & 15) == 0) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) xw[parity][wave][(lane >> 4) * 6 + i] = c[i];
+        }
         __syncthreads();
+        if (lane == 0) {
+          double z = 0.0;
 #pragma unroll
-        for (int j = 0; j < kNumAcc; ++j) {
-          double t = xw[parity][0][sum_slot(j)];
+          for (int j = 0; j < kSumSlots; ++j) {
+            double t = xw[parity][0][j];
 #pragma unroll
-          for (int w = 1; w < WPP; ++w) t += xw[parity][w][sum_slot(j)];
-          S[j] = t;
+            for (int w = 1; w < WPP; ++w) t += xw[parity][w][j];
+            slab[kSums + j] = t;
+            z = __builtin_fma(t, 0.0, z);
+          }
+          slab[kSumsFinite] = (z == 0.0) ? 1.0 : 0.0;
         }
         parity ^= 1;
-        double z = 0.0;
-#pragma unroll
-        for (int j = 0; j < kNumAcc; ++j) z = __builtin_fma(S[j], 0.0, z);
-        sums_finite = (z == 0.0);
-      } else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll
-        for (int j = 0; j < kNumAcc; ++j) S[j] = slab[kSums + sum_slot(j)];
       }
     }
 
-    PNEC_MARK("evaluate");
-    // ---- sums -> cost; the scaled normal equations are only formed when the point is kept
-    double cost_c = 0.5 * S[0];
-    const bool cost_ok = finite_d(cost_c);
-    // only consulted when the cost is finite, so the cost's own term in it is harmless
-    const bool rest_ok = sums_finite;
-
-    bool accept;
-    double rho = 0.0;
-    if (first) {
-      if (to_sgpr((int)(cost_ok && rest_ok)) == 0) {
-        if (lane == 0) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) slab[kQ + k] = slab[kQc + k];
-          slab[kTheta] = slab[kThetaC];
-          slab[kPhi] = slab[kPhiC];
-          slab[kCost] = cost_c;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        term = PNEC_HIP_TERM_BAD_INITIAL;
-        break;
-      }
-      // jacobi_scaling: s = 1 / (1 + sqrt(diag(J'J))) on the Ceres-tangent Jacobian (rotation
-      // columns = 2 x the omega columns accumulated by the pass); frozen after iteration zero.
-      // Parked: (f s)^2 and its inverse, f = 2 for the rotation columns.
-      if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-          const double f = (i >= 2) ? 2.0 : 1.0;
-          const double hii = S[6 + tri(i, i)] * (f * f);
-          const double a = (o.jacobi_scaling ? 1.0 + sqrt(hii) : 1.0) / f;  // 1 / (f s)
-          slab[kInvScaleSq + i] = a * a;
-          slab[kScaleSq + i] = 1.0 / (a * a);
-        }
-        slab[kRadius] = o.initial_trust_region_radius;
-        slab[kInvDec] = 0.5;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      accept = true;
-    } else {
-      if (!cost_ok) cost_c = 1.7976931348623157e308;
-      const double cost = slab[kCost];
-      if (o.check_convergence) {
-        double dn = (slab[kTheta] - slab[kThetaC]) * (slab[kTheta] - slab[kThetaC]) +
-                    (slab[kPhi] - slab[kPhiC]) * (slab[kPhi] - slab[kPhiC]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const double dq = slab[kQ + k] - slab[kQc + k];
-          dn = __builtin_fma(dq, dq, dn);
-        }
-        const double step_norm = fast_sqrt(dn);
-        if (to_sgpr((int)(step_norm <= o.parameter_tolerance * (slab[kXNorm] + o.parameter_tolerance)))) {
-          term = PNEC_HIP_TERM_PARAMETER_TOL; break;
-        }
-        if (to_sgpr((int)(fabs(cost - cost_c) <= o.function_tolerance * cost))) {
-          term = PNEC_HIP_TERM_FUNCTION_TOL; break;
-        }
-      }
-      rho = (cost - cost_c) * fast_rcp(slab[kModel]);
-      accept = to_sgpr((int)(rho > o.min_relative_decrease)) != 0;
-      if (accept && to_sgpr((int)rest_ok) == 0) {  // finite cost, non-finite Jacobian: Ceres fails here
-        term = PNEC_HIP_TERM_BAD_INITIAL; break;
-      }
-    }
-
-    PNEC_MARK("accept");
-    if (accept) {
-      // x <- candidate; park cost, x_norm and the normal equations
-      double gmax = 0.0;
-      const double qa0 = slab[kQc + 0], qa1 = slab[kQc + 1], qa2 = slab[kQc + 2], qa3 = slab[kQc + 3];
-      const double tha = slab[kThetaC], pha = slab[kPhiC];
-      const double xn = fast_sqrt(tha * tha + pha * pha + qa0 * qa0 + qa1 * qa1 + qa2 * qa2 + qa3 * qa3);
-#pragma unroll
-      for (int i = 0; i < 5; ++i) gmax = fmax(gmax, fabs(S[1 + i]) * ((i >= 2) ? 2.0 : 1.0));
-      double new_radius = 0.0;
-      if (!first) {
-        const double c1 = 2.0 * rho - 1.0;
-        new_radius = fmin(o.max_trust_region_radius,
-                          slab[kRadius] * fast_rcp(fmax(1.0 / 3.0, 1.0 - c1 * c1 * c1)));
-      }
-      if (lane == 0) {
-        slab[kQ + 0] = qa0; slab[kQ + 1] = qa1; slab[kQ + 2] = qa2; slab[kQ + 3] = qa3;
-        slab[kTheta] = tha;
-        slab[kPhi] = pha;
-        slab[kCost] = cost_c;
-        slab[kXNorm] = xn;
-        slab[kGmax] = gmax;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) slab[kGs + i] = S[1 + i];
-#pragma unroll
-        for (int i = 0; i < 15; ++i) slab[kHs + i] = S[6 + i];
-        if (!first) {
-          slab[kRadius] = new_radius;
-          slab[kInvDec] = 0.5;
-        }
-      }
-      step_ok = 1;
-      reuse_diagonal = 0;
-      first = 0;
-    } else {
-      if (lane == 0) {
-        const double inv_dec = slab[kInvDec];
-        slab[kRadius] = slab[kRadius] * inv_dec;
-        slab[kInvDec] = 0.5 * inv_dec;
-      }
-      reuse_diagonal = 1;
-    }
+    // ---- accept / reject, trust region, next candidate: one lane
+    PNEC_MARK("advance");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    int t = -1;
+    // the chain below is latency-bound: let it win the issue arbitration against the pass of the
+    // other wavefront on this SIMD, which has independent work to fill the gaps (+1.2 %)
+    __builtin_amdgcn_s_setprio(3);
+    if (lane == 0) t = lm_advance(slab, ist, unif, o);
+    term = to_sgpr(t);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (term >= 0) break;
   }
 
   PNEC_MARK("result");
-  // ---- PNECCeres::Result(): pnec_ceres.cc:201-207
   if (threadIdx.x == 0) {
-    const double q0 = slab[kQ + 0], q1 = slab[kQ + 1], q2 = slab[kQ + 2], q3 = slab[kQ + 3];
-    const double qn = fast_rsqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
-    if (a.out_q) {
-      a.out_q[4 * s + 0] = q0 * qn;
-      a.out_q[4 * s + 1] = q1 * qn;
-      a.out_q[4 * s + 2] = q2 * qn;
-      a.out_q[4 * s + 3] = q3 * qn;
-    }
-    if (a.out_t) {
-      double st, ct, sp, cp;
-      sincos_bounded(slab[kTheta], st, ct);
-      sincos_bounded(slab[kPhi], sp, cp);
-      a.out_t[3 * s + 0] = st * cp;
-      a.out_t[3 * s + 1] = st * sp;
-      a.out_t[3 * s + 2] = ct;
-    }
-    if (a.out_cost) a.out_cost[s] = slab[kCost];
-    if (a.out_iterations) a.out_iterations[s] = iteration;
-    if (a.out_status) a.out_status[s] = term;
+    write_result(a, s, slab, ist[kIIter], term);
     if (a.trace) {
       unsigned hw = 0;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));

@@ -33,4 +33,5 @@ hipError_t PNEC_CAT(launch_solve_mode_, PNEC_SOLVE_MODE)(int cpl, int wpp, int l
   return hipErrorInvalidConfiguration;
 }
 
+
 }  // namespace pnec_hip

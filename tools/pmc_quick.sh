@@ -5,8 +5,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
-rocprofv3 --kernel-trace --kernel-include-regex lm_solve --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/a -o b -- $BENCH > $OUT/a.log 2>&1
-rocprofv3 --kernel-trace --kernel-include-regex lm_solve --pmc SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_TRANS GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -o b -- $BENCH > $OUT/b.log 2>&1
+rocprofv3 --kernel-trace --kernel-include-regex "lm_solve|lm_group" --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/a -o b -- $BENCH > $OUT/a.log 2>&1
+rocprofv3 --kernel-trace --kernel-include-regex "lm_solve|lm_group" --pmc SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_TRANS GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -o b -- $BENCH > $OUT/b.log 2>&1
 python3 - <<PY
 import csv,glob,collections
 v=collections.defaultdict(list)

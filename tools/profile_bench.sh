@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+BENCH="python $REPO/bench.py --steps 10 --warmup 5 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $BENCH > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --kernel-include-regex lm_solve --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o bench -- $BENCH > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --kernel-include-regex lm_solve --pmc WRITE_SIZE --output-format csv -d $OUT/write -o bench -- $BENCH > $OUT/write.log 2>&1
