@@ -31,7 +31,10 @@ namespace pnec_hip {
 
 // ------------------------------------------------------------------------------------------
 // symmetric 3x3 eigen-decomposition, cyclic Jacobi; eigenvalues ascending, eigenvectors in the
-// columns of V (row-major), largest-magnitude component of each made positive
+// columns of V (row-major), largest-magnitude component of each made positive.
+// Works on the 6 unique entries; the rotation angle comes from t = sgn(d) apq / (|d| + hypot(d, apq)),
+// d = (aqq - app) / 2 -- the same t as 1 / (theta + sgn(theta) sqrt(theta^2 + 1)), theta = d / apq,
+// without the division by a vanishing apq -- with v_rcp / v_rsq + Newton instead of IEEE divide/sqrt.
 __device__ void sym_eig3(const double (&A_in)[9], double (&w)[3], double (&V)[9]) {
   double A[9];
 #pragma unroll
@@ -45,29 +48,27 @@ __device__ void sym_eig3(const double (&A_in)[9], double (&w)[3], double (&V)[9]
     if (off <= 1e-34 * dg || off == 0.0) break;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const int p = (k == 2) ? 1 : 0, q = (k == 0) ? 1 : 2;
+      constexpr int P[3] = {0, 0, 1}, Q[3] = {1, 2, 2}, O[3] = {2, 1, 0};
+      const int p = P[k], q = Q[k], o = O[k];  // rotate in the (p, q) plane; o = the third index
       const double apq = A[3 * p + q];
       if (apq == 0.0) continue;
-      const double theta = (A[3 * q + q] - A[3 * p + p]) / (2.0 * apq);
-      const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-      const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const double arp = A[3 * r + p], arq = A[3 * r + q];
-        A[3 * r + p] = c * arp - s * arq;
-        A[3 * r + q] = s * arp + c * arq;
-      }
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const double apr = A[3 * p + r], aqr = A[3 * q + r];
-        A[3 * p + r] = c * apr - s * aqr;
-        A[3 * q + r] = s * apr + c * aqr;
-      }
+      const double d = 0.5 * (A[3 * q + q] - A[3 * p + p]);
+      const double hyp = fast_sqrt(__builtin_fma(d, d, apq * apq));
+      double t = apq * fast_rcp(fabs(d) + hyp);
+      t = (d < 0.0) ? -t : t;
+      if (d == 0.0) t = 1.0;
+      const double c = fast_rsqrt(__builtin_fma(t, t, 1.0)), sn = t * c;
+      A[3 * p + p] = __builtin_fma(-t, apq, A[3 * p + p]);
+      A[3 * q + q] = __builtin_fma(t, apq, A[3 * q + q]);
+      A[3 * p + q] = A[3 * q + p] = 0.0;
+      const double aop = A[3 * o + p], aoq = A[3 * o + q];
+      A[3 * o + p] = A[3 * p + o] = c * aop - sn * aoq;
+      A[3 * o + q] = A[3 * q + o] = sn * aop + c * aoq;
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const double vrp = V[3 * r + p], vrq = V[3 * r + q];
-        V[3 * r + p] = c * vrp - s * vrq;
-        V[3 * r + q] = s * vrp + c * vrq;
+        V[3 * r + p] = c * vrp - sn * vrq;
+        V[3 * r + q] = sn * vrp + c * vrq;
       }
     }
   }
@@ -99,7 +100,7 @@ __device__ void sym_eig3(const double (&A_in)[9], double (&w)[3], double (&V)[9]
 
 __device__ void cayley_to_rot(const double (&v)[3], double (&R)[9]) {
   const double x = v[0], y = v[1], z = v[2];
-  const double s = 1.0 / (1.0 + x * x + y * y + z * z);
+  const double s = fast_rcp(1.0 + x * x + y * y + z * z);
   R[0] = s * (1 + x * x - y * y - z * z); R[1] = s * 2 * (x * y - z); R[2] = s * 2 * (x * z + y);
   R[3] = s * 2 * (x * y + z); R[4] = s * (1 - x * x + y * y - z * z); R[5] = s * 2 * (y * z - x);
   R[6] = s * 2 * (x * z - y); R[7] = s * 2 * (y * z + x); R[8] = s * (1 - x * x - y * y + z * z);
@@ -146,32 +147,61 @@ __device__ __forceinline__ void mul33t(const double (&A)[9], const double (&B)[9
 __device__ __forceinline__ constexpr int s3(int a, int c) {
   return a <= c ? (a * 3 - a * (a - 1) / 2 + (c - a)) : (c * 3 - c * (c - 1) / 2 + (a - c));
 }
-__device__ __forceinline__ void load_g(const double *G, int kl, double (&M)[9]) {
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) M[3 * a + c] = G[6 * kl + s3(a, c)];
+__device__ __forceinline__ void cross3(const double (&a)[3], const double (&b)[3], double (&c)[3]) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
 }
 
 // lambda_min(M(R(v))) from the 36 sums, optionally its gradient w.r.t. the Cayley vector (e' dM e).
-// M_out (row-major) is the composed matrix.
+// M_out (row-major) is the composed matrix.  The 36 sums are read as G[i * GS]: GS = 1 for a
+// table shared by the wavefront, GS = 64 for one table per lane interleaved in LDS (RANSAC).
+//   M = sum_kl [r_k]x G_kl [r_l]x'   (G_kl symmetric 3x3, G_lk = G_kl)
+//     = sum_k X_kk + sum_{k<l} (X_kl + X_kl'),   X_kl = [r_k]x G_kl [r_l]x'
+// with the skew products written as cross products: row j of [a]x G is a x g_j (g_j = row j of the
+// symmetric G, transposed into place), and row i of T [b]x' is b x T_i.
+template <int GS>
 __device__ double es_value_grad(const double *G, const double (&v)[3], double *g, double *M_out) {
   double R[9];
   cayley_to_rot(v, R);
+  double r[3][3];  // columns of R
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    r[k][0] = R[k]; r[k][1] = R[3 + k]; r[k][2] = R[6 + k];
+  }
   double M[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) M[i] = 0.0;
-  for (int k = 0; k < 3; ++k) {
-    double Sk[9];
-    skew9(R[k], R[3 + k], R[6 + k], Sk);
-    for (int l = 0; l < 3; ++l) {
-      double Sl[9], Gm[9], T[9], X[9];
-      skew9(R[l], R[3 + l], R[6 + l], Sl);
-      load_g(G, s3(k, l), Gm);
-      mul33(Sk, Gm, T);
-      mul33t(T, Sl, X);
 #pragma unroll
-      for (int i = 0; i < 9; ++i) M[i] += X[i];
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int l = k; l < 3; ++l) {
+      const double *Gp = G + 6 * s3(k, l) * GS;
+      // T = [r_k]x G: column j of T = r_k x (column j of G); stored by columns
+      double Tc[3][3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double gj[3] = {Gp[s3(0, j) * GS], Gp[s3(1, j) * GS], Gp[s3(2, j) * GS]};
+        cross3(r[k], gj, Tc[j]);
+      }
+      // X = T [r_l]x': row i of X = r_l x (row i of T)
+      double X[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double Ti[3] = {Tc[0][i], Tc[1][i], Tc[2][i]};
+        cross3(r[l], Ti, X[i]);
+      }
+      if (k == l) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) M[3 * i + j] += X[i][j];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) M[3 * i + j] += X[i][j] + X[j][i];
+      }
     }
   }
   // symmetrise (rounding)
@@ -185,28 +215,26 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
   double w[3], V[9];
   sym_eig3(M, w, V);
   if (!g) return w[0];
-  double Se[9];
-  skew9(V[0], V[3], V[6], Se);
-  // q_k = sum_l C_kl r_l with C_kl = [e]x' G_kl [e]x
+  // d lambda = e' dM e = 2 sum_k dr_k . q_k,  q_k = [e]x' (sum_l G_kl [e]x r_l) = (sum_l G_kl y_l) x e
+  const double e[3] = {V[0], V[3], V[6]};
+  double y[3][3];
+#pragma unroll
+  for (int l = 0; l < 3; ++l) cross3(e, r[l], y[l]);
   double q[3][3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) q[k][0] = q[k][1] = q[k][2] = 0.0;
-  for (int k = 0; k < 3; ++k)
+  for (int k = 0; k < 3; ++k) {
+    double z[3] = {0.0, 0.0, 0.0};
+#pragma unroll
     for (int l = 0; l < 3; ++l) {
-      double Gm[9], T[9];
-      load_g(G, s3(k, l), Gm);
-      // y = [e]x r_l ; z = G y ; q_k += [e]x' z
-      const double rl[3] = {R[l], R[3 + l], R[6 + l]};
-      double y[3], z[3];
+      const double *Gp = G + 6 * s3(k, l) * GS;
 #pragma unroll
-      for (int r = 0; r < 3; ++r) y[r] = Se[3 * r] * rl[0] + Se[3 * r + 1] * rl[1] + Se[3 * r + 2] * rl[2];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) z[r] = Gm[3 * r] * y[0] + Gm[3 * r + 1] * y[1] + Gm[3 * r + 2] * y[2];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) q[k][r] += Se[r] * z[0] + Se[3 + r] * z[1] + Se[6 + r] * z[2];
-      (void)T;
+      for (int a = 0; a < 3; ++a)
+        z[a] += Gp[s3(a, 0) * GS] * y[l][0] + Gp[s3(a, 1) * GS] * y[l][1] + Gp[s3(a, 2) * GS] * y[l][2];
     }
-  const double s = 1.0 + v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    cross3(z, e, q[k]);
+  }
+  const double inv_s = fast_rcp(1.0 + v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+#pragma unroll
   for (int j = 0; j < 3; ++j) {
     double dN[9];
 #pragma unroll
@@ -215,15 +243,18 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
     const int a = (j + 1) % 3, b = (j + 2) % 3;
     dN[3 * b + a] += 2.0;
     dN[3 * a + b] -= 2.0;
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
       dN[3 * j + i] += 2.0 * v[i];
       dN[3 * i + j] += 2.0 * v[i];
     }
     double acc = 0.0;
+#pragma unroll
     for (int k = 0; k < 3; ++k)
-      for (int r = 0; r < 3; ++r) {
-        const double drk = (dN[3 * r + k] - 2.0 * v[j] * R[3 * r + k]) / s;  // d r_k[r] / d v_j
-        acc += drk * q[k][r];
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        const double drk = (dN[3 * rr + k] - 2.0 * v[j] * R[3 * rr + k]) * inv_s;  // d r_k[rr] / d v_j
+        acc += drk * q[k][rr];
       }
     g[j] = 2.0 * acc;
   }
@@ -247,9 +278,10 @@ __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&
 }
 
 // damped Newton on the Cayley vector; returns the number of iterations taken (0 = already converged)
+template <int GS>
 __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double n_scale) {
   double g[3];
-  double f = es_value_grad(G, v, g, nullptr);
+  double f = es_value_grad<GS>(G, v, g, nullptr);
   int it = 0;
   for (; it < 50; ++it) {
     const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
@@ -259,7 +291,7 @@ __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double 
     for (int k = 0; k < 3; ++k) {
       double vp[3] = {v[0], v[1], v[2]}, gp[3];
       vp[k] += h;
-      es_value_grad(G, vp, gp, nullptr);
+      es_value_grad<GS>(G, vp, gp, nullptr);
       for (int r = 0; r < 3; ++r) H[3 * r + k] = (gp[r] - g[r]) / h;
     }
     H[1] = H[3] = 0.5 * (H[1] + H[3]);
@@ -283,7 +315,7 @@ __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double 
     for (int ls = 0; ls < 40; ++ls) {
       for (int k = 0; k < 3; ++k) vn[k] = v[k] + alpha * d[k];
       double Mn[9];
-      const double fn = es_value_grad(G, vn, nullptr, Mn);
+      const double fn = es_value_grad<GS>(G, vn, nullptr, Mn);
       // Armijo with a rounding-noise floor: lambda_min carries ~eps * trace(M) of error
       if (fn <= f + 1e-4 * alpha * slope + 4e-16 * (Mn[0] + Mn[4] + Mn[8])) { moved = true; break; }
       alpha *= 0.5;
@@ -291,7 +323,7 @@ __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double 
     if (!moved) break;
     const double smax = alpha * fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
     for (int k = 0; k < 3; ++k) v[k] = vn[k];
-    f = es_value_grad(G, v, g, nullptr);
+    f = es_value_grad<GS>(G, v, g, nullptr);
     if (smax < 1e-12) { ++it; break; }
   }
   return it;
@@ -399,9 +431,9 @@ __global__ __launch_bounds__(kWave) void nec_eigensolver_kernel(const FrontArgs 
   pass_sums36<false>(base, n, stride, R, t_dummy, 0.0, lane, G);
   double v[3];
   rot_to_cayley(R, v);
-  const int it = es_minimise(G, v, (double)(n > 0 ? n : 1));
+  const int it = es_minimise<1>(G, v, (double)(n > 0 ? n : 1));
   double M[9];
-  es_value_grad(G, v, nullptr, M);
+  es_value_grad<1>(G, v, nullptr, M);
   cayley_to_rot(v, R);
   if (n > 0) {  // ComposeM starts at i = 1 (C7): remove correspondence 0
     const double f1[3] = {base[0], base[stride], base[2 * (int64_t)stride]};
@@ -528,7 +560,7 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
   int fib_min_idx = -1;  // -1: no stored search yet
   int first_iterations = 0;
   for (int it = 0; it + 1 < a.weighted_iterations; ++it) {
-    const int newton = es_minimise(G, v, (double)(n > 0 ? n : 1));
+    const int newton = es_minimise<1>(G, v, (double)(n > 0 ? n : 1));
     if (it == 0) first_iterations = newton;
     const bool same_rotation = (it > 0 && newton == 0 && fib_min_idx >= 0);
     cayley_to_rot(v, R);  // bit-identical to the previous round's when the Newton iteration did not move
@@ -682,8 +714,8 @@ __device__ __forceinline__ double reprojection_score(const double (&f1)[3], cons
   const double a00 = f1[0] * f1[0] + f1[1] * f1[1] + f1[2] * f1[2];
   const double a10 = f1[0] * u[0] + f1[1] * u[1] + f1[2] * u[2];
   const double a01 = -a10, a11 = -(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-  const double det = a00 * a11 - a01 * a10;
-  const double l0 = (a11 * b0 - a01 * b1) / det, l1 = (-a10 * b0 + a00 * b1) / det;
+  const double inv_det = fast_rcp(a00 * a11 - a01 * a10);
+  const double l0 = (a11 * b0 - a01 * b1) * inv_det, l1 = (-a10 * b0 + a00 * b1) * inv_det;
   double p[3], d[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -692,10 +724,10 @@ __device__ __forceinline__ double reprojection_score(const double (&f1)[3], cons
   }
   const double p2[3] = {R[0] * d[0] + R[3] * d[1] + R[6] * d[2], R[1] * d[0] + R[4] * d[1] + R[7] * d[2],
                         R[2] * d[0] + R[5] * d[1] + R[8] * d[2]};
-  const double n1 = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
-  const double n2 = sqrt(p2[0] * p2[0] + p2[1] * p2[1] + p2[2] * p2[2]);
-  return (1.0 - (f1[0] * p[0] + f1[1] * p[1] + f1[2] * p[2]) / n1) +
-         (1.0 - (f2[0] * p2[0] + f2[1] * p2[1] + f2[2] * p2[2]) / n2);
+  const double in1 = fast_rsqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+  const double in2 = fast_rsqrt(p2[0] * p2[0] + p2[1] * p2[1] + p2[2] * p2[2]);
+  return (1.0 - (f1[0] * p[0] + f1[1] * p[1] + f1[2] * p[2]) * in1) +
+         (1.0 - (f2[0] * p2[0] + f2[1] * p2[1] + f2[2] * p2[2]) * in2);
 }
 
 __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacArgs a) {
@@ -705,7 +737,8 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
   const int stride = (n + kWave - 1) & ~(kWave - 1);
   const double *base = a.data + a.block_offset[pair];
   __shared__ double G[36];
-  __shared__ double best_model[12];  // R (9) + t (3)
+  __shared__ double Glane[36][kWave];  // one table of 36 sums per hypothesis (lane), interleaved
+  __shared__ double best_model[12];    // R (9) + t (3)
   double q0[4] = {a.init_q[4 * pair], a.init_q[4 * pair + 1], a.init_q[4 * pair + 2], a.init_q[4 * pair + 3]};
   {
     const double qn = 1.0 / sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
@@ -755,8 +788,11 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
       double v[3], R[9], t[3], M[9];
       for (int c = 0; c < 3; ++c)
         v[c] = v0[c] + (rng_uniform(a.seed, (unsigned long long)pair, h, 1000 + c) - 0.5) * 2.0 * 0.01;
-      es_minimise(Gl, v, (double)ss);
-      es_value_grad(Gl, v, nullptr, M);
+#pragma unroll
+      for (int i = 0; i < 36; ++i) Glane[i][lane] = Gl[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      es_minimise<kWave>(&Glane[0][lane], v, (double)ss);
+      es_value_grad<kWave>(&Glane[0][lane], v, nullptr, M);
       cayley_to_rot(v, R);
       {
         double w[3], V[9];
@@ -853,8 +889,8 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
   // optimizeModelCoefficients: eigensolver on the inliers from the best model's rotation
   double v[3], R[9], M[9];
   rot_to_cayley(bR, v);
-  es_minimise(G, v, (double)(total > 0 ? total : 1));
-  es_value_grad(G, v, nullptr, M);
+  es_minimise<1>(G, v, (double)(total > 0 ? total : 1));
+  es_value_grad<1>(G, v, nullptr, M);
   cayley_to_rot(v, R);
   if (total > 0) {
     const int idx = first;
