@@ -492,27 +492,118 @@ SE3d PNEC::NECCeresSolver(const bearingVectors_t &bvs1, const bearingVectors_t &
   return optimizer.Result();
 }
 
+namespace {
+// a ragged batch on the host, flattened the way pnec_hip_problem_fill ingests it
+struct FlatBatch {
+  std::vector<int64_t> offsets;
+  std::vector<Vector3d> b1, b2;
+  std::vector<Matrix3d> cv;
+  std::vector<double> q0, t0;
+  explicit FlatBatch(const std::vector<FramePair> &pairs) {
+    const int64_t B = (int64_t)pairs.size();
+    offsets.assign(B + 1, 0);
+    for (int64_t p = 0; p < B; ++p) {
+      if (pairs[p].bvs1.size() != pairs[p].bvs2.size() || pairs[p].bvs1.size() != pairs[p].projected_covs.size())
+        throw std::invalid_argument("FramePair arrays differ in size");
+      offsets[p + 1] = offsets[p] + (int64_t)pairs[p].bvs1.size();
+    }
+    b1.reserve(offsets[B]); b2.reserve(offsets[B]); cv.reserve(offsets[B]);
+    q0.resize(4 * B); t0.resize(3 * B);
+    for (int64_t p = 0; p < B; ++p) {
+      b1.insert(b1.end(), pairs[p].bvs1.begin(), pairs[p].bvs1.end());
+      b2.insert(b2.end(), pairs[p].bvs2.begin(), pairs[p].bvs2.end());
+      cv.insert(cv.end(), pairs[p].projected_covs.begin(), pairs[p].projected_covs.end());
+      const Quaterniond q(pairs[p].initial_pose.rotationMatrix());
+      std::memcpy(&q0[4 * p], q.coeffs(), 4 * sizeof(double));
+      std::memcpy(&t0[3 * p], pairs[p].initial_pose.translation().data(), 3 * sizeof(double));
+    }
+  }
+};
+}  // namespace
+
+std::vector<SE3d> PNEC::SolveBatch(const std::vector<FramePair> &pairs, std::vector<std::vector<int>> *inliers) {
+  // pnec.cc:77-124 for every pair, each stage one launch over the batch
+  const int64_t B = (int64_t)pairs.size();
+  std::vector<SE3d> out(B);
+  if (inliers) inliers->assign(B, {});
+  if (B == 0) return out;
+  const FlatBatch h(pairs);
+  const int64_t total = h.offsets[B];
+  const optimization::SolverOptions so;
+  Problem prob(so.device, PNEC_HIP_MODE_TARGET, h.offsets);
+  if (total > 0)
+    Check(pnec_hip_problem_fill(prob.p, 0, B, h.b1[0].data(), h.b2[0].data(), h.cv[0].data(), nullptr,
+                                PNEC_HIP_MEM_HOST, nullptr));
+  std::vector<double> q(4 * B), t(3 * B);
+  pnec_hip_problem *stage = prob.p;
+  pnec_hip_problem *selected = nullptr;
+  struct Guard {
+    pnec_hip_problem *&p;
+    ~Guard() { if (p) pnec_hip_problem_destroy(p); }
+  } guard{selected};
+  std::vector<uint8_t> mask;
+  if (options_.use_ransac_) {
+    mask.assign(total ? total : 1, 0);
+    Check(pnec_hip_ransac_eigensolver(prob.p, h.q0.data(), /*seed*/ 1, options_.max_ransac_iterations_,
+                                      options_.ransac_sample_size_, 1.0e-6, q.data(), t.data(), mask.data(),
+                                      nullptr, nullptr, PNEC_HIP_MEM_HOST, nullptr));
+    if (inliers)
+      for (int64_t p = 0; p < B; ++p)
+        for (int64_t i = h.offsets[p]; i < h.offsets[p + 1]; ++i)
+          if (mask[i]) (*inliers)[p].push_back((int)(i - h.offsets[p]));
+    Check(pnec_hip_problem_select(prob.p, mask.data(), PNEC_HIP_MEM_HOST, nullptr, &selected));
+    stage = selected;
+  } else {
+    Check(pnec_hip_nec_eigensolver(prob.p, h.q0.data(), q.data(), t.data(), PNEC_HIP_MEM_HOST, nullptr));
+  }
+  const pnec_hip_options o = so.ToHip();
+  std::vector<double> oq(4 * B), ot(3 * B);
+  auto poses = [&](const std::vector<double> &qq, const std::vector<double> &tt) {
+    for (int64_t p = 0; p < B; ++p) out[p] = PoseFromQT(&qq[4 * p], &tt[3 * p]);
+    return out;
+  };
+  if (options_.use_nec_) {
+    if (!options_.use_ceres_) return poses(q, t);
+    // NECCeresSolver on the (inlier) bearings: a NEC-family batch of the kept correspondences
+    std::vector<int64_t> noff(B + 1, 0);
+    std::vector<Vector3d> n1, n2;
+    for (int64_t p = 0; p < B; ++p) {
+      for (int64_t i = h.offsets[p]; i < h.offsets[p + 1]; ++i)
+        if (!options_.use_ransac_ || mask[i]) { n1.push_back(h.b1[i]); n2.push_back(h.b2[i]); }
+      noff[p + 1] = (int64_t)n1.size();
+    }
+    Problem nec(so.device, PNEC_HIP_MODE_NEC, noff);
+    if (!n1.empty())
+      Check(pnec_hip_problem_fill(nec.p, 0, B, n1[0].data(), n2[0].data(), nullptr, nullptr, PNEC_HIP_MEM_HOST,
+                                  nullptr));
+    Check(pnec_hip_solve(nec.p, q.data(), t.data(), 1, nullptr, 0.0, &o, oq.data(), ot.data(), nullptr, nullptr,
+                         nullptr, PNEC_HIP_MEM_HOST, nullptr));
+    return poses(oq, ot);
+  }
+  std::vector<double> qi(4 * B), ti(3 * B);
+  if (options_.weighted_iterations_ > 1) {
+    Check(pnec_hip_weighted_eigensolver(stage, q.data(), t.data(), options_.regularization_,
+                                        (int32_t)options_.weighted_iterations_, qi.data(), ti.data(),
+                                        PNEC_HIP_MEM_HOST, nullptr));
+  } else if (options_.weighted_iterations_ == 1) {
+    qi = q; ti = t;
+  } else {
+    qi = h.q0; ti = h.t0;
+  }
+  if (!options_.use_ceres_) return poses(qi, ti);
+  Check(pnec_hip_solve(stage, qi.data(), ti.data(), 1, nullptr, options_.regularization_, &o, oq.data(), ot.data(),
+                       nullptr, nullptr, nullptr, PNEC_HIP_MEM_HOST, nullptr));
+  return poses(oq, ot);
+}
+
 std::vector<SE3d> PNEC::CeresSolverBatch(const std::vector<FramePair> &pairs,
                                          std::vector<optimization::Summary> *summaries) {
   const int64_t B = (int64_t)pairs.size();
-  std::vector<int64_t> offsets(B + 1, 0);
-  for (int64_t p = 0; p < B; ++p) {
-    if (pairs[p].bvs1.size() != pairs[p].bvs2.size() || pairs[p].bvs1.size() != pairs[p].projected_covs.size())
-      throw std::invalid_argument("FramePair arrays differ in size");
-    offsets[p + 1] = offsets[p] + (int64_t)pairs[p].bvs1.size();
-  }
-  std::vector<Vector3d> b1, b2;
-  std::vector<Matrix3d> cv;
-  b1.reserve(offsets[B]); b2.reserve(offsets[B]); cv.reserve(offsets[B]);
-  std::vector<double> q0(4 * B), t0(3 * B);
-  for (int64_t p = 0; p < B; ++p) {
-    b1.insert(b1.end(), pairs[p].bvs1.begin(), pairs[p].bvs1.end());
-    b2.insert(b2.end(), pairs[p].bvs2.begin(), pairs[p].bvs2.end());
-    cv.insert(cv.end(), pairs[p].projected_covs.begin(), pairs[p].projected_covs.end());
-    const Quaterniond q(pairs[p].initial_pose.rotationMatrix());
-    std::memcpy(&q0[4 * p], q.coeffs(), 4 * sizeof(double));
-    std::memcpy(&t0[3 * p], pairs[p].initial_pose.translation().data(), 3 * sizeof(double));
-  }
+  const FlatBatch h(pairs);
+  const std::vector<int64_t> &offsets = h.offsets;
+  const auto &b1 = h.b1, &b2 = h.b2;
+  const auto &cv = h.cv;
+  const auto &q0 = h.q0, &t0 = h.t0;
   const optimization::SolverOptions so;  // defaults, as CeresSolver does
   Problem prob(so.device, PNEC_HIP_MODE_TARGET, offsets);
   if (offsets[B] > 0)

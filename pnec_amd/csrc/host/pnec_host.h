@@ -216,6 +216,12 @@ class PNEC {
   SE3d NECCeresSolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
                       const SE3d &initial_pose);                                 // pnec.cc:394-411
 
+  // Addition: Solve() for many frame pairs at once (ragged sizes allowed) -- every stage is one
+  // launch over the whole batch, which is where the device earns its keep.  Same Options handling
+  // and the same per-pair results as calling Solve() pair by pair (RANSAC draws are a function of
+  // the pair's index in the batch: pair i of a batch reproduces Solve() only for i = 0).
+  std::vector<SE3d> SolveBatch(const std::vector<FramePair> &pairs,
+                               std::vector<std::vector<int>> *inliers = nullptr);
   // Addition: CeresSolver for many pairs in one device launch (ragged sizes allowed).
   std::vector<SE3d> CeresSolverBatch(const std::vector<FramePair> &pairs,
                                      std::vector<optimization::Summary> *summaries = nullptr);

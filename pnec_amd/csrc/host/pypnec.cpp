@@ -116,6 +116,39 @@ py::list ceres_solver_batch(py::list bvs1, py::list bvs2, py::list covs, py::lis
   return out;
 }
 
+// PNEC::Solve with the reference's default Options (or the flags given) for a list of pairs: every
+// stage one launch over the batch.  Returns (poses, inliers).
+py::tuple solve_batch(py::list bvs1, py::list bvs2, py::list covs, py::list init_poses, bool use_ransac,
+                      bool use_nec, bool use_ceres, int weighted_iterations, double regularization) {
+  const size_t B = bvs1.size();
+  if (bvs2.size() != B || covs.size() != B || init_poses.size() != B)
+    throw std::invalid_argument("all lists must have one entry per frame pair");
+  std::vector<pnec::rel_pose_estimation::FramePair> pairs(B);
+  for (size_t p = 0; p < B; ++p) {
+    pairs[p].bvs1 = ToBearings(bvs1[p].cast<arr>(), "bvs1[i]");
+    pairs[p].bvs2 = ToBearings(bvs2[p].cast<arr>(), "bvs2[i]");
+    pairs[p].projected_covs = ToCovariances(covs[p].cast<arr>(), "covs[i]");
+    pairs[p].initial_pose = ToPose(init_poses[p].cast<arr>());
+  }
+  pnec::rel_pose_estimation::Options options;
+  options.use_ransac_ = use_ransac;
+  options.use_nec_ = use_nec;
+  options.use_ceres_ = use_ceres;
+  options.weighted_iterations_ = (size_t)weighted_iterations;
+  options.regularization_ = regularization;
+  std::vector<pnec::SE3d> poses;
+  std::vector<std::vector<int>> inliers;
+  {
+    py::gil_scoped_release release;
+    pnec::rel_pose_estimation::PNEC solver(options);
+    poses = solver.SolveBatch(pairs, &inliers);
+  }
+  py::list out, inl;
+  for (const auto &T : poses) out.append(FromPose(T));
+  for (const auto &v : inliers) inl.append(py::cast(v));
+  return py::make_tuple(out, inl);
+}
+
 // additions used by the tests: the small pnec::common helpers of the facade
 arr compose_m(arr bvs1, arr bvs2, arr rotation) {
   const auto b1 = ToBearings(bvs1, "bvs1"), b2 = ToBearings(bvs2, "bvs2");
@@ -156,6 +189,10 @@ PYBIND11_MODULE(pypnec, m) {
         "NEC refinement (NECCeres::Optimize)");
   m.def("compose_m", &compose_m, "pnec::common::ComposeM (loop from i = 1, like the reference)");
   m.def("translation_from_m", &translation_from_m, "pnec::common::TranslationFromM");
+  m.def("solve_batch", &solve_batch, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"), py::arg("init_poses"),
+        py::arg("use_ransac") = true, py::arg("use_nec") = false, py::arg("use_ceres") = true,
+        py::arg("weighted_iterations") = 10, py::arg("regularization") = 1e-13,
+        "PNEC::Solve for a list of frame pairs, every stage one device launch over the batch (addition)");
   m.def("ceres_solver_batch", &ceres_solver_batch, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"),
         py::arg("init_poses"), py::arg("regularization") = 1e-13,
         "PNEC::CeresSolver for a list of frame pairs in one device launch (addition)");

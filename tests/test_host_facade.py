@@ -25,7 +25,7 @@ def _pose4(R, t):
 def test_pypnec_module_surface():
     import pypnec
     assert pypnec.add(2, 3) == 5
-    for name in ("pyceres", "pyceresnec", "ceres_solver_batch"):
+    for name in ("pyceres", "pyceresnec", "ceres_solver_batch", "solve_batch"):
         assert callable(getattr(pypnec, name))
     with pytest.raises(ValueError):   # argument validation happens before any device work
         pypnec.pyceresnec(np.zeros((4, 2)), np.zeros((4, 3)), np.eye(4))
@@ -96,3 +96,39 @@ def test_common_helpers_of_the_facade_match_oracle(oracle):
     M = pypnec.compose_m(f1, f2, R)
     np.testing.assert_allclose(M, oracle.compose_m(f1, f2, R, skip_first=True), atol=1e-14)
     np.testing.assert_allclose(pypnec.translation_from_m(M), oracle.translation_from_m(M), atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_solve_batch_runs_the_default_pipeline_for_a_ragged_batch(oracle):
+    """PNEC::SolveBatch = PNEC::Solve (pnec.cc:77-124, reference-default Options) for many pairs, one
+    launch per stage: RANSAC inliers, weighted eigensolver + SCF, refinement -- against the oracle's
+    chain with the same counter-based draws (pair p of the batch draws as pair_id = p)."""
+    import pypnec
+    sizes = [200, 512, 90]
+    g = sim.generate(3, 512, seed=321)
+    rng = np.random.default_rng(5)
+    b1 = [g.bvs1[p, :n].numpy().copy() for p, n in enumerate(sizes)]
+    b2 = [g.bvs2[p, :n].numpy().copy() for p, n in enumerate(sizes)]
+    cv = [g.covs2[p, :n].numpy().copy() for p, n in enumerate(sizes)]
+    for p, n in enumerate(sizes):                      # 15 % gross outliers
+        bad = rng.choice(n, n * 15 // 100, replace=False)
+        v = rng.normal(size=(len(bad), 3))
+        b2[p][bad] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    poses = [_pose4(g.init_R[p].numpy(), g.init_t[p].numpy()) for p in range(3)]
+    out, inliers = pypnec.solve_batch(b1, b2, cv, poses)
+    for p, n in enumerate(sizes):
+        Ro, to, mo, _ = oracle.ransac_eigensolver(b1[p], b2[p], poses[p][:3, :3], seed=1, pair_id=p)
+        assert list(inliers[p]) == list(np.flatnonzero(mo))
+        Rw, tw = oracle.weighted_eigensolver(b1[p][mo], b2[p][mo], cv[p][mo], Ro, to, 1e-13, 10)
+        s = oracle.solve(oracle.MODE_TARGET, b1[p][mo], b2[p][mo], cv[p][mo], None, 1e-13,
+                         oracle.quat_from_rot(Rw), tw, oracle.default_options())
+        assert math.radians(oracle.rotational_difference_deg(out[p][:3, :3], s.R)) <= 1e-6
+        assert math.radians(oracle.rotational_difference_deg(out[p][:3, :3], g.R_gt[p].numpy())) < 0.01
+    # the flags: NEC refinement without RANSAC, and eigensolver only
+    out2, inl2 = pypnec.solve_batch(b1, b2, cv, poses, use_ransac=False, use_nec=True)
+    assert all(len(i) == 0 for i in inl2)
+    for p in range(3):
+        Ro, to = oracle.nec_eigensolver(b1[p], b2[p], poses[p][:3, :3])
+        s = oracle.solve(oracle.MODE_NEC, b1[p], b2[p], None, None, 0.0, oracle.quat_from_rot(Ro), to,
+                         oracle.default_options())
+        assert math.radians(oracle.rotational_difference_deg(out2[p][:3, :3], s.R)) <= 1e-6
