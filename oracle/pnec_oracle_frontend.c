@@ -402,6 +402,7 @@ void pnec_oracle_weighted_eigensolver(int64_t n, const double *bvs1, const doubl
   double *Bi = (double *)malloc(sizeof(double) * 9 * (size_t)(n > 0 ? n : 1));
   double fib[1500];
   pnec_oracle_fibonacci_sphere(500, fib);
+  int rotation_final = 0;
   for (int it = 0; it + 1 < weighted_iterations; ++it) {
     /* weights from the INITIAL pose every iteration (C3), scaled by 1e-8 (C4) */
     for (int64_t i = 0; i < n; ++i) {
@@ -411,8 +412,12 @@ void pnec_oracle_weighted_eigensolver(int64_t n, const double *bvs1, const doubl
     }
     double Rn[9];
     {
+      /* The weights never change (C3), so every iteration minimises the same function from the
+       * previous optimum: once a call has ended for any reason other than the iteration cap
+       * (gradient below tolerance, step below 1e-12, no descent left) the minimiser has nothing
+       * more to give and the rotation is final -- later iterations only redo the translation. */
       es_data D = {n, bvs1, w2};
-      eigensolver_cayley(&D, v);
+      if (!rotation_final) rotation_final = eigensolver_cayley(&D, v) < 50;
       pnec_oracle_cayley_to_rot(v, Rn);
     }
     pnec_oracle_build_ab(n, bvs1, bvs2, covs, Rn, reg, Ai, Bi);

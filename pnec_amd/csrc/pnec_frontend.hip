@@ -559,8 +559,16 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
   double fib_min_cost = 0.0;
   int fib_min_idx = -1;  // -1: no stored search yet
   int first_iterations = 0;
+  bool rotation_final = false;
   for (int it = 0; it + 1 < a.weighted_iterations; ++it) {
-    const int newton = es_minimise<1>(G, v, (double)(n > 0 ? n : 1));
+    // The weights never change (C3), so every round minimises the same function from the previous
+    // optimum: once a call has ended for any reason other than the iteration cap, the rotation is
+    // final and later rounds only redo the translation (newton = 0: "did not move").
+    int newton = 0;
+    if (!rotation_final) {
+      newton = es_minimise<1>(G, v, (double)(n > 0 ? n : 1));
+      rotation_final = newton < 50;
+    }
     if (it == 0) first_iterations = newton;
     const bool same_rotation = (it > 0 && newton == 0 && fib_min_idx >= 0);
     cayley_to_rot(v, R);  // bit-identical to the previous round's when the Newton iteration did not move
