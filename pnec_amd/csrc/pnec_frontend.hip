@@ -683,10 +683,11 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
 // of the midpoint triangulation, inlier if score < threshold, adaptive bound
 // k = log(1 - 0.99) / log(1 - w^s), eigensolver re-run on the inliers; rand() replaced by a
 // counter-based hash of (seed, pair, hypothesis, draw)) ------------------------------------------
-// One wavefront per pair, ONE LANE PER HYPOTHESIS: a round evaluates 64 hypotheses at once (sample,
-// 36 sums of the sample, damped Newton, translation, inlier count over all correspondences with
-// broadcast payload reads), then the lanes are scanned in hypothesis order with the sequential
-// rule (strictly better count wins, adaptive bound k) so the outcome equals the sequential loop.
+// One 16-lane quarter of a wavefront per pair, ONE LANE PER HYPOTHESIS: a round evaluates 16
+// hypotheses of each of the wavefront's 4 pairs at once (sample, 36 sums of the sample, damped
+// Newton, translation, inlier count over all correspondences with quarter-uniform payload reads),
+// then the lanes are scanned in hypothesis order with the sequential rule (strictly better count
+// wins, adaptive bound k) so the outcome equals the sequential loop.
 struct RansacArgs {
   const double *data;
   const int64_t *block_offset;
@@ -697,6 +698,7 @@ struct RansacArgs {
   uint8_t *out_mask;
   int32_t *out_count, *out_iterations;
   unsigned long long seed;
+  int64_t n_pairs;
   int max_iterations, sample_size;
   double threshold;
 };
@@ -738,15 +740,36 @@ __device__ __forceinline__ double reprojection_score(const double (&f1)[3], cons
          (1.0 - (f2[0] * p2[0] + f2[1] * p2[1] + f2[2] * p2[2]) * in2);
 }
 
+// Sum / minimum over the 16 lanes of a DPP row (a "quarter": the lanes of one frame pair)
+__device__ __forceinline__ int row_min_int(int x) {
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {
+    const int o = __shfl_xor(x, off);
+    x = o < x ? o : x;
+  }
+  return x;
+}
+
+constexpr int kHypLanes = 16;                    // hypotheses evaluated per pair and round = lanes per pair
+constexpr int kRansacPairs = kWave / kHypLanes;  // frame pairs per wavefront
+
+// One 16-lane quarter of a wavefront per frame pair, one lane per hypothesis.  The adaptive bound
+// stops the typical pair after ~15 hypotheses, so a 64-hypothesis round wasted three quarters of
+// the (dominant, divergent) per-hypothesis Newton iterations; with four pairs per wavefront the
+// one-value-per-pair work at the end (eigensolver on the inliers) is also shared four ways.
+// Everything that is one value per pair lives in registers, identical in the 16 lanes of its quarter.
 __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacArgs a) {
-  const int64_t pair = blockIdx.x;
   const int lane = threadIdx.x;
-  const int n = a.count[pair];
-  const int stride = (n + kWave - 1) & ~(kWave - 1);
+  const int sub = lane & (kHypLanes - 1), quarter = lane / kHypLanes;
+  const int64_t pair_raw = (int64_t)blockIdx.x * kRansacPairs + quarter;
+  const bool live = pair_raw < a.n_pairs;
+  const int64_t pair = live ? pair_raw : a.n_pairs - 1;
+  const int n = live ? a.count[pair] : 0;
+  const int stride = (a.count[pair] + kWave - 1) & ~(kWave - 1);
   const double *base = a.data + a.block_offset[pair];
-  __shared__ double G[36];
+  __shared__ double G[kRansacPairs][36];
   __shared__ double Glane[36][kWave];  // one table of 36 sums per hypothesis (lane), interleaved
-  __shared__ double best_model[12];    // R (9) + t (3)
+  __shared__ double best_model[kRansacPairs][12];  // R (9) + t (3)
   double q0[4] = {a.init_q[4 * pair], a.init_q[4 * pair + 1], a.init_q[4 * pair + 2], a.init_q[4 * pair + 3]};
   {
     const double qn = 1.0 / sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
@@ -756,104 +779,128 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
   rot_from_quat(q0, R0);
   rot_to_cayley(R0, v0);
   const int ss = a.sample_size > 16 ? 16 : a.sample_size;
-  const bool can_sample = (n >= ss && ss >= 1);
+  const bool can_sample = live && (n >= ss && ss >= 1);
   int it = 0;
-  double bR[9], bt[3] = {0.0, 0.0, 1.0};
-#pragma unroll
-  for (int i = 0; i < 9; ++i) bR[i] = R0[i];
 
-  if (can_sample) {
+  {
     int best_count = -1;
     double k = 1.0;
-    bool stop = false;
-    while (!stop && (double)it < k) {
-      const unsigned long long h = (unsigned long long)(it + lane);
-      // ---- this lane's hypothesis: sample, sums, minimise, translation
-      int sel[16];
-      int m = 0;
-      unsigned long long draw = 0;
-      while (m < ss) {
-        long long idx = (long long)(rng_uniform(a.seed, (unsigned long long)pair, h, draw++) * (double)n);
-        if (idx >= n) idx = n - 1;
-        bool dup = false;
-        for (int j = 0; j < m; ++j) dup = dup || (sel[j] == (int)idx);
-        if (!dup) sel[m++] = (int)idx;
-      }
-      double Gl[36];
-      for (int i = 0; i < 36; ++i) Gl[i] = 0.0;
-      double ev1[3] = {0, 0, 0};  // sum f1 (for the directional evidence)
-      for (int j = 0; j < ss; ++j) {
-        const int idx = sel[j];
-        const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
-        const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
-                              base[(int64_t)5 * stride + idx]};
-        const double p[6] = {f2[0] * f2[0], f2[0] * f2[1], f2[0] * f2[2], f2[1] * f2[1], f2[1] * f2[2], f2[2] * f2[2]};
-        const double qq[6] = {f1[0] * f1[0], f1[0] * f1[1], f1[0] * f1[2], f1[1] * f1[1], f1[1] * f1[2], f1[2] * f1[2]};
-        for (int kl = 0; kl < 6; ++kl)
-          for (int ac = 0; ac < 6; ++ac) Gl[6 * kl + ac] += p[kl] * qq[ac];
-        for (int c = 0; c < 3; ++c) ev1[c] += f1[c];
-      }
-      double v[3], R[9], t[3], M[9];
-      for (int c = 0; c < 3; ++c)
-        v[c] = v0[c] + (rng_uniform(a.seed, (unsigned long long)pair, h, 1000 + c) - 0.5) * 2.0 * 0.01;
+    bool stop = !can_sample;
+    // rounds of 16 hypotheses per pair while any pair of the wavefront still needs one
+    while (__builtin_amdgcn_ballot_w64(!stop && (double)it < k) != 0ull) {
+      const bool active = !stop && (double)it < k;  // same in the 16 lanes of a quarter
+      double R[9], t[3] = {0.0, 0.0, 1.0};
 #pragma unroll
-      for (int i = 0; i < 36; ++i) Glane[i][lane] = Gl[i];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      es_minimise<kWave>(&Glane[0][lane], v, (double)ss);
-      es_value_grad<kWave>(&Glane[0][lane], v, nullptr, M);
-      cayley_to_rot(v, R);
-      {
-        double w[3], V[9];
-        sym_eig3(M, w, V);
-        t[0] = V[0]; t[1] = V[3]; t[2] = V[6];
-        // directional evidence sum t.(f1 - R f2) over the sample
-        double ev = t[0] * ev1[0] + t[1] * ev1[1] + t[2] * ev1[2];
+      for (int i = 0; i < 9; ++i) R[i] = R0[i];
+      if (active) {
+        const unsigned long long h = (unsigned long long)(it + sub);
+        // ---- this lane's hypothesis: sample, sums, minimise, translation
+        int sel[16];
+        int m = 0;
+        unsigned long long draw = 0;
+        while (m < ss) {
+          long long idx = (long long)(rng_uniform(a.seed, (unsigned long long)pair, h, draw++) * (double)n);
+          if (idx >= n) idx = n - 1;
+          bool dup = false;
+          for (int j = 0; j < m; ++j) dup = dup || (sel[j] == (int)idx);
+          if (!dup) sel[m++] = (int)idx;
+        }
+        double Gl[36];
+        for (int i = 0; i < 36; ++i) Gl[i] = 0.0;
+        double ev1[3] = {0, 0, 0};  // sum f1 (for the directional evidence)
         for (int j = 0; j < ss; ++j) {
           const int idx = sel[j];
+          const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
           const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
                                 base[(int64_t)5 * stride + idx]};
-          const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
-                               R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
-          ev -= t[0] * u[0] + t[1] * u[1] + t[2] * u[2];
+          const double p[6] = {f2[0] * f2[0], f2[0] * f2[1], f2[0] * f2[2], f2[1] * f2[1], f2[1] * f2[2], f2[2] * f2[2]};
+          const double qq[6] = {f1[0] * f1[0], f1[0] * f1[1], f1[0] * f1[2], f1[1] * f1[1], f1[1] * f1[2], f1[2] * f1[2]};
+          for (int kl = 0; kl < 6; ++kl)
+            for (int ac = 0; ac < 6; ++ac) Gl[6 * kl + ac] += p[kl] * qq[ac];
+          for (int c = 0; c < 3; ++c) ev1[c] += f1[c];
         }
-        if (ev < 0.0) { t[0] = -t[0]; t[1] = -t[1]; t[2] = -t[2]; }
-      }
-      // ---- inlier count of this hypothesis over the whole pair (payload reads are wave-uniform)
-      int cnt = 0;
-      for (int i = 0; i < n; ++i) {
-        const double f1[3] = {base[i], base[(int64_t)stride + i], base[(int64_t)2 * stride + i]};
-        const double f2[3] = {base[(int64_t)3 * stride + i], base[(int64_t)4 * stride + i],
-                              base[(int64_t)5 * stride + i]};
-        cnt += reprojection_score(f1, f2, R, t) < a.threshold ? 1 : 0;
-      }
-      // ---- consume the 64 hypotheses in order with the sequential rule
-      int winner = -1;
-      for (int j = 0; j < kWave; ++j) {
-        if (!((double)it < k)) { stop = true; break; }
-        const int cj = __builtin_amdgcn_readlane(cnt, j);
-        if (cj > best_count) {
-          best_count = cj;
-          winner = j;
-          const double w = (double)cj / (double)n;
-          double p_no = 1.0 - pow(w, (double)ss);
-          p_no = fmax(2.220446049250313e-16, p_no);
-          p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
-          k = log(1.0 - 0.99) / log(p_no);
-        }
-        ++it;
-        if (it > a.max_iterations) { stop = true; break; }
-      }
-      if (winner >= 0 && lane == winner) {
+        double v[3], M[9];
+        for (int c = 0; c < 3; ++c)
+          v[c] = v0[c] + (rng_uniform(a.seed, (unsigned long long)pair, h, 1000 + c) - 0.5) * 2.0 * 0.01;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) best_model[i] = R[i];
-        best_model[9] = t[0]; best_model[10] = t[1]; best_model[11] = t[2];
+        for (int i = 0; i < 36; ++i) Glane[i][lane] = Gl[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        es_minimise<kWave>(&Glane[0][lane], v, (double)ss);
+        es_value_grad<kWave>(&Glane[0][lane], v, nullptr, M);
+        cayley_to_rot(v, R);
+        {
+          double w[3], V[9];
+          sym_eig3(M, w, V);
+          t[0] = V[0]; t[1] = V[3]; t[2] = V[6];
+          // directional evidence sum t.(f1 - R f2) over the sample
+          double ev = t[0] * ev1[0] + t[1] * ev1[1] + t[2] * ev1[2];
+          for (int j = 0; j < ss; ++j) {
+            const int idx = sel[j];
+            const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
+                                  base[(int64_t)5 * stride + idx]};
+            const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
+                                 R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
+            ev -= t[0] * u[0] + t[1] * u[1] + t[2] * u[2];
+          }
+          if (ev < 0.0) { t[0] = -t[0]; t[1] = -t[1]; t[2] = -t[2]; }
+        }
+      }
+      // ---- inlier count of this hypothesis over its whole pair (payload reads are uniform per quarter)
+      int cnt = 0;
+      {
+        const int n_act = active ? n : 0;
+        int n_max = n_act;
+#pragma unroll
+        for (int off = 32; off >= kHypLanes; off >>= 1) {
+          const int o = __shfl_xor(n_max, off);
+          n_max = o > n_max ? o : n_max;
+        }
+        n_max = __builtin_amdgcn_readfirstlane(n_max);
+        for (int i = 0; i < n_max; ++i) {
+          if (i < n_act) {
+            const double f1[3] = {base[i], base[(int64_t)stride + i], base[(int64_t)2 * stride + i]};
+            const double f2[3] = {base[(int64_t)3 * stride + i], base[(int64_t)4 * stride + i],
+                                  base[(int64_t)5 * stride + i]};
+            cnt += reprojection_score(f1, f2, R, t) < a.threshold ? 1 : 0;
+          }
+        }
+      }
+      // ---- consume the 16 hypotheses of every pair in order with the sequential rule
+      int winner = -1;
+      bool go = active;
+      for (int j = 0; j < kHypLanes; ++j) {
+        const int cj = __shfl(cnt, quarter * kHypLanes + j);  // all lanes take part in the exchange
+        if (go && !((double)it < k)) { stop = true; go = false; }
+        if (go) {
+          if (cj > best_count) {
+            best_count = cj;
+            winner = j;
+            const double w = (double)cj / (double)n;
+            double p_no = 1.0 - pow(w, (double)ss);
+            p_no = fmax(2.220446049250313e-16, p_no);
+            p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
+            k = log(1.0 - 0.99) / log(p_no);
+          }
+          ++it;
+          if (it > a.max_iterations) { stop = true; go = false; }
+        }
+      }
+      if (winner >= 0 && sub == winner) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) best_model[quarter][i] = R[i];
+        best_model[quarter][9] = t[0]; best_model[quarter][10] = t[1]; best_model[quarter][11] = t[2];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+  }
+  double bR[9], bt[3] = {0.0, 0.0, 1.0};
 #pragma unroll
-    for (int i = 0; i < 9; ++i) bR[i] = best_model[i];
-    bt[0] = best_model[9]; bt[1] = best_model[10]; bt[2] = best_model[11];
+  for (int i = 0; i < 9; ++i) bR[i] = R0[i];
+  if (can_sample) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) bR[i] = best_model[quarter][i];
+    bt[0] = best_model[quarter][9]; bt[1] = best_model[quarter][10]; bt[2] = best_model[quarter][11];
   }
 
   // ---- inliers of the best model (all correspondences when sampling is impossible), their 36 sums,
@@ -863,13 +910,13 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
   for (int i = 0; i < 36; ++i) acc[i] = 0.0;
   int my_count = 0, my_first = 0x7fffffff;
   const int64_t aos0 = a.offsets[pair];
-  for (int idx = lane; idx < stride; idx += kWave) {
+  for (int idx = sub; idx < n; idx += kHypLanes) {
     const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
     const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
                           base[(int64_t)5 * stride + idx]};
-    bool in = idx < n;
-    if (in && can_sample) in = reprojection_score(f1, f2, bR, bt) < a.threshold;
-    if (idx < n && a.out_mask) a.out_mask[aos0 + idx] = in ? 1 : 0;
+    bool in = true;
+    if (can_sample) in = reprojection_score(f1, f2, bR, bt) < a.threshold;
+    if (a.out_mask) a.out_mask[aos0 + idx] = in ? 1 : 0;
     if (in) {
       ++my_count;
       if (idx < my_first) my_first = idx;
@@ -883,22 +930,18 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
   }
 #pragma unroll
   for (int i = 0; i < 36; ++i) {
-    const double sres = wave_allreduce_sum(acc[i]);
-    if (lane == 0) G[i] = sres;
+    const double sres = row_allreduce_sum(acc[i]);
+    if (sub == 0) G[quarter][i] = sres;
   }
-  const int total = (int)wave_allreduce_sum((double)my_count);
-  int first = my_first;
-  for (int off = 32; off > 0; off >>= 1) {
-    const int o = __shfl_xor(first, off);
-    first = o < first ? o : first;
-  }
+  const int total = (int)row_allreduce_sum((double)my_count);
+  const int first = row_min_int(my_first);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
   // optimizeModelCoefficients: eigensolver on the inliers from the best model's rotation
   double v[3], R[9], M[9];
   rot_to_cayley(bR, v);
-  es_minimise<1>(G, v, (double)(total > 0 ? total : 1));
-  es_value_grad<1>(G, v, nullptr, M);
+  es_minimise<1>(G[quarter], v, (double)(total > 0 ? total : 1));
+  es_value_grad<1>(G[quarter], v, nullptr, M);
   cayley_to_rot(v, R);
   if (total > 0) {
     const int idx = first;
@@ -913,7 +956,7 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
   }
   double w3[3], V[9];
   sym_eig3(M, w3, V);
-  if (lane == 0) {
+  if (sub == 0 && live) {
     double qo[4];
     quat_from_rot_dev(R, qo);
     const double qn = 1.0 / sqrt(qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3]);
@@ -980,10 +1023,12 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   a.out_count = out_count;
   a.out_iterations = out_iterations;
   a.seed = seed;
+  a.n_pairs = n_pairs;
   a.max_iterations = max_iterations;
   a.sample_size = sample_size;
   a.threshold = threshold;
-  hipLaunchKernelGGL(ransac_eigensolver_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
+  hipLaunchKernelGGL(ransac_eigensolver_kernel, dim3((unsigned)((n_pairs + kRansacPairs - 1) / kRansacPairs)),
+                     dim3(kWave), 0, stream, a);
   return hipGetLastError();
 }
 
