@@ -35,12 +35,29 @@ namespace pnec_hip {
 // Works on the 6 unique entries; the rotation angle comes from t = sgn(d) apq / (|d| + hypot(d, apq)),
 // d = (aqq - app) / 2 -- the same t as 1 / (theta + sgn(theta) sqrt(theta^2 + 1)), theta = d / apq,
 // without the division by a vanishing apq -- with v_rcp / v_rsq + Newton instead of IEEE divide/sqrt.
-__device__ void sym_eig3(const double (&A_in)[9], double (&w)[3], double (&V)[9]) {
+// WARM: V holds an orthonormal basis on entry (the eigenvectors of a nearby matrix): the sweeps
+// run on V' A V, which is already almost diagonal, and converge in one or two instead of five.
+template <bool WARM>
+__device__ void sym_eig3_impl(const double (&A_in)[9], double (&w)[3], double (&V)[9]) {
   double A[9];
+  if constexpr (WARM) {
+    double B[9];  // B = A_in V
 #pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    A[i] = A_in[i];
-    V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        B[3 * r + c] = A_in[3 * r] * V[c] + A_in[3 * r + 1] * V[3 + c] + A_in[3 * r + 2] * V[6 + c];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = r; c < 3; ++c)
+        A[3 * r + c] = A[3 * c + r] = V[r] * B[c] + V[3 + r] * B[3 + c] + V[6 + r] * B[6 + c];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      A[i] = A_in[i];
+      V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
   }
   for (int sweep = 0; sweep < 12; ++sweep) {
     const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
@@ -97,6 +114,8 @@ __device__ void sym_eig3(const double (&A_in)[9], double (&w)[3], double (&V)[9]
 #pragma unroll
   for (int i = 0; i < 9; ++i) V[i] = Vs[i];
 }
+__device__ void sym_eig3(const double (&A)[9], double (&w)[3], double (&V)[9]) { sym_eig3_impl<false>(A, w, V); }
+__device__ void sym_eig3_warm(const double (&A)[9], double (&w)[3], double (&V)[9]) { sym_eig3_impl<true>(A, w, V); }
 
 __device__ void cayley_to_rot(const double (&v)[3], double (&R)[9]) {
   const double x = v[0], y = v[1], z = v[2];
@@ -330,13 +349,14 @@ __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double 
 }
 
 // ------------------------------------------------------------------------------------------
+constexpr int kFibStride = 9;  // t (3) | txx tyy tzz | 2 txy, 2 txz, 2 tyz
 struct FrontArgs {
   const double *data;           // SoA payload (12 planes for the weighted stage, >= 6 for NEC)
   const int64_t *block_offset;
   const int32_t *count;
   const double *init_q;  // [n_pairs,4] xyzw
   const double *init_t;  // [n_pairs,3] (weighted stage)
-  const double *fib;     // [500,3] Fibonacci directions
+  const double *fib;     // [500, kFibStride] Fibonacci directions t and their products (fibonacci_table)
   double *out_q;         // [n_pairs,4]
   double *out_t;         // [n_pairs,3]
   int32_t *out_iterations;  // [n_pairs] Newton iterations of the (first) eigensolver call, or null
@@ -560,6 +580,7 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
   int fib_min_idx = -1;  // -1: no stored search yet
   int first_iterations = 0;
   bool rotation_final = false;
+  double Vscf[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
   for (int it = 0; it + 1 < a.weighted_iterations; ++it) {
     // The weights never change (C3), so every round minimises the same function from the previous
     // optimum: once a call has ended for any reason other than the iteration cap, the rotation is
@@ -599,10 +620,17 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
         // 500 Fibonacci directions against the resident (n, B): one direction at a time
 #pragma unroll 2
         for (int c = 0; c < 500; ++c) {
-          const double tx = a.fib[3 * c], ty = a.fib[3 * c + 1], tz = a.fib[3 * c + 2];
+          const double *fc = a.fib + kFibStride * c;  // wave-uniform: scalar loads
+          const double tx = fc[0], ty = fc[1], tz = fc[2];
+          const double txx = fc[3], tyy = fc[4], tzz = fc[5], txy = fc[6], txz = fc[7], tyz = fc[8];
           double sacc = 0.0;
 #pragma unroll
-          for (int k = 0; k < KR; ++k) sacc += energy_term(tx, ty, tz, rn[k], rB[k]);
+          for (int k = 0; k < KR; ++k) {
+            const double aa = tx * rn[k][0] + ty * rn[k][1] + tz * rn[k][2];
+            const double d = rB[k][0] * txx + rB[k][3] * tyy + rB[k][5] * tzz + rB[k][1] * txy + rB[k][2] * txz +
+                             rB[k][4] * tyz;
+            sacc = __builtin_fma(aa * aa, fast_rcp(d), sacc);
+          }
           const double sum = wave_allreduce_sum(sacc);
           if (fib_min_idx < 0 || sum < fib_min_cost) {
             fib_min_cost = sum;
@@ -613,7 +641,7 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
         // streaming: 21 directions at a time, per correspondence n, B rebuilt once per batch
         for (int b0 = 0; b0 < 500; b0 += 21) {
           const int nb = (500 - b0 < 21) ? 500 - b0 : 21;
-          if (lane < nb * 3) cand[lane / 3][lane % 3] = a.fib[3 * b0 + lane];
+          if (lane < nb * 3) cand[lane / 3][lane % 3] = a.fib[kFibStride * (b0 + lane / 3) + lane % 3];
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           double acc[kNumAcc];
 #pragma unroll
@@ -645,9 +673,9 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
     });
     cur_cost = wave_allreduce_sum(cur_cost);
     if (fib_min_idx >= 0 && fib_min_cost < cur_cost) {
-      t[0] = a.fib[3 * fib_min_idx];
-      t[1] = a.fib[3 * fib_min_idx + 1];
-      t[2] = a.fib[3 * fib_min_idx + 2];
+      t[0] = a.fib[kFibStride * fib_min_idx];
+      t[1] = a.fib[kFibStride * fib_min_idx + 1];
+      t[2] = a.fib[kFibStride * fib_min_idx + 2];
     }
     // scf: 10 steps of  t <- eigenvector of the smallest eigenvalue of sum A_i / (t' B_i t)
     for (int step = 0; step < 10; ++step) {
@@ -662,9 +690,9 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
 #pragma unroll
       for (int k = 0; k < 6; ++k) e[k] = wave_allreduce_sum(e[k]);
       const double E[9] = {e[0], e[1], e[2], e[1], e[3], e[4], e[2], e[4], e[5]};
-      double w3[3], V[9];
-      sym_eig3(E, w3, V);
-      t[0] = V[0]; t[1] = V[3]; t[2] = V[6];
+      double w3[3];
+      sym_eig3_warm(E, w3, Vscf);  // E moves little from step to step: start from the last eigenvectors
+      t[0] = Vscf[0]; t[1] = Vscf[3]; t[2] = Vscf[6];
     }
   }
   if (lane == 0) {
@@ -1042,21 +1070,25 @@ hipError_t fibonacci_table(int device, const double **out) {
   std::lock_guard<std::mutex> lock(g_fib_mutex);
   if (device < 0 || device >= 64) return hipErrorInvalidDevice;
   if (!g_fib_dev[device]) {
-    std::vector<double> pts(1500);
+    std::vector<double> pts(kFibStride * 500);
     const int samples = 500;
     const double phi = M_PI * (3.0 - std::sqrt(5.0));
     for (int i = 0; i < samples; ++i) {
       const double y = 1.0 - ((float)i / (float)(samples - 1)) * 2.0;
       const double radius = std::sqrt(1 - y * y);
       const double theta = phi * (float)i;
-      pts[3 * i] = std::cos(theta) * radius;
-      pts[3 * i + 1] = y;
-      pts[3 * i + 2] = std::sin(theta) * radius;
+      double *p = &pts[(size_t)kFibStride * i];
+      p[0] = std::cos(theta) * radius;
+      p[1] = y;
+      p[2] = std::sin(theta) * radius;
+      // products of the direction, for t'Bt = B00 txx + B11 tyy + B22 tzz + B01 (2 txy) + ...
+      p[3] = p[0] * p[0]; p[4] = p[1] * p[1]; p[5] = p[2] * p[2];
+      p[6] = 2.0 * p[0] * p[1]; p[7] = 2.0 * p[0] * p[2]; p[8] = 2.0 * p[1] * p[2];
     }
     double *d = nullptr;
-    hipError_t e = hipMalloc(&d, sizeof(double) * 1500);
+    hipError_t e = hipMalloc(&d, sizeof(double) * pts.size());
     if (e != hipSuccess) return e;
-    e = hipMemcpy(d, pts.data(), sizeof(double) * 1500, hipMemcpyHostToDevice);
+    e = hipMemcpy(d, pts.data(), sizeof(double) * pts.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       (void)hipFree(d);
       return e;
