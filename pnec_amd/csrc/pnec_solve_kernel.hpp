@@ -217,17 +217,26 @@ __device__ __forceinline__ void pass_resident(const double (&d)[REGK][num_compon
 }
 
 // pose -> the correspondence-independent quantities of a pass, as plain doubles
-__device__ __forceinline__ void pose_uniforms(double theta, double phi, const double (&q)[4], double *u) {
+__device__ __forceinline__ void pose_uniforms_sc(double st, double ct, double sp, double cp, const double (&q)[4],
+                                                 double *u) {
   double R[9];
   rot_from_quat(q, R);
-  double st, ct, sp, cp;
-  sincos_bounded(theta, st, ct);
-  sincos_bounded(phi, sp, cp);
 #pragma unroll
   for (int i = 0; i < 9; ++i) u[i] = R[i];
   u[9] = st * cp;   u[10] = st * sp;  u[11] = ct;
   u[12] = ct * cp;  u[13] = ct * sp;  u[14] = -st;
   u[15] = -st * sp; u[16] = st * cp;
+}
+__device__ __forceinline__ void pose_uniforms(double theta, double phi, const double (&q)[4], double *u) {
+  double st, ct, sp, cp;
+  sincos_bounded(theta, st, ct);
+  sincos_bounded(phi, sp, cp);
+  pose_uniforms_sc(st, ct, sp, cp, q, u);
+}
+// value of lane K of the caller's quad (all four lanes of the quad must be active)
+template <int K>
+__device__ __forceinline__ double quad_broadcast(double x) {
+  return dpp_perm<K | (K << 2) | (K << 4) | (K << 6)>(x);
 }
 
 // PNECCeres::Result(): pnec_ceres.cc:201-207
@@ -254,7 +263,7 @@ __device__ __forceinline__ void write_result(const SolveArgs &a, int64_t s, cons
   if (a.out_status) a.out_status[s] = term;
 }
 
-// Advance ONE solve (the calling lane's): consume the sums of the pass at the candidate, run
+// Advance ONE solve (called by the four lanes of a quad, which all do the same): consume the sums of the pass at the candidate, run
 // Ceres' accept/reject + trust-region logic (TrustRegionMinimizer + LevenbergMarquardtStrategy,
 // SURVEY.md Appendix B), and either publish the next candidate (slab + pass uniforms) or
 // terminate.  Returns the termination code, or -1 while the solve goes on.
@@ -339,9 +348,11 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
       for (int i = 0; i < 5; ++i) g[i] = S[1 + i];
 #pragma unroll
       for (int i = 0; i < 15; ++i) H[i] = S[6 + i];
-      gmax = 0.0;
+      if (o.check_convergence) {  // only the gradient-tolerance test reads it
+        gmax = 0.0;
 #pragma unroll
-      for (int i = 0; i < 5; ++i) gmax = fmax(gmax, fabs(g[i]) * ((i >= 2) ? 2.0 : 1.0));
+        for (int i = 0; i < 5; ++i) gmax = fmax(gmax, fabs(g[i]) * ((i >= 2) ? 2.0 : 1.0));
+      }
       if (first) {
         radius = o.initial_trust_region_radius;
       } else {
@@ -357,8 +368,10 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
       slab[kTheta] = x[4];
       slab[kPhi] = x[5];
       slab[kCost] = cost_c;
-      slab[kXNorm] = fast_sqrt(x[4] * x[4] + x[5] * x[5] + x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
-      slab[kGmax] = gmax;
+      if (o.check_convergence) {  // |x| is only read by the parameter-tolerance test
+        slab[kXNorm] = fast_sqrt(x[4] * x[4] + x[5] * x[5] + x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+        slab[kGmax] = gmax;
+      }
 #pragma unroll
       for (int i = 0; i < 5; ++i) slab[kGs + i] = g[i];
 #pragma unroll
@@ -443,19 +456,25 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
       const double thc = x[4] + step[0];
       const double phc = x[5] + step[1];
       const double nd2 = dx * dx + dy * dy + dz * dz;
-      double qc[4] = {x[0], x[1], x[2], x[3]};
-      if (nd2 > 0.0) {
-        const double ind = fast_rsqrt(nd2), nd = nd2 * ind;
-        double sn, aw;
-        sincos_bounded(nd, sn, aw);
-        const double sbd = sn * ind;
-        const double ax = sbd * dx, ay = sbd * dy, az = sbd * dz;
-        qc[0] = aw * x[0] + ax * x[3] + ay * x[2] - az * x[1];
-        qc[1] = aw * x[1] - ax * x[2] + ay * x[3] + az * x[0];
-        qc[2] = aw * x[2] + ax * x[1] - ay * x[0] + az * x[3];
-        qc[3] = aw * x[3] - ax * x[0] - ay * x[1] - az * x[2];
-      }
-      pose_uniforms(thc, phc, qc, unif);
+      const double ind = nd2 > 0.0 ? fast_rsqrt(nd2) : 0.0, nd = nd2 * ind;
+      // the three sine/cosine pairs of the step (|delta|, theta, phi) in ONE evaluation: the caller
+      // runs this function on the four lanes of a quad, identical in all of them up to here; lane
+      // 0 / 1 / 2 takes its own angle and the results are exchanged inside the quad
+      const int role = (int)(threadIdx.x & 3);
+      const double angle = role == 0 ? nd : (role == 1 ? thc : phc);
+      double sa, ca;
+      sincos_bounded(angle, sa, ca);
+      const double sn = quad_broadcast<0>(sa), aw = quad_broadcast<0>(ca);
+      const double st = quad_broadcast<1>(sa), ct = quad_broadcast<1>(ca);
+      const double sp = quad_broadcast<2>(sa), cp = quad_broadcast<2>(ca);
+      const double sbd = sn * ind;  // sin|delta| / |delta| (0 for a zero step: qc = x)
+      const double ax = sbd * dx, ay = sbd * dy, az = sbd * dz;
+      double qc[4];
+      qc[0] = aw * x[0] + ax * x[3] + ay * x[2] - az * x[1];
+      qc[1] = aw * x[1] - ax * x[2] + ay * x[3] + az * x[0];
+      qc[2] = aw * x[2] + ax * x[1] - ay * x[0] + az * x[3];
+      qc[3] = aw * x[3] - ax * x[0] - ay * x[1] - az * x[2];
+      pose_uniforms_sc(st, ct, sp, cp, qc, unif);
 #pragma unroll
       for (int k = 0; k < 4; ++k) slab[kQc + k] = qc[k];
       slab[kThetaC] = thc;
@@ -627,7 +646,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
     // the chain below is latency-bound: let it win the issue arbitration against the pass of the
     // other wavefront on this SIMD, which has independent work to fill the gaps (+1.2 %)
     __builtin_amdgcn_s_setprio(3);
-    if (lane == 0) t = lm_advance(slab, ist, unif, o);
+    if (lane < 4) t = lm_advance(slab, ist, unif, o);  // one quad, identical work (see the sincos exchange)
     term = to_sgpr(t);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
