@@ -19,7 +19,7 @@
 //   * a pass ends with the 21 sums in a per-wavefront LDS slab (swap-halving + LDS-crossbar
 //     reduction, pnec_device.hpp);
 //   * everything that is one value per solve -- accept/reject, trust region, the 5x5 solve, the
-//     manifold update, the next pose's uniforms (lm_advance) -- runs in lane 0 on LDS-resident
+//     manifold update, the next pose's uniforms (lm_advance) -- runs in one quad on LDS-resident
 //     state (~80 doubles per wavefront): a ~500-instruction latency chain that the SIMD's other
 //     wavefront hides under its pass.  (Measured dead ends, DESIGN.md section 6: narrowing EXEC
 //     does not shorten the issue time of that chain, and sharing one chain between the
@@ -551,8 +551,9 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
 
   // ---- PNECCeres::InitValues(q, t): pnec_ceres.cc:182-186.  The start point is the first
   // "candidate"; the loop's first pass evaluates it (Ceres' iteration zero).
-  // Everything that is one value per solve -- here and in lm_advance below -- runs in lane 0
-  // only: a wavefront instruction with one live 16-lane quarter issues in a quarter of the time.
+  // Everything that is one value per solve runs in a few lanes only (here lane 0, lm_advance on
+  // a quad) against the LDS slab: not faster to issue (measured), but one copy of the state and
+  // plain per-lane control flow instead of wave-uniform bookkeeping in scalar registers.
   if (lane == 0) {
     double th, ph;
     const double *t0 = a.hyp_t ? a.hyp_t + 3 * s : a.init_t + 3 * pair;
