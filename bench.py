@@ -223,7 +223,10 @@ def main():
                 "note": "register-resident design: the payload (96 B/correspondence) is read from HBM "
                         "once per solve, not once per pass, so the kernel is FP64-VALU-bound, not "
                         "HBM-bound; see 'valu' for the binding roof and DESIGN.md",
+                # SURVEY.md 8(d) quotes the streaming model (N x 96 B x passes per solve); against it:
                 "streaming_equivalent_GBs": achieved_gbs * passes,
+                "streaming_equivalent_frac": achieved_gbs * passes / HBM_PEAK_GBS,
+                "streaming_bytes_per_solve": batch.payload_bytes // args.pairs * passes,
                 "valu": {"bound": "valu_fp64", "achieved": valu_tflops, "peak": FP64_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": valu_tflops / FP64_VALU_PEAK_TFLOPS,
                          "flop_per_corr_pass": FLOP_PER_CORR_PASS, "passes": passes},
