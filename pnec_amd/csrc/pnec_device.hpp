@@ -90,15 +90,10 @@ __device__ __forceinline__ void sincos_bounded(double x, double &s, double &c) {
 template <int CTRL>
 __device__ __forceinline__ double dpp_perm(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-#ifdef PNEC_DPP_OLD
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
-#else
   // every lane is written (full masks, in-row permutations): no "old" value to preserve, so the
   // compiler need not copy the source first
   lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
   hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
-#endif
   return make_double(hi, lo);
 }
 // lane ^ XOR inside a group of 32 through the LDS crossbar (ds_swizzle_b32, bit-mask mode): the
@@ -155,17 +150,21 @@ __device__ __forceinline__ double swap_add16(double x, double y) {
   const auto b = __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
   return make_double((int)b[0], (int)a[0]) + make_double((int)b[1], (int)a[1]);
 }
+// Sum over the 16 lanes of each DPP row.  Two forms: DPP moves (VALU: 2 moves + 1 add per level)
+// or the LDS crossbar (ds_swizzle: 1 add per level on the VALU, but an LDS round trip of latency
+// per level).  Measured on the solver: with the LM step's latency chain in
+// the same wavefront, the four extra round trips cost more than the 48 VALU slots they save.
 __device__ __forceinline__ double row_allreduce_sum(double x) {
-#ifdef PNEC_ROW_DPP
-  x += dpp_perm<0xB1>(x);
-  x += dpp_perm<0x4E>(x);
-  x += dpp_perm<0x141>(x);
-  x += dpp_perm<0x140>(x);
-#else
+#ifdef PNEC_ROW_SWIZZLE
   x += swizzle_xor<1>(x);
   x += swizzle_xor<2>(x);
   x += swizzle_xor<4>(x);
   x += swizzle_xor<8>(x);
+#else
+  x += dpp_perm<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += dpp_perm<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += dpp_perm<0x141>(x);  // row_half_mirror
+  x += dpp_perm<0x140>(x);  // row_mirror
 #endif
   return x;
 }
