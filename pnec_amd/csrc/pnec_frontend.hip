@@ -798,6 +798,7 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
   __shared__ double G[kRansacPairs][36];
   __shared__ double Glane[36][kWave];  // one table of 36 sums per hypothesis (lane), interleaved
   __shared__ double best_model[kRansacPairs][12];  // R (9) + t (3)
+  __shared__ double tile[kRansacPairs][6][kWave];   // bearings of 64 correspondences per pair (scoring)
   double q0[4] = {a.init_q[4 * pair], a.init_q[4 * pair + 1], a.init_q[4 * pair + 2], a.init_q[4 * pair + 3]};
   {
     const double qn = 1.0 / sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
@@ -884,13 +885,28 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
           n_max = o > n_max ? o : n_max;
         }
         n_max = __builtin_amdgcn_readfirstlane(n_max);
-        for (int i = 0; i < n_max; ++i) {
-          if (i < n_act) {
-            const double f1[3] = {base[i], base[(int64_t)stride + i], base[(int64_t)2 * stride + i]};
-            const double f2[3] = {base[(int64_t)3 * stride + i], base[(int64_t)4 * stride + i],
-                                  base[(int64_t)5 * stride + i]};
-            cnt += reprojection_score(f1, f2, R, t) < a.threshold ? 1 : 0;
+        // tiles of 64 correspondences per pair staged in LDS by the pair's 16 lanes (coalesced), then
+        // read back quarter-uniformly: an L2 round trip per correspondence was what this loop waited on
+        for (int i0 = 0; i0 < n_max; i0 += kWave) {
+#pragma unroll
+          for (int r = 0; r < kWave / kHypLanes; ++r) {
+            const int j = sub + kHypLanes * r, idx = i0 + j;
+            const bool in = idx < n_act;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) tile[quarter][c][j] = in ? base[(int64_t)c * stride + idx] : 0.0;
           }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const int left = n_max - i0 < kWave ? n_max - i0 : kWave;
+#pragma unroll 4
+          for (int j = 0; j < left; ++j) {
+            const double f1[3] = {tile[quarter][0][j], tile[quarter][1][j], tile[quarter][2][j]};
+            const double f2[3] = {tile[quarter][3][j], tile[quarter][4][j], tile[quarter][5][j]};
+            // padding entries are zeros: their score is NaN and never counts
+            cnt += (i0 + j < n_act && reprojection_score(f1, f2, R, t) < a.threshold) ? 1 : 0;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
         }
       }
       // ---- consume the 16 hypotheses of every pair in order with the sequential rule
