@@ -692,7 +692,11 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
       const double E[9] = {e[0], e[1], e[2], e[1], e[3], e[4], e[2], e[4], e[5]};
       double w3[3];
       sym_eig3_warm(E, w3, Vscf);  // E moves little from step to step: start from the last eigenvectors
+      const double moved = fmax(fabs(Vscf[0] - t[0]), fmax(fabs(Vscf[3] - t[1]), fabs(Vscf[6] - t[2])));
       t[0] = Vscf[0]; t[1] = Vscf[3]; t[2] = Vscf[6];
+      // the iteration has reached its fixed point to rounding (a few ulp): the remaining steps of
+      // the reference's fixed count of 10 would only reproduce that noise
+      if (moved <= 4e-15) break;
     }
   }
   if (lane == 0) {
