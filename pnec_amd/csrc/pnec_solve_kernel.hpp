@@ -107,12 +107,12 @@ enum : int { kIIter = 0, kIFirst, kIReuseDiag, kINumInvalid, kIStepOk, kINumI = 
 
 // Which (family, geometry) pairs are built: the payload must fit the 160 KB LDS and the
 // register budget of its occupancy target (<= 72 doubles of payload per lane at two wavefronts
-// per SIMD; the (8,W,0) shape runs one wavefront per SIMD with AGPR parking, 12 planes at most).
+// per SIMD; the (8,W,0) shape runs one wavefront per SIMD with AGPR parking).
 __host__ __device__ constexpr bool geometry_ok(int mode, int cpl, int wpp, int ldsk) {
   const int nc = num_components(mode);
   const long lds = (long)wpp * (ldsk * nc * kWave * 8 + (kSlab + kUnif) * 8 + kINumI * 4) + (wpp > 1 ? 2L * wpp * kSumSlots * 8 : 0);
   if (lds > 160 * 1024) return false;
-  if (cpl == 8 && ldsk == 0) return nc <= 12;
+  if (cpl == 8 && ldsk == 0) return nc <= 18;
   return nc * (cpl - ldsk) <= 72;
 }
 
