@@ -214,6 +214,12 @@ int pnec_hip_describe_launch(const pnec_hip_problem *p, const pnec_hip_options *
  * and the reciprocal / reciprocal-square-root refinements.  0 = all good. */
 int pnec_hip_selftest(int device);
 
+/* The library keeps freed device buffers of >= 1 MiB for reuse (batches are created and destroyed
+ * per frame set in a pipeline; hipMalloc/hipFree of GB-sized buffers are slow).  Cap: environment
+ * variable PNEC_HIP_CACHE_MB (default 16384, 0 disables).  This call returns the cached buffers
+ * of `device` (-1: all devices) to the driver; returns the number of bytes released. */
+int64_t pnec_hip_release_cache(int device);
+
 #ifdef __cplusplus
 }
 #endif

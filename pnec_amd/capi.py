@@ -50,6 +50,7 @@ SYMBOLS = [
     "pnec_hip_unscented_transform",
     "pnec_hip_describe_launch",
     "pnec_hip_selftest",
+    "pnec_hip_release_cache",
 ]
 
 
@@ -125,6 +126,8 @@ def lib() -> C.CDLL:
     L.pnec_hip_problem_select.argtypes = [_vp, _vp, C.c_int, _vp, C.POINTER(_vp)]
     L.pnec_hip_weighted_eigensolver.argtypes = [_vp, _vp, _vp, C.c_double, C.c_int32, _vp, _vp, C.c_int, _vp]
     L.pnec_hip_selftest.argtypes = [C.c_int]
+    L.pnec_hip_release_cache.argtypes = [C.c_int]
+    L.pnec_hip_release_cache.restype = C.c_int64
     _lib = L
     return L
 

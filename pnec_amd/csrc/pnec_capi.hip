@@ -8,6 +8,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
+#include <mutex>
 #include <vector>
 
 #include "pnec_device.hpp"
@@ -87,6 +89,98 @@ int fail_hip(hipError_t e, const char *what) {
     hipError_t e_ = (expr);                              \
     if (e_ != hipSuccess) return fail_hip(e_, #expr);    \
   } while (0)
+
+// ---- device memory with a small cache --------------------------------------------------------
+// Batches come and go in pipelines (create -> select -> destroy every frame set), and hipMalloc /
+// hipFree of GB-sized buffers cost up to hundreds of ms on some boxes.  Freed blocks of >= 1 MiB are
+// kept (per device, up to PNEC_HIP_CACHE_MB, default 16384) and handed out again to requests of
+// [size/2, size]; pnec_hip_release_cache() returns them to the driver.  A block is only cached after
+// the device has drained (what hipFree does implicitly), so a new owner never races an old kernel.
+struct DevBlock {
+  void *ptr;
+  size_t bytes;
+  int device;
+};
+std::mutex g_mem_mutex;
+std::unordered_map<void *, DevBlock> g_live;  // every block handed out
+std::vector<DevBlock> g_cache;               // free blocks kept for reuse
+size_t g_cached_bytes = 0;
+
+size_t cache_limit_bytes() {
+  static const size_t limit = [] {
+    const char *e = std::getenv("PNEC_HIP_CACHE_MB");
+    return (size_t)(e && *e ? std::strtoull(e, nullptr, 10) : 16384ull) << 20;
+  }();
+  return limit;
+}
+
+void release_cache_locked(int device /* -1: all */) {
+  for (size_t i = 0; i < g_cache.size();) {
+    if (device < 0 || g_cache[i].device == device) {
+      (void)hipFree(g_cache[i].ptr);
+      g_cached_bytes -= g_cache[i].bytes;
+      g_cache[i] = g_cache.back();
+      g_cache.pop_back();
+    } else {
+      ++i;
+    }
+  }
+}
+
+template <typename T>
+hipError_t dev_alloc(T **out, size_t bytes) {
+  *out = nullptr;
+  if (bytes == 0) bytes = 1;
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(g_mem_mutex);
+  size_t best = g_cache.size();
+  for (size_t i = 0; i < g_cache.size(); ++i)
+    if (g_cache[i].device == device && g_cache[i].bytes >= bytes && g_cache[i].bytes <= 2 * bytes &&
+        (best == g_cache.size() || g_cache[i].bytes < g_cache[best].bytes))
+      best = i;
+  DevBlock b{nullptr, bytes, device};
+  if (best != g_cache.size()) {
+    b = g_cache[best];
+    g_cached_bytes -= b.bytes;
+    g_cache[best] = g_cache.back();
+    g_cache.pop_back();
+  } else {
+    e = hipMalloc(&b.ptr, bytes);
+    if (e != hipSuccess) {  // out of memory: give the cache back and try once more
+      (void)hipGetLastError();
+      release_cache_locked(device);
+      e = hipMalloc(&b.ptr, bytes);
+      if (e != hipSuccess) return e;
+    }
+  }
+  g_live[b.ptr] = b;
+  *out = static_cast<T *>(b.ptr);
+  return hipSuccess;
+}
+
+hipError_t dev_free(void *ptr) {
+  if (!ptr) return hipSuccess;
+  std::lock_guard<std::mutex> lock(g_mem_mutex);
+  auto it = g_live.find(ptr);
+  if (it == g_live.end()) return hipFree(ptr);
+  const DevBlock b = it->second;
+  g_live.erase(it);
+  if (b.bytes >= (1u << 20) && g_cached_bytes + b.bytes <= cache_limit_bytes()) {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(b.device);
+    const hipError_t e = hipDeviceSynchronize();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (e == hipSuccess) {
+      g_cache.push_back(b);
+      g_cached_bytes += b.bytes;
+      return hipSuccess;
+    }
+  }
+  return hipFree(ptr);
+}
 
 struct DeviceGuard {
   int prev = -1;
@@ -445,24 +539,24 @@ int ensure_buckets(pnec_hip_problem *p) {
     p->buckets.push_back(bk);
     flat.insert(flat.end(), lists[(size_t)b].begin(), lists[(size_t)b].end());
   }
-  PNEC_HIP_TRY(hipMalloc(&p->d_bucket_pairs, sizeof(int32_t) * flat.size()));
+  PNEC_HIP_TRY(dev_alloc(&p->d_bucket_pairs, sizeof(int32_t) * flat.size()));
   PNEC_HIP_TRY(hipMemcpy(p->d_bucket_pairs, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice));
   return 0;
 }
 
 int ensure_stage(pnec_hip_problem *p, int64_t doubles, int64_t ints) {
   if (doubles > p->stage_doubles) {
-    if (p->d_stage) (void)hipFree(p->d_stage);
+    if (p->d_stage) (void)dev_free(p->d_stage);
     p->d_stage = nullptr;
     p->stage_doubles = 0;
-    PNEC_HIP_TRY(hipMalloc(&p->d_stage, sizeof(double) * doubles));
+    PNEC_HIP_TRY(dev_alloc(&p->d_stage, sizeof(double) * doubles));
     p->stage_doubles = doubles;
   }
   if (ints > p->stage_ints) {
-    if (p->d_stage_i) (void)hipFree(p->d_stage_i);
+    if (p->d_stage_i) (void)dev_free(p->d_stage_i);
     p->d_stage_i = nullptr;
     p->stage_ints = 0;
-    PNEC_HIP_TRY(hipMalloc(&p->d_stage_i, sizeof(int32_t) * ints));
+    PNEC_HIP_TRY(dev_alloc(&p->d_stage_i, sizeof(int32_t) * ints));
     p->stage_ints = ints;
   }
   return 0;
@@ -547,13 +641,13 @@ int pnec_hip_problem_create(int device, int mode, int64_t n_pairs, const int64_t
     return fail_hip(e, what);
   };
   hipError_t e;
-  if ((e = hipMalloc(&p->d_data, sizeof(double) * std::max<int64_t>(total, 1))) != hipSuccess)
+  if ((e = dev_alloc(&p->d_data, sizeof(double) * std::max<int64_t>(total, 1))) != hipSuccess)
     return cleanup(e, "hipMalloc(data)");
-  if ((e = hipMalloc(&p->d_block_offset, sizeof(int64_t) * std::max<int64_t>(n_pairs, 1))) != hipSuccess)
+  if ((e = dev_alloc(&p->d_block_offset, sizeof(int64_t) * std::max<int64_t>(n_pairs, 1))) != hipSuccess)
     return cleanup(e, "hipMalloc(block_offset)");
-  if ((e = hipMalloc(&p->d_offsets, sizeof(int64_t) * (n_pairs + 1))) != hipSuccess)
+  if ((e = dev_alloc(&p->d_offsets, sizeof(int64_t) * (n_pairs + 1))) != hipSuccess)
     return cleanup(e, "hipMalloc(offsets)");
-  if ((e = hipMalloc(&p->d_count, sizeof(int32_t) * std::max<int64_t>(n_pairs, 1))) != hipSuccess)
+  if ((e = dev_alloc(&p->d_count, sizeof(int32_t) * std::max<int64_t>(n_pairs, 1))) != hipSuccess)
     return cleanup(e, "hipMalloc(count)");
   if (n_pairs > 0) {
     if ((e = hipMemcpy(p->d_block_offset, block_offset.data(), sizeof(int64_t) * n_pairs,
@@ -573,13 +667,13 @@ int pnec_hip_problem_create(int device, int mode, int64_t n_pairs, const int64_t
 int pnec_hip_problem_destroy(pnec_hip_problem *p) {
   if (!p) return 0;
   DeviceGuard guard(p->device);
-  if (p->d_data) (void)hipFree(p->d_data);
-  if (p->d_block_offset) (void)hipFree(p->d_block_offset);
-  if (p->d_offsets) (void)hipFree(p->d_offsets);
-  if (p->d_count) (void)hipFree(p->d_count);
-  if (p->d_stage) (void)hipFree(p->d_stage);
-  if (p->d_stage_i) (void)hipFree(p->d_stage_i);
-  if (p->d_bucket_pairs) (void)hipFree(p->d_bucket_pairs);
+  if (p->d_data) (void)dev_free(p->d_data);
+  if (p->d_block_offset) (void)dev_free(p->d_block_offset);
+  if (p->d_offsets) (void)dev_free(p->d_offsets);
+  if (p->d_count) (void)dev_free(p->d_count);
+  if (p->d_stage) (void)dev_free(p->d_stage);
+  if (p->d_stage_i) (void)dev_free(p->d_stage_i);
+  if (p->d_bucket_pairs) (void)dev_free(p->d_bucket_pairs);
   delete p;
   return 0;
 }
@@ -604,7 +698,7 @@ int pnec_hip_problem_fill(pnec_hip_problem *p, int64_t first_pair, int64_t n_pai
   double *tmp = nullptr;
   if (space == PNEC_HIP_MEM_HOST && m > 0) {
     const int64_t per = 6 + (p->nc >= 12 ? 9 : 0) + (p->nc >= 18 ? 9 : 0);
-    PNEC_HIP_TRY(hipMalloc(&tmp, sizeof(double) * per * m));
+    PNEC_HIP_TRY(dev_alloc(&tmp, sizeof(double) * per * m));
     double *w = tmp;
     auto up = [&](const double *src, int64_t k, const double **dst) -> hipError_t {
       *dst = w;
@@ -617,7 +711,7 @@ int pnec_hip_problem_fill(pnec_hip_problem *p, int64_t first_pair, int64_t n_pai
     if (e == hipSuccess && p->nc >= 12) e = up(covs, 9, &d_c);
     if (e == hipSuccess && p->nc >= 18) e = up(covs_host, 9, &d_ch);
     if (e != hipSuccess) {
-      (void)hipFree(tmp);
+      (void)dev_free(tmp);
       return fail_hip(e, "hipMemcpyAsync(H2D)");
     }
   } else if (space != PNEC_HIP_MEM_DEVICE && space != PNEC_HIP_MEM_HOST) {
@@ -645,7 +739,7 @@ int pnec_hip_problem_fill(pnec_hip_problem *p, int64_t first_pair, int64_t n_pai
   hipError_t e = hipGetLastError();
   if (tmp) {
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(tmp);
+    (void)dev_free(tmp);
   }
   if (e != hipSuccess) return fail_hip(e, "pack_kernel");
   return 0;
@@ -758,7 +852,7 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
   const char *trace_path = std::getenv("PNEC_HIP_TRACE");
   unsigned long long *d_trace = nullptr;
   if (trace_path && *trace_path) {
-    PNEC_HIP_TRY(hipMalloc(&d_trace, sizeof(unsigned long long) * 4 * S));
+    PNEC_HIP_TRY(dev_alloc(&d_trace, sizeof(unsigned long long) * 4 * S));
     PNEC_HIP_TRY(hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 4 * S, stream));
     a.trace = d_trace;
   }
@@ -784,7 +878,7 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
     std::vector<unsigned long long> h(4 * (size_t)S);
     hipError_t te = hipStreamSynchronize(stream);
     if (te == hipSuccess) te = hipMemcpy(h.data(), d_trace, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
-    (void)hipFree(d_trace);
+    (void)dev_free(d_trace);
     if (te == hipSuccess) {
       if (FILE *f = std::fopen(trace_path, "ab")) {
         std::fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
@@ -820,13 +914,13 @@ int pnec_hip_select_best(int64_t n_pairs, int32_t n_hyp, const double *cost, int
   double *tmp_c = nullptr;
   int32_t *tmp_b = nullptr;
   if (space == PNEC_HIP_MEM_HOST) {
-    PNEC_HIP_TRY(hipMalloc(&tmp_c, sizeof(double) * n_pairs * n_hyp));
-    hipError_t e = hipMalloc(&tmp_b, sizeof(int32_t) * n_pairs);
+    PNEC_HIP_TRY(dev_alloc(&tmp_c, sizeof(double) * n_pairs * n_hyp));
+    hipError_t e = dev_alloc(&tmp_b, sizeof(int32_t) * n_pairs);
     if (e == hipSuccess)
       e = hipMemcpyAsync(tmp_c, cost, sizeof(double) * n_pairs * n_hyp, hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) {
-      (void)hipFree(tmp_c);
-      if (tmp_b) (void)hipFree(tmp_b);
+      (void)dev_free(tmp_c);
+      if (tmp_b) (void)dev_free(tmp_b);
       return fail_hip(e, "select_best staging");
     }
     d_cost = tmp_c;
@@ -839,8 +933,8 @@ int pnec_hip_select_best(int64_t n_pairs, int32_t n_hyp, const double *cost, int
     if (e == hipSuccess)
       e = hipMemcpyAsync(best_index, tmp_b, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(tmp_c);
-    (void)hipFree(tmp_b);
+    (void)dev_free(tmp_c);
+    (void)dev_free(tmp_b);
   }
   if (e != hipSuccess) return fail_hip(e, "select_best_kernel");
   return 0;
@@ -954,7 +1048,7 @@ int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint6
     d_cnt = p->d_stage_i;
     d_it = p->d_stage_i + P;
     if (out_inlier_mask) {
-      PNEC_HIP_TRY(hipMalloc(&tmp_mask, (size_t)std::max<int64_t>(M, 1)));
+      PNEC_HIP_TRY(dev_alloc(&tmp_mask, (size_t)std::max<int64_t>(M, 1)));
       d_mask = tmp_mask;
     }
   }
@@ -972,7 +1066,7 @@ int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint6
       e = hipMemcpyAsync(out_ransac_iterations, d_it, sizeof(int32_t) * P, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
   }
-  if (tmp_mask) (void)hipFree(tmp_mask);
+  if (tmp_mask) (void)dev_free(tmp_mask);
   if (e != hipSuccess) return fail_hip(e, "ransac_eigensolver_kernel");
   return 0;
 }
@@ -991,17 +1085,17 @@ int pnec_hip_problem_select(pnec_hip_problem *src, const uint8_t *mask, int spac
   int32_t *d_cnt = nullptr;
   std::vector<int32_t> counts((size_t)P);
   auto cleanup = [&]() {
-    if (tmp_mask) (void)hipFree(tmp_mask);
-    if (d_cnt) (void)hipFree(d_cnt);
+    if (tmp_mask) (void)dev_free(tmp_mask);
+    if (d_cnt) (void)dev_free(d_cnt);
   };
   if (space == PNEC_HIP_MEM_HOST && M > 0) {
-    PNEC_HIP_TRY(hipMalloc(&tmp_mask, (size_t)M));
+    PNEC_HIP_TRY(dev_alloc(&tmp_mask, (size_t)M));
     hipError_t e = hipMemcpyAsync(tmp_mask, mask, (size_t)M, hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) { cleanup(); return fail_hip(e, "mask upload"); }
     d_mask = tmp_mask;
   }
   if (P > 0) {
-    hipError_t e = hipMalloc(&d_cnt, sizeof(int32_t) * P);
+    hipError_t e = dev_alloc(&d_cnt, sizeof(int32_t) * P);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)P), dim3(kWave), 0, stream, d_mask, src->d_offsets,
                          src->d_count, d_cnt);
@@ -1043,7 +1137,7 @@ int pnec_hip_unscented_transform(int64_t n, const double *mu, const double *covs
   const double *d_mu = mu, *d_cov = covs, *d_K = K_inv;
   double *d_ob = out_bvs, *d_oc = out_covs, *tmp = nullptr;
   if (space == PNEC_HIP_MEM_HOST) {
-    PNEC_HIP_TRY(hipMalloc(&tmp, sizeof(double) * (24 * n + 9)));
+    PNEC_HIP_TRY(dev_alloc(&tmp, sizeof(double) * (24 * n + 9)));
     double *w = tmp;
     hipError_t e = hipMemcpyAsync(w, mu, sizeof(double) * 3 * n, hipMemcpyHostToDevice, stream);
     d_mu = w; w += 3 * n;
@@ -1054,7 +1148,7 @@ int pnec_hip_unscented_transform(int64_t n, const double *mu, const double *covs
     d_oc = w; w += 9 * n;
     d_ob = out_bvs ? w : nullptr;
     if (e != hipSuccess) {
-      (void)hipFree(tmp);
+      (void)dev_free(tmp);
       return fail_hip(e, "unscented_transform staging");
     }
   } else if (space != PNEC_HIP_MEM_DEVICE) {
@@ -1068,7 +1162,7 @@ int pnec_hip_unscented_transform(int64_t n, const double *mu, const double *covs
     if (e == hipSuccess && out_bvs)
       e = hipMemcpyAsync(out_bvs, d_ob, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(tmp);
+    (void)dev_free(tmp);
   }
   if (e != hipSuccess) return fail_hip(e, "unscented_kernel");
   return 0;
@@ -1078,12 +1172,12 @@ int pnec_hip_selftest(int device) {
   DeviceGuard guard(device);
   if (!guard.ok) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "hipSetDevice failed");
   double *d = nullptr;
-  PNEC_HIP_TRY(hipMalloc(&d, sizeof(double) * 160));
+  PNEC_HIP_TRY(dev_alloc(&d, sizeof(double) * 160));
   hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(kWave), 0, 0, d);
   double h[160];
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(double) * 152, hipMemcpyDeviceToHost);
-  (void)hipFree(d);
+  (void)dev_free(d);
   if (e != hipSuccess) return fail_hip(e, "selftest_kernel");
   for (int i = 0; i < kWave; ++i)
     if (h[i] != 89440.0) {
@@ -1108,6 +1202,13 @@ int pnec_hip_selftest(int device) {
       return fail(PNEC_HIP_ERR_HIP_RUNTIME, buf);
     }
   return 0;
+}
+
+int64_t pnec_hip_release_cache(int device) {
+  std::lock_guard<std::mutex> lock(g_mem_mutex);
+  const size_t before = g_cached_bytes;
+  release_cache_locked(device);
+  return (int64_t)(before - g_cached_bytes);
 }
 
 }  // extern "C"

@@ -203,7 +203,7 @@ __device__ __forceinline__ void pass_resident(const double (&d)[REGK][num_compon
   // scheduler hoist every slot's 12 loads and blows the 256-register budget)
 #pragma unroll 1
   for (int k = 0; k < LDSK; ++k) {
-    unsigned long long m = lanes_valid[REGK];
+    unsigned long long m = lanes_valid[LDSK > 0 ? REGK : 0];
 #pragma unroll
     for (int i = 1; i < LDSK; ++i) m = (k == i) ? lanes_valid[REGK + i] : m;
     if (m == 0ull) continue;

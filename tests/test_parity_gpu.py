@@ -479,3 +479,20 @@ def test_ransac_eigensolver_and_inlier_selection_device_vs_oracle(oracle):
         for p in (0, 1, 2):
             assert _rot_err(oracle, _quat_to_R(res.q[p]), g.R_gt[p].numpy()) < 0.01
         sel.close()
+
+
+def test_device_buffer_cache_reuses_and_releases():
+    """batches created and destroyed in a loop reuse cached device buffers; release_cache returns them"""
+    L = capi.lib()
+    L.pnec_hip_release_cache(-1)
+    offsets = np.arange(4001, dtype=np.int64) * 64          # 4000 pairs x 64 corr: a ~25 MB payload
+    g = sim.generate(4, 64, seed=3)
+    for _ in range(3):
+        with Batch(capi.MODE_TARGET, offsets) as b:
+            b.fill(np.tile(g.bvs1.reshape(-1, 3).numpy(), (1000, 1)), np.tile(g.bvs2.reshape(-1, 3).numpy(), (1000, 1)),
+                   np.tile(g.covs2.reshape(-1, 3, 3).numpy(), (1000, 1, 1)))
+            res = b.solve(np.tile(g.init_q.numpy(), (1000, 1)), np.tile(g.init_t.numpy(), (1000, 1)))
+            assert np.isfinite(res.q).all()
+    released = L.pnec_hip_release_cache(-1)
+    assert released >= 20 * 1024 * 1024          # the payload buffer was being kept
+    assert L.pnec_hip_release_cache(-1) == 0

@@ -45,7 +45,7 @@ def timed(fn, reps=3):
 
 t_nec, (qn, tn) = timed(lambda: batch.nec_eigensolver(q0))
 t_ran, (qr, tr, mask, cnt, its) = timed(lambda: batch.ransac_eigensolver(q0, seed=1))
-t_sel, sel = timed(lambda: batch.select(mask), reps=1)
+t_sel, sel = timed(lambda: batch.select(mask))
 t_wes, (qw, tw) = timed(lambda: sel.weighted_eigensolver(qr, tr, 1e-13, 10))
 t_ls, res = timed(lambda: sel.solve(qw, tw))
 Rg = torch.cat([sim.generate(min(5000, B - c), N, seed=1 + c, device=dev).R_gt for c in range(0, min(B, 5000), 5000)])
