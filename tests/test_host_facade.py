@@ -132,3 +132,45 @@ def test_solve_batch_runs_the_default_pipeline_for_a_ragged_batch(oracle):
         s = oracle.solve(oracle.MODE_NEC, b1[p], b2[p], None, None, 0.0, oracle.quat_from_rot(Ro), to,
                          oracle.default_options())
         assert math.radians(oracle.rotational_difference_deg(out2[p][:3, :3], s.R)) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_solve_batch_survives_degenerate_pairs():
+    """empty / tiny / NaN / all-identical / zero-covariance / outlier-dominated pairs in one ragged
+    batch, under every Options branch of PNEC::Solve: no error, one pose per pair, and the clean
+    pairs are unaffected by their neighbours"""
+    import pypnec
+    rng = np.random.default_rng(123)
+    B = 40
+    sizes = [int(x) for x in rng.choice([0, 1, 5, 9, 10, 11, 30, 64, 65, 128, 129, 300, 512, 513, 700], size=B)]
+    g = sim.generate(B, 700, seed=500)
+    b1 = [g.bvs1[p, :n].numpy().copy() for p, n in enumerate(sizes)]
+    b2 = [g.bvs2[p, :n].numpy().copy() for p, n in enumerate(sizes)]
+    cv = [g.covs2[p, :n].numpy().copy() for p, n in enumerate(sizes)]
+    clean = []
+    for p, n in enumerate(sizes):
+        kind = int(rng.integers(0, 5)) if n > 0 else 4
+        if kind == 0:
+            bad = rng.choice(n, max(1, n * 7 // 10), replace=False)
+            v = rng.normal(size=(len(bad), 3))
+            b2[p][bad] = v / np.linalg.norm(v, axis=1, keepdims=True)
+        elif kind == 1:
+            b2[p][rng.integers(0, n)] = np.nan
+        elif kind == 2:
+            b1[p][:] = b1[p][0]
+            b2[p][:] = b2[p][0]
+        elif kind == 3:
+            cv[p][:] = 0.0
+        clean.append(kind == 4 and n >= 64)
+    assert sum(clean) >= 3
+    poses = [_pose4(g.init_R[p].numpy(), g.init_t[p].numpy()) for p in range(B)]
+    for kw in (dict(), dict(use_ransac=False), dict(use_nec=True), dict(weighted_iterations=1), dict(use_ceres=False)):
+        out, inl = pypnec.solve_batch(b1, b2, cv, poses, **kw)
+        assert len(out) == B and len(inl) == B
+        for p in range(B):
+            if clean[p]:
+                assert np.isfinite(out[p]).all()
+                R = out[p][:3, :3]
+                assert np.allclose(R @ R.T, np.eye(3), atol=1e-9)
+                err = np.degrees(np.arccos(np.clip((np.trace(R.T @ g.R_gt[p].numpy()) - 1) / 2, -1, 1)))
+                assert err < 1.0, (kw, p, sizes[p], err)
