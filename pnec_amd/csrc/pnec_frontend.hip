@@ -179,8 +179,11 @@ __device__ __forceinline__ void cross3(const double (&a)[3], const double (&b)[3
 //     = sum_k X_kk + sum_{k<l} (X_kl + X_kl'),   X_kl = [r_k]x G_kl [r_l]x'
 // with the skew products written as cross products: row j of [a]x G is a x g_j (g_j = row j of the
 // symmetric G, transposed into place), and row i of T [b]x' is b x T_i.
+// Vw (optional): on entry an orthonormal basis close to M's eigenvectors (those of a nearby
+// point), on exit the eigenvectors -- the Jacobi sweeps then start almost diagonal.
 template <int GS>
-__device__ double es_value_grad(const double *G, const double (&v)[3], double *g, double *M_out) {
+__device__ double es_value_grad(const double *G, const double (&v)[3], double *g, double *M_out,
+                                double *Vw = nullptr) {
   double R[9];
   cayley_to_rot(v, R);
   double r[3][3];  // columns of R
@@ -232,7 +235,15 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
     for (int i = 0; i < 9; ++i) M_out[i] = M[i];
   }
   double w[3], V[9];
-  sym_eig3(M, w, V);
+  if (Vw) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) V[i] = Vw[i];
+    sym_eig3_warm(M, w, V);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Vw[i] = V[i];
+  } else {
+    sym_eig3(M, w, V);
+  }
   if (!g) return w[0];
   // d lambda = e' dM e = 2 sum_k dr_k . q_k,  q_k = [e]x' (sum_l G_kl [e]x r_l) = (sum_l G_kl y_l) x e
   const double e[3] = {V[0], V[3], V[6]};
@@ -300,7 +311,8 @@ __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&
 template <int GS>
 __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double n_scale) {
   double g[3];
-  double f = es_value_grad<GS>(G, v, g, nullptr);
+  double Vb[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};  // eigenvectors at the current point
+  double f = es_value_grad<GS>(G, v, g, nullptr, Vb);
   int it = 0;
   for (; it < 50; ++it) {
     const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
@@ -310,7 +322,9 @@ __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double 
     for (int k = 0; k < 3; ++k) {
       double vp[3] = {v[0], v[1], v[2]}, gp[3];
       vp[k] += h;
-      es_value_grad<GS>(G, vp, gp, nullptr);
+      double Vp[9];  // the probe is 1e-6 away: its eigenvectors are the current ones to 1e-6
+      for (int i = 0; i < 9; ++i) Vp[i] = Vb[i];
+      es_value_grad<GS>(G, vp, gp, nullptr, Vp);
       for (int r = 0; r < 3; ++r) H[3 * r + k] = (gp[r] - g[r]) / h;
     }
     H[1] = H[3] = 0.5 * (H[1] + H[3]);
@@ -334,7 +348,9 @@ __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double 
     for (int ls = 0; ls < 40; ++ls) {
       for (int k = 0; k < 3; ++k) vn[k] = v[k] + alpha * d[k];
       double Mn[9];
-      const double fn = es_value_grad<GS>(G, vn, nullptr, Mn);
+      double Vn[9];
+      for (int i = 0; i < 9; ++i) Vn[i] = Vb[i];
+      const double fn = es_value_grad<GS>(G, vn, nullptr, Mn, Vn);
       // Armijo with a rounding-noise floor: lambda_min carries ~eps * trace(M) of error
       if (fn <= f + 1e-4 * alpha * slope + 4e-16 * (Mn[0] + Mn[4] + Mn[8])) { moved = true; break; }
       alpha *= 0.5;
@@ -342,7 +358,7 @@ __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double 
     if (!moved) break;
     const double smax = alpha * fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
     for (int k = 0; k < 3; ++k) v[k] = vn[k];
-    f = es_value_grad<GS>(G, v, g, nullptr);
+    f = es_value_grad<GS>(G, v, g, nullptr, Vb);
     if (smax < 1e-12) { ++it; break; }
   }
   return it;

@@ -462,8 +462,10 @@ def test_ransac_eigensolver_and_inlier_selection_device_vs_oracle(oracle):
             assert its[p] == ito, (p, its[p], ito)
             np.testing.assert_array_equal(mask[sl].astype(bool), mo)
             assert cnt[p] == mo.sum()
-            assert _rot_err(oracle, _quat_to_R(q[p]), Ro) <= 1e-8
-            assert abs(abs(t[p] @ to) - 1) < 1e-8
+            # the eigensolver stops at |grad| <= 1e-14 (1 + |lambda|) n, which leaves the iterate free
+            # within ~1e-8 rad: device and oracle may stop one Newton step apart
+            assert _rot_err(oracle, _quat_to_R(q[p]), Ro) <= 1e-7
+            assert abs(abs(t[p] @ to) - 1) < 1e-7
         # InlierExtraction: the selected batch holds exactly the inliers, in order
         sel = b.select(mask)
         assert sel.num_correspondences == int(mask.sum())
@@ -472,7 +474,7 @@ def test_ransac_eigensolver_and_inlier_selection_device_vs_oracle(oracle):
             sl = slice(offsets[p], offsets[p + 1])
             m = mask[sl].astype(bool)
             Ro, to = oracle.nec_eigensolver(f1[sl][m], f2[sl][m], _quat_to_R(q[p]))
-            assert _rot_err(oracle, _quat_to_R(qs[p]), Ro) <= 1e-8
+            assert _rot_err(oracle, _quat_to_R(qs[p]), Ro) <= 1e-7   # same stopping-tolerance slack
         # the reference's whole default pipeline on the inliers: weighted ES + SCF, then refinement
         qw, tw = sel.weighted_eigensolver(q, t, 1e-13, 10)
         res = sel.solve(qw, tw)
