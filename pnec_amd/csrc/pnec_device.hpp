@@ -96,6 +96,15 @@ __device__ __forceinline__ double dpp_perm(double x) {
   hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return make_double(hi, lo);
 }
+// value of lane K of the caller's quad (all four lanes of the quad must be active)
+template <int K>
+__device__ __forceinline__ double quad_broadcast(double x) {
+  return dpp_perm<K | (K << 2) | (K << 4) | (K << 6)>(x);
+}
+template <int K>
+__device__ __forceinline__ int quad_broadcast(int x) {
+  return __builtin_amdgcn_mov_dpp(x, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true);
+}
 // lane ^ XOR inside a group of 32 through the LDS crossbar (ds_swizzle_b32, bit-mask mode): the
 // exchange runs on the LDS pipe, not the VALU the solver is bound by
 template <int XOR>

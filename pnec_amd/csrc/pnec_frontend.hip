@@ -364,6 +364,87 @@ __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double 
   return it;
 }
 
+// The same minimiser for a problem that is shared by (at least) the four lanes of every quad -- the
+// wave-uniform callers.  The quad splits the work that the lane-per-problem version does in
+// sequence: one evaluation yields f, g at the point (lane role 0) AND the three forward-difference
+// probes of the Hessian (roles 1..3), and one evaluation tries four step lengths of the Armijo
+// search (alpha, alpha/2, alpha/4, alpha/8; the first that passes, in that order, wins -- the
+// sequential rule).  ~2 evaluations per Newton iteration instead of ~6; same iterates up to the
+// warm-start basis of the Jacobi sweeps.
+template <int GS>
+__device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], double n_scale) {
+  const int role = (int)(threadIdx.x & 3);
+  const double h = 1e-6;
+  double Vb[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};  // eigenvectors at the current point
+  double f, g[3], H[9];
+  // f, g at v (role 0) and the gradients at v + h e_k (role k + 1), from one evaluation
+  auto evaluate = [&]() {
+    double vp[3] = {v[0] + (role == 1 ? h : 0.0), v[1] + (role == 2 ? h : 0.0), v[2] + (role == 3 ? h : 0.0)};
+    double gp[3], Vp[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Vp[i] = Vb[i];
+    const double fp = es_value_grad<GS>(G, vp, gp, nullptr, Vp);
+    f = quad_broadcast<0>(fp);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      g[r] = quad_broadcast<0>(gp[r]);
+      H[3 * r + 0] = (quad_broadcast<1>(gp[r]) - g[r]) / h;
+      H[3 * r + 1] = (quad_broadcast<2>(gp[r]) - g[r]) / h;
+      H[3 * r + 2] = (quad_broadcast<3>(gp[r]) - g[r]) / h;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Vb[i] = quad_broadcast<0>(Vp[i]);
+    H[1] = H[3] = 0.5 * (H[1] + H[3]);
+    H[2] = H[6] = 0.5 * (H[2] + H[6]);
+    H[5] = H[7] = 0.5 * (H[5] + H[7]);
+  };
+  evaluate();
+  int it = 0;
+  for (; it < 50; ++it) {
+    const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+    if (gmax <= 1e-14 * (1.0 + fabs(f)) * n_scale) break;
+    double mu = 0.0, d[3] = {0.0, 0.0, 0.0};
+    const double tr = fabs(H[0]) + fabs(H[4]) + fabs(H[8]);
+    bool ok = false;
+    for (int tries = 0; tries < 40; ++tries) {
+      double Hm[9];
+      for (int i = 0; i < 9; ++i) Hm[i] = H[i];
+      Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
+      const double mg[3] = {-g[0], -g[1], -g[2]};
+      if (solve3_spd(Hm, mg, d) && (d[0] * g[0] + d[1] * g[1] + d[2] * g[2]) < 0.0) { ok = true; break; }
+      mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * 10.0;
+    }
+    if (!ok) break;
+    const double slope = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];
+    double alpha = 1.0;
+    bool moved = false;
+    for (int ls = 0; ls < 40; ls += 4) {
+      const double scale = role == 0 ? 1.0 : (role == 1 ? 0.5 : (role == 2 ? 0.25 : 0.125));
+      const double a_mine = alpha * scale;
+      double vn[3], Mn[9], Vn[9];
+      for (int k = 0; k < 3; ++k) vn[k] = v[k] + a_mine * d[k];
+      for (int i = 0; i < 9; ++i) Vn[i] = Vb[i];
+      const double fn = es_value_grad<GS>(G, vn, nullptr, Mn, Vn);
+      // Armijo with a rounding-noise floor: lambda_min carries ~eps * trace(M) of error
+      const int pass = (fn <= f + 1e-4 * a_mine * slope + 4e-16 * (Mn[0] + Mn[4] + Mn[8])) ? 1 : 0;
+      const int p0 = quad_broadcast<0>(pass), p1 = quad_broadcast<1>(pass), p2 = quad_broadcast<2>(pass),
+                p3 = quad_broadcast<3>(pass);
+      if (p0 | p1 | p2 | p3) {
+        alpha *= p0 ? 1.0 : (p1 ? 0.5 : (p2 ? 0.25 : 0.125));
+        moved = true;
+        break;
+      }
+      alpha *= 0.0625;
+    }
+    if (!moved) break;
+    const double smax = alpha * fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
+    for (int k = 0; k < 3; ++k) v[k] = v[k] + alpha * d[k];
+    evaluate();
+    if (smax < 1e-12) { ++it; break; }
+  }
+  return it;
+}
+
 // ------------------------------------------------------------------------------------------
 constexpr int kFibStride = 9;  // t (3) | txx tyy tzz | 2 txy, 2 txz, 2 tyz
 struct FrontArgs {
@@ -467,7 +548,7 @@ __global__ __launch_bounds__(kWave) void nec_eigensolver_kernel(const FrontArgs 
   pass_sums36<false>(base, n, stride, R, t_dummy, 0.0, lane, G);
   double v[3];
   rot_to_cayley(R, v);
-  const int it = es_minimise<1>(G, v, (double)(n > 0 ? n : 1));
+  const int it = es_minimise_quad<1>(G, v, (double)(n > 0 ? n : 1));
   double M[9];
   es_value_grad<1>(G, v, nullptr, M);
   cayley_to_rot(v, R);
@@ -603,7 +684,7 @@ __global__ __launch_bounds__(kWave) void weighted_eigensolver_kernel(const Front
     // final and later rounds only redo the translation (newton = 0: "did not move").
     int newton = 0;
     if (!rotation_final) {
-      newton = es_minimise<1>(G, v, (double)(n > 0 ? n : 1));
+      newton = es_minimise_quad<1>(G, v, (double)(n > 0 ? n : 1));
       rotation_final = newton < 50;
     }
     if (it == 0) first_iterations = newton;
@@ -1004,7 +1085,7 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
   // optimizeModelCoefficients: eigensolver on the inliers from the best model's rotation
   double v[3], R[9], M[9];
   rot_to_cayley(bR, v);
-  es_minimise<1>(G[quarter], v, (double)(total > 0 ? total : 1));
+  es_minimise_quad<1>(G[quarter], v, (double)(total > 0 ? total : 1));
   es_value_grad<1>(G[quarter], v, nullptr, M);
   cayley_to_rot(v, R);
   if (total > 0) {

@@ -233,11 +233,6 @@ __device__ __forceinline__ void pose_uniforms(double theta, double phi, const do
   sincos_bounded(phi, sp, cp);
   pose_uniforms_sc(st, ct, sp, cp, q, u);
 }
-// value of lane K of the caller's quad (all four lanes of the quad must be active)
-template <int K>
-__device__ __forceinline__ double quad_broadcast(double x) {
-  return dpp_perm<K | (K << 2) | (K << 4) | (K << 6)>(x);
-}
 
 // PNECCeres::Result(): pnec_ceres.cc:201-207
 __device__ __forceinline__ void write_result(const SolveArgs &a, int64_t s, const double *slab, int iteration,
