@@ -4,20 +4,27 @@
 //   ComposeM / TranslationFromM / Weight              src/common/common.cc:127-136,157-181,183-208
 //   fibonacci_sphere / obj_fun / scf                  src/optimization/scf.cc:43-72,109-148
 //
-// One wavefront per frame pair.  The eigensolver (opengv::relative_pose::eigensolver in the
-// reference; opengv is not in the tree, so this is the published Kneip-Lynen algorithm: minimise
-// the smallest eigenvalue of M(R) = sum (f1 x R f2)(f1 x R f2)' over the Cayley parameters of R)
-// needs ONE pass over the payload: the 36 sums  G_kl[a][c] = sum_i w_i f2k f2l f1a f1c  determine
+// The eigensolver (opengv::relative_pose::eigensolver in the reference; opengv is not in the tree,
+// so this is the published Kneip-Lynen algorithm: minimise the smallest eigenvalue of
+// M(R) = sum (f1 x R f2)(f1 x R f2)' over the Cayley parameters of R) needs ONE pass over the
+// payload: the 36 sums  G_kl[a][c] = sum_i w_i f2k f2l f1a f1c  determine
 // M(R) = sum_kl [r_k]x G_kl [r_l]x' for every R (r_k = column k of R), so the damped-Newton
-// iteration on the Cayley vector runs on 36 numbers parked in LDS.  The translation search of the
-// weighted stage (500 Fibonacci directions + 10 SCF steps per iteration) streams the payload from
-// L2: per correspondence n = f1 x R f2 and B = f1hat R Sigma R' f1hat' + reg I are rebuilt per
-// batch of 21 candidate directions, whose 21 partial energies are reduced together
-// (wave_reduce21).  Reference quirks reproduced: C3 (weights from the initial pose in every
-// iteration), C4 (x1e-8), C5 (E = sum A_i / t'B_i t), C6 (float division in fibonacci_sphere),
-// C7 (ComposeM skips correspondence 0).  When an eigensolver call is already converged at entry
-// the rotation is bit-identical to the previous iteration's, and the 500-direction search of that
-// iteration is replayed from the stored minimum instead of recomputed (identical result).
+// iteration on the Cayley vector runs on 36 numbers parked in LDS.
+//
+// Work distribution (all of these stages are FP64-VALU-bound chains of one-value-per-pair work, so
+// the design question is how many lanes share one such chain):
+//   * NEC / weighted eigensolver: one wavefront per pair for the data-parallel passes; the Newton
+//     iteration is split over the four lanes of every quad (es_minimise_quad: the three
+//     finite-difference probes and four Armijo step lengths per evaluation);
+//   * weighted stage, pairs <= 512 correspondences: per correspondence n = f1 x R f2 and
+//     B = f1hat R Sigma R' f1hat' + reg I stay in registers; 500 Fibonacci directions (table with
+//     the direction products, scalar loads) + SCF steps with warm-started 3x3 Jacobi, stopped at
+//     the fixed point; larger pairs stream the payload, 21 directions per pass (wave_reduce21);
+//   * RANSAC: 16 lanes = 16 hypotheses per pair, 4 pairs per wavefront.
+// Reference quirks reproduced: C3 (weights from the initial pose in every iteration -- hence the
+// rotation is final after the first converged eigensolver call), C4 (x1e-8), C5
+// (E = sum A_i / t'B_i t), C6 (float division in fibonacci_sphere), C7 (ComposeM skips
+// correspondence 0).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
