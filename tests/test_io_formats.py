@@ -1,6 +1,9 @@
 """Data formats either side of the path: the reference simulator's experiment
 CSVs, run_simulation's result tables and the odometry pose stream."""
+import os
+
 import numpy as np
+import pytest
 
 from pnec_amd import io_formats as io
 from pnec_amd import simulation as sim
@@ -46,3 +49,51 @@ def test_result_tables_and_pose_stream(tmp_path):
     np.testing.assert_allclose(t, g.t_gt.numpy(), rtol=1e-8)
     np.testing.assert_allclose(io.quat_xyzw_to_matrix(q[0]), g.R_gt[0].numpy(), atol=1e-8)
     assert io.TIMING_HEADER.split()[:4] == ["ID", "FrameLoading", "FeatureCreation", "NEC-ES"]
+
+
+@pytest.mark.gpu
+def test_run_simulation_harness_matches_the_oracle_chain(tmp_path, oracle):
+    """pnec_amd.run_simulation = the reference's run_simulation ablation (run_simulation.cc:141-180) over a
+    simulator experiment folder: CSV in, r_error / t_error / cost tables out, every stage batched on the
+    device.  Checked per experiment against the oracle's chain on the same inputs and start poses."""
+    import csv
+    import torch
+    from pnec_amd import io_formats as io
+    from pnec_amd import run_simulation as rs
+    from pnec_amd import simulation as sim
+    E, N = 5, 60
+    g = sim.generate(E, N, seed=77)
+    rng = np.random.default_rng(4)
+    p1 = g.bvs1.numpy() * rng.uniform(2.0, 5.0, size=(E, N, 1))       # 3-D points in frame 1
+    p2 = g.bvs2.numpy() / g.bvs2.numpy()[..., 2:3]                       # pinhole points (z = 1) in frame 2
+    c2 = np.zeros((E, N, 3, 3))
+    s = rng.uniform(0.5, 1.5, size=(E, N)) * (1.0 / 800.0) ** 2
+    c2[..., 0, 0], c2[..., 1, 1] = s, 0.6 * s
+    q_gt = sim.matrix_to_quaternion_xyzw(g.R_gt).numpy()
+    poses_1 = np.tile(np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float64), (E, 1))
+    poses_2 = np.concatenate([q_gt, g.t_gt.numpy()], 1)
+    folder = str(tmp_path / "exp")
+    io.write_experiments(folder, poses_1, poses_2, p1, p2, np.zeros_like(c2), c2)
+    assert rs.main([folder, "--seed", "3"]) == 0
+    tables = {}
+    for name in ("r_error", "t_error", "cost"):
+        rows = list(csv.reader(open(os.path.join(folder, name + ".csv"))))
+        assert rows[0] == ["index"] + list(rs.METHODS) and len(rows) == E + 1
+        tables[name] = np.array([[float(v) for v in r[1:]] for r in rows[1:]])
+    assert np.isfinite(tables["r_error"]).all() and (tables["r_error"] < 5.0).all()
+    # the same chain through the oracle, from the values the folder actually holds (6 significant digits)
+    ex = io.read_experiments(folder)
+    R_gt, t_gt = io.relative_poses(ex["poses_1"], ex["poses_2"])
+    R0, t0 = rs.perturbed_start(R_gt, t_gt, np.random.default_rng(3), 1.0)
+    col = {m: i for i, m in enumerate(rs.METHODS)}
+    for e in range(E):
+        b1 = ex["points_1"][e] / np.linalg.norm(ex["points_1"][e], axis=1, keepdims=True)
+        cov = np.stack([oracle.unscented_transform(p, c) for p, c in zip(ex["points_2"][e], ex["covs_2"][e])])
+        b2 = ex["points_2"][e] / np.linalg.norm(ex["points_2"][e], axis=1, keepdims=True)
+        Rn, tn = oracle.nec_eigensolver(b1, b2, R0[e])
+        Rw, tw = oracle.weighted_eigensolver(b1, b2, cov, Rn, tn, 1e-13, 10)
+        sol = oracle.solve(oracle.MODE_TARGET, b1, b2, cov, None, 1e-13, oracle.quat_from_rot(Rw), tw,
+                           oracle.default_options())
+        assert abs(oracle.rotational_difference_deg(R_gt[e], Rn) - tables["r_error"][e, col["NEC"]]) < 2e-5
+        assert abs(oracle.rotational_difference_deg(R_gt[e], sol.R) - tables["r_error"][e, col["PNEC"]]) < 2e-5
+        assert tables["r_error"][e, col["PNEC w/o LS"]] == tables["r_error"][e, col["NEC"]]   # the reference's quirk
