@@ -189,6 +189,7 @@ def main():
         achieved_gbs = payload / (kernel_ms * 1e-3) / 1e9
         flops = FLOP_PER_CORR_PASS * batch.num_correspondences * passes
         valu_tflops = flops / (kernel_ms * 1e-3) / 1e12
+        valu_busy = None
         traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes, if they
         try:             # were taken on this very workload and geometry
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
@@ -196,6 +197,7 @@ def main():
             if (w["pairs"], w["corr"], w["iters"]) == (args.pairs, args.corr, args.iters) and \
                     w["geometry"] == [launch["corr_per_lane"], launch["waves_per_pair"], launch["lds_corr_per_lane"]]:
                 traffic = tj["hbm_bytes_per_launch"]
+                valu_busy = tj.get("valu_busy_frac")
         except (OSError, KeyError, ValueError):
             pass
         iters_done = out.iterations.to(torch.float64)
@@ -229,7 +231,10 @@ def main():
                 "streaming_bytes_per_solve": batch.payload_bytes // args.pairs * passes,
                 "valu": {"bound": "valu_fp64", "achieved": valu_tflops, "peak": FP64_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": valu_tflops / FP64_VALU_PEAK_TFLOPS,
-                         "flop_per_corr_pass": FLOP_PER_CORR_PASS, "passes": passes},
+                         "flop_per_corr_pass": FLOP_PER_CORR_PASS, "passes": passes,
+                         # share of cycles the vector ALU was issuing (any FP64/integer/cross-lane
+                         # instruction, useful or bookkeeping), from the committed rocprofv3 SQ counters
+                         "issue_busy_frac_profiled": valu_busy},
             },
         }
         if not args.no_cpu_baseline and world == 1:
