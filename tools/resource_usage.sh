@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools_resource_usage.sh file.hip  -> table of kernel resource usage (gfx950)
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I/root/repo/include -c "$1" -o /tmp/ru.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I/root/repo/include -mllvm -amdgpu-sched-strategy=max-ilp -c "$1" -o /tmp/ru.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import sys,re
 cur=None; rows=[]
 for l in sys.stdin:
