@@ -431,6 +431,21 @@ __global__ void selftest_kernel(double *out) {
   wave_reduce21(acc, sums);
   if (lane == 0)
     for (int j = 0; j < kNumAcc; ++j) out[67 + j] = sums[j];
+  // lean acos / atan2 against libm: a grid over the circle and over [-1, 1] with dense ends
+  {
+    double worst_a = 0.0;
+    for (int k = 0; k < 64; ++k) {
+      const int i = lane * 64 + k;
+      const double ang = -3.14159 + 6.28318 * i / 4095.0;
+      const double yy = sin(ang) * (1.0 + (i % 7)), xx = cos(ang) * (1.0 + (i % 7));
+      worst_a = fmax(worst_a, fabs(atan2_lean(yy, xx) - atan2(yy, xx)));
+      const double u = (double)i / 4095.0;
+      const double c = (i & 1) ? 1.0 - u * u * u * u : -1.0 + u * u * u * u;   // clusters at +-1
+      const double ref = acos(c);
+      worst_a = fmax(worst_a, fabs(acos_lean(c) - ref) / fmax(ref, 1e-300));
+    }
+    out[152 + lane] = worst_a;
+  }
   // bounded sincos against libm over [-40, 40]
   double worst = 0.0;
   for (int k = 0; k < 64; ++k) {
@@ -1172,11 +1187,11 @@ int pnec_hip_selftest(int device) {
   DeviceGuard guard(device);
   if (!guard.ok) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "hipSetDevice failed");
   double *d = nullptr;
-  PNEC_HIP_TRY(dev_alloc(&d, sizeof(double) * 160));
+  PNEC_HIP_TRY(dev_alloc(&d, sizeof(double) * 224));
   hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(kWave), 0, 0, d);
-  double h[160];
+  double h[224];
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(double) * 152, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(double) * 216, hipMemcpyDeviceToHost);
   (void)dev_free(d);
   if (e != hipSuccess) return fail_hip(e, "selftest_kernel");
   for (int i = 0; i < kWave; ++i)
@@ -1199,6 +1214,12 @@ int pnec_hip_selftest(int device) {
     if (!(h[88 + i] < 4e-16)) {
       char buf[128];
       std::snprintf(buf, sizeof(buf), "sincos_bounded deviates from libm by %.3g", h[88 + i]);
+      return fail(PNEC_HIP_ERR_HIP_RUNTIME, buf);
+    }
+  for (int i = 0; i < kWave; ++i)
+    if (!(h[152 + i] < 9e-16)) {
+      char buf[128];
+      std::snprintf(buf, sizeof(buf), "acos_lean / atan2_lean deviate from libm by %.3g", h[152 + i]);
       return fail(PNEC_HIP_ERR_HIP_RUNTIME, buf);
     }
   return 0;

@@ -301,11 +301,11 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
       // Parked: (f s)^2 and its inverse, f = 2 for the rotation columns.
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
-        const double f = (i >= 2) ? 2.0 : 1.0;
+        const double f = (i >= 2) ? 2.0 : 1.0, inv_f = (i >= 2) ? 0.5 : 1.0;
         const double hii = S[6 + tri(i, i)] * (f * f);
-        const double a = (o.jacobi_scaling ? 1.0 + sqrt(hii) : 1.0) / f;  // 1 / (f s)
+        const double a = (o.jacobi_scaling ? 1.0 + fast_sqrt(hii) : 1.0) * inv_f;  // 1 / (f s)
         slab[kInvScaleSq + i] = a * a;
-        slab[kScaleSq + i] = 1.0 / (a * a);
+        slab[kScaleSq + i] = fast_rcp(a * a);
       }
       accept = true;
     }
