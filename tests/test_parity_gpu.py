@@ -498,3 +498,34 @@ def test_device_buffer_cache_reuses_and_releases():
     released = L.pnec_hip_release_cache(-1)
     assert released >= 20 * 1024 * 1024          # the payload buffer was being kept
     assert L.pnec_hip_release_cache(-1) == 0
+
+
+@pytest.mark.parametrize("trial", range(8))
+def test_randomised_batches_against_oracle(oracle, trial):
+    """random residual family, batch size, ragged counts up to a random maximum (all launch geometries incl.
+    the streaming one), random iteration cap or Ceres-default termination: rotations, iteration counts"""
+    rng = np.random.default_rng(900 + trial)
+    mode = [capi.MODE_NEC, capi.MODE_TARGET, capi.MODE_HOST, capi.MODE_SYM][trial % 4]
+    B = int(rng.integers(1, 120))
+    nmax = int(rng.choice([17, 64, 100, 256, 400, 512, 600, 1024, 2048, 3000, 4096, 5000]))
+    counts = rng.integers(6, nmax + 1, size=B).astype(np.int64)
+    counts[rng.integers(0, B)] = nmax
+    offsets = np.concatenate([[0], np.cumsum(counts)])
+    g = sim.generate(B, nmax, seed=2000 + trial)
+    f1 = np.concatenate([g.bvs1[p].numpy()[:n] for p, n in enumerate(counts)])
+    f2 = np.concatenate([g.bvs2[p].numpy()[:n] for p, n in enumerate(counts)])
+    S2 = np.concatenate([g.covs2[p].numpy()[:n] for p, n in enumerate(counts)])
+    c2, c1 = _covs_for(mode, S2)
+    kw = dict(check_convergence=int(rng.integers(0, 2)))
+    if not kw["check_convergence"]:
+        kw["max_num_iterations"] = int(rng.integers(1, 12))
+    opts = capi.default_options(**kw)
+    reg = 1e-13
+    with Batch(mode, offsets) as b:
+        b.fill(f1, f2, c2, c1)
+        res = b.solve(g.init_q.numpy(), g.init_t.numpy(), reg=reg, options=opts)
+    q, t, cost, it, st = _oracle_batch(oracle, mode, offsets, f1, f2, c2, c1, reg, g.init_q.numpy(),
+                                       g.init_t.numpy(), _oracle_opts(oracle, opts, oracle.JAC_ANALYTIC))
+    worst = max(_rot_err(oracle, _quat_to_R(res.q[p]), _quat_to_R(q[p])) for p in range(B))
+    assert worst <= 10 * ROT_TOL_SAME_ALGO, worst   # pairs of 6..20 correspondences are weakly constrained
+    assert (res.iterations == it).mean() >= 0.98
