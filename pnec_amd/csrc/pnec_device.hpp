@@ -192,7 +192,7 @@ __device__ __forceinline__ double wave_allreduce_sum(double x) {
 // a second one, so one swap + one add reduces TWO accumulators at once with no selects:
 //   swap32(X, Y): X' = [X.lo | Y.lo], Y' = [X.hi | Y.hi]  =>  X' + Y' = [X.lo+X.hi | Y.lo+Y.hi]
 // 21 -> 11 values (lane halves) -> 6 values (rows of 16 lanes); the last four levels run as a
-// butterfly inside each row on those 6 values (exchanges on the LDS crossbar); the four row
+// butterfly inside each row on those 6 values (row_allreduce_sum); the four row
 // leaders then store their sums to LDS, from where every lane reads all 21 back (broadcast).
 __device__ __forceinline__ double swap_add32(double x, double y) {
   const unsigned xl = (unsigned)__double2loint(x), xh = (unsigned)__double2hiint(x);

@@ -16,7 +16,7 @@
 // Register / LDS plan (what makes one wavefront per 512-correspondence pair viable):
 //   * the pair's payload lives in VGPRs (+ LDS slots, + AGPRs when the compiler needs room) for
 //     the whole loop; the 17 pose uniforms of a pass live in SGPRs;
-//   * a pass ends with the 21 sums in a per-wavefront LDS slab (swap-halving + LDS-crossbar
+//   * a pass ends with the 21 sums in a per-wavefront LDS slab (swap-halving + DPP
 //     reduction, pnec_device.hpp);
 //   * everything that is one value per solve -- accept/reject, trust region, the 5x5 solve, the
 //     manifold update, the next pose's uniforms (lm_advance) -- runs in one quad on LDS-resident
