@@ -97,3 +97,25 @@ def test_run_simulation_harness_matches_the_oracle_chain(tmp_path, oracle):
         assert abs(oracle.rotational_difference_deg(R_gt[e], Rn) - tables["r_error"][e, col["NEC"]]) < 2e-5
         assert abs(oracle.rotational_difference_deg(R_gt[e], sol.R) - tables["r_error"][e, col["PNEC"]]) < 2e-5
         assert tables["r_error"][e, col["PNEC w/o LS"]] == tables["r_error"][e, col["NEC"]]   # the reference's quirk
+
+
+def test_run_simulation_start_poses_and_metrics():
+    """host logic of the run_simulation harness: start-pose perturbation (sim_common.cc:205-231) and the
+    error metrics (common.cc:210-235)"""
+    from pnec_amd import run_simulation as rs
+    rng = np.random.default_rng(0)
+    E = 200
+    g = sim.generate(E, 8, seed=5)
+    R_gt, t_gt = g.R_gt.numpy(), g.t_gt.numpy()
+    R0, t0 = rs.perturbed_start(R_gt, t_gt, rng, 1.0)
+    assert np.allclose(np.einsum("eij,ekj->eik", R0, R0), np.eye(3), atol=1e-12)        # rotations
+    assert np.allclose(np.linalg.norm(t0, axis=1), 1.0, atol=1e-12)                         # unit translations
+    ang = np.radians(rs.rotational_difference_deg(R_gt, R0))
+    assert ang.max() <= 0.01 + 1e-12 and ang.mean() > 0.004                                # sqrt(u) * 0.01 rad
+    # metrics: 90 degree rotation about z; antipodal translations are the same direction
+    Rz = np.array([[0.0, -1, 0], [1, 0, 0], [0, 0, 1]])
+    assert abs(rs.rotational_difference_deg(np.eye(3)[None], Rz[None])[0] - 90.0) < 1e-12
+    t = np.array([[0.0, 0, 1]])
+    assert rs.translational_difference_deg(t, -t)[0] < 1e-6
+    assert abs(rs.translational_difference_deg(t, np.array([[1.0, 0, 0]]))[0] - 90.0) < 1e-12
+    assert rs.translational_difference_deg(np.zeros((1, 3)), t)[0] == 90.0                 # degenerate input
