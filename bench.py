@@ -1,180 +1,355 @@
 #!/usr/bin/env python3
 """Headline benchmark: PNEC frame-pair solves/s (512 correspondences, 10 LM iterations).
 
-  python bench.py --gpus N --steps K --warmup W
-  (N>1: launched by torch.distributed.run, one rank per GPU, RCCL over xGMI)
+  python bench.py --gpus N --steps K --warmup W [--workload sim100k|kitti_all] [--tracks file.npz]
 
-A "step" = one pass of the hot path over one batch: every rank solves its own shard of
-independent synthetic frame pairs (BASELINE config 2: 100k pairs x 512 anisotropic-covariance
-correspondences per GPU; weak scaling) with exactly 10 LM iterations on the device, then the
-result records are gathered to rank 0 with ONE RCCL gather.  Inputs are resident in HBM before
-the timed region.  Rank 0 prints one JSON line.
+One process per GPU.  Launched under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* in the environment) it joins that job; launched plainly with --gpus N > 1 it SPAWNS the N
+ranks itself (one per GPU, RCCL over xGMI, rendezvous on 127.0.0.1 at a free port) -- the analogue of
+the reference's own fan-out scripts (scripts/run_simulation.sh:52-67, scripts/parallel_kitti.sh:60-69),
+which start one process per experiment / sequence.
+
+A "step" = one pass of the hot path over one batch: every rank solves its own shard of independent
+frame pairs on the device, then the fixed-size result records are gathered on rank 0 with ONE
+collective, issued on a side stream so that it overlaps the next step's solve.  Inputs are resident
+in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Workloads:
+  sim100k   (default; BASELINE configs[1], the headline) 100k simulated pairs x 512 anisotropic-
+            covariance correspondences PER GPU, exactly 10 LM iterations -> weak scaling.
+  kitti_all (BASELINE configs[4]) every frame pair of KITTI odometry 00-10 (23 190 ragged pairs),
+            partitioned over the ranks in contiguous ranges balanced by correspondence count
+            (pnec_amd.distributed.partition), Ceres-default termination -> strong scaling.  Real tracks
+            come from --tracks <file.npz> (format: pnec_amd/tracks.py); without it a labelled
+            SYNTHETIC KITTI-like stand-in with the real sequence lengths is generated.
+
+--dry-run-cpu replaces the device solve by a stub that fabricates records (gloo on CPU): it exists so
+that the spawn / partition / gather path can be exercised where there is no GPU (tests); its JSON
+line says so and carries no throughput claim.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
-FP64_VALU_PEAK_TFLOPS = 78.6  # vector FP64 (256 CU x 4 SIMD x 16 FMA/clk x 2.4 GHz)
-# FP64 operations the kernel issues per correspondence per pass (TARGET residual, counted from
-# pnec_device.hpp: eval_corr 70 FMA-class ops + 21 accumulations; an FMA = 2 flops)
-FLOP_PER_CORR_PASS = 2 * 91
+FP64_VALU_PEAK_TFLOPS = 78.6  # vector FP64 (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
+# FP64 work the kernel issues per correspondence per pass (TARGET residual; counted from
+# pnec_device.hpp eval_corr<TARGET> + accumulate): 62 FMA + 28 MUL + 1 v_rsq = 91 VALU instructions,
+# 62*2 + 28 + 1 = 153 flop.  The FP64 roof above prices every issue slot as an FMA (2 flop), so the
+# flop fraction (153) and the issue-slot fraction (91 slots) are reported side by side.
+VALU_INSTR_PER_CORR_PASS = 91
+FLOP_PER_CORR_PASS = 153
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20, help="untimed steps; ~20 of these 3.5 ms steps bring the GPU to its steady clocks")
-    ap.add_argument("--pairs", type=int, default=100_000, help="frame pairs per GPU")
-    ap.add_argument("--corr", type=int, default=512, help="correspondences per pair")
-    ap.add_argument("--iters", type=int, default=10, help="LM iterations per solve (fixed count)")
+    ap.add_argument("--workload", choices=("sim100k", "kitti_all"), default="sim100k")
+    ap.add_argument("--tracks", default=None, help="kitti_all: .npz of real tracks (pnec_amd/tracks.py)")
+    ap.add_argument("--pairs", type=int, default=100_000, help="sim100k: frame pairs per GPU")
+    ap.add_argument("--corr", type=int, default=512, help="sim100k: correspondences per pair")
+    ap.add_argument("--iters", type=int, default=10, help="sim100k: LM iterations per solve (fixed count)")
     ap.add_argument("--cpl", type=int, default=0, help="launch tuning: correspondences per lane")
     ap.add_argument("--wpp", type=int, default=0, help="launch tuning: wavefronts per solve")
     ap.add_argument("--ldsk", type=int, default=0, help="launch tuning: correspondences per lane kept in LDS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
-    return ap.parse_args()
+    ap.add_argument("--sync-gather", action="store_true", help="gather on the solve's stream (A/B of the overlap)")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="gloo + stubbed solve: exercises spawn/partition/gather without a GPU")
+    return ap.parse_args(argv)
 
 
-def build_shard(n_pairs, n_corr, rank, device):
+# ---------------------------------------------------------------------------------------------------
+# launch: join torchrun's job, or spawn the ranks ourselves
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """Start n copies of this script, one per GPU; rank 0 inherits stdout (it prints the JSON line)."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PNEC_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL between processes on this driver)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                deadline = time.time() + 30.0  # a rank died: give the others a moment, then stop them
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                p.kill()
+        time.sleep(0.05)
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------
+# workloads: each returns a Shard (this rank's pairs in HBM) + the global partition
+class Shard:
+    pass
+
+
+def build_sim100k(args, rank, world, device):
     """Synthetic shard, generated on the GPU in chunks straight into the solver's SoA layout."""
+    import torch
+
     from pnec_amd import Batch, capi
     from pnec_amd import simulation as sim
-    batch = Batch.uniform(capi.MODE_TARGET, n_pairs, n_corr, device=device.index)
+    sh = Shard()
+    sh.sizes = [args.pairs] * world                       # weak scaling: same work on every rank
+    sh.total_pairs = args.pairs * world
+    sh.scaling = "weak"
+    sh.data = "synthetic"
+    sh.opts = dict(max_num_iterations=args.iters, check_convergence=0)
+    sh.workload = ("configs[1]: batch of 100k simulated frame pairs x 512 anisotropic-covariance "
+                   "correspondences per GPU")
+    if args.dry_run_cpu:
+        sh.batch, sh.q0, sh.t0, sh.sample = None, None, None, None
+        return sh
+    batch = Batch.uniform(capi.MODE_TARGET, args.pairs, args.corr, device=device.index)
     chunk = 10_000
     qs, ts, sample = [], [], None
-    for c, first in enumerate(range(0, n_pairs, chunk)):
-        m = min(chunk, n_pairs - first)
-        g = sim.generate(m, n_corr, noise_type="anisotropic_inhomogeneous", noise_level=1.0,
+    for c, first in enumerate(range(0, args.pairs, chunk)):
+        m = min(chunk, args.pairs - first)
+        g = sim.generate(m, args.corr, noise_type="anisotropic_inhomogeneous", noise_level=1.0,
                          seed=1 + 1000 * rank + c, device=device)
         batch.fill(g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3),
                    first_pair=first, n_pairs=m)
         qs.append(g.init_q)
         ts.append(g.init_t)
-        if sample is None:
-            sample = g  # first chunk doubles as the CPU-baseline / parity sample
-        else:
-            del g
-    return batch, torch.cat(qs), torch.cat(ts), sample
+        if sample is None:  # first chunk doubles as the CPU-baseline / parity sample
+            k = min(m, 4096)
+            sample = (np.arange(k + 1, dtype=np.int64) * args.corr, g.bvs1[:k].reshape(-1, 3),
+                      g.bvs2[:k].reshape(-1, 3), g.covs2[:k].reshape(-1, 3, 3), g.init_q[:k], g.init_t[:k])
+        del g
+    sh.batch, sh.q0, sh.t0, sh.sample = batch, torch.cat(qs), torch.cat(ts), sample
+    return sh
 
 
+def build_kitti_all(args, rank, world, device):
+    """Config 5: all pairs of the 11 sequences, contiguous ranges balanced by correspondence count."""
+    from pnec_amd import tracks as tk
+    from pnec_amd.distributed import partition
+    sh = Shard()
+    sizes = tk.sizes_of(args.tracks) if args.tracks else tk.kitti_all_sizes()
+    bounds = partition(sizes, world)
+    sh.bounds = bounds
+    sh.sizes = [int(bounds[r + 1] - bounds[r]) for r in range(world)]
+    sh.total_pairs = int(len(sizes))
+    sh.shard_corr = [int(sizes[bounds[r]:bounds[r + 1]].sum()) for r in range(world)]
+    sh.scaling = "strong"
+    sh.opts = dict()                                       # Ceres-default termination (what the VO runs)
+    sh.workload = ("configs[4]: all KITTI 00-10 frame pairs (23 190 ragged pairs) sharded as independent "
+                   "batches, contiguous ranges balanced by correspondence count")
+    sh.data = f"tracks:{os.path.basename(args.tracks)}" if args.tracks else "synthetic"
+    sh.pair_sizes = sizes
+    if args.dry_run_cpu:
+        sh.batch, sh.q0, sh.t0, sh.sample = None, None, None, None
+        return sh
+    import torch
+
+    from pnec_amd import Batch, capi
+    a, b = int(bounds[rank]), int(bounds[rank + 1])
+    tr = tk.load_tracks(args.tracks, a, b) if args.tracks else tk.kitti_all_shard(a, b, device=device)
+    as_dev = lambda x: x if hasattr(x, "is_cuda") and x.is_cuda else torch.as_tensor(np.asarray(x), device=device)
+    batch = Batch(capi.MODE_TARGET, tr.offsets, device=device.index)
+    if tr.n_pairs:
+        batch.fill(as_dev(tr.bvs1), as_dev(tr.bvs2), as_dev(tr.covs))
+    sh.batch, sh.q0, sh.t0 = batch, as_dev(tr.init_q).contiguous(), as_dev(tr.init_t).contiguous()
+    k = min(tr.n_pairs, 2048)
+    m = int(tr.offsets[k])
+    sh.sample = (tr.offsets[:k + 1], as_dev(tr.bvs1)[:m], as_dev(tr.bvs2)[:m], as_dev(tr.covs)[:m], sh.q0[:k], sh.t0[:k])
+    return sh
+
+
+# ---------------------------------------------------------------------------------------------------
 def cpu_baseline(sample, n_sample, opts_hip, gpu_q):
     """The oracle (reference-faithful port: central differences + Ceres LM policy) timed on this
     box's host cores over a bounded sample of the same workload; also the parity figure."""
-    import math
     from oracle import pnec_oracle as po
     cores = po.max_threads()
-    n_corr = sample.bvs1.shape[1]
-    f1 = sample.bvs1[:n_sample].reshape(-1, 3).cpu().numpy()
-    f2 = sample.bvs2[:n_sample].reshape(-1, 3).cpu().numpy()
-    c9 = po.covs_to_colmajor9(sample.covs2[:n_sample].reshape(-1, 3, 3).cpu().numpy())
-    q0 = sample.init_q[:n_sample].cpu().numpy()
-    t0 = sample.init_t[:n_sample].cpu().numpy()
-    offsets = np.arange(n_sample + 1, dtype=np.int64) * n_corr
+    offsets, b1, b2, cv, iq, it = sample
+    offsets = np.asarray(offsets[:n_sample + 1], dtype=np.int64)
+    m = int(offsets[-1])
+    f1, f2 = b1[:m].cpu().numpy(), b2[:m].cpu().numpy()
+    c9 = po.covs_to_colmajor9(cv[:m].cpu().numpy())
+    q0, t0 = iq[:n_sample].cpu().numpy(), it[:n_sample].cpu().numpy()
     o = po.default_options(jacobian_mode=po.JAC_NUMERIC_CENTRAL,
                            max_num_iterations=opts_hip.max_num_iterations,
                            check_convergence=opts_hip.check_convergence)
     # single thread (the reference's real execution model) on a small slice
     n1 = max(8, min(64, n_sample))
     t = time.perf_counter()
-    po.solve_batch(po.MODE_TARGET, offsets[:n1 + 1], f1, f2, c9, None, 1e-13, q0, t0, options=o,
-                   num_threads=1)
+    po.solve_batch(po.MODE_TARGET, offsets[:n1 + 1], f1, f2, c9, None, 1e-13, q0, t0, options=o, num_threads=1)
     single = n1 / (time.perf_counter() - t)
-    # all cores, median of 3
-    rates = []
+    rates = []  # all cores, median of 3
     for _ in range(3):
         t = time.perf_counter()
-        q, tt, cost, it, st = po.solve_batch(po.MODE_TARGET, offsets, f1, f2, c9, None, 1e-13, q0,
-                                             t0, options=o, num_threads=cores)
+        q, tt, cost, its, st = po.solve_batch(po.MODE_TARGET, offsets, f1, f2, c9, None, 1e-13, q0, t0,
+                                              options=o, num_threads=cores)
         rates.append(n_sample / (time.perf_counter() - t))
     rate = float(np.median(rates))
-    # parity of the GPU result on the same pairs
-    gq = gpu_q[:n_sample].cpu().numpy()
+    gq = gpu_q[:n_sample].cpu().numpy()   # parity of the GPU result on the same pairs
     dots = np.clip(np.abs(np.sum(gq * q, axis=1)), 0.0, 1.0)
-    # angle between rotations from quaternion dot; small-angle safe via the vector part
     dq = np.stack([
         gq[:, 3] * q[:, 0] - gq[:, 0] * q[:, 3] - gq[:, 1] * q[:, 2] + gq[:, 2] * q[:, 1],
         gq[:, 3] * q[:, 1] + gq[:, 0] * q[:, 2] - gq[:, 1] * q[:, 3] - gq[:, 2] * q[:, 0],
         gq[:, 3] * q[:, 2] - gq[:, 0] * q[:, 1] + gq[:, 1] * q[:, 0] - gq[:, 2] * q[:, 3]], 1)
-    ang = 2.0 * np.arctan2(np.linalg.norm(dq, axis=1), dots)
+    ang = 2.0 * np.arctan2(np.linalg.norm(dq, axis=1), dots)  # small-angle safe
+    sizes = np.diff(offsets)
     base = {"value": rate, "unit": "solves/s", "cores": cores, "kind": "port",
             "single_thread_value": single,
-            "sample": f"{n_sample} of the benchmark's own pairs ({n_corr} corr, "
-                      f"{opts_hip.max_num_iterations} LM iterations, central-difference Jacobian + "
-                      f"Ceres LM policy, OpenMP over pairs, median of 3)"}
+            "sample": f"{n_sample} of the benchmark's own pairs ({int(sizes.min())}..{int(sizes.max())} corr, "
+                      f"{'Ceres-default termination' if opts_hip.check_convergence else str(opts_hip.max_num_iterations) + ' LM iterations'}, "
+                      f"central-difference Jacobian + Ceres LM policy, OpenMP over pairs, median of 3)"}
     parity = {"max_rot_err_rad": float(ang.max()), "median_rot_err_rad": float(np.median(ang)),
-              "n_pairs": int(n_sample), "against": "oracle (reference-faithful port), same inputs, same iteration count",
+              "n_pairs": int(n_sample), "against": "oracle (reference-faithful port), same inputs, same options",
               "tolerance_rad": 1e-6}
     return base, parity
 
 
-def main():
-    args = parse_args()
+def profiled_counters(lib_path, key):
+    """HBM traffic / VALU-busy of the dominant kernel from the committed rocprofv3 PMC passes -- only if
+    they were taken on THIS build of the library (sha256) and this workload + geometry; else None."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+        sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()
+        w = tj["workload"]
+        if tj.get("lib_sha256") == sha and [w["name"], w["pairs"], w["corr"], w["iters"], w["geometry"]] == key:
+            return tj["hbm_bytes_per_launch"], tj.get("valu_busy_frac"), None
+        return None, None, "profiles/traffic_latest.json was measured on another build or workload"
+    except (OSError, KeyError, ValueError):
+        return None, None, "no committed PMC record"
+
+
+# ---------------------------------------------------------------------------------------------------
+def run(args):
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(1, args.gpus) and world > 1:
+    if world != max(1, args.gpus):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the solver has no CPU fallback")
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    cpu = args.dry_run_cpu
+    if not cpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the solver has no CPU fallback")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: no GPU {local_rank} ({torch.cuda.device_count()} visible)")
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
+    else:
+        device = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if cpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    n_ranks = dist.get_world_size() if world > 1 else 1
 
-    from pnec_amd import capi
-    from pnec_amd.distributed import gather_records, pack_records
+    from pnec_amd.distributed import RecordGather
+    sh = (build_kitti_all if args.workload == "kitti_all" else build_sim100k)(args, rank, world, device)
+    my_pairs = sh.sizes[rank]
+    first_global = sum(sh.sizes[:rank])
+    gather = RecordGather(world, rank, sizes=sh.sizes, device=None if (cpu or args.sync_gather) else device)
+    outs = [None, None]
 
-    batch, q0, t0, sample = build_shard(args.pairs, args.corr, rank, device)
-    opts = capi.default_options(max_num_iterations=args.iters, check_convergence=0,
-                                corr_per_lane=args.cpl, waves_per_pair=args.wpp,
-                                lds_corr_per_lane=args.ldsk)
-    launch = batch.describe_launch(opts)
-    out = None
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    if cpu:
+        from pnec_amd.batch import SolveResult
+        opts = launch = None
+        step_no = [0]
+
+        def solve(slot):
+            # stub: records a real solve would produce in shape, with the GLOBAL pair index as "cost" so
+            # that rank 0 can check the gathered order; no arithmetic of the solver is imitated
+            idx = torch.arange(first_global, first_global + my_pairs, dtype=torch.float64)
+            q = torch.zeros(my_pairs, 4, dtype=torch.float64)
+            q[:, 3] = 1.0
+            t = torch.zeros(my_pairs, 3, dtype=torch.float64)
+            t[:, 2] = 1.0
+            step_no[0] += 1
+            return SolveResult(q, t, idx, torch.full((my_pairs,), step_no[0], dtype=torch.int32),
+                               torch.full((my_pairs,), rank, dtype=torch.int32))
+    else:
+        from pnec_amd import capi
+        opts = capi.default_options(corr_per_lane=args.cpl, waves_per_pair=args.wpp,
+                                    lds_corr_per_lane=args.ldsk, **sh.opts)
+        launch = sh.batch.describe_launch(opts)
+
+        def solve(slot):
+            outs[slot] = sh.batch.solve(sh.q0, sh.t0, reg=1e-13, options=opts, out=outs[slot])
+            return outs[slot]
+
+    ev0 = ev1 = None
+    if not cpu:
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     def step(i=None):
-        nonlocal out
-        if i is not None:
+        slot = gather.acquire()
+        if i is not None and ev0:
             ev0[i].record()
-        out = batch.solve(q0, t0, reg=1e-13, options=opts, out=out)
-        if i is not None:
+        res = solve(slot)
+        if i is not None and ev1:
             ev1[i].record()
-        rec = pack_records(out)
-        return gather_records(rec, world, rank) if world > 1 else rec
+        gather.submit(slot, res)
+        return res
 
     def fence():
-        torch.cuda.synchronize()
+        if not cpu:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not cpu:
+                torch.cuda.synchronize()
 
     # setup: the first ~10 launches after an idle period run ~4 % slower (clock ramp).  Bring the
     # GPU to its steady clocks before the contract's W untimed warm-up steps, whatever W is.
-    setup_launches = max(0, 20 - args.warmup)
+    setup_launches = 0 if cpu else max(0, 20 - args.warmup)
     for _ in range(setup_launches):
-        out = batch.solve(q0, t0, reg=1e-13, options=opts, out=out)
+        solve(0)
     for _ in range(args.warmup):
         step()
+    gather.drain()
     fence()
     t_start = time.perf_counter()
+    res = None
     for i in range(args.steps):
-        gathered = step(i)
+        res = step(i)
+    gathered = gather.drain()
     fence()
     elapsed = time.perf_counter() - t_start
     if world > 1:
@@ -182,49 +357,67 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
-    solves_per_step = args.pairs * world
-    value = solves_per_step * args.steps / elapsed
-
     if rank == 0:
-        assert gathered.shape[0] == solves_per_step
+        value = sh.total_pairs * args.steps / elapsed
+        assert gathered.shape == (sh.total_pairs, 10), (tuple(gathered.shape), sh.total_pairs)
         assert bool(torch.isfinite(gathered[:, :8]).all())
-        payload = batch.payload_bytes                      # bytes the kernel must read once
-        passes = args.iters + 1                            # iteration zero + one per LM iteration
-        achieved_gbs = payload / (kernel_ms * 1e-3) / 1e9
-        flops = FLOP_PER_CORR_PASS * batch.num_correspondences * passes
-        valu_tflops = flops / (kernel_ms * 1e-3) / 1e12
-        valu_busy = None
-        traffic = None   # HBM bytes per launch from the committed rocprofv3 PMC passes, if they
-        try:             # were taken on this very workload and geometry
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-            w = tj["workload"]
-            if (w["pairs"], w["corr"], w["iters"]) == (args.pairs, args.corr, args.iters) and \
-                    w["geometry"] == [launch["corr_per_lane"], launch["waves_per_pair"], launch["lds_corr_per_lane"]]:
-                traffic = tj["hbm_bytes_per_launch"]
-                valu_busy = tj.get("valu_busy_frac")
-        except (OSError, KeyError, ValueError):
-            pass
-        iters_done = out.iterations.to(torch.float64)
         line = {
-            "metric": "PNEC pose solves/sec (512 corr, 10 GN iters)",
-            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            "metric": "PNEC pose solves/sec (512 corr, 10 GN iters)" if args.workload == "sim100k"
+                      else "PNEC pose solves/sec (all KITTI 00-10 pairs, ragged, Ceres-default termination)",
+            "value": value, "unit": "solves/s", "n_gpus": n_ranks, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": "configs[1]: batch of 100k simulated frame pairs x 512 "
-                                   "anisotropic-covariance correspondences per GPU",
-                       "pairs_per_gpu": args.pairs, "correspondences": args.corr,
-                       "lm_iterations": args.iters, "setup_launches_before_warmup": setup_launches,
-                       "lm_iterations_done_min_mean_max": [float(iters_done.min()), float(iters_done.mean()),
-                                                           float(iters_done.max())],
-                       "residual": "PNEC target frame",
-                       "sharding": f"independent pairs, {world} rank(s), one RCCL gather of result records",
-                       "launch": launch},
-            "roofline": {
-                "bound": "hbm", "kernel": "lm_solve_kernel<TARGET>",
+            "higher_is_better": True, "scaling": sh.scaling, "vs_baseline": None, "dtype": "f64",
+            "data": sh.data,
+            "config": {"workload": sh.workload, "pairs_total": sh.total_pairs, "pairs_per_rank": sh.sizes,
+                       "launcher": "torch.distributed.run" if not os.environ.get("PNEC_BENCH_SPAWNED") and world > 1
+                                   else ("self-spawned ranks" if world > 1 else "single process"),
+                       "sharding": f"independent pairs, {n_ranks} rank(s), one {'gloo' if cpu else 'RCCL'} gather of "
+                                   f"80-B result records per step" + ("" if args.sync_gather or cpu else
+                                                                      ", on a side stream (overlaps the next step)")},
+        }
+        if cpu:
+            # the gathered "cost" column must be the global pair index, in order, from the LAST step
+            assert torch.equal(gathered[:, 7], torch.arange(sh.total_pairs, dtype=torch.float64))
+            assert bool((gathered[:, 8] == args.warmup + args.steps).all())
+            want_rank = torch.repeat_interleave(torch.arange(world), torch.tensor(sh.sizes)).to(torch.float64)
+            assert torch.equal(gathered[:, 9], want_rank)
+            line.update({"metric": "DRY RUN (stubbed solve, no GPU): launch/partition/gather plumbing only",
+                         "value": None, "dry_run": True, "records_in_order": True})
+            if args.workload == "kitti_all":
+                line["config"]["corr_per_rank"] = sh.shard_corr
+        else:
+            kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+            batch = sh.batch
+            payload = batch.payload_bytes                      # bytes the kernel must read once
+            iters_done = res.iterations.to(torch.float64)
+            passes = float(iters_done.mean()) + 1.0 if my_pairs else 0.0   # iteration zero + one per LM iteration
+            achieved_gbs = payload / (kernel_ms * 1e-3) / 1e9
+            corr_passes = batch.num_correspondences * passes
+            if args.workload == "kitti_all" and my_pairs:      # ragged: weight each pair's passes by its size
+                w = torch.as_tensor(np.diff(batch.offsets), dtype=torch.float64, device=iters_done.device)
+                corr_passes = float(((iters_done + 1.0) * w).sum())
+            valu_tflops = FLOP_PER_CORR_PASS * corr_passes / (kernel_ms * 1e-3) / 1e12
+            issue_tflops_equiv = 2 * VALU_INSTR_PER_CORR_PASS * corr_passes / (kernel_ms * 1e-3) / 1e12
+            key = [args.workload, args.pairs if args.workload == "sim100k" else sh.total_pairs,
+                   args.corr if args.workload == "sim100k" else 0, args.iters if args.workload == "sim100k" else 0,
+                   [launch["corr_per_lane"], launch["waves_per_pair"], launch["lds_corr_per_lane"]]]
+            traffic, valu_busy, why = profiled_counters(capi.LIB_PATH, key)
+            line["config"].update({
+                "lm_iterations_done_min_mean_max": [float(iters_done.min()), float(iters_done.mean()),
+                                                    float(iters_done.max())] if my_pairs else None,
+                "residual": "PNEC target frame", "launch": launch,
+                "setup_launches_before_warmup": setup_launches})
+            if args.workload == "sim100k":
+                line["config"].update({"pairs_per_gpu": args.pairs, "correspondences": args.corr,
+                                       "lm_iterations": args.iters})
+            else:
+                line["config"].update({"corr_per_rank": sh.shard_corr,
+                                       "corr_min_mean_max": [int(sh.pair_sizes.min()), float(sh.pair_sizes.mean()),
+                                                             int(sh.pair_sizes.max())]})
+            line["roofline"] = {
+                "bound": "hbm", "kernel": "lm_solve_kernel<TARGET>", "rank": 0,
                 "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": why,
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": payload,
                 "note": "register-resident design: the payload (96 B/correspondence) is read from HBM "
@@ -233,27 +426,37 @@ def main():
                 # SURVEY.md 8(d) quotes the streaming model (N x 96 B x passes per solve); against it:
                 "streaming_equivalent_GBs": achieved_gbs * passes,
                 "streaming_equivalent_frac": achieved_gbs * passes / HBM_PEAK_GBS,
-                "streaming_bytes_per_solve": batch.payload_bytes // args.pairs * passes,
                 "valu": {"bound": "valu_fp64", "achieved": valu_tflops, "peak": FP64_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": valu_tflops / FP64_VALU_PEAK_TFLOPS,
                          "flop_per_corr_pass": FLOP_PER_CORR_PASS, "passes": passes,
+                         "flop_note": "62 FMA + 28 MUL + 1 rsq per correspondence per pass = 153 flop in 91 issue slots",
+                         # the same work priced in issue slots (every VALU instruction = one FMA-sized slot)
+                         "issue_slot_frac_useful": issue_tflops_equiv / FP64_VALU_PEAK_TFLOPS,
                          # share of cycles the vector ALU was issuing (any FP64/integer/cross-lane
                          # instruction, useful or bookkeeping), from the committed rocprofv3 SQ counters
                          "issue_busy_frac_profiled": valu_busy},
-            },
-        }
-        if not args.no_cpu_baseline and world == 1:
-            from oracle import pnec_oracle as po
-            cores = po.max_threads()
-            n_sample = args.cpu_sample or int(min(sample.bvs1.shape[0], max(64, 64 * cores)))
-            base, parity = cpu_baseline(sample, n_sample, opts, out.q)
-            line["cpu_baseline"] = base
-            line["parity"] = parity
+            }
+            if not args.no_cpu_baseline and world == 1 and sh.sample is not None:
+                from oracle import pnec_oracle as po
+                cores = po.max_threads()
+                avail = len(sh.sample[0]) - 1
+                n_sample = args.cpu_sample or int(min(avail, max(64, 32 * cores)))
+                base, parity = cpu_baseline(sh.sample, n_sample, opts, res.q)
+                line["cpu_baseline"] = base
+                line["parity"] = parity
         print(json.dumps(line), flush=True)
 
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, argv))
+    run(args)
 
 
 if __name__ == "__main__":

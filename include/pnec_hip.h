@@ -45,7 +45,8 @@
 extern "C" {
 #endif
 
-#define PNEC_HIP_ABI_VERSION 1
+#define PNEC_HIP_ABI_VERSION 2
+#define PNEC_HIP_MAX_RANSAC_SAMPLE 16 /* largest Options::ransac_sample_size_ the RANSAC kernel is built for */
 
 typedef enum pnec_hip_status {
   PNEC_HIP_OK = 0,
@@ -128,6 +129,9 @@ int64_t pnec_hip_problem_num_correspondences(const pnec_hip_problem *p);
 int64_t pnec_hip_problem_max_correspondences(const pnec_hip_problem *p);
 /* bytes of bearing/covariance payload the solver reads per pass over the batch (algorithmic) */
 int64_t pnec_hip_problem_payload_bytes(const pnec_hip_problem *p);
+/* The batch's correspondence offsets, HOST int64[n_pairs+1] (what problem_create was given; for a
+ * batch made by pnec_hip_problem_select: the offsets of the kept correspondences). */
+int pnec_hip_problem_offsets(const pnec_hip_problem *p, int64_t *out);
 int pnec_hip_problem_mode(const pnec_hip_problem *p);
 int pnec_hip_problem_device(const pnec_hip_problem *p);
 
@@ -172,7 +176,8 @@ int pnec_hip_nec_eigensolver(pnec_hip_problem *p, const double *init_q, double *
  * its rand() draws are replaced by a counter-based hash of (seed, pair, hypothesis, draw).
  * out_inlier_mask [sum N] (1 = inlier, in the caller's correspondence order), out_inlier_count
  * [n_pairs], out_ransac_iterations [n_pairs] may each be NULL.  Pairs with fewer than sample_size
- * correspondences fall back to the plain eigensolver with every correspondence an inlier. */
+ * correspondences fall back to the plain eigensolver with every correspondence an inlier.
+ * sample_size > PNEC_HIP_MAX_RANSAC_SAMPLE (16) returns PNEC_HIP_ERR_UNSUPPORTED. */
 int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint64_t seed,
                                 int32_t max_iterations, int32_t sample_size, double threshold, double *out_q,
                                 double *out_t, uint8_t *out_inlier_mask, int32_t *out_inlier_count,

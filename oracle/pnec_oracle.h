@@ -184,7 +184,18 @@ int pnec_oracle_ransac_eigensolver(int64_t n, const double *bvs1, const double *
                                    uint64_t seed, uint64_t pair_id, int max_iterations, int sample_size,
                                    double threshold, double R_out[9], double t_out[3], uint8_t *inlier_mask,
                                    int32_t *n_inliers, int32_t *iterations);
-/* pnec.cc:283-348 */
+/* pnec.cc:283-348, literal: every round re-runs the eigensolver, every scf call runs its 10 steps */
+void pnec_oracle_weighted_eigensolver_ex(int64_t n, const double *bvs1, const double *bvs2,
+                                         const double *covs, const double R_init[9], const double t_init[3],
+                                         double reg, int weighted_iterations,
+                                         int device_early_exits /* 0 = the reference; 1 = the device's two
+                                                                   declared early exits (NOT the reference) */,
+                                         double R_out[9], double t_out[3]);
+void pnec_oracle_weighted_eigensolver_batch(int64_t n_pairs, const int64_t *offsets, const double *bvs1,
+                                            const double *bvs2, const double *covs, const double *R_init,
+                                            const double *t_init, double reg, int weighted_iterations,
+                                            int device_early_exits, int num_threads, double *R_out,
+                                            double *t_out);
 void pnec_oracle_weighted_eigensolver(int64_t n, const double *bvs1, const double *bvs2,
                                       const double *covs, const double R_init[9], const double t_init[3],
                                       double reg, int weighted_iterations, double R_out[9],

@@ -129,6 +129,10 @@ def lib() -> C.CDLL:
                                                         C.c_int, C.c_double, _dp, _dp, C.POINTER(C.c_uint8), _ip, _ip]
         _lib.pnec_oracle_weighted_eigensolver.argtypes = [C.c_int64, _dp, _dp, _dp, _dp, _dp, C.c_double,
                                                           C.c_int, _dp, _dp]
+        _lib.pnec_oracle_weighted_eigensolver_batch.argtypes = [C.c_int64, _lp, _dp, _dp, _dp, _dp, _dp, C.c_double,
+                                                                C.c_int, C.c_int, C.c_int, _dp, _dp]
+        _lib.pnec_oracle_weighted_eigensolver_ex.argtypes = [C.c_int64, _dp, _dp, _dp, _dp, _dp, C.c_double,
+                                                             C.c_int, C.c_int, _dp, _dp]
     return _lib
 
 
@@ -298,17 +302,39 @@ def reprojection_score(f1, f2, R, t):
     return lib().pnec_oracle_reprojection_score(ap, bp, rp, cp)
 
 
-def weighted_eigensolver(bvs1, bvs2, covs, R_init, t_init, reg=1e-13, weighted_iterations=10):
-    """PNEC::WeightedEigensolver (pnec.cc:283-348) -> (R, t)"""
+def weighted_eigensolver(bvs1, bvs2, covs, R_init, t_init, reg=1e-13, weighted_iterations=10,
+                         device_early_exits=False):
+    """PNEC::WeightedEigensolver (pnec.cc:283-348) -> (R, t).  Literal by default (every round re-runs
+    the eigensolver, every scf call runs its 10 steps).  device_early_exits=True is NOT the reference:
+    it takes the device kernel's two declared early exits (see pnec_oracle_frontend.c)."""
     b1, b1p = _d(bvs1)
     b2, b2p = _d(bvs2)
     c, cp = _d(covs_to_colmajor9(covs))
     r, rp = _d(np.asarray(R_init).reshape(9))
     t0, t0p = _d(t_init)
     R, t = np.zeros(9), np.zeros(3)
-    lib().pnec_oracle_weighted_eigensolver(len(b1), b1p, b2p, cp, rp, t0p, reg, weighted_iterations,
-                                           R.ctypes.data_as(_dp), t.ctypes.data_as(_dp))
+    lib().pnec_oracle_weighted_eigensolver_ex(len(b1), b1p, b2p, cp, rp, t0p, reg, weighted_iterations,
+                                              1 if device_early_exits else 0,
+                                              R.ctypes.data_as(_dp), t.ctypes.data_as(_dp))
     return R.reshape(3, 3), t
+
+
+def weighted_eigensolver_batch(offsets, bvs1, bvs2, covs, R_init, t_init, reg=1e-13, weighted_iterations=10,
+                               device_early_exits=False, num_threads=0):
+    """weighted_eigensolver for a ragged batch (OpenMP over pairs) -> (R [P,3,3], t [P,3])"""
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    P = len(off) - 1
+    b1, b1p = _d(bvs1)
+    b2, b2p = _d(bvs2)
+    c, cp = _d(covs_to_colmajor9(covs))
+    r, rp = _d(np.asarray(R_init).reshape(P, 9))
+    t0, t0p = _d(np.asarray(t_init).reshape(P, 3))
+    R, t = np.zeros((P, 9)), np.zeros((P, 3))
+    lib().pnec_oracle_weighted_eigensolver_batch(P, off.ctypes.data_as(_lp), b1p, b2p, cp, rp, t0p, reg,
+                                                 weighted_iterations, 1 if device_early_exits else 0,
+                                                 num_threads or max_threads(), R.ctypes.data_as(_dp),
+                                                 t.ctypes.data_as(_dp))
+    return R.reshape(P, 3, 3), t
 
 
 def angles_from_vec(v):

@@ -16,9 +16,14 @@
  *              restates the PUBLISHED algorithm (Kneip & Lynen, "Direct optimization of
  *              frame-to-frame rotation", ICCV 2013): minimise the smallest eigenvalue of
  *              M(R) = sum_i (f1_i x R f2_i)(f1_i x R f2_i)' over the Cayley parameters of R,
- *              starting from the supplied rotation.  opengv drives that with MINPACK's lmdif on
- *              the eigenvalue's Jacobian (ftol 5e-5, <= 100 evaluations); here it is a damped
- *              Newton iteration run to a tight tolerance -- same minimiser, different path.
+ *              starting from the supplied rotation.  opengv (as far as it can be recalled without
+ *              its source: modules/main.cpp eigensolver_main) walks down the normalised
+ *              finite-difference gradient with a step length that doubles while the eigenvalue
+ *              falls and halves while it rises, and stops when the step length drops below its
+ *              xtol or after 50 iterations -- i.e. it reaches the minimiser only to about its step
+ *              tolerance.  Here it is a damped Newton iteration run to a tight tolerance: same
+ *              minimiser, different path, smaller stopping slack.  Trajectory parity with opengv
+ *              is therefore UNPINNED and cannot be pinned in this image.
  *              Eigenvector signs (TranslationFromM, scf) are arbitrary in Eigen; here: the
  *              component of largest magnitude is made positive.
  *   Reference quirks reproduced: ComposeM skips correspondence 0 (C7); WeightedEigensolver
@@ -335,20 +340,11 @@ double pnec_oracle_obj_fun(const double t[3], int64_t n, const double *Ai, const
 }
 
 /* scf.cc:128-148 with alt_construct_E's resize/push_back slip (C5): E = sum A_i / (t'B_i t) */
+static void scf_steps(int64_t n, const double *Ai, const double *Bi, const double t0[3], int steps,
+                      int stop_at_fixed_point, double t_out[3]);
 void pnec_oracle_scf(int64_t n, const double *Ai, const double *Bi, const double t0[3], int steps,
                      double t_out[3]) {
-  double t[3] = {t0[0], t0[1], t0[2]};
-  for (int s = 0; s < steps; ++s) {
-    double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int64_t i = 0; i < n; ++i) {
-      const double w = 1.0 / quad9(Bi + 9 * i, t);
-      for (int k = 0; k < 9; ++k) E[k] += w * Ai[9 * i + k];
-    }
-    double w3[3], V[9];
-    pnec_oracle_sym_eig3(E, w3, V);
-    t[0] = V[0]; t[1] = V[3]; t[2] = V[6];
-  }
-  memcpy(t_out, t, sizeof(t));
+  scf_steps(n, Ai, Bi, t0, steps, 0, t_out);
 }
 
 /* A_i = n n', B_i = f1hat R Sigma R' f1hat' + reg I   (pnec.cc:317-328); row-major outputs */
@@ -385,17 +381,46 @@ void pnec_oracle_nec_eigensolver(int64_t n, const double *bvs1, const double *bv
   pnec_oracle_translation_from_m(M, t_out);
 }
 
-/* ---- pnec.cc:283-348 -------------------------------------------------------------------------- */
-void pnec_oracle_weighted_eigensolver(int64_t n, const double *bvs1, const double *bvs2,
-                                      const double *covs, const double R_init[9], const double t_init[3],
-                                      double reg, int weighted_iterations, double R_out[9],
-                                      double t_out[3]) {
+/* ---- pnec.cc:283-348 --------------------------------------------------------------------------
+ * LITERAL restatement of PNEC::WeightedEigensolver: for each of the weighted_iterations - 1 rounds
+ *   weights from the INITIAL pose (pnec.cc:297-301, quirk C3) x 1e-8 (C4), bvs2 scaled by sqrt(w)
+ *   (:304-308), adapter started at rel_pose.rotationMatrix() (:310-311), eigensolver (:315), A_i, B_i
+ *   from the new rotation (:317-328), the current translation against 500 Fibonacci directions
+ *   (:330-340), scf with exactly 10 steps (:342-343, scf.cc:128-148), rel_pose <- (R, t) (:345).
+ * Every round calls the eigensolver and every scf call runs all of its steps, as the reference reads.
+ *
+ * device_early_exits != 0 is NOT the reference: it reproduces the two early exits the DEVICE kernel
+ * takes (declared deviations) so that tests can separate "the kernel's arithmetic differs
+ * from this file's" (tight tolerance, against this twin) from "the early exits change the result"
+ * (bounded, measured against the literal form: profiles/r02_frontend_literal_parity.json):
+ *   (1) once an eigensolver call has ended below its iteration cap the rotation is kept for the
+ *       remaining rounds (the weights never change, C3, so later calls restart at the optimum);
+ *   (2) scf stops when its iterate repeats to 4e-15 instead of running all 10 steps. */
+static void scf_steps(int64_t n, const double *Ai, const double *Bi, const double t0[3], int steps,
+                      int stop_at_fixed_point, double t_out[3]) {
+  double t[3] = {t0[0], t0[1], t0[2]};
+  for (int s = 0; s < steps; ++s) {
+    double E[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = 0; i < n; ++i) {
+      const double w = 1.0 / quad9(Bi + 9 * i, t);
+      for (int k = 0; k < 9; ++k) E[k] += w * Ai[9 * i + k];
+    }
+    double w3[3], V[9];
+    pnec_oracle_sym_eig3(E, w3, V);
+    const double moved = fmax(fabs(V[0] - t[0]), fmax(fabs(V[3] - t[1]), fabs(V[6] - t[2])));
+    t[0] = V[0]; t[1] = V[3]; t[2] = V[6];
+    if (stop_at_fixed_point && moved <= 4e-15) break;
+  }
+  memcpy(t_out, t, 3 * sizeof(double));
+}
+
+void pnec_oracle_weighted_eigensolver_ex(int64_t n, const double *bvs1, const double *bvs2,
+                                         const double *covs, const double R_init[9], const double t_init[3],
+                                         double reg, int weighted_iterations, int device_early_exits,
+                                         double R_out[9], double t_out[3]) {
   double R[9], t[3], v[3];
   memcpy(R, R_init, sizeof(R));
   memcpy(t, t_init, sizeof(t));
-  /* the rotation is carried between iterations as its Cayley vector, so an eigensolver call that is
-   * already converged at entry returns bit-identical R (iterations 2.. of the reference only
-   * restart opengv's eigensolver from the previous optimum with unchanged weights, C3) */
   pnec_oracle_rot_to_cayley(R_init, v);
   double *w2 = (double *)malloc(sizeof(double) * 3 * (size_t)(n > 0 ? n : 1));
   double *Ai = (double *)malloc(sizeof(double) * 9 * (size_t)(n > 0 ? n : 1));
@@ -412,12 +437,15 @@ void pnec_oracle_weighted_eigensolver(int64_t n, const double *bvs1, const doubl
     }
     double Rn[9];
     {
-      /* The weights never change (C3), so every iteration minimises the same function from the
-       * previous optimum: once a call has ended for any reason other than the iteration cap
-       * (gradient below tolerance, step below 1e-12, no descent left) the minimiser has nothing
-       * more to give and the rotation is final -- later iterations only redo the translation. */
       es_data D = {n, bvs1, w2};
-      if (!rotation_final) rotation_final = eigensolver_cayley(&D, v) < 50;
+      if (device_early_exits) {
+        /* the Cayley vector is carried between rounds, early exit (1) */
+        if (!rotation_final) rotation_final = eigensolver_cayley(&D, v) < 50;
+      } else {
+        /* pnec.cc:310-315: a new adapter holding rel_pose's rotation MATRIX, a new eigensolver call */
+        pnec_oracle_rot_to_cayley(R, v);
+        eigensolver_cayley(&D, v);
+      }
       pnec_oracle_cayley_to_rot(v, Rn);
     }
     pnec_oracle_build_ab(n, bvs1, bvs2, covs, Rn, reg, Ai, Bi);
@@ -430,7 +458,7 @@ void pnec_oracle_weighted_eigensolver(int64_t n, const double *bvs1, const doubl
         memcpy(best, fib + 3 * k, sizeof(best));
       }
     }
-    pnec_oracle_scf(n, Ai, Bi, best, 10, t);
+    scf_steps(n, Ai, Bi, best, 10, device_early_exits, t);
     memcpy(R, Rn, sizeof(R));
   }
   memcpy(R_out, R, sizeof(R));
@@ -438,6 +466,29 @@ void pnec_oracle_weighted_eigensolver(int64_t n, const double *bvs1, const doubl
   free(w2);
   free(Ai);
   free(Bi);
+}
+
+/* OpenMP over pairs (test tooling: thousands of pairs against the device) */
+void pnec_oracle_weighted_eigensolver_batch(int64_t n_pairs, const int64_t *offsets, const double *bvs1,
+                                            const double *bvs2, const double *covs, const double *R_init,
+                                            const double *t_init, double reg, int weighted_iterations,
+                                            int device_early_exits, int num_threads, double *R_out,
+                                            double *t_out) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads > 0 ? num_threads : 1)
+  for (int64_t p = 0; p < n_pairs; ++p) {
+    const int64_t a = offsets[p], n = offsets[p + 1] - offsets[p];
+    pnec_oracle_weighted_eigensolver_ex(n, bvs1 + 3 * a, bvs2 + 3 * a, covs + 9 * a, R_init + 9 * p, t_init + 3 * p,
+                                        reg, weighted_iterations, device_early_exits, R_out + 9 * p, t_out + 3 * p);
+  }
+}
+
+/* the reference's behaviour: the literal form */
+void pnec_oracle_weighted_eigensolver(int64_t n, const double *bvs1, const double *bvs2,
+                                      const double *covs, const double R_init[9], const double t_init[3],
+                                      double reg, int weighted_iterations, double R_out[9],
+                                      double t_out[3]) {
+  pnec_oracle_weighted_eigensolver_ex(n, bvs1, bvs2, covs, R_init, t_init, reg, weighted_iterations, 0, R_out,
+                                      t_out);
 }
 
 /* ---- RANSAC around the eigensolver: pnec.cc:239-272 -------------------------------------------

@@ -100,6 +100,36 @@ class Batch:
                 "lds_corr_per_lane": ldsk.value, "threads_per_block": tpb.value,
                 "resident": bool(res.value)}
 
+    # -- argument hygiene (DEVICE space: the ABI reinterprets the pointer as float64 on self.device)
+    def _dev_tensor(self, a, name, shape=None, dtype=None):
+        """A contiguous CUDA tensor of `dtype` (float64 by default) on this batch's GPU, or an error."""
+        import torch
+        if a is None:
+            return None
+        dtype = dtype or torch.float64
+        if not _is_torch(a):
+            raise TypeError(f"{name}: mixing numpy and torch arguments in one call is not supported")
+        if not a.is_cuda:
+            raise ValueError(f"{name}: torch arguments must be CUDA tensors (or pass numpy arrays)")
+        if a.device.index != self.device:
+            raise ValueError(f"{name}: tensor lives on cuda:{a.device.index}, the batch on cuda:{self.device}")
+        if a.dtype != dtype:
+            if dtype != torch.float64 or not a.dtype.is_floating_point:
+                raise TypeError(f"{name}: expected {dtype}, got {a.dtype}")
+            a = a.to(dtype)
+        a = a.contiguous()
+        if shape is not None and tuple(a.shape) != tuple(shape):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(a.shape)}")
+        return a
+
+    def _dev_out(self, a, name, shape, dtype):
+        """A caller-supplied output buffer: must already be exactly what the kernel writes."""
+        if not (_is_torch(a) and a.is_cuda and a.device.index == self.device and a.dtype == dtype
+                and a.is_contiguous() and tuple(a.shape) == tuple(shape)):
+            raise ValueError(f"out.{name}: need a contiguous {dtype} CUDA tensor of shape {tuple(shape)} "
+                             f"on cuda:{self.device}")
+        return a
+
     # -- ingest -----------------------------------------------------------------------------
     def fill(self, bvs1, bvs2, covs=None, covs_host=None, first_pair: int = 0,
              n_pairs: int | None = None):
@@ -121,8 +151,10 @@ class Batch:
             width = 3 if i < 2 else 9
             if on_device:
                 import torch
-                if not a.is_cuda:
+                if not _is_torch(a) or not a.is_cuda:
                     raise ValueError("torch inputs must be CUDA tensors (or pass numpy)")
+                if a.device.index != self.device:
+                    raise ValueError(f"array {i}: tensor on cuda:{a.device.index}, batch on cuda:{self.device}")
                 if a.dim() == 3:  # [M,3,3] symmetric == its own column-major image
                     a = a.reshape(a.shape[0], 9)
                 a = a.contiguous().to(torch.float64)
@@ -154,19 +186,28 @@ class Batch:
               out: SolveResult | None = None) -> SolveResult:
         """InitValues + Optimize + Result for every (pair, hypothesis) on the device."""
         on_device = _is_torch(init_q)
-        S = self.n_pairs * (n_hyp if hyp_t is not None else 1)
+        n_hyp = int(n_hyp) if hyp_t is not None else 1
+        if n_hyp < 1:
+            raise ValueError("n_hyp must be >= 1")
+        S = self.n_pairs * n_hyp
         if on_device:
             import torch
+            init_q = self._dev_tensor(init_q, "init_q", (self.n_pairs, 4))
+            init_t = self._dev_tensor(init_t, "init_t", (self.n_pairs, 3))
+            hyp_t = self._dev_tensor(hyp_t, "hyp_t", (S, 3))
             dev = init_q.device
             f64 = dict(dtype=torch.float64, device=dev)
-            init_q = init_q.contiguous()
-            init_t = init_t.contiguous() if init_t is not None else None
-            hyp_t = hyp_t.contiguous() if hyp_t is not None else None
             if out is None:
                 out = SolveResult(torch.empty((S, 4), **f64), torch.empty((S, 3), **f64),
                                   torch.empty((S,), **f64),
                                   torch.empty((S,), dtype=torch.int32, device=dev),
                                   torch.empty((S,), dtype=torch.int32, device=dev))
+            else:
+                self._dev_out(out.q, "q", (S, 4), torch.float64)
+                self._dev_out(out.t, "t", (S, 3), torch.float64)
+                self._dev_out(out.cost, "cost", (S,), torch.float64)
+                self._dev_out(out.iterations, "iterations", (S,), torch.int32)
+                self._dev_out(out.status, "status", (S,), torch.int32)
             p = lambda a: None if a is None else a.data_ptr()
             stream = torch.cuda.current_stream(self.device).cuda_stream
             space = capi.MEM_DEVICE
@@ -177,6 +218,12 @@ class Batch:
             if out is None:
                 out = SolveResult(np.empty((S, 4)), np.empty((S, 3)), np.empty(S),
                                   np.empty(S, dtype=np.int32), np.empty(S, dtype=np.int32))
+            else:
+                for name, shape, dt in (("q", (S, 4), np.float64), ("t", (S, 3), np.float64), ("cost", (S,), np.float64),
+                                        ("iterations", (S,), np.int32), ("status", (S,), np.int32)):
+                    a = getattr(out, name)
+                    if not (isinstance(a, np.ndarray) and a.dtype == dt and a.shape == shape and a.flags.c_contiguous):
+                        raise ValueError(f"out.{name}: need a C-contiguous {np.dtype(dt).name} array of shape {shape}")
             p = lambda a: None if a is None else a.ctypes.data
             stream = None
             space = capi.MEM_HOST
@@ -196,17 +243,16 @@ class Batch:
         on_device = _is_torch(init_q)
         if on_device:
             import torch
-            f64 = dict(dtype=torch.float64, device=init_q.device)
+            keep = [self._dev_tensor(init_q, "init_q", (self.n_pairs, 4)),
+                    self._dev_tensor(init_t, "init_t", (self.n_pairs, 3))]
+            f64 = dict(dtype=torch.float64, device=keep[0].device)
             oq, ot = torch.empty((self.n_pairs, 4), **f64), torch.empty((self.n_pairs, 3), **f64)
-            p = lambda a: None if a is None else a.contiguous().data_ptr()
             stream, space = torch.cuda.current_stream(self.device).cuda_stream, capi.MEM_DEVICE
-            keep = [init_q.contiguous(), None if init_t is None else init_t.contiguous()]
             pq, pt = keep[0].data_ptr(), (None if keep[1] is None else keep[1].data_ptr())
         else:
             keep = [np.ascontiguousarray(init_q, dtype=np.float64),
                     None if init_t is None else np.ascontiguousarray(init_t, dtype=np.float64)]
             oq, ot = np.empty((self.n_pairs, 4)), np.empty((self.n_pairs, 3))
-            p = lambda a: None if a is None else a.ctypes.data
             stream, space = None, capi.MEM_HOST
             pq, pt = keep[0].ctypes.data, (None if keep[1] is None else keep[1].ctypes.data)
         po, pto = (oq.data_ptr(), ot.data_ptr()) if on_device else (oq.ctypes.data, ot.ctypes.data)
@@ -224,6 +270,7 @@ class Batch:
         M, P = self.num_correspondences, self.n_pairs
         if _is_torch(init_q):
             import torch
+            init_q = self._dev_tensor(init_q, "init_q", (P, 4))
             dev = init_q.device
             q = torch.empty((P, 4), dtype=torch.float64, device=dev)
             t = torch.empty((P, 3), dtype=torch.float64, device=dev)
@@ -248,21 +295,25 @@ class Batch:
     def select(self, mask) -> "Batch":
         """PNEC::InlierExtraction (pnec.cc:210-229): new Batch with the masked correspondences."""
         h = C.c_void_p()
+        M = self.num_correspondences
         if _is_torch(mask):
             import torch
-            m = mask.contiguous().to(torch.uint8)
+            m = mask if mask.dtype == torch.uint8 else (mask != 0).to(torch.uint8)
+            m = self._dev_tensor(m, "mask", (M,), dtype=torch.uint8)
             capi.check(self._lib.pnec_hip_problem_select(self._h, m.data_ptr(), capi.MEM_DEVICE,
                                                          torch.cuda.current_stream(self.device).cuda_stream,
                                                          C.byref(h)))
-            counts = None
         else:
             m = np.ascontiguousarray(mask, dtype=np.uint8)
+            if m.shape != (M,):
+                raise ValueError(f"mask: expected shape ({M},), got {m.shape}")
             capi.check(self._lib.pnec_hip_problem_select(self._h, m.ctypes.data, capi.MEM_HOST, None, C.byref(h)))
         out = Batch.__new__(Batch)
         out._lib, out.mode, out.device, out._h = self._lib, self.mode, self.device, h
         out.n_pairs = self.n_pairs
-        # offsets of the new batch are known to the library; rebuild them from its pair sizes lazily
-        out.offsets = None
+        # the library knows the kept counts (it sized the new batch from them): fetch its offsets
+        out.offsets = np.empty(self.n_pairs + 1, dtype=np.int64)
+        capi.check(self._lib.pnec_hip_problem_offsets(h, out.offsets.ctypes.data))
         return out
 
     def nec_eigensolver(self, init_q):
@@ -277,9 +328,11 @@ class Batch:
         """pnec::common::CostFunction per pair (TARGET-mode batches)."""
         if _is_torch(q):
             import torch
+            q = self._dev_tensor(q, "q", (self.n_pairs, 4))
+            t = self._dev_tensor(t, "t", (self.n_pairs, 3))
             out = torch.empty((self.n_pairs,), dtype=torch.float64, device=q.device)
             capi.check(self._lib.pnec_hip_cost_function(
-                self._h, q.contiguous().data_ptr(), t.contiguous().data_ptr(), out.data_ptr(),
+                self._h, q.data_ptr(), t.data_ptr(), out.data_ptr(),
                 capi.MEM_DEVICE, torch.cuda.current_stream(self.device).cuda_stream))
             return out
         q = np.ascontiguousarray(q, dtype=np.float64)

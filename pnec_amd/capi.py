@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PNEC_HIP_LIB: load an alternative build of the same ABI (kernel A/B experiments only)
 LIB_PATH = os.environ.get("PNEC_HIP_LIB") or os.path.join(_HERE, "libpnec_hip.so")
 
+ABI_VERSION = 2  # PNEC_HIP_ABI_VERSION of include/pnec_hip.h this binding was written against
 MODE_NEC, MODE_TARGET, MODE_HOST, MODE_SYM = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 TERM_NAMES = {
@@ -38,6 +39,7 @@ SYMBOLS = [
     "pnec_hip_problem_num_correspondences",
     "pnec_hip_problem_max_correspondences",
     "pnec_hip_problem_payload_bytes",
+    "pnec_hip_problem_offsets",
     "pnec_hip_problem_mode",
     "pnec_hip_problem_device",
     "pnec_hip_solve",
@@ -100,6 +102,9 @@ def lib() -> C.CDLL:
             "There is no CPU fallback.")
     L = C.CDLL(LIB_PATH)
     L.pnec_hip_abi_version.restype = C.c_int
+    if L.pnec_hip_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {L.pnec_hip_abi_version()}, this binding needs "
+                          f"{ABI_VERSION}: rebuild with `make -C pnec_amd/csrc`")
     L.pnec_hip_last_error.restype = C.c_char_p
     L.pnec_hip_device_count.argtypes = [C.POINTER(C.c_int)]
     L.pnec_hip_default_options.argtypes = [C.POINTER(Options)]
@@ -111,6 +116,7 @@ def lib() -> C.CDLL:
         f = getattr(L, "pnec_hip_problem_" + name)
         f.argtypes = [_vp]
         f.restype = C.c_int64
+    L.pnec_hip_problem_offsets.argtypes = [_vp, _vp]
     L.pnec_hip_problem_mode.argtypes = [_vp]
     L.pnec_hip_problem_device.argtypes = [_vp]
     L.pnec_hip_solve.argtypes = [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.POINTER(Options),

@@ -168,7 +168,7 @@ std::vector<Matrix3d> UnscentedTransform(const std::vector<Vector3d> &mus, const
   if (!mus.empty())
     Check(pnec_hip_unscented_transform((int64_t)mus.size(), mus[0].data(), covs[0].data(), K_inv.data(), kappa,
                                        camera_model == Pinhole ? 1 : 0, nullptr, out[0].data(),
-                                       PNEC_HIP_MEM_HOST, 0, nullptr));
+                                       PNEC_HIP_MEM_HOST, optimization::SolverOptions().device, nullptr));
   return out;
 }
 
@@ -179,8 +179,12 @@ Matrix3d UnscentedTransform(const Vector3d &mu, const Matrix3d &cov, const Matri
 
 double CostFunction(const bearingVectors_t &bvs_1, const bearingVectors_t &bvs_2,
                     const std::vector<Matrix3d> &covs, const SE3d &camera_pose) {
+  if (bvs_1.size() != bvs_2.size() || bvs_1.size() != covs.size())
+    throw std::invalid_argument("bvs_1, bvs_2 and covs differ in size");
+  // empty input: the reference divides 0.0 by size() == 0 (common.cc:258) -> NaN
+  if (bvs_1.empty()) return std::nan("");
   const std::vector<int64_t> offsets = {0, (int64_t)bvs_1.size()};
-  Problem prob(0, PNEC_HIP_MODE_TARGET, offsets);
+  Problem prob(optimization::SolverOptions().device, PNEC_HIP_MODE_TARGET, offsets);
   Check(pnec_hip_problem_fill(prob.p, 0, 1, bvs_1[0].data(), bvs_2[0].data(), covs[0].data(), nullptr,
                               PNEC_HIP_MEM_HOST, nullptr));
   const Quaterniond q(camera_pose.rotationMatrix());
@@ -406,7 +410,8 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
     return nec;
   }
   double qi[4], ti[3];
-  if (timing) timing->it_es_ = timing->avg_it_es_ = 0;
+  // it_es_ is written in every branch, avg_it_es_ only when the weighted stage runs (pnec.cc:178-195)
+  if (timing) timing->it_es_ = 0;
   if (options_.weighted_iterations_ > 1) {
     tic = clock::now();
     Check(pnec_hip_weighted_eigensolver(stage, q, t, options_.regularization_,

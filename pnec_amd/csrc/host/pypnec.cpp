@@ -175,6 +175,81 @@ arr translation_from_m(arr M) {
   return out;
 }
 
+pnec::Matrix3d ToMatrix3(const arr &a, const char *name) {
+  if (a.ndim() != 2 || a.shape(0) != 3 || a.shape(1) != 3) throw std::invalid_argument(std::string(name) + " must be 3x3");
+  auto r = a.unchecked<2>();
+  pnec::Matrix3d M;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) M(i, j) = r(i, j);
+  return M;
+}
+pnec::Vector3d ToVector3(const arr &a, const char *name) {
+  if (a.ndim() != 1 || a.shape(0) != 3) throw std::invalid_argument(std::string(name) + " must be a 3-vector");
+  auto r = a.unchecked<1>();
+  return pnec::Vector3d(r(0), r(1), r(2));
+}
+// pnec::common metric helpers of the facade (common.cc:210-259), degrees
+double rotational_difference(arr R1, arr R2) {
+  return pnec::common::RotationalDifference(ToMatrix3(R1, "rotation_1"), ToMatrix3(R2, "rotation_2"));
+}
+double translational_difference(arr t1, arr t2, bool both_directions) {
+  return pnec::common::TranslationalDifference(ToVector3(t1, "translation_1"), ToVector3(t2, "translation_2"),
+                                               both_directions);
+}
+double cost_function(arr bvs1, arr bvs2, arr covs, arr pose) {
+  return pnec::common::CostFunction(ToBearings(bvs1, "bvs_1"), ToBearings(bvs2, "bvs_2"),
+                                    ToCovariances(covs, "covs"), ToPose(pose));
+}
+
+// PNEC::Solve for ONE frame pair through the overload asked for (pnec.cc:69-75, :77-124, :126-134,
+// :135-208): overload 0 = (bvs1, bvs2, covs, init), 1 = (+ inliers), 2 = (+ timing), 3 = (+ inliers,
+// timing).  Returns (pose 4x4, inliers or None, timing dict or None).
+py::tuple solve(arr bvs1, arr bvs2, arr covs, arr init_pose, int overload, bool use_ransac, bool use_nec,
+                bool use_ceres, int weighted_iterations, double regularization) {
+  const auto b1 = ToBearings(bvs1, "bvs1"), b2 = ToBearings(bvs2, "bvs2");
+  const auto cv = ToCovariances(covs, "covs");
+  const pnec::SE3d init = ToPose(init_pose);
+  pnec::rel_pose_estimation::Options options;
+  options.use_ransac_ = use_ransac;
+  options.use_nec_ = use_nec;
+  options.use_ceres_ = use_ceres;
+  options.weighted_iterations_ = (size_t)weighted_iterations;
+  options.regularization_ = regularization;
+  if (overload < 0 || overload > 3) throw std::invalid_argument("overload must be 0..3");
+  pnec::SE3d pose;
+  std::vector<int> inliers;
+  pnec::common::FrameTiming timing(7);
+  // sentinels: the timed overloads only write the fields the reference writes (pnec.cc:135-208)
+  timing.nec_es_ = timing.it_es_ = timing.avg_it_es_ = timing.ceres_ = -1;
+  {
+    py::gil_scoped_release release;
+    pnec::rel_pose_estimation::PNEC solver(options);
+    switch (overload) {
+      case 0: pose = solver.Solve(b1, b2, cv, init); break;
+      case 1: pose = solver.Solve(b1, b2, cv, init, inliers); break;
+      case 2: pose = solver.Solve(b1, b2, cv, init, timing); break;
+      default: pose = solver.Solve(b1, b2, cv, init, inliers, timing); break;
+    }
+  }
+  py::object inl = py::none(), tim = py::none();
+  if (overload == 1 || overload == 3) inl = py::cast(inliers);
+  if (overload >= 2) {
+    py::dict d;
+    d["id"] = timing.id_;
+    d["nec_es"] = timing.nec_es_;
+    d["it_es"] = timing.it_es_;
+    d["avg_it_es"] = timing.avg_it_es_;
+    d["ceres"] = timing.ceres_;
+    d["frame_loading"] = timing.frame_loading_;
+    d["feature_creation"] = timing.feature_creation_;
+    d["optimization"] = timing.OptimizationTime();
+    d["total"] = timing.TotalTime();
+    d["header"] = pnec::common::FrameTiming::TimingHeader();
+    tim = d;
+  }
+  return py::make_tuple(FromPose(pose), inl, tim);
+}
+
 int add(int i, int j) { return i + j; }  // the reference module's smoke function (pypnec.cpp:34)
 
 }  // namespace
@@ -189,6 +264,14 @@ PYBIND11_MODULE(pypnec, m) {
         "NEC refinement (NECCeres::Optimize)");
   m.def("compose_m", &compose_m, "pnec::common::ComposeM (loop from i = 1, like the reference)");
   m.def("translation_from_m", &translation_from_m, "pnec::common::TranslationFromM");
+  m.def("rotational_difference", &rotational_difference, "pnec::common::RotationalDifference (degrees)");
+  m.def("translational_difference", &translational_difference, py::arg("translation_1"), py::arg("translation_2"),
+        py::arg("both_directions") = true, "pnec::common::TranslationalDifference (degrees)");
+  m.def("cost_function", &cost_function, "pnec::common::CostFunction (device)");
+  m.def("solve", &solve, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"), py::arg("init_pose"),
+        py::arg("overload") = 1, py::arg("use_ransac") = true, py::arg("use_nec") = false,
+        py::arg("use_ceres") = true, py::arg("weighted_iterations") = 10, py::arg("regularization") = 1e-13,
+        "PNEC::Solve for one frame pair through one of its four overloads");
   m.def("solve_batch", &solve_batch, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"), py::arg("init_poses"),
         py::arg("use_ransac") = true, py::arg("use_nec") = false, py::arg("use_ceres") = true,
         py::arg("weighted_iterations") = 10, py::arg("regularization") = 1e-13,

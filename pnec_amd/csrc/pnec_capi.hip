@@ -542,6 +542,7 @@ int ensure_buckets(pnec_hip_problem *p) {
     lists[(size_t)b].push_back((int32_t)i);
   }
   std::vector<int32_t> flat;
+  std::vector<pnec_hip_problem::Bucket> buckets;
   flat.reserve((size_t)p->n_pairs);
   for (int b = 0; b <= count; ++b) {
     if (lists[(size_t)b].empty()) continue;
@@ -551,11 +552,19 @@ int ensure_buckets(pnec_hip_problem *p) {
     } else {
       bk = {1, kStreamWaves, 0, false, (int64_t)lists[(size_t)b].size(), (int64_t)flat.size()};
     }
-    p->buckets.push_back(bk);
+    buckets.push_back(bk);
     flat.insert(flat.end(), lists[(size_t)b].begin(), lists[(size_t)b].end());
   }
-  PNEC_HIP_TRY(dev_alloc(&p->d_bucket_pairs, sizeof(int32_t) * flat.size()));
-  PNEC_HIP_TRY(hipMemcpy(p->d_bucket_pairs, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice));
+  int32_t *d_pairs = nullptr;
+  PNEC_HIP_TRY(dev_alloc(&d_pairs, sizeof(int32_t) * flat.size()));
+  const hipError_t e = hipMemcpy(d_pairs, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)dev_free(d_pairs);
+    return fail_hip(e, "hipMemcpy(bucket pairs)");
+  }
+  // published only now: a failed attempt leaves the problem as it was (no buckets, no table)
+  p->d_bucket_pairs = d_pairs;
+  p->buckets = std::move(buckets);
   return 0;
 }
 
@@ -766,6 +775,11 @@ int64_t pnec_hip_problem_max_correspondences(const pnec_hip_problem *p) { return
 int64_t pnec_hip_problem_payload_bytes(const pnec_hip_problem *p) {
   return p ? p->n_corr * p->nc * (int64_t)sizeof(double) : 0;
 }
+int pnec_hip_problem_offsets(const pnec_hip_problem *p, int64_t *out) {
+  if (!p || !out) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+  std::memcpy(out, p->offsets.data(), sizeof(int64_t) * p->offsets.size());
+  return 0;
+}
 int pnec_hip_problem_mode(const pnec_hip_problem *p) { return p ? p->mode : -1; }
 int pnec_hip_problem_device(const pnec_hip_problem *p) { return p ? p->device : -1; }
 
@@ -866,16 +880,20 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
   // device synchronisation, so never set it for timed runs)
   const char *trace_path = std::getenv("PNEC_HIP_TRACE");
   unsigned long long *d_trace = nullptr;
-  if (trace_path && *trace_path) {
-    PNEC_HIP_TRY(dev_alloc(&d_trace, sizeof(unsigned long long) * 4 * S));
-    PNEC_HIP_TRY(hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 4 * S, stream));
-    a.trace = d_trace;
-  }
-  hipError_t e = hipSuccess;
   const bool forced = opt.corr_per_lane > 0 || opt.waves_per_pair > 0;
   if (!forced) {
     if (int rc = ensure_buckets(p)) return rc;
   }
+  if (trace_path && *trace_path) {
+    PNEC_HIP_TRY(dev_alloc(&d_trace, sizeof(unsigned long long) * 4 * S));
+    const hipError_t te = hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 4 * S, stream);
+    if (te != hipSuccess) {
+      (void)dev_free(d_trace);
+      return fail_hip(te, "hipMemsetAsync(trace)");
+    }
+    a.trace = d_trace;
+  }
+  hipError_t e = hipSuccess;
   if (forced || p->buckets.size() <= 1) {
     e = launch(g, a);
   } else {
@@ -884,6 +902,7 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
       SolveArgs ab = a;
       ab.pair_index = p->d_bucket_pairs + bk.first;
       ab.n_solves = bk.count * (int64_t)n_hyp;
+      if (ab.trace) ab.trace += 4 * (size_t)(bk.first * (int64_t)n_hyp);  // records are indexed by blockIdx per launch
       const Geometry gb = {bk.cpl, bk.wpp, bk.ldsk, bk.resident};
       e = launch(gb, ab);
       if (e != hipSuccess) break;
@@ -1042,6 +1061,8 @@ int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint6
                                 int32_t *out_ransac_iterations, int space, void *stream_) {
   if (!p || !init_q || !out_q || !out_t) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
   if (max_iterations < 0 || sample_size < 1) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad RANSAC parameters");
+  if (sample_size > PNEC_HIP_MAX_RANSAC_SAMPLE)
+    return fail(PNEC_HIP_ERR_UNSUPPORTED, "ransac sample_size > 16 is not built (a hypothesis keeps its sample in registers)");
   if (space != PNEC_HIP_MEM_DEVICE && space != PNEC_HIP_MEM_HOST)
     return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad memory space");
   if (p->n_pairs == 0) return 0;

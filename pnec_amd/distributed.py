@@ -6,6 +6,10 @@ fixed-size result records (10 doubles = 80 B per solve) to rank 0 at the end -- 
 100k pairs per GPU, latency-bound, nowhere near the per-link xGMI ceiling.
 The partition is a pure function of (sizes, world), so every rank knows every shard's size and no
 size exchange is needed.
+
+`RecordGather` is the pipelined form of that collective: the gather of step i runs on a side stream
+(its own RCCL work queue) while the solve of step i+1 runs on the compute stream; result buffers are
+double-buffered and guarded by events, so nothing is overwritten while the collective reads it.
 """
 from __future__ import annotations
 
@@ -72,3 +76,53 @@ def gather_records(rec: torch.Tensor, world: int, rank: int, sizes=None, dst: in
     if rank != dst:
         return None
     return torch.cat([b[: int(s)] for b, s in zip(bufs, sizes)])
+
+
+class RecordGather:
+    """The single gather of a step, issued off the solve's stream so that it overlaps the next step.
+
+    Usage per step i:   slot = g.acquire()            # waits until the gather that last read this
+                                                      # slot's buffers (step i-2) has finished
+                        out = solve(..., out=bufs[slot])   # on the current (compute) stream
+                        g.submit(slot, out)           # pack + gather on the side stream
+    and once at the end g.drain() -> the last step's gathered records on `dst` (None elsewhere).
+    On CPU tensors (gloo; the tests) the same calls run synchronously.
+    """
+
+    SLOTS = 2
+
+    def __init__(self, world: int, rank: int, sizes=None, dst: int = 0, device=None):
+        self.world, self.rank, self.sizes, self.dst = world, rank, sizes, dst
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.next_slot = 0
+        self.last = None
+        if self.cuda:
+            self.device = torch.device(device)
+            self.side = torch.cuda.Stream(device=self.device)
+            self.solved = [torch.cuda.Event() for _ in range(self.SLOTS)]
+            self.gathered = [None] * self.SLOTS
+
+    def acquire(self) -> int:
+        slot = self.next_slot
+        self.next_slot = (slot + 1) % self.SLOTS
+        if self.cuda and self.gathered[slot] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.gathered[slot])
+        return slot
+
+    def submit(self, slot: int, res) -> None:
+        if not self.cuda:
+            self.last = gather_records(pack_records(res), self.world, self.rank, self.sizes, self.dst)
+            return
+        self.solved[slot].record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.solved[slot])
+            rec = pack_records(res)
+            self.last = gather_records(rec, self.world, self.rank, self.sizes, self.dst)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.gathered[slot] = ev
+
+    def drain(self):
+        if self.cuda:
+            self.side.synchronize()
+        return self.last

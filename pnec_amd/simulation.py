@@ -261,20 +261,25 @@ def generate(n_pairs: int, n_corr: int, noise_type: str = "anisotropic_inhomogen
 
 
 def generate_kitti_like(n_pairs: int, mean_corr: int = 500, seed: int = 1,
-                        device: str | torch.device = "cpu"):
+                        device: str | torch.device = "cpu", counts=None):
     """KITTI-like SYNTHETIC stream (no KITTI data exists in this environment): forward motion
     (t ~ +z, the (theta,phi) chart's singular direction, Appendix C12), small yaw, pinhole
     fx = 718.856 on a 1241x376 image (data/config_kitti00-02.yaml:8-11), ragged track counts.
     Returns (offsets int64 [B+1] numpy, bvs1 [M,3], bvs2 [M,3], covs2 [M,3,3], R_gt, t_gt,
-    init_q [B,4], init_t [B,3])."""
+    init_q [B,4], init_t [B,3]).  counts: optional int64 [B] pair sizes (else drawn here)."""
     dev = torch.device(device)
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     f64 = dict(dtype=torch.float64, device=dev)
     U = lambda *shape: torch.rand(*shape, generator=g, **f64)
     B = n_pairs
-    counts = torch.clamp((mean_corr + 60.0 * torch.randn(B, generator=g, **f64)).round(),
-                         min=64, max=mean_corr + 200).to(torch.int64)
+    if counts is None:
+        counts = torch.clamp((mean_corr + 60.0 * torch.randn(B, generator=g, **f64)).round(),
+                             min=64, max=mean_corr + 200).to(torch.int64)
+    else:
+        counts = torch.as_tensor(counts, dtype=torch.int64, device=dev)
+        if counts.shape != (B,):
+            raise ValueError("counts must be [n_pairs]")
     offsets = torch.zeros(B + 1, dtype=torch.int64, device=dev)
     offsets[1:] = torch.cumsum(counts, 0)
     M = int(offsets[-1].item())

@@ -1,0 +1,113 @@
+"""The multi-rank launch path of bench.py, run where there is no GPU: the SAME spawn / rendezvous /
+partition / side-stream-free gather code with 2 ranks on gloo and a stubbed solve (--dry-run-cpu).
+What a real N-GPU run adds on top is only the device solve and the RCCL backend."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _line(out: str) -> dict:
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out           # rank 0 prints exactly one JSON line
+    return json.loads(lines[0])
+
+
+def _run(cmd, env=None):
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return _line(p.stdout)
+
+
+def test_plain_invocation_with_gpus_2_spawns_two_ranks():
+    """`python bench.py --gpus 2` (no torchrun): must run TWO ranks and say so, not silently one."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    d = _run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "1000",
+              "--dry-run-cpu"], env)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["config"]["pairs_per_rank"] == [1000, 1000] and d["config"]["pairs_total"] == 2000
+    assert d["config"]["launcher"] == "self-spawned ranks"
+    assert d["scaling"] == "weak" and d["dry_run"] is True and d["value"] is None
+    assert d["records_in_order"] is True   # rank 0 checked order, step stamp and owner of every record
+
+
+def test_kitti_all_workload_is_partitioned_by_correspondence_count():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    d = _run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "kitti_all",
+              "--dry-run-cpu"], env)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["pairs_total"] == 23190 and sum(d["config"]["pairs_per_rank"]) == 23190
+    c = d["config"]["corr_per_rank"]
+    assert abs(c[0] - c[1]) <= 2 * 700     # balanced to within a couple of pairs' worth of correspondences
+    assert d["records_in_order"] is True
+
+
+def test_torchrun_launch_joins_the_existing_job():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+              "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "2",
+              "--warmup", "0", "--pairs", "64", "--dry-run-cpu"])
+    assert d["n_gpus"] == 2 and d["config"]["launcher"] == "torch.distributed.run"
+
+
+def test_gpus_must_match_world_size():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run-cpu"], capture_output=True, text=True,
+                       timeout=120, env=env, cwd=ROOT)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_without_gpu_the_real_bench_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p = subprocess.run([sys.executable, BENCH, "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=120, cwd=ROOT)
+    assert p.returncode != 0 and "no CPU fallback" in (p.stderr + p.stdout)
+
+
+def test_tracks_format_round_trip_and_sharded_loading(tmp_path):
+    from pnec_amd import tracks as tk
+    from pnec_amd.distributed import partition
+    whole = tk.kitti_all_shard(1000, 1040, frames=(1101, 271))
+    tk.validate(whole)
+    assert whole.n_pairs == 40 and whole.sequence is not None
+    path = str(tmp_path / "t.npz")
+    tk.save_tracks(path, whole)
+    sizes = tk.sizes_of(path)
+    np.testing.assert_array_equal(sizes, whole.sizes)
+    b = partition(sizes, 3)
+    got = [tk.load_tracks(path, int(b[r]), int(b[r + 1])) for r in range(3)]
+    assert sum(g.n_pairs for g in got) == 40
+    np.testing.assert_allclose(np.concatenate([g.bvs2 for g in got]), whole.bvs2.numpy())
+    np.testing.assert_allclose(np.concatenate([g.init_q for g in got]), whole.init_q.numpy())
+    for g in got:
+        assert g.offsets[0] == 0 and g.offsets[-1] == len(g.bvs1)
+    # any range of the synthetic set is the same whoever builds it (chunk-seeded)
+    sub = tk.kitti_all_shard(1010, 1020, frames=(1101, 271))
+    o = whole.offsets
+    assert bool((sub.bvs1 == whole.bvs1[o[10]:o[20]]).all())
+    with pytest.raises(ValueError):
+        tk.load_tracks(path, 5, 50)
+    bad = tk.Tracks(whole.offsets, whole.bvs1[:-1], whole.bvs2, whole.covs, whole.init_q, whole.init_t)
+    with pytest.raises(ValueError, match="bvs1"):
+        tk.validate(bad)
+
+
+def test_kitti_all_set_has_the_real_sequence_lengths():
+    from pnec_amd import tracks as tk
+    assert tk.kitti_all_num_pairs() == 23190
+    s = tk.kitti_all_sizes()
+    assert len(s) == 23190 and s.min() >= 64 and 450 < s.mean() < 550
+    ids = tk.kitti_all_sequence_ids()
+    assert np.bincount(ids).tolist() == [f - 1 for f in tk.KITTI_FRAMES]

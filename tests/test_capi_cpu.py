@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_loads_and_exports_every_declared_symbol():
     L = capi.lib()
-    assert L.pnec_hip_abi_version() == 1
+    assert L.pnec_hip_abi_version() == capi.ABI_VERSION
     header = open(os.path.join(ROOT, "include", "pnec_hip.h")).read()
     declared = set(re.findall(r"\b(pnec_hip_[a-z_]+)\s*\(", header))
     assert declared, "no declarations parsed"

@@ -174,3 +174,89 @@ def test_solve_batch_survives_degenerate_pairs():
                 assert np.allclose(R @ R.T, np.eye(3), atol=1e-9)
                 err = np.degrees(np.arccos(np.clip((np.trace(R.T @ g.R_gt[p].numpy()) - 1) / 2, -1, 1)))
                 assert err < 1.0, (kw, p, sizes[p], err)
+
+
+def test_metric_helpers_of_the_facade_follow_the_reference_semantics(oracle):
+    """pnec::common::RotationalDifference / TranslationalDifference of the C++ facade against an
+    independent numpy statement of common.cc:210-235: |log(R1' R2)| in DEGREES; the angle between the
+    translations in degrees, the smaller of t2 / -t2 when both_directions, 90 when translation_1 is
+    (nearly) zero -- and, because the reference tests translation_1.norm() twice (quirk C8), NaN rather
+    than 90 when only translation_2 is zero."""
+    import pypnec
+    rng = np.random.default_rng(4)
+
+    def rot(axis, ang):
+        a = np.asarray(axis, float) / np.linalg.norm(axis)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * K @ K
+
+    for ang in (0.0, 1e-9, 1e-4, 0.3, 1.5, 3.0, math.pi - 1e-6):
+        for _ in range(4):
+            R1 = rot(rng.normal(size=3), rng.uniform(0, 3))
+            R2 = R1 @ rot(rng.normal(size=3), ang)
+            got = pypnec.rotational_difference(R1, R2)
+            assert got == pytest.approx(math.degrees(ang), abs=1e-9 if ang > 1e-6 else 1e-12)
+            assert got == pytest.approx(oracle.rotational_difference_deg(R1, R2), abs=1e-9)
+            assert got >= 0.0
+    for _ in range(20):
+        t1, t2 = rng.normal(size=3) * rng.uniform(0.1, 5), rng.normal(size=3) * rng.uniform(0.1, 5)
+        c = t1 @ t2 / (np.linalg.norm(t1) * np.linalg.norm(t2))
+        one = math.degrees(math.acos(c))
+        assert pypnec.translational_difference(t1, t2, False) == pytest.approx(one, abs=1e-10)
+        assert pypnec.translational_difference(t1, t2, True) == pytest.approx(min(one, 180.0 - one), abs=1e-10)
+        assert pypnec.translational_difference(t1, t2) == pytest.approx(min(one, 180.0 - one), abs=1e-10)  # default
+    z = np.zeros(3)
+    e = np.array([0.0, 0.0, 1.0])
+    assert pypnec.translational_difference(z, e) == 90.0            # M_PI / 2 branch
+    assert pypnec.translational_difference(1e-11 * e, e) == 90.0
+    assert math.isnan(pypnec.translational_difference(e, z))        # C8: the second norm is never tested
+    assert pypnec.translational_difference(e, -e, True) == pytest.approx(0.0, abs=1e-6)
+    assert pypnec.translational_difference(e, -e, False) == pytest.approx(180.0, abs=1e-6)
+
+
+@pytest.mark.gpu
+def test_all_four_solve_overloads_agree_and_fill_the_timing_like_the_reference(oracle):
+    """PNEC::Solve has four overloads (pnec.cc:69-75, :77-124, :126-134, :135-208): same pose from all,
+    the inlier list from the two that take one, and a FrameTiming whose fields are written exactly where
+    the reference writes them (nec_es_ always; it_es_ in the PNEC branch; avg_it_es_ only when the
+    weighted stage runs; ceres_ always)."""
+    import pypnec
+    g = sim.generate(1, 300, seed=411)
+    rng = np.random.default_rng(6)
+    b1, b2, cv = g.bvs1[0].numpy().copy(), g.bvs2[0].numpy().copy(), g.covs2[0].numpy().copy()
+    bad = rng.choice(300, 45, replace=False)
+    v = rng.normal(size=(45, 3))
+    b2[bad] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    init = _pose4(g.init_R[0].numpy(), g.init_t[0].numpy())
+    outs = [pypnec.solve(b1, b2, cv, init, overload=k) for k in range(4)]
+    for T, inl, tim in outs[1:]:
+        np.testing.assert_array_equal(T, outs[0][0])              # bit-identical poses
+    assert outs[0][1] is None and outs[0][2] is None and outs[2][1] is None
+    assert outs[1][1] == outs[3][1] and 150 < len(outs[1][1]) <= 300 - 40
+    assert len(set(outs[1][1]) & set(bad.tolist())) <= 2          # gross outliers are (all but) gone
+    # against the oracle chain (pair_id 0, seed 1 -- what a single Solve draws)
+    Ro, to, mo, _ = oracle.ransac_eigensolver(b1, b2, init[:3, :3], seed=1, pair_id=0)
+    assert outs[1][1] == list(np.flatnonzero(mo))
+    Rw, tw = oracle.weighted_eigensolver(b1[mo], b2[mo], cv[mo], Ro, to, 1e-13, 10)
+    s = oracle.solve(oracle.MODE_TARGET, b1[mo], b2[mo], cv[mo], None, 1e-13, oracle.quat_from_rot(Rw), tw,
+                     oracle.default_options())
+    assert math.radians(oracle.rotational_difference_deg(outs[0][0][:3, :3], s.R)) <= 1e-6
+    for T, inl, tim in (outs[2], outs[3]):
+        assert tim["id"] == 7 and tim["header"] == "ID FrameLoading FeatureCreation NEC-ES IT-ES AVG-IT-ES CERES OPTIMIZATION TOTAL"
+        assert min(tim["nec_es"], tim["it_es"], tim["avg_it_es"], tim["ceres"]) >= 0     # all written (ms)
+        assert tim["avg_it_es"] == tim["it_es"] // 10
+        assert tim["optimization"] == tim["nec_es"] + tim["it_es"] + tim["ceres"] and tim["total"] == tim["optimization"]
+    # which fields each Options branch writes (-1 = left as the caller had it)
+    _, _, tim = pypnec.solve(b1, b2, cv, init, overload=3, use_nec=True)
+    assert tim["nec_es"] >= 0 and tim["ceres"] >= 0 and tim["it_es"] == -1 and tim["avg_it_es"] == -1
+    _, _, tim = pypnec.solve(b1, b2, cv, init, overload=3, use_nec=True, use_ceres=False)
+    assert tim["ceres"] == 0 and tim["it_es"] == -1
+    _, _, tim = pypnec.solve(b1, b2, cv, init, overload=2, weighted_iterations=1)
+    assert tim["it_es"] == 0 and tim["avg_it_es"] == -1 and tim["ceres"] >= 0
+    _, _, tim = pypnec.solve(b1, b2, cv, init, overload=2, weighted_iterations=0, use_ceres=False)
+    assert tim["it_es"] == 0 and tim["avg_it_es"] == -1 and tim["ceres"] == 0
+    # CostFunction of the facade (device) against the oracle; empty input is NaN like the reference
+    T = outs[0][0]
+    want = oracle.cost_function(b1, b2, cv, T[:3, :3], T[:3, 3])
+    assert pypnec.cost_function(b1, b2, cv, T) == pytest.approx(want, rel=1e-10)
+    assert math.isnan(pypnec.cost_function(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3, 3)), T))

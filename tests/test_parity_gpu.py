@@ -349,7 +349,76 @@ def test_full_size_batch_properties(oracle):
             worst = max(worst, _rot_err(oracle, _quat_to_R(rq[p]), s.R))
             assert int(res.iterations[p]) == s.iterations
     assert worst <= ROT_TOL_REFERENCE, worst
+
+    # ---- the BENCH mode on the same 100k x 512 batch: exactly 10 LM iterations, no convergence tests
+    # (bench.py's timed configuration), against the central-difference oracle run the same way
+    fixed = capi.default_options(max_num_iterations=10, check_convergence=0)
+    r10 = batch.solve(q0, t0, options=fixed)
+    torch.cuda.synchronize()
+    assert torch.isfinite(r10.q).all() and torch.isfinite(r10.cost).all()
+    assert int(r10.iterations.min()) == 10 and int(r10.iterations.max()) == 10
+    assert bool((r10.status == 3).all())                       # PNEC_HIP_TERM_MAX_ITERATIONS
+    assert (r10.cost <= start.cost * (1 + 1e-12)).all()
+    assert float(((r10.q * r10.q).sum(-1) - 1).abs().max()) < 1e-12
+    o10 = _oracle_opts(oracle, fixed, oracle.JAC_NUMERIC_CENTRAL)
+    rq10, rc10 = r10.q.cpu().numpy(), r10.cost.cpu().numpy()
+    worst10 = 0.0
+    for c, (f1, f2, c2) in keep.items():
+        for j in range(4):
+            p = c * chunk + j
+            s = oracle.solve(oracle.MODE_TARGET, f1[j], f2[j], c2[j], None, 1e-13,
+                             q0[p].cpu().numpy(), t0[p].cpu().numpy(), o10)
+            worst10 = max(worst10, _rot_err(oracle, _quat_to_R(rq10[p]), s.R))
+            assert s.iterations == 10
+            assert rc10[p] == pytest.approx(s.cost, rel=1e-6)
+    assert worst10 <= ROT_TOL_REFERENCE, worst10
     batch.close()
+
+
+def test_config4_full_size_multi_hypothesis(oracle):
+    """BASELINE config 4 at its stated size: 64 pairs x 4096 correspondences x 64 random t-hat starts
+    (4096 solves sharing 64 payloads, the (8,8,3) geometry: 8 wavefronts per solve).  Properties on all
+    4096 solves; reference-faithful oracle parity on sampled (pair, hypothesis) solves."""
+    Bp, N, H = 64, 4096, 64
+    dev = torch.device("cuda:0")
+    g = sim.generate(Bp, N, seed=9, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    hyp = torch.randn(Bp * H, 3, generator=gen, dtype=torch.float64, device=dev)
+    hyp = hyp / hyp.norm(dim=1, keepdim=True)
+    hyp[::H] = g.init_t                                        # hypothesis 0 = the good start
+    with Batch.uniform(capi.MODE_TARGET, Bp, N) as b:
+        b.fill(g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3))
+        assert b.describe_launch()["waves_per_pair"] == 8 and b.describe_launch()["resident"]
+        for opts in (capi.default_options(max_num_iterations=10, check_convergence=0), capi.default_options()):
+            start = b.solve(g.init_q, None, options=capi.default_options(max_num_iterations=0), hyp_t=hyp, n_hyp=H)
+            res = b.solve(g.init_q, None, options=opts, hyp_t=hyp, n_hyp=H)
+            torch.cuda.synchronize()
+            assert res.q.shape == (Bp * H, 4)
+            assert torch.isfinite(res.q).all() and torch.isfinite(res.t).all() and torch.isfinite(res.cost).all()
+            assert float(((res.q * res.q).sum(-1) - 1).abs().max()) < 1e-12
+            assert float(((res.t * res.t).sum(-1) - 1).abs().max()) < 1e-12
+            assert (res.cost <= start.cost * (1 + 1e-12)).all()          # LM never ends above its start
+            best = select_best(res.cost, H)
+            assert torch.equal(best.long(), res.cost.reshape(Bp, H).argmin(dim=1))
+            # the good start wins or ties, and its rotation is the ground truth to the noise level
+            cost = res.cost.reshape(Bp, H)
+            assert bool((cost[:, 0] <= cost.min(dim=1).values * (1 + 1e-6)).all())
+            R = res.rotation_matrices().reshape(Bp, H, 3, 3)[:, 0].cpu().numpy()
+            for p in range(0, Bp, 8):
+                assert _rot_err(oracle, R[p], g.R_gt[p].cpu().numpy()) < 0.01
+            # sampled oracle parity (central differences + Ceres LM policy, the same options)
+            oo = _oracle_opts(oracle, opts, oracle.JAC_NUMERIC_CENTRAL)
+            rng = np.random.default_rng(17)
+            samples = [(0, 0), (63, 63)] + [(int(rng.integers(Bp)), int(rng.integers(H))) for _ in range(8)]
+            rq, rit, rst = res.q.cpu().numpy(), res.iterations.cpu().numpy(), res.status.cpu().numpy()
+            for (p, h) in samples:
+                s = oracle.solve(oracle.MODE_TARGET, g.bvs1[p].cpu().numpy(), g.bvs2[p].cpu().numpy(),
+                                 g.covs2[p].cpu().numpy(), None, 1e-13, g.init_q[p].cpu().numpy(),
+                                 hyp[p * H + h].cpu().numpy(), oo)
+                assert rit[p * H + h] == s.iterations, (p, h, rit[p * H + h], s.iterations)
+                assert rst[p * H + h] == s.status, (p, h)
+                assert _rot_err(oracle, _quat_to_R(rq[p * H + h]), s.R) <= ROT_TOL_REFERENCE, (p, h)
 
 
 def test_unscented_transform_device_vs_oracle_and_goldens(oracle, golden_dir):
@@ -409,8 +478,17 @@ def test_nec_eigensolver_device_vs_oracle(oracle):
     del poses
 
 
+# Declared deviation of the weighted stage: the device keeps the rotation once an
+# eigensolver call has converged and stops the SCF at its fixed point; the reference (and the oracle)
+# re-run the eigensolver in all 9 rounds and always take 10 SCF steps.  Bound measured over 2 048 pairs
+# (tools/verify_frontend_literal.py -> profiles/r02_frontend_literal_parity.json): < 1e-8 rad.
+WEIGHTED_EARLY_EXIT_BOUND = 1e-7   # rad, device vs the LITERAL oracle (10x the measured worst case)
+
+
 def test_weighted_eigensolver_device_vs_oracle(oracle):
-    """SURVEY 8f row 1: PNEC::WeightedEigensolver (weights, eigensolver, Fibonacci search, scf)"""
+    """SURVEY 8f row 1: PNEC::WeightedEigensolver (weights, eigensolver, Fibonacci search, scf) against the
+    literal oracle (every round re-runs the eigensolver, 10 SCF steps) within the declared bound, and
+    against the oracle's early-exit twin (same control flow as the kernel) tightly"""
     B, N = 6, 512
     g = sim.generate(B, N, seed=93)
     f1, f2 = g.bvs1.reshape(-1, 3).numpy(), g.bvs2.reshape(-1, 3).numpy()
@@ -424,8 +502,12 @@ def test_weighted_eigensolver_device_vs_oracle(oracle):
                 sl = slice(p * N, (p + 1) * N)
                 Rn = _quat_to_R(qn[p])
                 Ro, to = oracle.weighted_eigensolver(f1[sl], f2[sl], c2[sl], Rn, tn[p], 1e-13, iters)
-                assert _rot_err(oracle, _quat_to_R(qw[p]), Ro) <= 1e-8, (iters, p)
+                assert _rot_err(oracle, _quat_to_R(qw[p]), Ro) <= WEIGHTED_EARLY_EXIT_BOUND, (iters, p)
                 assert abs(abs(tw[p] @ to) - 1) < 1e-8, (iters, p)
+                Rt, tt = oracle.weighted_eigensolver(f1[sl], f2[sl], c2[sl], Rn, tn[p], 1e-13, iters,
+                                                     device_early_exits=True)
+                assert _rot_err(oracle, _quat_to_R(qw[p]), Rt) <= 1e-8, (iters, p)
+                assert abs(abs(tw[p] @ tt) - 1) < 1e-8, (iters, p)
         # device space, and the whole PNEC::Solve chain (no RANSAC): ES -> weighted ES -> refinement
         qd, td = b.weighted_eigensolver(torch.from_numpy(qn).cuda(), torch.from_numpy(tn).cuda(), 1e-13, 10)
         res = b.solve(qd, td)
@@ -528,4 +610,11 @@ def test_randomised_batches_against_oracle(oracle, trial):
                                        g.init_t.numpy(), _oracle_opts(oracle, opts, oracle.JAC_ANALYTIC))
     worst = max(_rot_err(oracle, _quat_to_R(res.q[p]), _quat_to_R(q[p])) for p in range(B))
     assert worst <= 10 * ROT_TOL_SAME_ALGO, worst   # pairs of 6..20 correspondences are weakly constrained
-    assert (res.iterations == it).mean() >= 0.98
+    # iteration counts and termination codes are EQUAL; the only admissible difference is a stopping or
+    # acceptance test decided inside rounding of its threshold, which shows as both runs ending in the
+    # same tolerance ball -- every such pair is checked, and there may be at most one per batch
+    diff = np.flatnonzero((res.iterations != it) | (res.status != st))
+    assert len(diff) <= 1, (diff, res.iterations[diff], it[diff])
+    for p in diff:
+        assert abs(int(res.iterations[p]) - int(it[p])) == 1, (p, res.iterations[p], it[p])
+        assert abs(res.cost[p] - cost[p]) <= 2e-6 * abs(cost[p]), (p, res.cost[p], cost[p])
