@@ -832,6 +832,7 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
   a.n_hyp = n_hyp;
   a.reg = reg;
   a.opt = opt;
+  finish_args(a);
 
   if (space == PNEC_HIP_MEM_DEVICE) {
     a.init_q = init_q;

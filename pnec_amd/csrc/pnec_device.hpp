@@ -254,6 +254,13 @@ __device__ __forceinline__ void wave_reduce21_rows(const double (&acc)[kNumAcc],
 #pragma unroll
   for (int i = 0; i < 6; ++i) c[i] = row_allreduce_sum(c[i]);
 }
+// accumulator 0 alone, through the same tree (same additions in the same order as in
+// wave_reduce21_rows, so the sum has the same bits): valid in the 16 lanes of row 0
+__device__ __forceinline__ double wave_reduce_acc0_row0(double acc0) {
+  const double b0 = swap_add32(acc0, 0.0);
+  const double c0 = swap_add16(b0, 0.0);
+  return row_allreduce_sum(c0);
+}
 // the same sums as wave-uniform values, picked from the owning rows with v_readlane
 __device__ __forceinline__ void wave_reduce21(const double (&acc)[kNumAcc], double (&sum)[kNumAcc]) {
   double c[6];
@@ -422,6 +429,63 @@ __device__ __forceinline__ void eval_corr(const double (&d)[num_components(MODE)
   const double jz = f1x * uy - f1y * ux + hz;
   J[0] = U.bth[0] * jx + U.bth[1] * jy + U.bth[2] * jz;
   J[1] = U.bph[0] * jx + U.bph[1] * jy;
+}
+
+// The residual alone (the pass whose Jacobian can never be used: the candidate evaluated at the
+// iteration cap).  Same operations in the same order as eval_corr up to r, so the cost is the bits a
+// full pass would have produced.  `k` is a quantity that is non-finite whenever the Jacobian would be
+// (n / den^(3/2): every Jacobian entry is a bounded multiple of y and of k), 0 * k is accumulated as
+// the finite-Jacobian witness Ceres' "Jacobian evaluation failed" test needs.
+template <int MODE>
+__device__ __forceinline__ void eval_cost(const double (&d)[num_components(MODE)], bool valid,
+                                          const PassUniforms &U, double reg, double &r, double &k) {
+  const double f1x = d[0], f1y = d[1], f1z = d[2];
+  const double f2x = d[3], f2y = d[4], f2z = d[5];
+  const double *R = U.R;
+  const double mx = U.t[1] * f1z - U.t[2] * f1y;
+  const double my = U.t[2] * f1x - U.t[0] * f1z;
+  const double mz = U.t[0] * f1y - U.t[1] * f1x;
+  const double gx = R[0] * mx + R[3] * my + R[6] * mz;
+  const double gy = R[1] * mx + R[4] * my + R[7] * mz;
+  const double gz = R[2] * mx + R[5] * my + R[8] * mz;
+  const double n = f2x * gx + f2y * gy + f2z * gz;
+  if constexpr (MODE == PNEC_HIP_MODE_NEC) {
+    r = n;
+    k = n;
+  } else if constexpr (MODE == PNEC_HIP_MODE_TARGET) {
+    const double sgx = d[6] * gx + d[7] * gy + d[8] * gz;
+    const double sgy = d[7] * gx + d[9] * gy + d[10] * gz;
+    const double sgz = d[8] * gx + d[10] * gy + d[11] * gz;
+    const double den = gx * sgx + gy * sgy + gz * sgz + reg;
+    const double y_all = fast_rsqrt(den);
+    const double y = valid ? y_all : 0.0;
+    r = n * y;
+    k = (r * y) * y;
+  } else {
+    constexpr bool kSym = (MODE == PNEC_HIP_MODE_SYM);
+    const double ax = kSym ? f2x : f1x, ay = kSym ? f2y : f1y, az = kSym ? f2z : f1z;
+    const double px = R[0] * ax + R[1] * ay + R[2] * az;
+    const double py = R[3] * ax + R[4] * ay + R[5] * az;
+    const double pz = R[6] * ax + R[7] * ay + R[8] * az;
+    const double qx = U.t[1] * pz - U.t[2] * py;
+    const double qy = U.t[2] * px - U.t[0] * pz;
+    const double qz = U.t[0] * py - U.t[1] * px;
+    constexpr int o = kSym ? 12 : 6;
+    const double shx = d[o + 0] * qx + d[o + 1] * qy + d[o + 2] * qz;
+    const double shy = d[o + 1] * qx + d[o + 3] * qy + d[o + 4] * qz;
+    const double shz = d[o + 2] * qx + d[o + 4] * qy + d[o + 5] * qz;
+    double den = qx * shx + qy * shy + qz * shz + reg;
+    if constexpr (kSym) {
+      const double sgx = d[6] * gx + d[7] * gy + d[8] * gz;
+      const double sgy = d[7] * gx + d[9] * gy + d[10] * gz;
+      const double sgz = d[8] * gx + d[10] * gy + d[11] * gz;
+      den += gx * sgx + gy * sgy + gz * sgz;
+    }
+    const double y_all = fast_rsqrt(den);
+    const double y = valid ? y_all : 0.0;
+    r = n * y;
+    k = (r * y) * y;
+  }
 }
 
 __device__ __forceinline__ void accumulate(double r, const double (&J)[5], double (&acc)[kNumAcc]) {

@@ -66,8 +66,14 @@ struct SolveArgs {
   int32_t n_hyp;
   int32_t pad_;
   double reg;
+  double inv_max_radius;  // 1 / opt.max_trust_region_radius, 1 / opt.min_trust_region_radius: the loop
+  double inv_min_radius;  // carries the inverse radius (lm_advance); filled by the host (finish_args)
   pnec_hip_options opt;
 };
+inline void finish_args(SolveArgs &a) {
+  a.inv_max_radius = 1.0 / a.opt.max_trust_region_radius;
+  a.inv_min_radius = 1.0 / a.opt.min_trust_region_radius;
+}
 
 // Contiguous chunks of solves per XCD: block b runs on XCD b%8 (observed dispatch order), so the
 // hypotheses of one pair -- consecutive solve indices reading the same payload -- share one L2.
@@ -85,25 +91,29 @@ enum : int {
   kPhi = 5,      // 1
   kCost = 6,     // 1
   kXNorm = 7,    // 1
-  kRadius = 8,   // 1
-  kInvDec = 9,   // 1  1 / decrease_factor (a power of two)
+  kInvRadius = 8,  // 1  1 / trust-region radius (the radius itself is never needed: see lm_advance)
+  kDec = 9,      // 1  decrease_factor (a power of two)
   kModel = 10,   // 1  model cost change of the pending step
   kQc = 11,      // 4  candidate quaternion
   kThetaC = 15,  // 1
   kPhiC = 16,    // 1
-  kHs = 17,      // 15 J'J at the current point (upper triangle), as the pass accumulates it
-  kGs = 32,      // 5  J'r
-  kDiag = 37,    // 5  LM diagonal, mapped to the pass's parameter scale (see the step below)
-  kScaleSq = 42, // 5  (Jacobi scale x (2 for the rotation columns))^2
-  kGmax = 47,    // 1
-  kSums = 48,    // 24 the pass's 21 sums, as the row leaders store them (sum_slot)
-  kInvScaleSq = 72,  // 5
-  kSumsFinite = 78,  // 1  1.0 when all 21 sums are finite
-  kSlab = 80
+  kDiag = 17,    // 5  LM diagonal, mapped to the pass's parameter scale (see the step below)
+  kScaleSq = 22, // 5  (Jacobi scale x (2 for the rotation columns))^2
+  kInvScaleSq = 27,  // 5
+  kGmax = 32,    // 1
+  kSumsFinite = 33,  // 1  1.0 when all 21 sums are finite
+  // two tables of the pass's 21 sums as the row leaders store them (sum_slot): one holds the normal
+  // equations of the current (accepted) point, the pass writes the candidate's into the other; accepting
+  // a step flips which is which (ist[kIPark]) instead of copying 20 doubles
+  kSums = 36,    // 2 x 24
+  kSlab = 84
 };
 constexpr int kUnif = 18;   // pass uniforms of the candidate: R[9] | t[3] | dt/dtheta[3] | dt/dphi[2] | pad
 // per-solve integer state (LDS)
-enum : int { kIIter = 0, kIFirst, kIReuseDiag, kINumInvalid, kIStepOk, kINumI = 6 };
+enum : int { kIIter = 0, kIFirst, kIReuseDiag, kINumInvalid, kIStepOk,
+              kILast,  // the published candidate is evaluated at the iteration cap: its Jacobian can never be used
+              kIPark,  // which table of sums (0 / 1) belongs to the current point
+              kINumI = 8 };
 
 // Which (family, geometry) pairs are built: the payload must fit the 160 KB LDS and the
 // register budget of its occupancy target (<= 72 doubles of payload per lane at two wavefronts
@@ -216,6 +226,52 @@ __device__ __forceinline__ void pass_resident(const double (&d)[REGK][num_compon
   }
 }
 
+// The pass at the iteration cap: the candidate's cost decides accept / reject of the last step and
+// the solve ends either way (Ceres tests max_num_iterations before it looks at the new gradient), so
+// residual and propagated variance are all that is needed -- 40 of the full pass's 91 instructions
+// per correspondence.  acc0 = sum r^2; z = 0, or NaN when a Jacobian entry would not be finite.
+template <int MODE, int REGK, int LDSK>
+__device__ __forceinline__ void pass_cost_resident(const double (&d)[REGK][num_components(MODE)],
+                                                   const double *lds /* [LDSK][NC][64] */,
+                                                   const unsigned long long (&lanes_valid)[REGK + LDSK],
+                                                   int lane, const PassUniforms &U, double reg,
+                                                   double &acc0, double &z) {
+  constexpr int NC = num_components(MODE);
+  auto eval_slot = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    double r, kk;
+    eval_cost<MODE>(d[k], __builtin_amdgcn_inverse_ballot_w64(lanes_valid[k]), U, reg, r, kk);
+    acc0 = __builtin_fma(r, r, acc0);
+    z = __builtin_fma(kk, 0.0, z);
+  };
+  eval_slot(std::integral_constant<int, 0>{});
+  if constexpr (REGK > 1) eval_slot(std::integral_constant<int, 1>{});
+  if constexpr (REGK > 2) {
+    if (lanes_valid[2] != 0ull) {
+      eval_slot(std::integral_constant<int, 2>{});
+      if constexpr (REGK > 3) eval_slot(std::integral_constant<int, 3>{});
+      if constexpr (REGK > 4) eval_slot(std::integral_constant<int, 4>{});
+      if constexpr (REGK > 5) eval_slot(std::integral_constant<int, 5>{});
+      if constexpr (REGK > 6) eval_slot(std::integral_constant<int, 6>{});
+      if constexpr (REGK > 7) eval_slot(std::integral_constant<int, 7>{});
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < LDSK; ++k) {
+    unsigned long long m = lanes_valid[LDSK > 0 ? REGK : 0];
+#pragma unroll
+    for (int i = 1; i < LDSK; ++i) m = (k == i) ? lanes_valid[REGK + i] : m;
+    if (m == 0ull) continue;
+    double e[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) e[c] = lds[(k * NC + c) * kWave + lane];
+    double r, kk;
+    eval_cost<MODE>(e, __builtin_amdgcn_inverse_ballot_w64(m), U, reg, r, kk);
+    acc0 = __builtin_fma(r, r, acc0);
+    z = __builtin_fma(kk, 0.0, z);
+  }
+}
+
 // pose -> the correspondence-independent quantities of a pass, as plain doubles
 __device__ __forceinline__ void pose_uniforms_sc(double st, double ct, double sp, double cp, const double (&q)[4],
                                                  double *u) {
@@ -267,21 +323,29 @@ __device__ __forceinline__ void write_result(const SolveArgs &a, int64_t s, cons
 // wavefront of the SIMD runs its pass, so it is written to keep LDS round trips off the chain:
 // everything is loaded in one batch up front, values are forwarded in registers (an accepted
 // point's J'J / J'r are the pass's sums themselves), and the stores trail.
-__device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, const pnec_hip_options &o) {
+__device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, const pnec_hip_options &o,
+                                          double inv_max_radius, double inv_min_radius) {
   int iteration = ist[kIIter], reuse_diagonal = ist[kIReuseDiag];
   int num_invalid = ist[kINumInvalid], step_ok = ist[kIStepOk];
   const int first = ist[kIFirst];
+  const bool last = ist[kILast] != 0;  // the pass was the cost-only one: sums 1..20 do not exist
+  int park = ist[kIPark];
   int term = -1;
 
-  // ---- one batch of loads
+  // ---- one batch of loads (the candidate's sums: the table the current point does not own)
   double S[kNumAcc];
+  const double *cand_sums = slab + kSums + (park ^ 1) * kSumSlots;
 #pragma unroll
-  for (int j = 0; j < kNumAcc; ++j) S[j] = slab[kSums + sum_slot(j)];
+  for (int j = 0; j < kNumAcc; ++j) S[j] = cand_sums[sum_slot(j)];
   const bool rest_ok = slab[kSumsFinite] != 0.0;
   const double qc0 = slab[kQc + 0], qc1 = slab[kQc + 1], qc2 = slab[kQc + 2], qc3 = slab[kQc + 3];
   const double thc0 = slab[kThetaC], phc0 = slab[kPhiC];
   const double cost = slab[kCost], model = slab[kModel], xnorm = slab[kXNorm];
-  double radius = slab[kRadius], inv_dec = slab[kInvDec], gmax = slab[kGmax];
+  // The trust region is carried as 1 / radius: LevenbergMarquardtStrategy only ever divides by the
+  // radius (D / radius), the update radius / max(1/3, 1 - (2 rho - 1)^3) is a multiplication of the
+  // inverse, and the two bounds are comparisons against 1 / max_radius and 1 / min_radius -- no
+  // reciprocal on the chain.  dec = Ceres' decrease_factor (2, 4, 8, ...: exact).
+  double inv_radius = slab[kInvRadius], dec = slab[kDec], gmax = slab[kGmax];
   double x[6];
 
   double cost_c = 0.5 * S[0];
@@ -334,6 +398,17 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
     }
   }
 
+  if (term < 0 && last) {
+    // at the iteration cap the solve ends here whatever the verdict on the step (Ceres checks
+    // max_num_iterations before anything that would read the new Jacobian)
+    if (accept) {
+      slab[kQ + 0] = qc0; slab[kQ + 1] = qc1; slab[kQ + 2] = qc2; slab[kQ + 3] = qc3;
+      slab[kTheta] = thc0;
+      slab[kPhi] = phc0;
+      slab[kCost] = cost_c;
+    }
+    term = PNEC_HIP_TERM_MAX_ITERATIONS;
+  }
   if (term < 0) {
     double H[15], g[5], diag[5];
     if (accept) {
@@ -349,12 +424,13 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
         for (int i = 0; i < 5; ++i) gmax = fmax(gmax, fabs(g[i]) * ((i >= 2) ? 2.0 : 1.0));
       }
       if (first) {
-        radius = o.initial_trust_region_radius;
+        inv_radius = fast_rcp(o.initial_trust_region_radius);
       } else {
         const double c1 = 2.0 * rho - 1.0;
-        radius = fmin(o.max_trust_region_radius, radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - c1 * c1 * c1)));
+        inv_radius = fmax(inv_max_radius, inv_radius * fmax(1.0 / 3.0, 1.0 - c1 * c1 * c1));
       }
-      inv_dec = 0.5;
+      dec = 2.0;
+      park ^= 1;  // the candidate's table is the current point's from now on (nothing is copied)
       step_ok = 1;
       reuse_diagonal = 0;
       // park (stores only; nothing below reads them back)
@@ -367,22 +443,19 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
         slab[kXNorm] = fast_sqrt(x[4] * x[4] + x[5] * x[5] + x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
         slab[kGmax] = gmax;
       }
-#pragma unroll
-      for (int i = 0; i < 5; ++i) slab[kGs + i] = g[i];
-#pragma unroll
-      for (int i = 0; i < 15; ++i) slab[kHs + i] = H[i];
     } else {
-      // rejected: back to the parked point, smaller region
+      // rejected: back to the parked point (its normal equations are still in its table), smaller region
 #pragma unroll
       for (int k = 0; k < 4; ++k) x[k] = slab[kQ + k];
       x[4] = slab[kTheta];
       x[5] = slab[kPhi];
+      const double *cur_sums = slab + kSums + park * kSumSlots;
 #pragma unroll
-      for (int i = 0; i < 5; ++i) g[i] = slab[kGs + i];
+      for (int i = 0; i < 5; ++i) g[i] = cur_sums[sum_slot(1 + i)];
 #pragma unroll
-      for (int i = 0; i < 15; ++i) H[i] = slab[kHs + i];
-      radius = radius * inv_dec;
-      inv_dec = 0.5 * inv_dec;
+      for (int i = 0; i < 15; ++i) H[i] = cur_sums[sum_slot(6 + i)];
+      inv_radius = inv_radius * dec;
+      dec = 2.0 * dec;
       reuse_diagonal = 1;
     }
     if (reuse_diagonal) {
@@ -394,14 +467,15 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
     for (bool retry = false;; retry = true) {
       if (iteration >= o.max_num_iterations) { term = PNEC_HIP_TERM_MAX_ITERATIONS; break; }
       if (retry) {
-        // (rare) the previous attempt consumed H in place: fetch the parked copy again
+        // (rare) the previous attempt consumed H in place: fetch it from the current point's table again
+        const double *cur_sums = slab + kSums + park * kSumSlots;
 #pragma unroll
-        for (int i = 0; i < 15; ++i) H[i] = slab[kHs + i];
+        for (int i = 0; i < 15; ++i) H[i] = cur_sums[sum_slot(6 + i)];
       }
       if (o.check_convergence && step_ok && gmax <= o.gradient_tolerance) {
         term = PNEC_HIP_TERM_GRADIENT_TOL; break;
       }
-      if (radius < o.min_trust_region_radius) { term = PNEC_HIP_TERM_MIN_RADIUS; break; }
+      if (inv_radius > inv_min_radius) { term = PNEC_HIP_TERM_MIN_RADIUS; break; }  // radius < min_radius
       ++iteration;
       step_ok = 0;
 
@@ -418,7 +492,6 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
           slab[kDiag + i] = diag[i];
         }
       }
-      const double inv_radius = fast_rcp(radius);
       double dr[5], y[5], step[5];
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
@@ -439,8 +512,8 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
       valid = valid && (model_change > 0.0);
       if (!valid) {
         if (++num_invalid >= o.max_num_consecutive_invalid_steps) { term = PNEC_HIP_TERM_INVALID_STEPS; break; }
-        radius = radius * inv_dec;
-        inv_dec = 0.5 * inv_dec;
+        inv_radius = inv_radius * dec;
+        dec = 2.0 * dec;
         reuse_diagonal = 1;
         continue;
       }
@@ -475,11 +548,13 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
       slab[kThetaC] = thc;
       slab[kPhiC] = phc;
       slab[kModel] = model_change;
+      ist[kILast] = iteration >= o.max_num_iterations ? 1 : 0;
       break;
     }
-    slab[kRadius] = radius;
-    slab[kInvDec] = inv_dec;
+    slab[kInvRadius] = inv_radius;
+    slab[kDec] = dec;
   }
+  ist[kIPark] = park;
 
   ist[kIIter] = iteration;
   ist[kIFirst] = (term < 0 || !first) ? 0 : 1;
@@ -567,7 +642,10 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
     ist[kIReuseDiag] = 0;
     ist[kINumInvalid] = 0;
     ist[kIStepOk] = 1;
+    ist[kILast] = o.max_num_iterations <= 0 ? 1 : 0;
+    ist[kIPark] = 0;
   }
+  const double inv_max_radius = a.inv_max_radius, inv_min_radius = a.inv_min_radius;  // kernel arguments: scalar
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
   int term;
@@ -586,31 +664,48 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
       U.bph[0] = to_sgpr(unif[15]);
       U.bph[1] = to_sgpr(unif[16]);
       U.bph[2] = 0.0;
-      double acc[kNumAcc];
-#pragma unroll
-      for (int j = 0; j < kNumAcc; ++j) acc[j] = 0.0;
-      PNEC_MARK("pass");
-      if constexpr (RESIDENT) {
-        pass_resident<MODE, REGK, LDSK>(d, &ldata[LDSK > 0 ? wave : 0][0][0][0], lanes_valid, lane, U, reg, acc);
-      } else {
-        for (int idx = threadIdx.x; idx < stride; idx += kWave * WPP) {
-          double e[NC];
-#pragma unroll
-          for (int c = 0; c < NC; ++c) e[c] = base[(int64_t)c * stride + idx];
-          double r, J[5];
-          eval_corr<MODE>(e, idx < n, U, reg, r, J);
-          accumulate(r, J, acc);
-        }
-      }
-      PNEC_MARK("reduce");
       double c[6];
-      wave_reduce21_rows(acc, c);
-      // the four row leaders store the sums they own (sum_slot layout)
+      bool cost_only = false;
+      if constexpr (RESIDENT) cost_only = to_sgpr(ist[kILast]) != 0;  // wave-uniform
+      if (cost_only) {
+        PNEC_MARK("pass_cost");
+        if constexpr (RESIDENT) {
+          double a0 = 0.0, z = 0.0;
+          pass_cost_resident<MODE, REGK, LDSK>(d, &ldata[LDSK > 0 ? wave : 0][0][0][0], lanes_valid, lane, U, reg,
+                                               a0, z);
+          c[0] = wave_reduce_acc0_row0(a0);  // row 0: the sum; rows 1..3: zero
+          // the finite-Jacobian witness as a wave-uniform 0 / NaN in the place of sum 1
+          c[1] = __builtin_amdgcn_ballot_w64(!(z == 0.0)) == 0ull ? 0.0 : __builtin_nan("");
+          c[2] = c[3] = c[4] = c[5] = 0.0;
+        }
+      } else {
+        double acc[kNumAcc];
+#pragma unroll
+        for (int j = 0; j < kNumAcc; ++j) acc[j] = 0.0;
+        PNEC_MARK("pass");
+        if constexpr (RESIDENT) {
+          pass_resident<MODE, REGK, LDSK>(d, &ldata[LDSK > 0 ? wave : 0][0][0][0], lanes_valid, lane, U, reg, acc);
+        } else {
+          for (int idx = threadIdx.x; idx < stride; idx += kWave * WPP) {
+            double e[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) e[c] = base[(int64_t)c * stride + idx];
+            double r, J[5];
+            eval_corr<MODE>(e, idx < n, U, reg, r, J);
+            accumulate(r, J, acc);
+          }
+        }
+        PNEC_MARK("reduce");
+        wave_reduce21_rows(acc, c);
+      }
+      // the four row leaders store the sums they own (sum_slot layout) into the table the current
+      // point does not own
+      double *cand_sums = slab + kSums + (to_sgpr(ist[kIPark]) ^ 1) * kSumSlots;
       if constexpr (WPP == 1) {
         const bool fin = rows_all_finite(c);
         if ((lane & 15) == 0) {
 #pragma unroll
-          for (int i = 0; i < 6; ++i) slab[kSums + (lane >> 4) * 6 + i] = c[i];
+          for (int i = 0; i < 6; ++i) cand_sums[(lane >> 4) * 6 + i] = c[i];
           if (lane == 0) slab[kSumsFinite] = fin ? 1.0 : 0.0;
         }
       } else {
@@ -626,7 +721,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
             double t = xw[parity][0][j];
 #pragma unroll
             for (int w = 1; w < WPP; ++w) t += xw[parity][w][j];
-            slab[kSums + j] = t;
+            cand_sums[j] = t;
             z = __builtin_fma(t, 0.0, z);
           }
           slab[kSumsFinite] = (z == 0.0) ? 1.0 : 0.0;
@@ -642,7 +737,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
     // the chain below is latency-bound: let it win the issue arbitration against the pass of the
     // other wavefront on this SIMD, which has independent work to fill the gaps (+1.2 %)
     __builtin_amdgcn_s_setprio(3);
-    if (lane < 4) t = lm_advance(slab, ist, unif, o);  // one quad, identical work (see the sincos exchange)
+    if (lane < 4) t = lm_advance(slab, ist, unif, o, inv_max_radius, inv_min_radius);  // one quad, identical work (see the sincos exchange)
     term = to_sgpr(t);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
