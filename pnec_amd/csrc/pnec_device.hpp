@@ -334,8 +334,15 @@ __device__ __forceinline__ void angles_from_vec(double x, double y, double z, do
 // omega columns are for R <- Exp(omega) R; the caller scales them by 2 (delta = omega/2) once,
 // after the reduction.  d[] = this correspondence's planes:
 //   0..2 f1 | 3..5 f2 | 6..11 cov (xx,xy,xz,yy,yz,zz) | 12..17 cov_host (SYM only)
+// Padding slots (a lane's share beyond the pair's last correspondence) hold zeros in every plane:
+// f2 = 0 makes n = 0 and dr/dg = 0, so residual and Jacobian come out exactly 0 without a per-
+// correspondence select -- provided 1/sqrt(den) is finite there.  den of a padding slot is `reg`,
+// which may be 0, hence the clamp below; for a real correspondence den >= kTinyDen always unless the
+// input is degenerate (zero covariance AND zero regularisation), where the reference's own
+// arithmetic is Inf/NaN and the solve is reported as failed either way.
+constexpr double kTinyDen = 1e-300;
 template <int MODE>
-__device__ __forceinline__ void eval_corr(const double (&d)[num_components(MODE)], bool valid,
+__device__ __forceinline__ void eval_corr(const double (&d)[num_components(MODE)],
                                           const PassUniforms &U, double reg, double &r,
                                           double (&J)[5]) {
   const double f1x = d[0], f1y = d[1], f1z = d[2];
@@ -362,10 +369,7 @@ __device__ __forceinline__ void eval_corr(const double (&d)[num_components(MODE)
     const double sgy = d[7] * gx + d[9] * gy + d[10] * gz;
     const double sgz = d[8] * gx + d[10] * gy + d[11] * gz;
     const double den = gx * sgx + gy * sgy + gz * sgz + reg;
-    // padding slots: select AFTER the (unconditional) reciprocal square root -- a conditional
-    // evaluation turns into a branch per correspondence and serialises the unrolled pass
-    const double y_all = fast_rsqrt(den);
-    const double y = valid ? y_all : 0.0;
+    const double y = fast_rsqrt(fmax(den, kTinyDen));
     r = n * y;
     const double c = r * y;  // n / den
     wx = y * (f2x - c * sgx);
@@ -394,8 +398,7 @@ __device__ __forceinline__ void eval_corr(const double (&d)[num_components(MODE)
       sgz = d[8] * gx + d[10] * gy + d[11] * gz;
       den += gx * sgx + gy * sgy + gz * sgz;
     }
-    const double y_all = fast_rsqrt(den);
-    const double y = valid ? y_all : 0.0;
+    const double y = fast_rsqrt(fmax(den, kTinyDen));
     r = n * y;
     const double c = r * y;
     wx = y * (f2x - c * sgx);
@@ -437,7 +440,7 @@ __device__ __forceinline__ void eval_corr(const double (&d)[num_components(MODE)
 // (n / den^(3/2): every Jacobian entry is a bounded multiple of y and of k), 0 * k is accumulated as
 // the finite-Jacobian witness Ceres' "Jacobian evaluation failed" test needs.
 template <int MODE>
-__device__ __forceinline__ void eval_cost(const double (&d)[num_components(MODE)], bool valid,
+__device__ __forceinline__ void eval_cost(const double (&d)[num_components(MODE)],
                                           const PassUniforms &U, double reg, double &r, double &k) {
   const double f1x = d[0], f1y = d[1], f1z = d[2];
   const double f2x = d[3], f2y = d[4], f2z = d[5];
@@ -457,8 +460,7 @@ __device__ __forceinline__ void eval_cost(const double (&d)[num_components(MODE)
     const double sgy = d[7] * gx + d[9] * gy + d[10] * gz;
     const double sgz = d[8] * gx + d[10] * gy + d[11] * gz;
     const double den = gx * sgx + gy * sgy + gz * sgz + reg;
-    const double y_all = fast_rsqrt(den);
-    const double y = valid ? y_all : 0.0;
+    const double y = fast_rsqrt(fmax(den, kTinyDen));
     r = n * y;
     k = (r * y) * y;
   } else {
@@ -481,8 +483,7 @@ __device__ __forceinline__ void eval_cost(const double (&d)[num_components(MODE)
       const double sgz = d[8] * gx + d[10] * gy + d[11] * gz;
       den += gx * sgx + gy * sgy + gz * sgz;
     }
-    const double y_all = fast_rsqrt(den);
-    const double y = valid ? y_all : 0.0;
+    const double y = fast_rsqrt(fmax(den, kTinyDen));
     r = n * y;
     k = (r * y) * y;
   }

@@ -122,7 +122,57 @@ __device__ void sym_eig3_impl(const double (&A_in)[9], double (&w)[3], double (&
   for (int i = 0; i < 9; ++i) V[i] = Vs[i];
 }
 __device__ void sym_eig3(const double (&A)[9], double (&w)[3], double (&V)[9]) { sym_eig3_impl<false>(A, w, V); }
-__device__ void sym_eig3_warm(const double (&A)[9], double (&w)[3], double (&V)[9]) { sym_eig3_impl<true>(A, w, V); }
+
+// Smallest eigenpair of a symmetric 3x3 from a nearby eigenvector (the previous point's, the
+// previous SCF step's): Rayleigh-quotient iteration.  One step = the quotient mu = e'Me, the adjugate
+// of M - mu I (six 2x2 minors: cross products of its rows; no division, so an exactly singular shift
+// is harmless -- the adjugate is then the rank-one projector onto the eigenvector) applied to e, and a
+// normalisation: ~50 FP64 instructions against ~300 per warm Jacobi sweep set; convergence is cubic,
+// so a probe 1e-6 away needs two steps and a line-search point a few.  The iteration stops when the
+// vector moved by < 1e-6 (the NEW vector is then converged to ~1e-18).  It can only be trusted to
+// deliver the SMALLEST pair when it started near it, so the result is checked against the
+// characteristic polynomial (lambda is the smallest root iff p'(lambda) >= 0 and trace - 3 lambda
+// >= 0); on failure, or if it has not settled in 8 steps, the caller falls back to the Jacobi sweeps.
+// Accuracy is the same kind as Jacobi's (eps * |M| in lambda, eps * |M| / gap in the vector).
+__device__ __forceinline__ bool sym_eig3_min_rqi(const double (&M)[9], double (&e)[3], double &lambda) {
+  const double m00 = M[0], m01 = M[1], m02 = M[2], m11 = M[4], m12 = M[5], m22 = M[8];
+  double ex = e[0], ey = e[1], ez = e[2];
+  bool settled = false;
+  double mu = 0.0;
+  for (int step = 0; step < 8 && !settled; ++step) {
+    const double mx = m00 * ex + m01 * ey + m02 * ez;
+    const double my = m01 * ex + m11 * ey + m12 * ez;
+    const double mz = m02 * ex + m12 * ey + m22 * ez;
+    mu = ex * mx + ey * my + ez * mz;
+    const double a00 = m00 - mu, a11 = m11 - mu, a22 = m22 - mu;
+    const double c00 = a11 * a22 - m12 * m12, c01 = m02 * m12 - m01 * a22, c02 = m01 * m12 - m02 * a11;
+    const double c11 = a00 * a22 - m02 * m02, c12 = m01 * m02 - m12 * a00, c22 = a00 * a11 - m01 * m01;
+    double x = c00 * ex + c01 * ey + c02 * ez;
+    double y = c01 * ex + c11 * ey + c12 * ez;
+    double z = c02 * ex + c12 * ey + c22 * ez;
+    const double n2 = x * x + y * y + z * z;
+    if (!(n2 > 0.0) || !finite_d(n2)) return false;
+    double inv = fast_rsqrt(n2);
+    if (x * ex + y * ey + z * ez < 0.0) inv = -inv;  // keep the orientation (adj is only defined up to sign)
+    x *= inv; y *= inv; z *= inv;
+    const double moved = fmax(fabs(x - ex), fmax(fabs(y - ey), fabs(z - ez)));
+    ex = x; ey = y; ez = z;
+    settled = moved < 1e-6;
+  }
+  if (!settled) return false;
+  const double mx = m00 * ex + m01 * ey + m02 * ez;
+  const double my = m01 * ex + m11 * ey + m12 * ez;
+  const double mz = m02 * ex + m12 * ey + m22 * ez;
+  lambda = ex * mx + ey * my + ez * mz;
+  // smallest root?  p(x) = x^3 - tr x^2 + c2 x - det:  p'(lambda) = (lambda - l2)(lambda - l3)
+  const double tr = m00 + m11 + m22;
+  const double c2 = (m00 * m11 - m01 * m01) + (m00 * m22 - m02 * m02) + (m11 * m22 - m12 * m12);
+  const double dp = (3.0 * lambda - 2.0 * tr) * lambda + c2;
+  const double tol = 1e-12 * tr * tr;
+  if (!(dp >= -tol) || !(tr - 3.0 * lambda >= 0.0)) return false;
+  e[0] = ex; e[1] = ey; e[2] = ez;
+  return true;
+}
 
 __device__ void cayley_to_rot(const double (&v)[3], double (&R)[9]) {
   const double x = v[0], y = v[1], z = v[2];
@@ -186,11 +236,12 @@ __device__ __forceinline__ void cross3(const double (&a)[3], const double (&b)[3
 //     = sum_k X_kk + sum_{k<l} (X_kl + X_kl'),   X_kl = [r_k]x G_kl [r_l]x'
 // with the skew products written as cross products: row j of [a]x G is a x g_j (g_j = row j of the
 // symmetric G, transposed into place), and row i of T [b]x' is b x T_i.
-// Vw (optional): on entry an orthonormal basis close to M's eigenvectors (those of a nearby
-// point), on exit the eigenvectors -- the Jacobi sweeps then start almost diagonal.
+// ew (optional): on entry the eigenvector of the smallest eigenvalue at a nearby point (`warm`), on
+// exit the one at this point -- Rayleigh-quotient iteration from it instead of Jacobi sweeps from
+// scratch (sym_eig3_min_rqi; falls back to the sweeps when it cannot vouch for the result).
 template <int GS>
 __device__ double es_value_grad(const double *G, const double (&v)[3], double *g, double *M_out,
-                                double *Vw = nullptr) {
+                                double *ew = nullptr, bool warm = false) {
   double R[9];
   cayley_to_rot(v, R);
   double r[3][3];  // columns of R
@@ -241,19 +292,21 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
 #pragma unroll
     for (int i = 0; i < 9; ++i) M_out[i] = M[i];
   }
-  double w[3], V[9];
-  if (Vw) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) V[i] = Vw[i];
-    sym_eig3_warm(M, w, V);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) Vw[i] = V[i];
-  } else {
-    sym_eig3(M, w, V);
+  double lam = 0.0, e[3] = {0.0, 0.0, 1.0};
+  bool have = false;
+  if (ew && warm) {
+    e[0] = ew[0]; e[1] = ew[1]; e[2] = ew[2];
+    have = sym_eig3_min_rqi(M, e, lam);
   }
-  if (!g) return w[0];
+  if (!have) {
+    double w[3], V[9];
+    sym_eig3(M, w, V);
+    lam = w[0];
+    e[0] = V[0]; e[1] = V[3]; e[2] = V[6];
+  }
+  if (ew) { ew[0] = e[0]; ew[1] = e[1]; ew[2] = e[2]; }
+  if (!g) return lam;
   // d lambda = e' dM e = 2 sum_k dr_k . q_k,  q_k = [e]x' (sum_l G_kl [e]x r_l) = (sum_l G_kl y_l) x e
-  const double e[3] = {V[0], V[3], V[6]};
   double y[3][3];
 #pragma unroll
   for (int l = 0; l < 3; ++l) cross3(e, r[l], y[l]);
@@ -295,22 +348,26 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
       }
     g[j] = 2.0 * acc;
   }
-  return w[0];
+  return lam;
 }
 
+// 3x3 Cholesky solve with reciprocal square roots (v_rsq_f64 + refinement) in place of the IEEE
+// sqrt / divide sequences (~400 instructions per call otherwise)
 __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&x)[3]) {
   if (!(H[0] > 0.0)) return false;
-  const double l00 = sqrt(H[0]), l10 = H[3] / l00, l20 = H[6] / l00;
+  const double i0 = fast_rsqrt(H[0]);
+  const double l10 = H[3] * i0, l20 = H[6] * i0;
   const double l11s = H[4] - l10 * l10;
   if (!(l11s > 0.0)) return false;
-  const double l11 = sqrt(l11s), l21 = (H[7] - l20 * l10) / l11;
+  const double i1 = fast_rsqrt(l11s);
+  const double l21 = (H[7] - l20 * l10) * i1;
   const double l22s = H[8] - l20 * l20 - l21 * l21;
   if (!(l22s > 0.0)) return false;
-  const double l22 = sqrt(l22s);
-  const double z0 = b[0] / l00, z1 = (b[1] - l10 * z0) / l11, z2 = (b[2] - l20 * z0 - l21 * z1) / l22;
-  x[2] = z2 / l22;
-  x[1] = (z1 - l21 * x[2]) / l11;
-  x[0] = (z0 - l10 * x[1] - l20 * x[2]) / l00;
+  const double i2 = fast_rsqrt(l22s);
+  const double z0 = b[0] * i0, z1 = (b[1] - l10 * z0) * i1, z2 = (b[2] - l20 * z0 - l21 * z1) * i2;
+  x[2] = z2 * i2;
+  x[1] = (z1 - l21 * x[2]) * i1;
+  x[0] = (z0 - l10 * x[1] - l20 * x[2]) * i0;
   return true;
 }
 
@@ -318,21 +375,20 @@ __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&
 template <int GS>
 __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double n_scale) {
   double g[3];
-  double Vb[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};  // eigenvectors at the current point
-  double f = es_value_grad<GS>(G, v, g, nullptr, Vb);
+  double eb[3] = {0.0, 0.0, 1.0};  // eigenvector of the smallest eigenvalue at the current point
+  double f = es_value_grad<GS>(G, v, g, nullptr, eb, false);
   int it = 0;
   for (; it < 50; ++it) {
     const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
     if (gmax <= 1e-14 * (1.0 + fabs(f)) * n_scale) break;
     double H[9];
-    const double h = 1e-6;
+    const double h = 1e-6, inv_h = 1.0 / h;
     for (int k = 0; k < 3; ++k) {
       double vp[3] = {v[0], v[1], v[2]}, gp[3];
       vp[k] += h;
-      double Vp[9];  // the probe is 1e-6 away: its eigenvectors are the current ones to 1e-6
-      for (int i = 0; i < 9; ++i) Vp[i] = Vb[i];
-      es_value_grad<GS>(G, vp, gp, nullptr, Vp);
-      for (int r = 0; r < 3; ++r) H[3 * r + k] = (gp[r] - g[r]) / h;
+      double ep[3] = {eb[0], eb[1], eb[2]};  // the probe is 1e-6 away: its eigenvector is the current one to 1e-6
+      es_value_grad<GS>(G, vp, gp, nullptr, ep, true);
+      for (int r = 0; r < 3; ++r) H[3 * r + k] = (gp[r] - g[r]) * inv_h;
     }
     H[1] = H[3] = 0.5 * (H[1] + H[3]);
     H[2] = H[6] = 0.5 * (H[2] + H[6]);
@@ -355,9 +411,8 @@ __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double 
     for (int ls = 0; ls < 40; ++ls) {
       for (int k = 0; k < 3; ++k) vn[k] = v[k] + alpha * d[k];
       double Mn[9];
-      double Vn[9];
-      for (int i = 0; i < 9; ++i) Vn[i] = Vb[i];
-      const double fn = es_value_grad<GS>(G, vn, nullptr, Mn, Vn);
+      double en[3] = {eb[0], eb[1], eb[2]};
+      const double fn = es_value_grad<GS>(G, vn, nullptr, Mn, en, true);
       // Armijo with a rounding-noise floor: lambda_min carries ~eps * trace(M) of error
       if (fn <= f + 1e-4 * alpha * slope + 4e-16 * (Mn[0] + Mn[4] + Mn[8])) { moved = true; break; }
       alpha *= 0.5;
@@ -365,7 +420,7 @@ __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double 
     if (!moved) break;
     const double smax = alpha * fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
     for (int k = 0; k < 3; ++k) v[k] = vn[k];
-    f = es_value_grad<GS>(G, v, g, nullptr, Vb);
+    f = es_value_grad<GS>(G, v, g, nullptr, eb, true);
     if (smax < 1e-12) { ++it; break; }
   }
   return it;
@@ -381,31 +436,29 @@ __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double 
 template <int GS>
 __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], double n_scale) {
   const int role = (int)(threadIdx.x & 3);
-  const double h = 1e-6;
-  double Vb[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};  // eigenvectors at the current point
+  const double h = 1e-6, inv_h = 1.0 / h;
+  double eb[3] = {0.0, 0.0, 1.0};  // eigenvector of the smallest eigenvalue at the current point
   double f, g[3], H[9];
   // f, g at v (role 0) and the gradients at v + h e_k (role k + 1), from one evaluation
-  auto evaluate = [&]() {
+  auto evaluate = [&](bool warm) {
     double vp[3] = {v[0] + (role == 1 ? h : 0.0), v[1] + (role == 2 ? h : 0.0), v[2] + (role == 3 ? h : 0.0)};
-    double gp[3], Vp[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) Vp[i] = Vb[i];
-    const double fp = es_value_grad<GS>(G, vp, gp, nullptr, Vp);
+    double gp[3], ep[3] = {eb[0], eb[1], eb[2]};
+    const double fp = es_value_grad<GS>(G, vp, gp, nullptr, ep, warm);
     f = quad_broadcast<0>(fp);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       g[r] = quad_broadcast<0>(gp[r]);
-      H[3 * r + 0] = (quad_broadcast<1>(gp[r]) - g[r]) / h;
-      H[3 * r + 1] = (quad_broadcast<2>(gp[r]) - g[r]) / h;
-      H[3 * r + 2] = (quad_broadcast<3>(gp[r]) - g[r]) / h;
+      H[3 * r + 0] = (quad_broadcast<1>(gp[r]) - g[r]) * inv_h;
+      H[3 * r + 1] = (quad_broadcast<2>(gp[r]) - g[r]) * inv_h;
+      H[3 * r + 2] = (quad_broadcast<3>(gp[r]) - g[r]) * inv_h;
     }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) Vb[i] = quad_broadcast<0>(Vp[i]);
+    for (int i = 0; i < 3; ++i) eb[i] = quad_broadcast<0>(ep[i]);
     H[1] = H[3] = 0.5 * (H[1] + H[3]);
     H[2] = H[6] = 0.5 * (H[2] + H[6]);
     H[5] = H[7] = 0.5 * (H[5] + H[7]);
   };
-  evaluate();
+  evaluate(false);
   int it = 0;
   for (; it < 50; ++it) {
     const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
@@ -428,10 +481,9 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
     for (int ls = 0; ls < 40; ls += 4) {
       const double scale = role == 0 ? 1.0 : (role == 1 ? 0.5 : (role == 2 ? 0.25 : 0.125));
       const double a_mine = alpha * scale;
-      double vn[3], Mn[9], Vn[9];
+      double vn[3], Mn[9], en[3] = {eb[0], eb[1], eb[2]};
       for (int k = 0; k < 3; ++k) vn[k] = v[k] + a_mine * d[k];
-      for (int i = 0; i < 9; ++i) Vn[i] = Vb[i];
-      const double fn = es_value_grad<GS>(G, vn, nullptr, Mn, Vn);
+      const double fn = es_value_grad<GS>(G, vn, nullptr, Mn, en, true);
       // Armijo with a rounding-noise floor: lambda_min carries ~eps * trace(M) of error
       const int pass = (fn <= f + 1e-4 * a_mine * slope + 4e-16 * (Mn[0] + Mn[4] + Mn[8])) ? 1 : 0;
       const int p0 = quad_broadcast<0>(pass), p1 = quad_broadcast<1>(pass), p2 = quad_broadcast<2>(pass),
@@ -446,7 +498,7 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
     if (!moved) break;
     const double smax = alpha * fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
     for (int k = 0; k < 3; ++k) v[k] = v[k] + alpha * d[k];
-    evaluate();
+    evaluate(true);
     if (smax < 1e-12) { ++it; break; }
   }
   return it;
@@ -686,7 +738,6 @@ __global__ __launch_bounds__(kWave, 2) void weighted_eigensolver_kernel(const Fr
   int fib_min_idx = -1;  // -1: no stored search yet
   int first_iterations = 0;
   bool rotation_final = false;
-  double Vscf[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
   for (int it = 0; it + 1 < a.weighted_iterations; ++it) {
     // The weights never change (C3), so every round minimises the same function from the previous
     // optimum: once a call has ended for any reason other than the iteration cap, the rotation is
@@ -796,10 +847,22 @@ __global__ __launch_bounds__(kWave, 2) void weighted_eigensolver_kernel(const Fr
 #pragma unroll
       for (int k = 0; k < 6; ++k) e[k] = wave_allreduce_sum(e[k]);
       const double E[9] = {e[0], e[1], e[2], e[1], e[3], e[4], e[2], e[4], e[5]};
-      double w3[3];
-      sym_eig3_warm(E, w3, Vscf);  // E moves little from step to step: start from the last eigenvectors
-      const double moved = fmax(fabs(Vscf[0] - t[0]), fmax(fabs(Vscf[3] - t[1]), fabs(Vscf[6] - t[2])));
-      t[0] = Vscf[0]; t[1] = Vscf[3]; t[2] = Vscf[6];
+      // smallest eigenvector of E: Rayleigh-quotient iteration from the current t (the iteration is
+      // near its fixed point after the first step or two), Jacobi sweeps when that cannot be vouched for
+      double tn[3] = {t[0], t[1], t[2]}, lam;
+      if (!sym_eig3_min_rqi(E, tn, lam)) {
+        double w3[3], V[9];
+        sym_eig3(E, w3, V);
+        tn[0] = V[0]; tn[1] = V[3]; tn[2] = V[6];
+      }
+      {  // the decomposition's sign convention: largest-magnitude component positive
+        double big = tn[0];
+        if (fabs(tn[1]) > fabs(big)) big = tn[1];
+        if (fabs(tn[2]) > fabs(big)) big = tn[2];
+        if (big < 0.0) { tn[0] = -tn[0]; tn[1] = -tn[1]; tn[2] = -tn[2]; }
+      }
+      const double moved = fmax(fabs(tn[0] - t[0]), fmax(fabs(tn[1] - t[1]), fabs(tn[2] - t[2])));
+      t[0] = tn[0]; t[1] = tn[1]; t[2] = tn[2];
       // the iteration has reached its fixed point to rounding (a few ulp): the remaining steps of
       // the reference's fixed count of 10 would only reproduce that noise
       if (moved <= 4e-15) break;

@@ -179,28 +179,29 @@ __device__ __forceinline__ unsigned load_resident(const double *__restrict__ bas
 
 // One fused pass of a wavefront over its resident correspondences: acc = this lane's partial
 // sums of r^2, J'r and J'J at the pose in U.
+// nslots = how many of the wavefront's slots hold at least one correspondence (wave-uniform; slot k
+// is empty for every lane once the pair's count is below the slot's first correspondence).
 template <int MODE, int REGK, int LDSK>
 __device__ __forceinline__ void pass_resident(const double (&d)[REGK][num_components(MODE)],
-                                              const double *lds /* [LDSK][NC][64] */,
-                                              const unsigned long long (&lanes_valid)[REGK + LDSK],
+                                              const double *lds /* [LDSK][NC][64] */, int nslots,
                                               int lane, const PassUniforms &U, double reg,
                                               double (&acc)[kNumAcc]) {
   constexpr int NC = num_components(MODE);
-  // The first two slots are always evaluated (their masks zero the padding).  The rest of
-  // the register slots, and each LDS slot, are skipped by a wave-uniform branch when no
+  // The first two slots are always evaluated (padding contributes exact zeros, see eval_corr).  The
+  // rest of the register slots, and each LDS slot, are skipped by a wave-uniform branch when no
   // lane holds a correspondence there -- the tail of a ragged pair -- so a short pair does
   // not pay for what the geometry could hold.  (Measured: < 0.5 % on full-size pairs,
   // +8 % solves/s on pairs of 513..600 correspondences.)
   auto eval_slot = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     double r, J[5];
-    eval_corr<MODE>(d[k], __builtin_amdgcn_inverse_ballot_w64(lanes_valid[k]), U, reg, r, J);
+    eval_corr<MODE>(d[k], U, reg, r, J);
     accumulate(r, J, acc);
   };
   eval_slot(std::integral_constant<int, 0>{});
   if constexpr (REGK > 1) eval_slot(std::integral_constant<int, 1>{});
   if constexpr (REGK > 2) {
-    if (lanes_valid[2] != 0ull) {
+    if (nslots > 2) {
       eval_slot(std::integral_constant<int, 2>{});
       if constexpr (REGK > 3) eval_slot(std::integral_constant<int, 3>{});
       if constexpr (REGK > 4) eval_slot(std::integral_constant<int, 4>{});
@@ -213,15 +214,12 @@ __device__ __forceinline__ void pass_resident(const double (&d)[REGK][num_compon
   // blowing the register budget (+0.5 %; the default scheduler hoisted all of them and spilled)
 #pragma unroll
   for (int k = 0; k < LDSK; ++k) {
-    unsigned long long m = lanes_valid[LDSK > 0 ? REGK : 0];
-#pragma unroll
-    for (int i = 1; i < LDSK; ++i) m = (k == i) ? lanes_valid[REGK + i] : m;
-    if (m == 0ull) continue;
+    if (REGK + k >= nslots) continue;
     double e[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) e[c] = lds[(k * NC + c) * kWave + lane];
     double r, J[5];
-    eval_corr<MODE>(e, __builtin_amdgcn_inverse_ballot_w64(m), U, reg, r, J);
+    eval_corr<MODE>(e, U, reg, r, J);
     accumulate(r, J, acc);
   }
 }
@@ -232,22 +230,21 @@ __device__ __forceinline__ void pass_resident(const double (&d)[REGK][num_compon
 // per correspondence.  acc0 = sum r^2; z = 0, or NaN when a Jacobian entry would not be finite.
 template <int MODE, int REGK, int LDSK>
 __device__ __forceinline__ void pass_cost_resident(const double (&d)[REGK][num_components(MODE)],
-                                                   const double *lds /* [LDSK][NC][64] */,
-                                                   const unsigned long long (&lanes_valid)[REGK + LDSK],
+                                                   const double *lds /* [LDSK][NC][64] */, int nslots,
                                                    int lane, const PassUniforms &U, double reg,
                                                    double &acc0, double &z) {
   constexpr int NC = num_components(MODE);
   auto eval_slot = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
     double r, kk;
-    eval_cost<MODE>(d[k], __builtin_amdgcn_inverse_ballot_w64(lanes_valid[k]), U, reg, r, kk);
+    eval_cost<MODE>(d[k], U, reg, r, kk);
     acc0 = __builtin_fma(r, r, acc0);
     z = __builtin_fma(kk, 0.0, z);
   };
   eval_slot(std::integral_constant<int, 0>{});
   if constexpr (REGK > 1) eval_slot(std::integral_constant<int, 1>{});
   if constexpr (REGK > 2) {
-    if (lanes_valid[2] != 0ull) {
+    if (nslots > 2) {
       eval_slot(std::integral_constant<int, 2>{});
       if constexpr (REGK > 3) eval_slot(std::integral_constant<int, 3>{});
       if constexpr (REGK > 4) eval_slot(std::integral_constant<int, 4>{});
@@ -258,15 +255,12 @@ __device__ __forceinline__ void pass_cost_resident(const double (&d)[REGK][num_c
   }
 #pragma unroll
   for (int k = 0; k < LDSK; ++k) {
-    unsigned long long m = lanes_valid[LDSK > 0 ? REGK : 0];
-#pragma unroll
-    for (int i = 1; i < LDSK; ++i) m = (k == i) ? lanes_valid[REGK + i] : m;
-    if (m == 0ull) continue;
+    if (REGK + k >= nslots) continue;
     double e[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) e[c] = lds[(k * NC + c) * kWave + lane];
     double r, kk;
-    eval_cost<MODE>(e, __builtin_amdgcn_inverse_ballot_w64(m), U, reg, r, kk);
+    eval_cost<MODE>(e, U, reg, r, kk);
     acc0 = __builtin_fma(r, r, acc0);
     z = __builtin_fma(kk, 0.0, z);
   }
@@ -606,12 +600,16 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   unsigned vmask = 0;
   if constexpr (RESIDENT)
     vmask = load_resident<NC, CPL, REGK>(base, n, stride, wave * CPL * kWave, lane, d, &ldata[LDSK > 0 ? wave : 0][0][0][0]);
-  // validity of slot k as a 64-lane mask in scalar registers: the pass's selects then take the
-  // mask operand directly instead of re-deriving a per-lane predicate for every correspondence
-  [[maybe_unused]] unsigned long long lanes_valid[REGK + LDSK];
+  // how many of this wavefront's CPL slots hold any correspondence of the pair (wave-uniform): slot k
+  // starts at correspondence first + 128 (k / 2) + (k & 1) (load_resident), lane 0 being the first
+  [[maybe_unused]] int nslots = 0;
   if constexpr (RESIDENT) {
+    (void)vmask;
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) lanes_valid[k] = __builtin_amdgcn_ballot_w64(((vmask >> k) & 1u) != 0u);
+    for (int k = 0; k < CPL; ++k) {
+      const int first_of_slot = wave * CPL * kWave + (CPL == 1 ? 0 : 2 * kWave * (k / 2) + (k & 1));
+      nslots += (n > first_of_slot) ? 1 : 0;
+    }
   }
   if (a.trace) {
     // make "payload on chip" mean what it says: wait for the loads before stamping
@@ -671,7 +669,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
         PNEC_MARK("pass_cost");
         if constexpr (RESIDENT) {
           double a0 = 0.0, z = 0.0;
-          pass_cost_resident<MODE, REGK, LDSK>(d, &ldata[LDSK > 0 ? wave : 0][0][0][0], lanes_valid, lane, U, reg,
+          pass_cost_resident<MODE, REGK, LDSK>(d, &ldata[LDSK > 0 ? wave : 0][0][0][0], nslots, lane, U, reg,
                                                a0, z);
           c[0] = wave_reduce_acc0_row0(a0);  // row 0: the sum; rows 1..3: zero
           // the finite-Jacobian witness as a wave-uniform 0 / NaN in the place of sum 1
@@ -684,14 +682,14 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
         for (int j = 0; j < kNumAcc; ++j) acc[j] = 0.0;
         PNEC_MARK("pass");
         if constexpr (RESIDENT) {
-          pass_resident<MODE, REGK, LDSK>(d, &ldata[LDSK > 0 ? wave : 0][0][0][0], lanes_valid, lane, U, reg, acc);
+          pass_resident<MODE, REGK, LDSK>(d, &ldata[LDSK > 0 ? wave : 0][0][0][0], nslots, lane, U, reg, acc);
         } else {
           for (int idx = threadIdx.x; idx < stride; idx += kWave * WPP) {
             double e[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) e[c] = base[(int64_t)c * stride + idx];
             double r, J[5];
-            eval_corr<MODE>(e, idx < n, U, reg, r, J);
+            eval_corr<MODE>(e, U, reg, r, J);
             accumulate(r, J, acc);
           }
         }

@@ -31,6 +31,7 @@ with Batch.uniform(capi.MODE_TARGET, P, N) as b:
     res = sel.solve(qw, tw)
     sel.close()
 gq = res.q.cpu().numpy()
+gqr, gqw, git_ls = qr.cpu().numpy(), qw.cpu().numpy(), res.iterations.cpu().numpy()
 gmask = mask.cpu().numpy().reshape(P, N).astype(bool)
 gits = its.cpu().numpy()
 f1, f2, c2, R0 = g.bvs1.cpu().numpy(), g.bvs2.cpu().numpy(), g.covs2.cpu().numpy(), g.init_R.cpu().numpy()
@@ -40,13 +41,22 @@ def one(p):
     Rr, trr, m, it = po.ransac_eigensolver(f1[p], f2[p], R0[p], seed=1, pair_id=p)
     Rw, tww = po.weighted_eigensolver(f1[p][m], f2[p][m], c2[p][m], Rr, trr)
     s = po.solve(po.MODE_TARGET, f1[p][m], f2[p][m], c2[p][m], None, 1e-13, po.quat_from_rot(Rw), tww, po.default_options())
-    return (np.radians(po.rotational_difference_deg(s.R, po.rot_from_quat(gq[p]))), bool((m == gmask[p]).all()), int(it) == int(gits[p]))
+    return (np.radians(po.rotational_difference_deg(s.R, po.rot_from_quat(gq[p]))), bool((m == gmask[p]).all()), int(it) == int(gits[p]),
+            np.radians(po.rotational_difference_deg(Rr, po.rot_from_quat(gqr[p]))),
+            np.radians(po.rotational_difference_deg(Rw, po.rot_from_quat(gqw[p]))), int(s.iterations), int(git_ls[p]))
 
 
 with ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 8)) as ex:
     out = list(ex.map(one, range(P)))
 ang = np.array([o[0] for o in out])
-print(json.dumps({"pairs": P, "corr": N, "chain": "RANSAC eigensolver -> inlier extraction -> weighted eigensolver + SCF -> refinement",
+a_r, a_w = np.array([o[3] for o in out]), np.array([o[4] for o in out])
+worst = np.argsort(-ang)[:5]
+stages = {"after_ransac_eigensolver_rot_diff_rad": {"max": float(a_r.max()), "p99": float(np.percentile(a_r, 99))},
+          "after_weighted_eigensolver_rot_diff_rad": {"max": float(a_w.max()), "p99": float(np.percentile(a_w, 99))},
+          "ls_iteration_counts_identical": int(sum(o[5] == o[6] for o in out)),
+          "worst_pairs": [{"pair": int(p), "final": float(ang[p]), "after_ransac": float(a_r[p]), "after_weighted": float(a_w[p]),
+                           "ls_iterations_oracle_device": [out[p][5], out[p][6]]} for p in worst]}
+print(json.dumps({"stages": stages, "pairs": P, "corr": N, "chain": "RANSAC eigensolver -> inlier extraction -> weighted eigensolver + SCF -> refinement",
                   "max_rot_diff_rad": float(ang.max()), "p99_rot_diff_rad": float(np.percentile(ang, 99)),
                   "median_rot_diff_rad": float(np.median(ang)), "pairs_over_1e-6_rad": int((ang > 1e-6).sum()),
                   "inlier_masks_identical": int(sum(o[1] for o in out)), "ransac_iteration_counts_identical": int(sum(o[2] for o in out))}))
