@@ -184,7 +184,11 @@ int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint6
                                 int32_t *out_ransac_iterations, int space, void *stream);
 
 /* PNEC::InlierExtraction (src/rel_pose_estimation/pnec.cc:210-229): a new batch holding, pair by pair
- * and in order, the correspondences whose mask byte is non-zero.  Blocks until done. */
+ * and in order, the correspondences whose mask byte is non-zero.  Done on the device: DEVICE-space calls
+ * are asynchronous on `stream` and nothing is read back -- the new batch keeps the source's capacity and
+ * its pair sizes stay in HBM until a host-side number is asked for (pnec_hip_problem_offsets /
+ * _num_correspondences / _max_correspondences / _payload_bytes wait for the stream and fetch them).
+ * HOST-space calls block (the caller may reuse `mask` on return). */
 int pnec_hip_problem_select(pnec_hip_problem *src, const uint8_t *mask, int space, void *stream,
                             pnec_hip_problem **out);
 
@@ -196,6 +200,66 @@ int pnec_hip_problem_select(pnec_hip_problem *src, const uint8_t *mask, int spac
 int pnec_hip_weighted_eigensolver(pnec_hip_problem *p, const double *init_q, const double *init_t,
                                   double reg, int32_t weighted_iterations, double *out_q, double *out_t,
                                   int space, void *stream);
+
+/* ---- the whole PNEC::Solve chain, device-resident ------------------------------------------------
+ * pnec::rel_pose_estimation::Options as PNEC::Solve reads it (include/rel_pose_estimation/pnec_config.h:
+ * 46-65; pnec.cc:87,96,97,105,109,116,239,246,249,300,327,367).  Fill with
+ * pnec_hip_default_pipeline_options() (the reference's defaults). */
+typedef struct pnec_hip_pipeline_options {
+  int32_t use_ransac;            /* 1     Options::use_ransac_ */
+  int32_t use_nec;               /* 0     Options::use_nec_ */
+  int32_t use_ceres;             /* 1     Options::use_ceres_ */
+  int32_t weighted_iterations;   /* 10    Options::weighted_iterations_ */
+  int32_t max_ransac_iterations; /* 5000  Options::max_ransac_iterations_ */
+  int32_t ransac_sample_size;    /* 10    Options::ransac_sample_size_ (<= PNEC_HIP_MAX_RANSAC_SAMPLE) */
+  int32_t reserved[2];           /* must be 0 */
+  double regularization;         /* 1e-13 Options::regularization_ */
+  double ransac_threshold;       /* 1e-6  pnec.cc:248 */
+  uint64_t ransac_seed;          /* 1     counter-based draws (see pnec_hip_ransac_eigensolver) */
+  pnec_hip_options solver;       /* the refinement's ceres::Solver::Options; PNEC::CeresSolver and
+                                    NECCeresSolver default-construct theirs (pnec.cc:355,399) */
+} pnec_hip_pipeline_options;
+void pnec_hip_default_pipeline_options(pnec_hip_pipeline_options *opt);
+
+/* PNEC::Solve (src/rel_pose_estimation/pnec.cc:77-124) for every pair of a batch: Eigensolver (with
+ * RANSAC when use_ransac) -> InlierExtraction -> NECCeresSolver (use_nec) or WeightedEigensolver +
+ * CeresSolver, each stage one launch over the batch on `stream`, the stages handing their results to
+ * each other in HBM (no host round trip, no allocation after the first call on a batch).
+ *   init_q [n_pairs,4] xyzw, init_t [n_pairs,3]   initial_pose per pair
+ *   out_q [n_pairs,4], out_t [n_pairs,3]          the pose Solve returns
+ *   out_inlier_mask [sum N] / out_inlier_count [n_pairs]  the `inliers` of the four-argument overload
+ *                                                 (all zero without RANSAC: inliers.clear()); may be NULL
+ * TARGET-mode problems (use_nec also accepts NEC-mode ones).  space as in pnec_hip_solve. */
+int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const double *init_t,
+                            const pnec_hip_pipeline_options *opt, double *out_q, double *out_t,
+                            uint8_t *out_inlier_mask, int32_t *out_inlier_count, int space, void *stream);
+
+/* ---- streaming: one frame pair (or a few) per call, as the reference's odometry calls the solver ----
+ * (Frame2Frame::PNECAlign -> PNEC::Solve once per frame, src/rel_pose_estimation/frame2frame.cc:122-141;
+ * PNECCeres::Optimize once per pybind call, python/pypnec.cpp:55-65.)  A handle owns `slots` staging
+ * slots in pinned, device-mapped host memory and one HIP stream; nothing is allocated per call.
+ *   submit  copies the caller's reference-layout arrays (as in pnec_hip_problem_fill; offsets[n_pairs+1]
+ *           with offsets[0] == 0) and start poses into a free slot and launches ONE kernel that reads
+ *           them over PCIe, runs InitValues + Optimize + Result on chip and writes the result records
+ *           back into the slot; returns a ticket at once.  With all slots in flight it first waits for
+ *           the oldest.  Pairs beyond the register-resident geometries (> 4096 correspondences; > 2048
+ *           for SYM) are staged through a batch owned by the handle instead.
+ *   poll    done = 1 once the ticket's results are in host memory (never blocks).
+ *   wait    blocks (polling a flag the kernel raises -- no stream synchronisation), copies the results
+ *           out (any pointer may be NULL) and frees the slot.  Tickets must be collected with wait.
+ * max_corr / max_pairs bound ONE submit.  stream: NULL = a stream of the handle's own.
+ * A handle is not thread-safe; use one per thread. */
+typedef struct pnec_hip_stream pnec_hip_stream;
+int pnec_hip_stream_create(int device, int32_t max_corr, int32_t max_pairs, int32_t slots, void *stream,
+                           pnec_hip_stream **out);
+int pnec_hip_stream_destroy(pnec_hip_stream *s);
+int pnec_hip_stream_submit(pnec_hip_stream *s, int mode, int64_t n_pairs, const int64_t *offsets,
+                           const double *bvs1, const double *bvs2, const double *covs, const double *covs_host,
+                           const double *init_q, const double *init_t, double reg, const pnec_hip_options *opt,
+                           int64_t *ticket);
+int pnec_hip_stream_poll(pnec_hip_stream *s, int64_t ticket, int32_t *done);
+int pnec_hip_stream_wait(pnec_hip_stream *s, int64_t ticket, double *out_q, double *out_t, double *out_cost,
+                         int32_t *out_iterations, int32_t *out_status);
 
 /* Input side of the path: pnec::common::UnscentedTransform (src/common/common.cc:467-525) and
  * pnec::common::Unproject (:460-465) for n keypoints at once -- what KeyPoint::Unproject

@@ -47,14 +47,23 @@ class Batch:
         self._lib = capi.lib()
         self.mode = int(mode)
         self.device = int(device)
-        self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
-        if self.offsets.ndim != 1 or len(self.offsets) < 1:
+        self._offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if self._offsets.ndim != 1 or len(self._offsets) < 1:
             raise ValueError("offsets must be a 1-D array of length n_pairs+1")
-        self.n_pairs = len(self.offsets) - 1
+        self.n_pairs = len(self._offsets) - 1
         h = C.c_void_p()
         capi.check(self._lib.pnec_hip_problem_create(self.device, self.mode, self.n_pairs,
-                                                     self.offsets.ctypes.data, C.byref(h)))
+                                                     self._offsets.ctypes.data, C.byref(h)))
         self._h = h
+
+    @property
+    def offsets(self) -> np.ndarray:
+        """int64 [n_pairs+1]; for a batch made by select() the first access waits for the device."""
+        if self._offsets is None:
+            off = np.empty(self.n_pairs + 1, dtype=np.int64)
+            capi.check(self._lib.pnec_hip_problem_offsets(self._h, off.ctypes.data))
+            self._offsets = off
+        return self._offsets
 
     @classmethod
     def uniform(cls, mode: int, n_pairs: int, n_corr: int, device: int = 0) -> "Batch":
@@ -311,10 +320,42 @@ class Batch:
         out = Batch.__new__(Batch)
         out._lib, out.mode, out.device, out._h = self._lib, self.mode, self.device, h
         out.n_pairs = self.n_pairs
-        # the library knows the kept counts (it sized the new batch from them): fetch its offsets
-        out.offsets = np.empty(self.n_pairs + 1, dtype=np.int64)
-        capi.check(self._lib.pnec_hip_problem_offsets(h, out.offsets.ctypes.data))
+        # InlierExtraction ran on the device and nothing was read back: the new batch's offsets are
+        # fetched from the library on first use (that call waits for the stream)
+        out._offsets = None
         return out
+
+    def solve_pipeline(self, init_q, init_t, options: capi.PipelineOptions | None = None, want_inliers: bool = False):
+        """PNEC::Solve (pnec.cc:77-124) for every pair, all stages on the device without a host round
+        trip: -> (q [P,4], t [P,3]) or, with want_inliers, (q, t, inlier_mask [sumN] uint8, inlier_count [P])."""
+        P = self.n_pairs
+        opt = C.byref(options) if options is not None else None
+        if _is_torch(init_q):
+            import torch
+            iq = self._dev_tensor(init_q, "init_q", (P, 4))
+            it = self._dev_tensor(init_t, "init_t", (P, 3))
+            q = torch.empty((P, 4), dtype=torch.float64, device=iq.device)
+            t = torch.empty((P, 3), dtype=torch.float64, device=iq.device)
+            mask = cnt = None
+            if want_inliers:
+                mask = torch.empty((max(self.num_correspondences, 1),), dtype=torch.uint8, device=iq.device)
+                cnt = torch.empty((P,), dtype=torch.int32, device=iq.device)
+            capi.check(self._lib.pnec_hip_solve_pipeline(
+                self._h, iq.data_ptr(), it.data_ptr(), opt, q.data_ptr(), t.data_ptr(),
+                None if mask is None else mask.data_ptr(), None if cnt is None else cnt.data_ptr(), capi.MEM_DEVICE,
+                torch.cuda.current_stream(self.device).cuda_stream))
+            return (q, t, mask[:self.num_correspondences], cnt) if want_inliers else (q, t)
+        iq = np.ascontiguousarray(init_q, dtype=np.float64)
+        it = np.ascontiguousarray(init_t, dtype=np.float64)
+        if iq.shape != (P, 4) or it.shape != (P, 3):
+            raise ValueError("init_q must be [n_pairs,4], init_t [n_pairs,3]")
+        q, t = np.empty((P, 4)), np.empty((P, 3))
+        mask = np.zeros(max(self.num_correspondences, 1), dtype=np.uint8) if want_inliers else None
+        cnt = np.zeros(P, dtype=np.int32) if want_inliers else None
+        capi.check(self._lib.pnec_hip_solve_pipeline(
+            self._h, iq.ctypes.data, it.ctypes.data, opt, q.ctypes.data, t.ctypes.data,
+            None if mask is None else mask.ctypes.data, None if cnt is None else cnt.ctypes.data, capi.MEM_HOST, None))
+        return (q, t, mask[:self.num_correspondences], cnt) if want_inliers else (q, t)
 
     def nec_eigensolver(self, init_q):
         """PNEC::Eigensolver without RANSAC (pnec.cc:273-278): -> (q [P,4], t [P,3])"""

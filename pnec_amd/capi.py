@@ -49,6 +49,13 @@ SYMBOLS = [
     "pnec_hip_ransac_eigensolver",
     "pnec_hip_problem_select",
     "pnec_hip_weighted_eigensolver",
+    "pnec_hip_default_pipeline_options",
+    "pnec_hip_solve_pipeline",
+    "pnec_hip_stream_create",
+    "pnec_hip_stream_destroy",
+    "pnec_hip_stream_submit",
+    "pnec_hip_stream_poll",
+    "pnec_hip_stream_wait",
     "pnec_hip_unscented_transform",
     "pnec_hip_describe_launch",
     "pnec_hip_selftest",
@@ -77,6 +84,24 @@ class Options(C.Structure):
         ("min_relative_decrease", C.c_double),
         ("min_lm_diagonal", C.c_double),
         ("max_lm_diagonal", C.c_double),
+    ]
+
+
+class PipelineOptions(C.Structure):
+    """``pnec_hip_pipeline_options``: the Options fields PNEC::Solve reads."""
+
+    _fields_ = [
+        ("use_ransac", C.c_int32),
+        ("use_nec", C.c_int32),
+        ("use_ceres", C.c_int32),
+        ("weighted_iterations", C.c_int32),
+        ("max_ransac_iterations", C.c_int32),
+        ("ransac_sample_size", C.c_int32),
+        ("reserved", C.c_int32 * 2),
+        ("regularization", C.c_double),
+        ("ransac_threshold", C.c_double),
+        ("ransac_seed", C.c_uint64),
+        ("solver", Options),
     ]
 
 
@@ -131,6 +156,15 @@ def lib() -> C.CDLL:
                                               _vp, _vp, _vp, C.c_int, _vp]
     L.pnec_hip_problem_select.argtypes = [_vp, _vp, C.c_int, _vp, C.POINTER(_vp)]
     L.pnec_hip_weighted_eigensolver.argtypes = [_vp, _vp, _vp, C.c_double, C.c_int32, _vp, _vp, C.c_int, _vp]
+    L.pnec_hip_default_pipeline_options.argtypes = [C.POINTER(PipelineOptions)]
+    L.pnec_hip_default_pipeline_options.restype = None
+    L.pnec_hip_solve_pipeline.argtypes = [_vp, _vp, _vp, C.POINTER(PipelineOptions), _vp, _vp, _vp, _vp, C.c_int, _vp]
+    L.pnec_hip_stream_create.argtypes = [C.c_int, C.c_int32, C.c_int32, C.c_int32, _vp, C.POINTER(_vp)]
+    L.pnec_hip_stream_destroy.argtypes = [_vp]
+    L.pnec_hip_stream_submit.argtypes = [_vp, C.c_int, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double,
+                                         C.POINTER(Options), C.POINTER(C.c_int64)]
+    L.pnec_hip_stream_poll.argtypes = [_vp, C.c_int64, C.POINTER(C.c_int32)]
+    L.pnec_hip_stream_wait.argtypes = [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp]
     L.pnec_hip_selftest.argtypes = [C.c_int]
     L.pnec_hip_release_cache.argtypes = [C.c_int]
     L.pnec_hip_release_cache.restype = C.c_int64
@@ -146,6 +180,16 @@ def check(rc: int) -> None:
 def default_options(**overrides) -> Options:
     o = Options()
     lib().pnec_hip_default_options(C.byref(o))
+    for k, v in overrides.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def default_pipeline_options(**overrides) -> PipelineOptions:
+    o = PipelineOptions()
+    lib().pnec_hip_default_pipeline_options(C.byref(o))
     for k, v in overrides.items():
         if not hasattr(o, k):
             raise AttributeError(k)

@@ -1,9 +1,13 @@
 // host_demo.cc -- compiled into a small executable: run_simulation's call pattern
 // (src/run_simulation.cc:74-86) for one synthetic pair through the C++ facade; used by the GPU
 // tests to exercise the facade without Python.
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
+#include <vector>
 
 #include "pnec_host.h"
 
@@ -27,6 +31,33 @@ int main(int argc, char **argv) {
     b1[i] = P.normalized();
     b2[i] = P2.normalized();
     covs[i] = pnec::Matrix3d::Identity() * (s * s);
+  }
+  if (argc > 2 && std::strcmp(argv[2], "latency") == 0) {
+    // one-pair PNECCeres::Optimize latency, host arrays in, pose out (the reference's per-call pattern:
+    // pnec_ceres.cc:70-111 / python/pypnec.cpp:55-65): median and 90th percentile over `reps` calls
+    const int reps = argc > 3 ? std::atoi(argv[3]) : 2000;
+    const pnec::Quaterniond q0 = pnec::Quaterniond(0.975, 0.1, -0.14, 0.115).normalized();
+    const pnec::Vector3d t0 = pnec::Vector3d(0.28, -0.22, 0.92).normalized();
+    std::vector<double> us;
+    us.reserve((size_t)reps);
+    double sink = 0.0;
+    int iterations = 0;
+    for (int r = 0; r < reps + 50; ++r) {
+      pnec::optimization::PNECCeres optimizer;
+      optimizer.InitValues(q0, t0);
+      const auto tic = std::chrono::steady_clock::now();
+      optimizer.Optimize(b1, b2, covs, 1.0e-13);
+      const auto toc = std::chrono::steady_clock::now();
+      if (r >= 50) us.push_back(std::chrono::duration<double, std::micro>(toc - tic).count());
+      sink += optimizer.Translation()[2];
+      iterations = optimizer.summary().iterations;
+    }
+    std::sort(us.begin(), us.end());
+    std::printf("{\"call\": \"PNECCeres::Optimize (target frame), host arrays in, pose out\", \"correspondences\": %d, "
+                "\"lm_iterations\": %d, \"reps\": %d, \"median_us\": %.2f, \"p10_us\": %.2f, \"p90_us\": %.2f, "
+                "\"min_us\": %.2f, \"checksum\": %.6f}\n",
+                n, iterations, reps, us[us.size() / 2], us[us.size() / 10], us[us.size() * 9 / 10], us[0], sink / reps);
+    return 0;
   }
   // the reference's default Options: RANSAC eigensolver -> inliers -> 9 weighted eigensolver rounds +
   // SCF -> Ceres-style refinement (run_simulation.cc:74-86 calls it exactly like this)

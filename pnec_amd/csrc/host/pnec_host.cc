@@ -27,6 +27,29 @@ Vector3d TranslationFromAngles(double theta, double phi) {
   return Vector3d(std::sin(theta) * std::cos(phi), std::sin(theta) * std::sin(phi), std::cos(theta));
 }
 
+// The per-thread streaming handle of a device (pnec_hip_stream: pinned staging + one HIP stream, created
+// once): what makes a single Optimize() call cost one memcpy + one kernel launch instead of a batch
+// object's create / fill / solve / destroy.  Grown (re-created) when a pair exceeds its capacity.
+struct ThreadStream {
+  pnec_hip_stream *s = nullptr;
+  int device = -1;
+  int32_t max_corr = 0;
+  ~ThreadStream() { pnec_hip_stream_destroy(s); }
+  pnec_hip_stream *Get(int dev, int64_t n) {
+    if (!s || dev != device || n > max_corr) {
+      pnec_hip_stream_destroy(s);
+      s = nullptr;
+      int32_t cap = 4096;
+      while (cap < n) cap *= 2;
+      Check(pnec_hip_stream_create(dev, cap, 1, 4, nullptr, &s));
+      device = dev;
+      max_corr = cap;
+    }
+    return s;
+  }
+};
+thread_local ThreadStream g_stream;
+
 // One solve through the ABI: host arrays in the reference's layout in, pose + summary out.
 void SolveOne(int mode, const optimization::SolverOptions &options, const std::vector<Vector3d> &b1,
               const std::vector<Vector3d> &b2, const std::vector<Matrix3d> *covs,
@@ -35,19 +58,19 @@ void SolveOne(int mode, const optimization::SolverOptions &options, const std::v
   if (b1.size() != b2.size()) throw std::invalid_argument("bvs_1 and bvs_2 differ in size");
   if (covs && covs->size() != b1.size()) throw std::invalid_argument("covs and bvs differ in size");
   if (covs_host && covs_host->size() != b1.size()) throw std::invalid_argument("covs_1 and bvs differ in size");
-  const std::vector<int64_t> offsets = {0, (int64_t)b1.size()};
-  Problem prob(options.device, mode, offsets);
-  Check(pnec_hip_problem_fill(prob.p, 0, 1, b1.empty() ? nullptr : b1[0].data(),
-                              b2.empty() ? nullptr : b2[0].data(),
-                              covs && !covs->empty() ? (*covs)[0].data() : nullptr,
-                              covs_host && !covs_host->empty() ? (*covs_host)[0].data() : nullptr,
-                              PNEC_HIP_MEM_HOST, nullptr));
+  const int64_t offsets[2] = {0, (int64_t)b1.size()};
+  pnec_hip_stream *stream = g_stream.Get(options.device, offsets[1]);
   const Vector3d t0 = TranslationFromAngles(theta, phi);
   const pnec_hip_options o = options.ToHip();
+  int64_t ticket = 0;
+  Check(pnec_hip_stream_submit(stream, mode, 1, offsets, b1.empty() ? nullptr : b1[0].data(),
+                               b2.empty() ? nullptr : b2[0].data(),
+                               covs && !covs->empty() ? (*covs)[0].data() : nullptr,
+                               covs_host && !covs_host->empty() ? (*covs_host)[0].data() : nullptr, q.coeffs(),
+                               t0.data(), reg, &o, &ticket));
   double out_q[4], out_t[3], cost = 0.0;
   int32_t it = 0, st = 0;
-  Check(pnec_hip_solve(prob.p, q.coeffs(), t0.data(), 1, nullptr, reg, &o, out_q, out_t, &cost, &it,
-                       &st, PNEC_HIP_MEM_HOST, nullptr));
+  Check(pnec_hip_stream_wait(stream, ticket, out_q, out_t, &cost, &it, &st));
   q = Quaterniond(out_q[3], out_q[0], out_q[1], out_q[2]);
   common::AnglesFromVec(Vector3d(out_t[0], out_t[1], out_t[2]), theta, phi);
   summary.final_cost = cost;
@@ -335,6 +358,22 @@ struct PairOnDevice {
   }
 };
 
+// the Options fields PNEC::Solve reads (pnec.cc:87,96,97,105,109,116,239,246,249,300,327,367); the
+// refinement uses default solver options whatever Options::ceres_options_ says (quirk C1, pnec.cc:355)
+pnec_hip_pipeline_options ToPipeline(const Options &o) {
+  pnec_hip_pipeline_options p;
+  pnec_hip_default_pipeline_options(&p);
+  p.use_ransac = o.use_ransac_ ? 1 : 0;
+  p.use_nec = o.use_nec_ ? 1 : 0;
+  p.use_ceres = o.use_ceres_ ? 1 : 0;
+  p.weighted_iterations = (int32_t)o.weighted_iterations_;
+  p.max_ransac_iterations = o.max_ransac_iterations_;
+  p.ransac_sample_size = o.ransac_sample_size_;
+  p.regularization = o.regularization_;
+  p.solver = optimization::SolverOptions().ToHip();
+  return p;
+}
+
 SE3d PoseFromQT(const double q[4], const double t[3]) {
   return SE3d(Quaterniond(q[3], q[0], q[1], q[2]).toRotationMatrix(), Vector3d(t[0], t[1], t[2]));
 }
@@ -369,6 +408,19 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
   PairOnDevice dev(optimization::SolverOptions().device, bvs1, bvs2, projected_covs);
   const Quaterniond q0(initial_pose.rotationMatrix());
   double q[4], t[3];
+  if (!timing) {
+    // the untimed overloads: the whole chain in one call, stages chained on the device
+    const pnec_hip_pipeline_options po = ToPipeline(options_);
+    std::vector<uint8_t> mask(bvs1.size() ? bvs1.size() : 1, 0);
+    Check(pnec_hip_solve_pipeline(dev.prob.p, q0.coeffs(), initial_pose.translation().data(), &po, q, t,
+                                  mask.data(), nullptr, PNEC_HIP_MEM_HOST, nullptr));
+    inliers.clear();
+    if (options_.use_ransac_)
+      for (size_t i = 0; i < bvs1.size(); ++i)
+        if (mask[i]) inliers.push_back((int)i);
+    return PoseFromQT(q, t);
+  }
+  // the timed overloads run stage by stage (each stage's wall time is what FrameTiming reports)
   pnec_hip_problem *stage = dev.prob.p;   // the batch the later stages run on (inliers under RANSAC)
   pnec_hip_problem *selected = nullptr;
   struct Guard {
@@ -527,7 +579,8 @@ struct FlatBatch {
 }  // namespace
 
 std::vector<SE3d> PNEC::SolveBatch(const std::vector<FramePair> &pairs, std::vector<std::vector<int>> *inliers) {
-  // pnec.cc:77-124 for every pair, each stage one launch over the batch
+  // pnec.cc:77-124 for every pair: one upload, every stage one launch over the batch with the results
+  // handed on in HBM (pnec_hip_solve_pipeline), one download
   const int64_t B = (int64_t)pairs.size();
   std::vector<SE3d> out(B);
   if (inliers) inliers->assign(B, {});
@@ -539,66 +592,18 @@ std::vector<SE3d> PNEC::SolveBatch(const std::vector<FramePair> &pairs, std::vec
   if (total > 0)
     Check(pnec_hip_problem_fill(prob.p, 0, B, h.b1[0].data(), h.b2[0].data(), h.cv[0].data(), nullptr,
                                 PNEC_HIP_MEM_HOST, nullptr));
+  const pnec_hip_pipeline_options po = ToPipeline(options_);
   std::vector<double> q(4 * B), t(3 * B);
-  pnec_hip_problem *stage = prob.p;
-  pnec_hip_problem *selected = nullptr;
-  struct Guard {
-    pnec_hip_problem *&p;
-    ~Guard() { if (p) pnec_hip_problem_destroy(p); }
-  } guard{selected};
   std::vector<uint8_t> mask;
-  if (options_.use_ransac_) {
-    mask.assign(total ? total : 1, 0);
-    Check(pnec_hip_ransac_eigensolver(prob.p, h.q0.data(), /*seed*/ 1, options_.max_ransac_iterations_,
-                                      options_.ransac_sample_size_, 1.0e-6, q.data(), t.data(), mask.data(),
-                                      nullptr, nullptr, PNEC_HIP_MEM_HOST, nullptr));
-    if (inliers)
-      for (int64_t p = 0; p < B; ++p)
-        for (int64_t i = h.offsets[p]; i < h.offsets[p + 1]; ++i)
-          if (mask[i]) (*inliers)[p].push_back((int)(i - h.offsets[p]));
-    Check(pnec_hip_problem_select(prob.p, mask.data(), PNEC_HIP_MEM_HOST, nullptr, &selected));
-    stage = selected;
-  } else {
-    Check(pnec_hip_nec_eigensolver(prob.p, h.q0.data(), q.data(), t.data(), PNEC_HIP_MEM_HOST, nullptr));
-  }
-  const pnec_hip_options o = so.ToHip();
-  std::vector<double> oq(4 * B), ot(3 * B);
-  auto poses = [&](const std::vector<double> &qq, const std::vector<double> &tt) {
-    for (int64_t p = 0; p < B; ++p) out[p] = PoseFromQT(&qq[4 * p], &tt[3 * p]);
-    return out;
-  };
-  if (options_.use_nec_) {
-    if (!options_.use_ceres_) return poses(q, t);
-    // NECCeresSolver on the (inlier) bearings: a NEC-family batch of the kept correspondences
-    std::vector<int64_t> noff(B + 1, 0);
-    std::vector<Vector3d> n1, n2;
-    for (int64_t p = 0; p < B; ++p) {
+  if (inliers && options_.use_ransac_) mask.assign(total ? total : 1, 0);
+  Check(pnec_hip_solve_pipeline(prob.p, h.q0.data(), h.t0.data(), &po, q.data(), t.data(),
+                                mask.empty() ? nullptr : mask.data(), nullptr, PNEC_HIP_MEM_HOST, nullptr));
+  if (!mask.empty())
+    for (int64_t p = 0; p < B; ++p)
       for (int64_t i = h.offsets[p]; i < h.offsets[p + 1]; ++i)
-        if (!options_.use_ransac_ || mask[i]) { n1.push_back(h.b1[i]); n2.push_back(h.b2[i]); }
-      noff[p + 1] = (int64_t)n1.size();
-    }
-    Problem nec(so.device, PNEC_HIP_MODE_NEC, noff);
-    if (!n1.empty())
-      Check(pnec_hip_problem_fill(nec.p, 0, B, n1[0].data(), n2[0].data(), nullptr, nullptr, PNEC_HIP_MEM_HOST,
-                                  nullptr));
-    Check(pnec_hip_solve(nec.p, q.data(), t.data(), 1, nullptr, 0.0, &o, oq.data(), ot.data(), nullptr, nullptr,
-                         nullptr, PNEC_HIP_MEM_HOST, nullptr));
-    return poses(oq, ot);
-  }
-  std::vector<double> qi(4 * B), ti(3 * B);
-  if (options_.weighted_iterations_ > 1) {
-    Check(pnec_hip_weighted_eigensolver(stage, q.data(), t.data(), options_.regularization_,
-                                        (int32_t)options_.weighted_iterations_, qi.data(), ti.data(),
-                                        PNEC_HIP_MEM_HOST, nullptr));
-  } else if (options_.weighted_iterations_ == 1) {
-    qi = q; ti = t;
-  } else {
-    qi = h.q0; ti = h.t0;
-  }
-  if (!options_.use_ceres_) return poses(qi, ti);
-  Check(pnec_hip_solve(stage, qi.data(), ti.data(), 1, nullptr, options_.regularization_, &o, oq.data(), ot.data(),
-                       nullptr, nullptr, nullptr, PNEC_HIP_MEM_HOST, nullptr));
-  return poses(oq, ot);
+        if (mask[i]) (*inliers)[p].push_back((int)(i - h.offsets[p]));
+  for (int64_t p = 0; p < B; ++p) out[p] = PoseFromQT(&q[4 * p], &t[3 * p]);
+  return out;
 }
 
 std::vector<SE3d> PNEC::CeresSolverBatch(const std::vector<FramePair> &pairs,

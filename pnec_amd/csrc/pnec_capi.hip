@@ -22,6 +22,12 @@ hipError_t launch_solve_mode_1(int, int, int, bool, const SolveArgs &, hipStream
 hipError_t launch_solve_mode_2(int, int, int, bool, const SolveArgs &, hipStream_t);
 hipError_t launch_solve_mode_3(int, int, int, bool, const SolveArgs &, hipStream_t);
 
+// pnec_stream_<family>.hip: the same kernels reading the reference's AoS arrays (streaming handle)
+hipError_t launch_solve_aos_mode_0(int, int, int, const SolveArgs &, hipStream_t);
+hipError_t launch_solve_aos_mode_1(int, int, int, const SolveArgs &, hipStream_t);
+hipError_t launch_solve_aos_mode_2(int, int, int, const SolveArgs &, hipStream_t);
+hipError_t launch_solve_aos_mode_3(int, int, int, const SolveArgs &, hipStream_t);
+
 // pnec_frontend.hip
 hipError_t launch_ransac_eigensolver(const double *, const int64_t *, const int64_t *, const int32_t *, int64_t,
                                      const double *, unsigned long long, int, int, double, double *, double *,
@@ -71,6 +77,16 @@ struct pnec_hip_problem {
   std::vector<Bucket> buckets;
   int32_t *d_bucket_pairs = nullptr;
   std::vector<int32_t> host_counts;
+  // A batch produced by InlierExtraction on the device (pnec_hip_problem_select, the pipeline): it keeps
+  // the source's block layout (capacity) and its real pair sizes exist only in d_count until somebody
+  // asks for host-side numbers.  While `lazy`, host_counts / n_max / n_corr / offsets hold the SOURCE's
+  // values, i.e. upper bounds -- all the launch selection needs.
+  bool lazy = false;
+  hipStream_t lazy_stream = nullptr;   // the stream the device-side sizes were produced on
+  bool owns_data = true;               // false: a re-typed view of another batch's buffers (NEC view of a TARGET batch)
+  pnec_hip_problem *sel_view = nullptr;  // pipeline: cached InlierExtraction target (same capacity, reused)
+  pnec_hip_problem *nec_view = nullptr;  // pipeline: this batch's bearings as a NEC-family batch (no copy)
+  uint8_t *d_mask = nullptr;             // pipeline: inlier mask [n_corr]
 };
 
 namespace {
@@ -101,6 +117,7 @@ struct DevBlock {
   size_t bytes;
   int device;
 };
+constexpr size_t kMinCachedBytes = 1u << 20;
 std::mutex g_mem_mutex;
 std::unordered_map<void *, DevBlock> g_live;  // every block handed out
 std::vector<DevBlock> g_cache;               // free blocks kept for reuse
@@ -167,7 +184,7 @@ hipError_t dev_free(void *ptr) {
   if (it == g_live.end()) return hipFree(ptr);
   const DevBlock b = it->second;
   g_live.erase(it);
-  if (b.bytes >= (1u << 20) && g_cached_bytes + b.bytes <= cache_limit_bytes()) {
+  if (b.bytes >= kMinCachedBytes && g_cached_bytes + b.bytes <= cache_limit_bytes()) {
     int prev = -1;
     (void)hipGetDevice(&prev);
     (void)hipSetDevice(b.device);
@@ -395,6 +412,33 @@ __global__ __launch_bounds__(kWave) void mask_count_kernel(const uint8_t *__rest
   if (threadIdx.x == 0) out[p] = c;
 }
 
+// exclusive prefix sum of the pair sizes -> AoS offsets [n+1] (one workgroup; n is at most a few 1e5)
+__global__ __launch_bounds__(1024) void offsets_scan_kernel(const int32_t *__restrict__ count,
+                                                            int64_t *__restrict__ offsets, int64_t n) {
+  __shared__ long long part[1024];
+  const int t = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024, a = std::min<int64_t>(n, per * t), b = std::min<int64_t>(n, a + per);
+  long long sacc = 0;
+  for (int64_t i = a; i < b; ++i) sacc += count[i];
+  part[t] = sacc;
+  __syncthreads();
+  if (t == 0) {
+    long long run = 0;
+    for (int i = 0; i < 1024; ++i) {
+      const long long v = part[i];
+      part[i] = run;
+      run += v;
+    }
+    offsets[n] = run;
+  }
+  __syncthreads();
+  long long run = part[t];
+  for (int64_t i = a; i < b; ++i) {
+    offsets[i] = run;
+    run += count[i];
+  }
+}
+
 // ---- device self-test kernels (cross-lane reduction, 5x5 solve) ---------------------------
 __global__ void selftest_kernel(double *out) {
   const int lane = threadIdx.x;
@@ -591,6 +635,8 @@ int ensure_stage(pnec_hip_problem *p, int64_t doubles, int64_t ints) {
 // ==========================================================================================
 extern "C" {
 
+static int materialize(const pnec_hip_problem *cp);
+
 int pnec_hip_abi_version(void) { return PNEC_HIP_ABI_VERSION; }
 
 const char *pnec_hip_last_error(void) { return g_last_error.c_str(); }
@@ -691,10 +737,15 @@ int pnec_hip_problem_create(int device, int mode, int64_t n_pairs, const int64_t
 int pnec_hip_problem_destroy(pnec_hip_problem *p) {
   if (!p) return 0;
   DeviceGuard guard(p->device);
-  if (p->d_data) (void)dev_free(p->d_data);
-  if (p->d_block_offset) (void)dev_free(p->d_block_offset);
-  if (p->d_offsets) (void)dev_free(p->d_offsets);
-  if (p->d_count) (void)dev_free(p->d_count);
+  if (p->sel_view) pnec_hip_problem_destroy(p->sel_view);
+  if (p->nec_view) pnec_hip_problem_destroy(p->nec_view);
+  if (p->d_mask) (void)dev_free(p->d_mask);
+  if (p->owns_data) {
+    if (p->d_data) (void)dev_free(p->d_data);
+    if (p->d_block_offset) (void)dev_free(p->d_block_offset);
+    if (p->d_offsets) (void)dev_free(p->d_offsets);
+    if (p->d_count) (void)dev_free(p->d_count);
+  }
   if (p->d_stage) (void)dev_free(p->d_stage);
   if (p->d_stage_i) (void)dev_free(p->d_stage_i);
   if (p->d_bucket_pairs) (void)dev_free(p->d_bucket_pairs);
@@ -709,6 +760,7 @@ int pnec_hip_problem_fill(pnec_hip_problem *p, int64_t first_pair, int64_t n_pai
   if (first_pair < 0 || n_pairs < 0 || first_pair + n_pairs > p->n_pairs)
     return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "pair range out of bounds");
   if (n_pairs == 0) return 0;
+  if (int rc = materialize(p)) return rc;
   const int64_t m = p->offsets[(size_t)(first_pair + n_pairs)] - p->offsets[(size_t)first_pair];
   if (m > 0 && (!bvs1 || !bvs2)) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bvs1/bvs2 is NULL");
   if (m > 0 && p->nc >= 12 && !covs)
@@ -769,14 +821,42 @@ int pnec_hip_problem_fill(pnec_hip_problem *p, int64_t first_pair, int64_t n_pai
   return 0;
 }
 
+// Host-side sizes of a batch whose real pair sizes so far exist only on the device (a batch made by
+// InlierExtraction): wait for the producing stream, fetch the counts, rebuild offsets / totals.
+static int materialize(const pnec_hip_problem *cp) {
+  pnec_hip_problem *p = const_cast<pnec_hip_problem *>(cp);
+  if (!p || !p->lazy) return 0;
+  DeviceGuard guard(p->device);
+  PNEC_HIP_TRY(hipStreamSynchronize(p->lazy_stream));
+  if (p->n_pairs > 0)
+    PNEC_HIP_TRY(hipMemcpy(p->host_counts.data(), p->d_count, sizeof(int32_t) * p->n_pairs, hipMemcpyDeviceToHost));
+  p->n_max = 0;
+  for (int64_t i = 0; i < p->n_pairs; ++i) {
+    p->offsets[(size_t)i + 1] = p->offsets[(size_t)i] + p->host_counts[(size_t)i];
+    p->n_max = std::max(p->n_max, p->host_counts[(size_t)i]);
+  }
+  p->n_corr = p->offsets[(size_t)p->n_pairs];
+  p->lazy = false;
+  // the geometry buckets were chosen from the source's sizes (upper bounds): rebuild them from the real ones
+  p->buckets.clear();
+  if (p->d_bucket_pairs) (void)dev_free(p->d_bucket_pairs);
+  p->d_bucket_pairs = nullptr;
+  return 0;
+}
+
 int64_t pnec_hip_problem_num_pairs(const pnec_hip_problem *p) { return p ? p->n_pairs : 0; }
-int64_t pnec_hip_problem_num_correspondences(const pnec_hip_problem *p) { return p ? p->n_corr : 0; }
-int64_t pnec_hip_problem_max_correspondences(const pnec_hip_problem *p) { return p ? p->n_max : 0; }
+int64_t pnec_hip_problem_num_correspondences(const pnec_hip_problem *p) {
+  return p && materialize(p) == 0 ? p->n_corr : 0;
+}
+int64_t pnec_hip_problem_max_correspondences(const pnec_hip_problem *p) {
+  return p && materialize(p) == 0 ? p->n_max : 0;
+}
 int64_t pnec_hip_problem_payload_bytes(const pnec_hip_problem *p) {
-  return p ? p->n_corr * p->nc * (int64_t)sizeof(double) : 0;
+  return p && materialize(p) == 0 ? p->n_corr * p->nc * (int64_t)sizeof(double) : 0;
 }
 int pnec_hip_problem_offsets(const pnec_hip_problem *p, int64_t *out) {
   if (!p || !out) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (int rc = materialize(p)) return rc;
   std::memcpy(out, p->offsets.data(), sizeof(int64_t) * p->offsets.size());
   return 0;
 }
@@ -1067,6 +1147,8 @@ int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint6
   if (space != PNEC_HIP_MEM_DEVICE && space != PNEC_HIP_MEM_HOST)
     return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad memory space");
   if (p->n_pairs == 0) return 0;
+  if (space == PNEC_HIP_MEM_HOST)  // host-side per-correspondence arrays need the exact sizes
+    if (int rc = materialize(p)) return rc;
   DeviceGuard guard(p->device);
   hipStream_t stream = (hipStream_t)stream_;
   const int64_t P = p->n_pairs, M = p->n_corr;
@@ -1108,6 +1190,64 @@ int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint6
   return 0;
 }
 
+// A batch with the capacity (block layout) of `src` and no contents yet: the target of InlierExtraction.
+static int alloc_like(pnec_hip_problem *src, hipStream_t stream, pnec_hip_problem **out) {
+  *out = nullptr;
+  pnec_hip_problem *d = new (std::nothrow) pnec_hip_problem();
+  if (!d) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "out of host memory");
+  d->device = src->device;
+  d->mode = src->mode;
+  d->nc = src->nc;
+  d->n_pairs = src->n_pairs;
+  d->n_corr = src->n_corr;          // upper bounds until materialize()
+  d->n_max = src->n_max;
+  d->host_counts = src->host_counts;
+  d->offsets = src->offsets;
+  d->data_doubles = src->data_doubles;
+  const int64_t P = std::max<int64_t>(src->n_pairs, 1);
+  hipError_t e = dev_alloc(&d->d_data, sizeof(double) * std::max<int64_t>(src->data_doubles, 1));
+  if (e == hipSuccess) e = dev_alloc(&d->d_block_offset, sizeof(int64_t) * P);
+  if (e == hipSuccess) e = dev_alloc(&d->d_offsets, sizeof(int64_t) * (P + 1));
+  if (e == hipSuccess) e = dev_alloc(&d->d_count, sizeof(int32_t) * P);
+  if (e == hipSuccess && src->n_pairs > 0)
+    e = hipMemcpyAsync(d->d_block_offset, src->d_block_offset, sizeof(int64_t) * src->n_pairs,
+                       hipMemcpyDeviceToDevice, stream);
+  if (e != hipSuccess) {
+    pnec_hip_problem_destroy(d);
+    return fail_hip(e, "InlierExtraction target allocation");
+  }
+  *out = d;
+  return 0;
+}
+
+// PNEC::InlierExtraction on the device, nothing read back: counts by ballot, offsets by a scan, the kept
+// correspondences compacted pair by pair into dst (which has src's capacity).  All on `stream`.
+static int select_into(pnec_hip_problem *src, const uint8_t *d_mask, hipStream_t stream, pnec_hip_problem *dst) {
+  const int64_t P = src->n_pairs;
+  if (P > 0) {
+    hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)P), dim3(kWave), 0, stream, d_mask, src->d_offsets,
+                       src->d_count, dst->d_count);
+    hipLaunchKernelGGL(offsets_scan_kernel, dim3(1), dim3(1024), 0, stream, dst->d_count, dst->d_offsets, P);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+      e = launch_select(src->nc, src->d_data, src->d_block_offset, src->d_offsets, src->d_count, d_mask, dst->d_data,
+                        dst->d_block_offset, dst->d_count, P, stream);
+    if (e != hipSuccess) return fail_hip(e, "select_kernel");
+  }
+  if (!dst->lazy) {  // it had been given exact sizes: back to the source's bounds, buckets included
+    dst->buckets.clear();
+    if (dst->d_bucket_pairs) (void)dev_free(dst->d_bucket_pairs);
+    dst->d_bucket_pairs = nullptr;
+    dst->offsets = src->offsets;
+  }
+  dst->lazy = true;
+  dst->lazy_stream = stream;
+  dst->n_corr = src->n_corr;
+  dst->n_max = src->n_max;
+  dst->host_counts = src->host_counts;
+  return 0;
+}
+
 int pnec_hip_problem_select(pnec_hip_problem *src, const uint8_t *mask, int space, void *stream_,
                             pnec_hip_problem **out) {
   if (!src || !mask || !out) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -1116,47 +1256,33 @@ int pnec_hip_problem_select(pnec_hip_problem *src, const uint8_t *mask, int spac
   *out = nullptr;
   DeviceGuard guard(src->device);
   hipStream_t stream = (hipStream_t)stream_;
-  const int64_t P = src->n_pairs, M = src->n_corr;
-  const uint8_t *d_mask = mask;
-  uint8_t *tmp_mask = nullptr;
-  int32_t *d_cnt = nullptr;
-  std::vector<int32_t> counts((size_t)P);
-  auto cleanup = [&]() {
-    if (tmp_mask) (void)dev_free(tmp_mask);
-    if (d_cnt) (void)dev_free(d_cnt);
-  };
-  if (space == PNEC_HIP_MEM_HOST && M > 0) {
-    PNEC_HIP_TRY(dev_alloc(&tmp_mask, (size_t)M));
-    hipError_t e = hipMemcpyAsync(tmp_mask, mask, (size_t)M, hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) { cleanup(); return fail_hip(e, "mask upload"); }
-    d_mask = tmp_mask;
-  }
-  if (P > 0) {
-    hipError_t e = dev_alloc(&d_cnt, sizeof(int32_t) * P);
-    if (e == hipSuccess) {
-      hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)P), dim3(kWave), 0, stream, d_mask, src->d_offsets,
-                         src->d_count, d_cnt);
-      e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_cnt, sizeof(int32_t) * P, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) { cleanup(); return fail_hip(e, "mask_count_kernel"); }
-  }
-  std::vector<int64_t> offsets((size_t)P + 1, 0);
-  for (int64_t i = 0; i < P; ++i) offsets[(size_t)i + 1] = offsets[(size_t)i] + counts[(size_t)i];
+  // a host mask is in the caller's correspondence order: its length is the source's exact total
+  if (space == PNEC_HIP_MEM_HOST)
+    if (int rc = materialize(src)) return rc;
   pnec_hip_problem *dst = nullptr;
-  if (int rc = pnec_hip_problem_create(src->device, src->mode, P, offsets.data(), &dst)) { cleanup(); return rc; }
-  if (P > 0) {
-    hipError_t e = launch_select(src->nc, src->d_data, src->d_block_offset, src->d_offsets, src->d_count, d_mask,
-                                 dst->d_data, dst->d_block_offset, dst->d_count, P, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (int rc = alloc_like(src, stream, &dst)) return rc;
+  const uint8_t *d_mask = mask;
+  if (space == PNEC_HIP_MEM_HOST) {
+    hipError_t e = dev_alloc(&dst->d_mask, (size_t)std::max<int64_t>(src->n_corr, 1));
+    if (e == hipSuccess && src->n_corr > 0)
+      e = hipMemcpyAsync(dst->d_mask, mask, (size_t)src->n_corr, hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) {
-      cleanup();
+      pnec_hip_problem_destroy(dst);
+      return fail_hip(e, "mask upload");
+    }
+    d_mask = dst->d_mask;
+  }
+  if (int rc = select_into(src, d_mask, stream, dst)) {
+    pnec_hip_problem_destroy(dst);
+    return rc;
+  }
+  if (space == PNEC_HIP_MEM_HOST) {  // HOST space calls block (the caller may reuse `mask` right away)
+    const hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
       pnec_hip_problem_destroy(dst);
       return fail_hip(e, "select_kernel");
     }
   }
-  cleanup();
   *out = dst;
   return 0;
 }
@@ -1246,6 +1372,9 @@ int pnec_hip_selftest(int device) {
     }
   return 0;
 }
+
+#include "pnec_pipeline.inl"
+#include "pnec_stream.inl"
 
 int64_t pnec_hip_release_cache(int device) {
   std::lock_guard<std::mutex> lock(g_mem_mutex);

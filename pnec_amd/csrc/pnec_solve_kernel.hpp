@@ -43,6 +43,10 @@
 #define PNEC_FOR_EACH_GEOMETRY(X) \
   X(1, 1, 0) X(2, 1, 0) X(4, 1, 0) X(4, 2, 0) X(4, 4, 0) X(4, 8, 0) \
   X(8, 1, 3) X(8, 2, 3) X(8, 4, 3) X(8, 8, 3) X(8, 1, 0) X(1, 8, 0)
+// the geometries the auto-tuner's ladders can pick (pnec_capi.hip geometry_ladder): what the AoS-source
+// kernels of the streaming handle are built for
+#define PNEC_FOR_EACH_AOS_GEOMETRY(X) \
+  X(1, 1, 0) X(2, 1, 0) X(4, 1, 0) X(4, 4, 0) X(4, 8, 0) X(8, 1, 3) X(8, 2, 3) X(8, 4, 3) X(8, 8, 3) X(8, 1, 0)
 constexpr int kStreamWaves = 8;  // block shape of the streaming (non-resident) fallback
 
 namespace pnec_hip {
@@ -65,6 +69,14 @@ struct SolveArgs {
   int64_t n_solves;
   int32_t n_hyp;
   int32_t pad_;
+  // SRC_AOS (streaming handle, pnec_stream.hip): the pairs are read straight from the caller's arrays in
+  // the REFERENCE layout (bvs 3 doubles, covs 9 doubles column-major per correspondence) -- pinned host
+  // memory mapped into the device, so one launch ingests, solves and reports without a staging copy
+  const double *aos_bvs1, *aos_bvs2, *aos_covs, *aos_covs_host;
+  const int64_t *aos_offsets;            // [n_pairs + 1] correspondence offsets of the submit
+  unsigned long long *done_counter;      // device: blocks of this submit that have written their result
+  unsigned long long *host_flag;         // pinned host: receives flag_value when all n_blocks_total are done
+  unsigned long long flag_value, n_blocks_total;
   double reg;
   double inv_max_radius;  // 1 / opt.max_trust_region_radius, 1 / opt.min_trust_region_radius: the loop
   double inv_min_radius;  // carries the inverse radius (lm_advance); filled by the host (finish_args)
@@ -175,6 +187,61 @@ __device__ __forceinline__ unsigned load_resident(const double *__restrict__ bas
     }
   }
   return vmask;
+}
+
+// The same slots filled from the reference's AoS arrays (what pack_kernel + load_resident produce,
+// value for value: the symmetric part of the column-major 3x3, zeros in the padding).
+template <int NC, int CPL, int REGK>
+__device__ __forceinline__ void load_resident_aos(const double *__restrict__ b1, const double *__restrict__ b2,
+                                                  const double *__restrict__ cv, const double *__restrict__ ch,
+                                                  int n, int first_corr, int lane, double (&d)[REGK][NC],
+                                                  double *lds /* [CPL-REGK][NC][64] */) {
+  auto put = [&](auto kc, int c, double v) {
+    constexpr int k = decltype(kc)::value;
+    if constexpr (k < REGK) d[k][c] = v;
+    else lds[((k - REGK) * NC + c) * kWave + lane] = v;
+  };
+  auto load_slot = [&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    const int idx = first_corr + (CPL == 1 ? lane : 2 * kWave * (k / 2) + 2 * lane + (k & 1));
+    const bool in = idx < n;
+    const int64_t j = in ? idx : 0;  // a valid address for the masked lanes
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      put(kc, c, in ? b1[3 * j + c] : 0.0);
+      put(kc, 3 + c, in ? b2[3 * j + c] : 0.0);
+    }
+    if constexpr (NC >= 12) {
+      const double *C = cv + 9 * j;
+      put(kc, 6, in ? C[0] : 0.0);
+      put(kc, 7, in ? 0.5 * (C[1] + C[3]) : 0.0);
+      put(kc, 8, in ? 0.5 * (C[2] + C[6]) : 0.0);
+      put(kc, 9, in ? C[4] : 0.0);
+      put(kc, 10, in ? 0.5 * (C[5] + C[7]) : 0.0);
+      put(kc, 11, in ? C[8] : 0.0);
+    }
+    if constexpr (NC >= 18) {
+      const double *C = ch + 9 * j;
+      put(kc, 12, in ? C[0] : 0.0);
+      put(kc, 13, in ? 0.5 * (C[1] + C[3]) : 0.0);
+      put(kc, 14, in ? 0.5 * (C[2] + C[6]) : 0.0);
+      put(kc, 15, in ? C[4] : 0.0);
+      put(kc, 16, in ? 0.5 * (C[5] + C[7]) : 0.0);
+      put(kc, 17, in ? C[8] : 0.0);
+    }
+  };
+  load_slot(std::integral_constant<int, 0>{});
+  if constexpr (CPL >= 2) load_slot(std::integral_constant<int, 1>{});
+  if constexpr (CPL >= 4) {
+    load_slot(std::integral_constant<int, 2>{});
+    load_slot(std::integral_constant<int, 3>{});
+  }
+  if constexpr (CPL >= 8) {
+    load_slot(std::integral_constant<int, 4>{});
+    load_slot(std::integral_constant<int, 5>{});
+    load_slot(std::integral_constant<int, 6>{});
+    load_slot(std::integral_constant<int, 7>{});
+  }
 }
 
 // One fused pass of a wavefront over its resident correspondences: acc = this lane's partial
@@ -565,9 +632,12 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
 #define PNEC_MARK(name)
 #endif
 
-template <int MODE, int CPL, int WPP, int LDSK, bool RESIDENT>
+constexpr int SRC_PLANES = 0;  // the batch's SoA planes in HBM (pnec_hip_problem)
+constexpr int SRC_AOS = 1;     // the caller's arrays in the reference layout (streaming handle)
+template <int MODE, int CPL, int WPP, int LDSK, bool RESIDENT, int SRC = SRC_PLANES>
 __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void lm_solve_kernel(
     const SolveArgs a) {
+  static_assert(SRC == SRC_PLANES || RESIDENT, "the AoS source is only built for the on-chip-resident geometries");
   constexpr int NC = num_components(MODE);
   constexpr int REGK = RESIDENT ? CPL - LDSK : 1;  // correspondences per lane kept in registers
   const int lane = threadIdx.x & (kWave - 1);
@@ -575,8 +645,16 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   const int64_t slot = xcd_contiguous_index(blockIdx.x, a.n_solves);
   const int64_t pair = a.pair_index ? (int64_t)a.pair_index[slot / a.n_hyp] : slot / a.n_hyp;
   const int64_t s = pair * a.n_hyp + slot % a.n_hyp;
-  const double *__restrict__ base = a.data + a.block_offset[pair];
-  const int n = a.count[pair];
+  const double *__restrict__ base = nullptr;
+  int n;
+  int64_t aos0 = 0;
+  if constexpr (SRC == SRC_AOS) {
+    aos0 = a.aos_offsets[pair];
+    n = (int)(a.aos_offsets[pair + 1] - aos0);
+  } else {
+    base = a.data + a.block_offset[pair];
+    n = a.count[pair];
+  }
   const int stride = (n + kWave - 1) & ~(kWave - 1);
   const pnec_hip_options &o = a.opt;
   const double reg = a.reg;
@@ -598,7 +676,11 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   // ---- load this lane's correspondences once (coalesced: consecutive lanes, consecutive doubles)
   double d[REGK][NC];
   unsigned vmask = 0;
-  if constexpr (RESIDENT)
+  if constexpr (RESIDENT && SRC == SRC_AOS)
+    load_resident_aos<NC, CPL, REGK>(a.aos_bvs1 + 3 * aos0, a.aos_bvs2 + 3 * aos0, NC >= 12 ? a.aos_covs + 9 * aos0 : nullptr,
+                                     NC >= 18 ? a.aos_covs_host + 9 * aos0 : nullptr, n, wave * CPL * kWave, lane, d,
+                                     &ldata[LDSK > 0 ? wave : 0][0][0][0]);
+  else if constexpr (RESIDENT)
     vmask = load_resident<NC, CPL, REGK>(base, n, stride, wave * CPL * kWave, lane, d, &ldata[LDSK > 0 ? wave : 0][0][0][0]);
   // how many of this wavefront's CPL slots hold any correspondence of the pair (wave-uniform): slot k
   // starts at correspondence first + 128 (k / 2) + (k & 1) (load_resident), lane 0 being the first
@@ -745,6 +827,15 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   PNEC_MARK("result");
   if (threadIdx.x == 0) {
     write_result(a, s, slab, ist[kIIter], term);
+    if constexpr (SRC == SRC_AOS) {
+      // results live in pinned host memory: make them visible system-wide, then count this block in;
+      // the block that completes the submit raises the host's flag (the host polls it, no stream sync)
+      __threadfence_system();
+      const unsigned long long done = atomicAdd(a.done_counter, 1ull) + 1ull;
+      if (done == a.n_blocks_total) {
+        __hip_atomic_store(a.host_flag, a.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
     if (a.trace) {
       unsigned hw = 0;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));

@@ -1,0 +1,211 @@
+"""The per-frame call pattern on the GPU: the streaming handle (pnec_hip_stream_*) and the device-resident
+PNEC::Solve chain (pnec_hip_solve_pipeline).  Reference call sites: Frame2Frame::PNECAlign -> PNEC::Solve
+once per frame (src/rel_pose_estimation/frame2frame.cc:122-141), PNECCeres::Optimize once per pybind call
+(python/pypnec.cpp:55-65)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from pnec_amd import Batch, capi
+from pnec_amd import simulation as sim
+from pnec_amd.streaming import Stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _quat_to_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def test_streamed_kitti_like_sequence_is_bit_identical_to_the_batched_call():
+    """BASELINE config 3: ~4.5k consecutive frame pairs streamed on one GPU, ONE PAIR PER CALL as the
+    odometry does, against the same pairs solved as one ragged batch: every output bit for bit."""
+    P = 4541
+    offsets, f1, f2, c2, R_gt, t_gt, q0, t0 = sim.generate_kitti_like(P, mean_corr=500, seed=3)
+    f1, f2, c2, q0, t0 = (x.numpy() for x in (f1, f2, c2, q0, t0))
+    with Batch(capi.MODE_TARGET, offsets) as b:
+        b.fill(f1, f2, c2)
+        ref = b.solve(q0, t0)
+    got = {k: [] for k in ("q", "t", "cost", "iterations", "status")}
+    with Stream(max_corr=int(np.diff(offsets).max()), slots=8) as st:
+        tickets = []
+        for p in range(P):                       # a window of 8 frames in flight
+            a, e = offsets[p], offsets[p + 1]
+            tickets.append(st.submit(capi.MODE_TARGET, f1[a:e], f2[a:e], c2[a:e], None, q0[p], t0[p]))
+            if len(tickets) == 8:
+                r = st.wait(tickets.pop(0))
+                for k in got:
+                    got[k].append(getattr(r, k)[0])
+        while tickets:
+            r = st.wait(tickets.pop(0))
+            for k in got:
+                got[k].append(getattr(r, k)[0])
+    np.testing.assert_array_equal(np.stack(got["q"]), ref.q)
+    np.testing.assert_array_equal(np.stack(got["t"]), ref.t)
+    np.testing.assert_array_equal(np.array(got["cost"]), ref.cost)
+    np.testing.assert_array_equal(np.array(got["iterations"]), ref.iterations)
+    np.testing.assert_array_equal(np.array(got["status"]), ref.status)
+
+
+@pytest.mark.parametrize("mode", [capi.MODE_NEC, capi.MODE_TARGET, capi.MODE_HOST, capi.MODE_SYM])
+def test_stream_families_sizes_and_multi_pair_submits_match_the_batch_path(mode, oracle):
+    """every residual family, sizes across the geometry ladder (incl. empty, > 4096 = the staged route),
+    several pairs per submit, poll before wait, options honoured -- same bits as the batch path, and the
+    oracle within the north-star tolerance"""
+    rng = np.random.default_rng(5)
+    sizes = [0, 1, 9, 64, 65, 100, 256, 300, 512, 513, 1024, 2048, 2049]
+    if mode != capi.MODE_SYM:
+        sizes += [4096]
+    g = sim.generate(len(sizes), max(sizes), seed=77)
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    f1 = np.concatenate([g.bvs1[p].numpy()[:n] for p, n in enumerate(sizes)])
+    f2 = np.concatenate([g.bvs2[p].numpy()[:n] for p, n in enumerate(sizes)])
+    S2 = np.concatenate([g.covs2[p].numpy()[:n] for p, n in enumerate(sizes)])
+    c2 = None if mode == capi.MODE_NEC else S2
+    c1 = np.roll(S2, 1, axis=0) * 0.8 if mode == capi.MODE_SYM else None
+    q0, t0 = g.init_q.numpy(), g.init_t.numpy()
+    opts = capi.default_options(max_num_iterations=7, check_convergence=int(rng.integers(0, 2)))
+    with Batch(mode, offsets) as b:
+        b.fill(f1, f2, c2, c1)
+        ref = b.solve(q0, t0, reg=1e-13, options=opts)
+    with Stream(max_corr=int(offsets[-1]), max_pairs=len(sizes), slots=3) as st:
+        # (a) one pair per submit
+        for p, n in enumerate(sizes):
+            a, e = offsets[p], offsets[p + 1]
+            tk = st.submit(mode, f1[a:e], f2[a:e], None if c2 is None else c2[a:e], None if c1 is None else c1[a:e],
+                           q0[p], t0[p], 1e-13, opts)
+            r = st.wait(tk)
+            np.testing.assert_array_equal(r.q[0], ref.q[p])
+            np.testing.assert_array_equal(r.t[0], ref.t[p])
+            assert r.cost[0] == ref.cost[p] or (np.isnan(r.cost[0]) and np.isnan(ref.cost[p]))
+            assert r.iterations[0] == ref.iterations[p] and r.status[0] == ref.status[p]
+        # (b) all pairs in ONE submit (one launch per geometry in use), polled
+        tk = st.submit(mode, f1, f2, c2, c1, q0, t0, 1e-13, opts, offsets=offsets)
+        while not st.poll(tk):
+            pass
+        r = st.wait(tk)
+        np.testing.assert_array_equal(r.q, ref.q)
+        np.testing.assert_array_equal(r.iterations, ref.iterations)
+        # (c) a pair beyond the register-resident geometries takes the staged route
+        big = 5000 if mode != capi.MODE_SYM else 2100
+        gb = sim.generate(1, big, seed=78)
+        Sb = gb.covs2[0].numpy()
+        cb2 = None if mode == capi.MODE_NEC else Sb
+        cb1 = np.roll(Sb, 1, axis=0) * 0.8 if mode == capi.MODE_SYM else None
+        with Stream(max_corr=big, slots=2) as st2:
+            rb = st2.solve(mode, gb.bvs1[0].numpy(), gb.bvs2[0].numpy(), cb2, cb1, gb.init_q[0].numpy(), gb.init_t[0].numpy())
+        s = oracle.solve(mode, gb.bvs1[0].numpy(), gb.bvs2[0].numpy(), cb2, cb1, 1e-13 if mode != capi.MODE_NEC else 0.0,
+                         gb.init_q[0].numpy(), gb.init_t[0].numpy(), oracle.default_options())
+        assert math.radians(oracle.rotational_difference_deg(_quat_to_R(rb.q[0]), s.R)) <= 1e-6
+        assert rb.iterations[0] == s.iterations
+    # the oracle on a few of the streamed pairs
+    oo = oracle.default_options(max_num_iterations=7, check_convergence=opts.check_convergence)
+    for p in (4, 8, 10):
+        a, e = offsets[p], offsets[p + 1]
+        s = oracle.solve(mode, f1[a:e], f2[a:e], None if c2 is None else c2[a:e], None if c1 is None else c1[a:e],
+                         1e-13, q0[p], t0[p], oo)
+        assert math.radians(oracle.rotational_difference_deg(_quat_to_R(ref.q[p]), s.R)) <= 1e-6
+
+
+def test_stream_argument_errors_and_ticket_rules():
+    g = sim.generate(1, 32, seed=1)
+    f1, f2, c2, q, t = (x[0].numpy() for x in (g.bvs1, g.bvs2, g.covs2, g.init_q, g.init_t))
+    with Stream(max_corr=16, slots=2) as st:
+        with pytest.raises(capi.PnecHipError, match="more correspondences"):
+            st.submit(capi.MODE_TARGET, f1, f2, c2, None, q, t)
+        with pytest.raises(capi.PnecHipError):           # TARGET needs covariances
+            st.submit(capi.MODE_TARGET, f1[:8], f2[:8], None, None, q, t)
+        tk = st.submit(capi.MODE_NEC, f1[:16], f2[:16], None, None, q, t)
+        r = st.wait(tk)
+        assert np.isfinite(r.q).all()
+        st._pairs[tk] = 1
+        with pytest.raises(capi.PnecHipError, match="ticket"):   # a ticket is collected once
+            st.wait(tk)
+    with pytest.raises(capi.PnecHipError):
+        Stream(max_corr=0)
+
+
+def test_pipeline_equals_the_stage_by_stage_chain_and_never_needs_host_sizes(oracle):
+    """pnec_hip_solve_pipeline = RANSAC eigensolver -> InlierExtraction -> weighted eigensolver -> refinement
+    chained on the device: same bits as the stage-by-stage calls, in both memory spaces, for every Options
+    branch PNEC::Solve has; the inlier batch's sizes are only fetched when asked for"""
+    sizes = [300, 512, 128, 8, 40, 0, 700]
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    B = len(sizes)
+    g = sim.generate(B, 700, seed=95)
+    rng = np.random.default_rng(2)
+    f1 = np.concatenate([g.bvs1[p].numpy()[:n] for p, n in enumerate(sizes)])
+    f2 = np.concatenate([g.bvs2[p].numpy()[:n] for p, n in enumerate(sizes)])
+    c2 = np.concatenate([g.covs2[p].numpy()[:n] for p, n in enumerate(sizes)])
+    for p in range(B):
+        sl = np.arange(offsets[p], offsets[p + 1])
+        if len(sl) >= 20:
+            bad = rng.choice(sl, len(sl) // 5, replace=False)
+            v = rng.normal(size=(len(bad), 3))
+            f2[bad] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    q0, t0 = g.init_q.numpy(), g.init_t.numpy()
+    with Batch(capi.MODE_TARGET, offsets) as b:
+        b.fill(f1, f2, c2)
+        # stage by stage (host space)
+        qr, tr, mask, cnt, its = b.ransac_eigensolver(q0, seed=1)
+        sel = b.select(mask)
+        qw, tw = sel.weighted_eigensolver(qr, tr, 1e-13, 10)
+        want = sel.solve(qw, tw)
+        np.testing.assert_array_equal(np.diff(sel.offsets), cnt)      # sizes fetched on demand
+        assert sel.num_correspondences == int(mask.sum())
+        # the chain, host space
+        q, t, m2, c2n = b.solve_pipeline(q0, t0, want_inliers=True)
+        np.testing.assert_array_equal(m2, mask)
+        np.testing.assert_array_equal(c2n, cnt)
+        np.testing.assert_array_equal(q, want.q)
+        np.testing.assert_array_equal(t, want.t)
+        # device space (asynchronous), twice on the same batch (cached inlier batch re-used)
+        for _ in range(2):
+            qd, td, md, cd = b.solve_pipeline(torch.from_numpy(q0).cuda(), torch.from_numpy(t0).cuda(), want_inliers=True)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(qd.cpu().numpy(), want.q)
+            np.testing.assert_array_equal(md.cpu().numpy(), mask)
+        # Options branches
+        o = capi.default_pipeline_options(use_ransac=0)
+        qn, tn = b.nec_eigensolver(q0)
+        qw2, tw2 = b.weighted_eigensolver(qn, tn, 1e-13, 10)
+        w2 = b.solve(qw2, tw2)
+        q, t = b.solve_pipeline(q0, t0, o)
+        np.testing.assert_array_equal(q, w2.q)
+        o = capi.default_pipeline_options(use_ceres=0)
+        q, t = b.solve_pipeline(q0, t0, o)
+        np.testing.assert_array_equal(q, qw)
+        np.testing.assert_array_equal(t, tw)
+        o = capi.default_pipeline_options(weighted_iterations=1)
+        q, t = b.solve_pipeline(q0, t0, o)
+        np.testing.assert_array_equal(q, sel.solve(qr, tr).q)
+        o = capi.default_pipeline_options(weighted_iterations=0, use_ransac=0)
+        q, t = b.solve_pipeline(q0, t0, o)
+        np.testing.assert_array_equal(q, b.solve(q0, t0).q)
+        o = capi.default_pipeline_options(use_nec=1)
+        q, t = b.solve_pipeline(q0, t0, o)
+        with Batch(capi.MODE_NEC, sel.offsets) as nb:           # NECCeresSolver on the inlier bearings
+            keep = mask.astype(bool)
+            nb.fill(f1[keep], f2[keep])
+            wn = nb.solve(qr, tr, reg=0.0)
+        for p in range(B):
+            assert math.radians(oracle.rotational_difference_deg(_quat_to_R(q[p]), _quat_to_R(wn.q[p]))) <= 1e-9
+        o = capi.default_pipeline_options(use_nec=1, use_ceres=0)
+        q, t = b.solve_pipeline(q0, t0, o)
+        np.testing.assert_array_equal(q, qr)
+        with pytest.raises(capi.PnecHipError):
+            b.solve_pipeline(q0, t0, capi.default_pipeline_options(ransac_sample_size=17))
+        sel.close()
+    # against the oracle's chain on the pairs RANSAC can work with
+    for p in (0, 1, 2, 6):
+        sl = slice(offsets[p], offsets[p + 1])
+        Ro, to, mo, _ = oracle.ransac_eigensolver(f1[sl], f2[sl], g.init_R[p].numpy(), seed=1, pair_id=p)
+        Rw, tw_ = oracle.weighted_eigensolver(f1[sl][mo], f2[sl][mo], c2[sl][mo], Ro, to, 1e-13, 10)
+        s = oracle.solve(oracle.MODE_TARGET, f1[sl][mo], f2[sl][mo], c2[sl][mo], None, 1e-13, oracle.quat_from_rot(Rw),
+                         tw_, oracle.default_options())
+        assert math.radians(oracle.rotational_difference_deg(_quat_to_R(want.q[p]), s.R)) <= 1e-6

@@ -7,7 +7,7 @@ NAME=$1; FLAGS=$2
 cd "$(dirname "$0")/../pnec_amd/csrc"
 OUT=build/var_$NAME
 mkdir -p $OUT
-for f in pnec_capi pnec_frontend pnec_solve_nec pnec_solve_target pnec_solve_host pnec_solve_sym pnec_stream; do
+for f in pnec_capi pnec_frontend pnec_solve_nec pnec_solve_target pnec_solve_host pnec_solve_sym pnec_stream_nec pnec_stream_target pnec_stream_host pnec_stream_sym; do
   [ -f $f.hip ] || continue
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Wall -Wno-unused-function \
         -mllvm -amdgpu-sched-strategy=max-ilp $FLAGS -c $f.hip -o $OUT/$f.o &
