@@ -124,6 +124,25 @@ int pnec_hip_problem_fill(pnec_hip_problem *p, int64_t first_pair, int64_t n_pai
                           const double *bvs1, const double *bvs2, const double *covs,
                           const double *covs_host, int space, void *stream);
 
+/* Fused keypoint ingest: KeyPoint::Unproject (src/frames/keypoints.cc:49-62) for the keypoints of both
+ * frames -- bearing = normalised K^-1 (u, v, 1); bearing covariance = UnscentedTransform(mu, 2x2 image
+ * covariance, K^-1, kappa, Pinhole) (src/common/common.cc:460-525) -- written straight into the batch's
+ * SoA planes: 56 B per correspondence cross the bus instead of 120 B, and no AoS 3x3 covariance is ever
+ * stored.  Same bits as pnec_hip_unscented_transform followed by pnec_hip_problem_fill.
+ *   pts1, pts2 [M,2]   pixel coordinates (KeyPoint::point_) of frame 1 / frame 2
+ *   cov2 [M,3]         frame-2 image covariance (xx, xy, yy) (KeyPoint::img_covariance_); NULL for NEC batches
+ *   cov1 [M,3]         frame-1 image covariance, SYM batches only (else NULL)
+ *   K_inv [9] column-major, kappa (1.0 in the reference), camera_model must be 1 (Pinhole)
+ * M = correspondences of pairs [first_pair, first_pair + n_pairs), pointing at the first of them. */
+int pnec_hip_problem_fill_keypoints(pnec_hip_problem *p, int64_t first_pair, int64_t n_pairs, const double *pts1,
+                                    const double *pts2, const double *cov2, const double *cov1, const double *K_inv,
+                                    double kappa, int camera_model, int space, void *stream);
+
+/* The batch's SoA planes as stored in HBM (pair blocks of round_up(N_p, 64)-double planes; the layout in
+ * the header of pnec_capi.hip / DESIGN.md): size in doubles, and a copy out (tests, debugging). */
+int64_t pnec_hip_problem_payload_doubles(const pnec_hip_problem *p);
+int pnec_hip_problem_export_payload(const pnec_hip_problem *p, double *out, int space, void *stream);
+
 int64_t pnec_hip_problem_num_pairs(const pnec_hip_problem *p);
 int64_t pnec_hip_problem_num_correspondences(const pnec_hip_problem *p);
 int64_t pnec_hip_problem_max_correspondences(const pnec_hip_problem *p);

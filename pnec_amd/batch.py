@@ -189,6 +189,58 @@ class Batch:
             capi.MEM_DEVICE if on_device else capi.MEM_HOST, stream))
         return self
 
+    def fill_keypoints(self, pts1, pts2, cov2=None, cov1=None, K_inv=None, kappa: float = 1.0,
+                       first_pair: int = 0, n_pairs: int | None = None):
+        """Fused ingest from keypoints (KeyPoint::Unproject, keypoints.cc:49-62): pixel positions [M,2] of
+        both frames + image-plane covariances [M,2,2] (or [M,3] = xx, xy, yy) -> bearings and bearing
+        covariances computed on the device straight into the SoA planes.  numpy -> HOST space,
+        torch.cuda -> DEVICE space."""
+        if n_pairs is None:
+            n_pairs = self.n_pairs - first_pair
+        m = int(self.offsets[first_pair + n_pairs] - self.offsets[first_pair])
+        on_device = _is_torch(pts1)
+        xp = __import__("torch") if on_device else np
+
+        def c3(a):
+            if a is None:
+                return None
+            if a.ndim == 3:  # [M,2,2] -> (xx, xy, yy)
+                a = xp.stack([a[:, 0, 0], a[:, 1, 0], a[:, 1, 1]], -1)
+            return a
+        K = np.eye(3) if K_inv is None else K_inv
+        arrays = [(pts1, 2), (pts2, 2), (c3(cov2), 3), (c3(cov1), 3)]
+        ptrs, keep = [], []
+        for a, width in arrays:
+            if a is None:
+                ptrs.append(None)
+                continue
+            if on_device:
+                a = self._dev_tensor(a, "keypoint array")
+                ptrs.append(a.data_ptr())
+            else:
+                a = np.ascontiguousarray(a, dtype=np.float64)
+                ptrs.append(a.ctypes.data)
+            if int(np.prod(a.shape)) != m * width:
+                raise ValueError(f"expected {m}x{width} values, got {tuple(a.shape)}")
+            keep.append(a)
+        if on_device:
+            import torch
+            Kd = torch.as_tensor(np.asarray(K.cpu() if _is_torch(K) else K, dtype=np.float64).T.copy().reshape(9),
+                                 device=f"cuda:{self.device}")
+            kp, stream, space = Kd.data_ptr(), torch.cuda.current_stream(self.device).cuda_stream, capi.MEM_DEVICE
+        else:
+            Kd = np.ascontiguousarray(np.asarray(K, dtype=np.float64).T.reshape(9))
+            kp, stream, space = Kd.ctypes.data, None, capi.MEM_HOST
+        capi.check(self._lib.pnec_hip_problem_fill_keypoints(self._h, first_pair, n_pairs, ptrs[0], ptrs[1], ptrs[2],
+                                                             ptrs[3], kp, float(kappa), 1, space, stream))
+        return self
+
+    def export_payload(self) -> np.ndarray:
+        """The SoA planes as they sit in HBM (float64 [payload_doubles]); for tests."""
+        out = np.empty(self._lib.pnec_hip_problem_payload_doubles(self._h))
+        capi.check(self._lib.pnec_hip_problem_export_payload(self._h, out.ctypes.data, capi.MEM_HOST, None))
+        return out
+
     # -- solve ------------------------------------------------------------------------------
     def solve(self, init_q, init_t=None, reg: float = 1e-13,
               options: capi.Options | None = None, hyp_t=None, n_hyp: int = 1,

@@ -35,6 +35,9 @@ SYMBOLS = [
     "pnec_hip_problem_create",
     "pnec_hip_problem_destroy",
     "pnec_hip_problem_fill",
+    "pnec_hip_problem_fill_keypoints",
+    "pnec_hip_problem_payload_doubles",
+    "pnec_hip_problem_export_payload",
     "pnec_hip_problem_num_pairs",
     "pnec_hip_problem_num_correspondences",
     "pnec_hip_problem_max_correspondences",
@@ -137,7 +140,10 @@ def lib() -> C.CDLL:
     L.pnec_hip_problem_create.argtypes = [C.c_int, C.c_int, C.c_int64, _vp, C.POINTER(_vp)]
     L.pnec_hip_problem_destroy.argtypes = [_vp]
     L.pnec_hip_problem_fill.argtypes = [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, C.c_int, _vp]
-    for name in ("num_pairs", "num_correspondences", "max_correspondences", "payload_bytes"):
+    L.pnec_hip_problem_fill_keypoints.argtypes = [_vp, C.c_int64, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.c_double,
+                                                  C.c_int, C.c_int, _vp]
+    L.pnec_hip_problem_export_payload.argtypes = [_vp, _vp, C.c_int, _vp]
+    for name in ("num_pairs", "num_correspondences", "max_correspondences", "payload_bytes", "payload_doubles"):
         f = getattr(L, "pnec_hip_problem_" + name)
         f.argtypes = [_vp]
         f.restype = C.c_int64

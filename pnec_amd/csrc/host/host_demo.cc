@@ -59,6 +59,37 @@ int main(int argc, char **argv) {
                 n, iterations, reps, us[us.size() / 2], us[us.size() / 10], us[us.size() * 9 / 10], us[0], sink / reps);
     return 0;
   }
+  if (argc > 2 && std::strcmp(argv[2], "stream") == 0) {
+    // sustained per-frame rate through the C ABI's streaming handle with `window` submits in flight
+    const int window = argc > 3 ? std::atoi(argv[3]) : 4, reps = argc > 4 ? std::atoi(argv[4]) : 20000;
+    pnec_hip_stream *st = nullptr;
+    if (pnec_hip_stream_create(0, n, 1, window, nullptr, &st) != 0) { std::printf("%s\n", pnec_hip_last_error()); return 1; }
+    const int64_t offsets[2] = {0, n};
+    const pnec::Quaterniond q0 = pnec::Quaterniond(0.975, 0.1, -0.14, 0.115).normalized();
+    const pnec::Vector3d t0 = pnec::Vector3d(0.28, -0.22, 0.92).normalized();
+    std::vector<int64_t> tickets;
+    double q[4], t[3], sink = 0.0;
+    auto tic = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps + 200; ++r) {
+      if (r == 200) tic = std::chrono::steady_clock::now();
+      int64_t tk = 0;
+      if (pnec_hip_stream_submit(st, PNEC_HIP_MODE_TARGET, 1, offsets, b1[0].data(), b2[0].data(), covs[0].data(), nullptr,
+                                 q0.coeffs(), t0.data(), 1.0e-13, nullptr, &tk) != 0) { std::printf("%s\n", pnec_hip_last_error()); return 1; }
+      tickets.push_back(tk);
+      if ((int)tickets.size() >= window) {
+        pnec_hip_stream_wait(st, tickets.front(), q, t, nullptr, nullptr, nullptr);
+        tickets.erase(tickets.begin());
+        sink += q[3];
+      }
+    }
+    for (int64_t tk : tickets) pnec_hip_stream_wait(st, tk, q, t, nullptr, nullptr, nullptr);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - tic).count();
+    std::printf("{\"call\": \"pnec_hip_stream_submit/wait, one pair per submit\", \"correspondences\": %d, \"window\": %d, "
+                "\"pairs_per_s\": %.1f, \"us_per_pair\": %.2f, \"checksum\": %.6f}\n",
+                n, window, reps / secs, secs / reps * 1e6, sink / reps);
+    pnec_hip_stream_destroy(st);
+    return 0;
+  }
   // the reference's default Options: RANSAC eigensolver -> inliers -> 9 weighted eigensolver rounds +
   // SCF -> Ceres-style refinement (run_simulation.cc:74-86 calls it exactly like this)
   pnec::rel_pose_estimation::Options options;

@@ -316,8 +316,57 @@ __global__ __launch_bounds__(kWave) void cost_function_kernel(const double *__re
 }
 
 // ---- covariance propagation: pnec::common::UnscentedTransform + Unproject -----------------
-// (src/common/common.cc:460-525; one thread per keypoint, 5 sigma points, kappa-weighted).
-// All matrices column-major like Eigen.  camera_model: 0 omnidirectional, 1 pinhole.
+// (src/common/common.cc:460-525; 5 sigma points, kappa-weighted).  All matrices column-major like
+// Eigen.  camera_model: 0 omnidirectional, 1 pinhole.  One function shared by the stand-alone kernel and
+// the fused keypoint ingest, compiled WITHOUT floating-point contraction so that both produce the same
+// bits whatever code surrounds the call (the ingest test compares them bitwise).
+//   m:  the image point (x, y, 1) [or (x, y, f) with K_inv = I];  c0, c1: the two columns added to /
+//   subtracted from it (columns of the covariance's Cholesky factor).
+__device__ __forceinline__ void unscented_core(const double (&m)[3], const double (&c0)[3], const double (&c1)[3],
+                                               const double (&K)[9], double kappa, int camera_model,
+                                               double (&bearing)[3], double (&S)[9]) {
+#pragma clang fp contract(off)
+  const double w0 = kappa / (2.0 + kappa), wi = 0.5 / (2.0 + kappa);
+  double tp[5][3], mean[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    const double sg = (p == 0) ? 0.0 : (p <= 2 ? 1.0 : -1.0);
+    const double *col = (p == 1 || p == 3) ? c0 : c1;
+    const double x = m[0] + sg * col[0], y = m[1] + sg * col[1], z = m[2] + sg * col[2];
+    double tx = x, ty = y, tz = z;
+    if (camera_model != 0) {
+      tx = K[0] * x + K[3] * y + K[6] * z;
+      ty = K[1] * x + K[4] * y + K[7] * z;
+      tz = K[2] * x + K[5] * y + K[8] * z;
+    }
+    const double nn = 1.0 / sqrt(tx * tx + ty * ty + tz * tz);
+    tp[p][0] = tx * nn; tp[p][1] = ty * nn; tp[p][2] = tz * nn;
+    const double w = (p == 0) ? w0 : wi;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mean[k] += w * tp[p][k];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) S[k] = 0.0;
+#pragma unroll
+  for (int p = 0; p < 5; ++p) {
+    const double w = (p == 0) ? w0 : wi;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) S[3 * c + r] += w * (tp[p][r] - mean[r]) * (tp[p][c] - mean[c]);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) bearing[k] = tp[0][k];  // normalised (K^-1) mu = Unproject
+}
+// the pinhole branch's sigma-point offsets: columns of the lower Cholesky factor of the image-plane
+// covariance [[a, b], [b, d]] (common.cc:488-489)
+__device__ __forceinline__ void pinhole_columns(double a, double b, double d, double (&c0)[3], double (&c1)[3]) {
+#pragma clang fp contract(off)
+  const double l00 = sqrt(a), l10 = b / l00, l11 = sqrt(d - l10 * l10);
+  c0[0] = l00; c0[1] = l10; c0[2] = 0.0;
+  c1[0] = 0.0; c1[1] = l11; c1[2] = 0.0;
+}
+
 __global__ __launch_bounds__(256) void unscented_kernel(int64_t n, const double *__restrict__ mu,
                                                         const double *__restrict__ covs,
                                                         const double *__restrict__ K_inv_, double kappa,
@@ -328,13 +377,13 @@ __global__ __launch_bounds__(256) void unscented_kernel(int64_t n, const double 
   double K[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) K[k] = K_inv_[k];
-  const double m0 = mu[3 * i], m1 = mu[3 * i + 1], m2 = mu[3 * i + 2];
+  const double m[3] = {mu[3 * i], mu[3 * i + 1], mu[3 * i + 2]};
   const double *C9 = covs + 9 * i;
   double c0[3], c1[3];  // the two columns added to / subtracted from mu
   if (camera_model == 0) {
     // rotation taking (0,0,1) to the bearing (RotationBetweenPoints, common.cc:118-124)
-    const double nm = fast_rsqrt(m0 * m0 + m1 * m1 + m2 * m2);
-    const double vx = m0 * nm, vy = m1 * nm, vz = m2 * nm;
+    const double nm = fast_rsqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+    const double vx = m[0] * nm, vy = m[1] * nm, vz = m[2] * nm;
     const double cx = -vy, cy = vx;  // (0,0,1) x v = (-vy, vx, 0)
     double R[9];                     // column-major
     const double f = 1.0 / (1.0 + vz);
@@ -358,44 +407,88 @@ __global__ __launch_bounds__(256) void unscented_kernel(int64_t n, const double 
       c1[r] = R[3 + r] * l11;
     }
   } else {
-    const double a = C9[0], b = C9[1], d = C9[4];
-    const double l00 = sqrt(a), l10 = b / l00, l11 = sqrt(d - l10 * l10);
-    c0[0] = l00; c0[1] = l10; c0[2] = 0.0;
-    c1[0] = 0.0; c1[1] = l11; c1[2] = 0.0;
+    pinhole_columns(C9[0], C9[1], C9[4], c0, c1);
   }
-  const double w0 = kappa / (2.0 + kappa), wi = 0.5 / (2.0 + kappa);
-  double tp[5][3], mean[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-  for (int p = 0; p < 5; ++p) {
-    const double sg = (p == 0) ? 0.0 : (p <= 2 ? 1.0 : -1.0);
-    const double *col = (p == 1 || p == 3) ? c0 : c1;
-    const double x = m0 + sg * col[0], y = m1 + sg * col[1], z = m2 + sg * col[2];
-    double tx = x, ty = y, tz = z;
-    if (camera_model != 0) {
-      tx = K[0] * x + K[3] * y + K[6] * z;
-      ty = K[1] * x + K[4] * y + K[7] * z;
-      tz = K[2] * x + K[5] * y + K[8] * z;
-    }
-    const double nn = 1.0 / sqrt(tx * tx + ty * ty + tz * tz);
-    tp[p][0] = tx * nn; tp[p][1] = ty * nn; tp[p][2] = tz * nn;
-    const double w = (p == 0) ? w0 : wi;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) mean[k] += w * tp[p][k];
-  }
-  double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int p = 0; p < 5; ++p) {
-    const double w = (p == 0) ? w0 : wi;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) S[3 * c + r] += w * (tp[p][r] - mean[r]) * (tp[p][c] - mean[c]);
-  }
+  double bearing[3], S[9];
+  unscented_core(m, c0, c1, K, kappa, camera_model, bearing, S);
 #pragma unroll
   for (int k = 0; k < 9; ++k) out_covs[9 * i + k] = S[k];
   if (out_bvs) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) out_bvs[3 * i + k] = tp[0][k];  // normalised (K^-1) mu = Unproject
+    for (int k = 0; k < 3; ++k) out_bvs[3 * i + k] = bearing[k];
+  }
+}
+
+// ---- fused keypoint ingest: KeyPoint::Unproject (src/frames/keypoints.cc:49-62) for both frames'
+// keypoints -- bearing = normalised K^-1 (u, v, 1), covariance = UnscentedTransform of the 2x2 image
+// covariance, kappa = 1, pinhole -- written straight into the batch's SoA planes.  Per correspondence the
+// device reads 56 B (two pixel positions, one symmetric 2x2) instead of the 120 B of ready-made bearings
+// + 3x3 covariance, and the AoS covariances never exist in HBM.  Same bits as unscented_kernel followed
+// by pack_kernel (both call unscented_core; the 3x3 it returns is exactly symmetric, so pack_kernel's
+// symmetrisation is the identity on it).
+template <int NC>
+__global__ __launch_bounds__(256) void ingest_keypoints_kernel(double *__restrict__ data,
+                                                               const int64_t *__restrict__ block_offset,
+                                                               const int64_t *__restrict__ offsets,
+                                                               const int32_t *__restrict__ count, int64_t first_pair,
+                                                               int64_t n_pairs, const double *__restrict__ pts1,
+                                                               const double *__restrict__ pts2,
+                                                               const double *__restrict__ cov2,
+                                                               const double *__restrict__ cov1,
+                                                               const double *__restrict__ K_inv_, double kappa) {
+  double K[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) K[k] = K_inv_[k];
+  const int64_t src0 = offsets[first_pair];
+  const double zero3[3] = {0.0, 0.0, 0.0};
+  for (int64_t p = first_pair + blockIdx.y; p < first_pair + n_pairs; p += gridDim.y) {
+    const int n = count[p];
+    const int stride = (n + kWave - 1) & ~(kWave - 1);
+    double *blk = data + block_offset[p];
+    const int64_t src = offsets[p] - src0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < stride; i += gridDim.x * blockDim.x) {
+      const bool in = i < n;
+      const int64_t j = in ? src + i : src;  // a valid address for the padding lanes
+      double b1[3], b2[3], S2[9], S1[9];
+      {
+        const double m[3] = {pts2[2 * j], pts2[2 * j + 1], 1.0};
+        double c0[3], c1[3];
+        if constexpr (NC >= 12) pinhole_columns(cov2[3 * j], cov2[3 * j + 1], cov2[3 * j + 2], c0, c1);
+        else { c0[0] = c0[1] = c0[2] = c1[0] = c1[1] = c1[2] = 0.0; }
+        unscented_core(m, c0, c1, K, kappa, 1, b2, S2);
+      }
+      {
+        const double m[3] = {pts1[2 * j], pts1[2 * j + 1], 1.0};
+        if constexpr (NC >= 18) {
+          double c0[3], c1[3];
+          pinhole_columns(cov1[3 * j], cov1[3 * j + 1], cov1[3 * j + 2], c0, c1);
+          unscented_core(m, c0, c1, K, kappa, 1, b1, S1);
+        } else {
+          unscented_core(m, zero3, zero3, K, kappa, 1, b1, S1);  // only the bearing is kept
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        blk[(int64_t)c * stride + i] = in ? b1[c] : 0.0;
+        blk[(int64_t)(3 + c) * stride + i] = in ? b2[c] : 0.0;
+      }
+      if constexpr (NC >= 12) {
+        blk[(int64_t)6 * stride + i] = in ? S2[0] : 0.0;
+        blk[(int64_t)7 * stride + i] = in ? 0.5 * (S2[1] + S2[3]) : 0.0;
+        blk[(int64_t)8 * stride + i] = in ? 0.5 * (S2[2] + S2[6]) : 0.0;
+        blk[(int64_t)9 * stride + i] = in ? S2[4] : 0.0;
+        blk[(int64_t)10 * stride + i] = in ? 0.5 * (S2[5] + S2[7]) : 0.0;
+        blk[(int64_t)11 * stride + i] = in ? S2[8] : 0.0;
+      }
+      if constexpr (NC >= 18) {
+        blk[(int64_t)12 * stride + i] = in ? S1[0] : 0.0;
+        blk[(int64_t)13 * stride + i] = in ? 0.5 * (S1[1] + S1[3]) : 0.0;
+        blk[(int64_t)14 * stride + i] = in ? 0.5 * (S1[2] + S1[6]) : 0.0;
+        blk[(int64_t)15 * stride + i] = in ? S1[4] : 0.0;
+        blk[(int64_t)16 * stride + i] = in ? 0.5 * (S1[5] + S1[7]) : 0.0;
+        blk[(int64_t)17 * stride + i] = in ? S1[8] : 0.0;
+      }
+    }
   }
 }
 
@@ -818,6 +911,88 @@ int pnec_hip_problem_fill(pnec_hip_problem *p, int64_t first_pair, int64_t n_pai
     (void)dev_free(tmp);
   }
   if (e != hipSuccess) return fail_hip(e, "pack_kernel");
+  return 0;
+}
+
+int pnec_hip_problem_fill_keypoints(pnec_hip_problem *p, int64_t first_pair, int64_t n_pairs, const double *pts1,
+                                    const double *pts2, const double *cov2, const double *cov1, const double *K_inv,
+                                    double kappa, int camera_model, int space, void *stream_) {
+  if (!p) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "problem is NULL");
+  if (first_pair < 0 || n_pairs < 0 || first_pair + n_pairs > p->n_pairs)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "pair range out of bounds");
+  if (camera_model != 1)
+    return fail(PNEC_HIP_ERR_UNSUPPORTED, "keypoint ingest is pinhole only (KeyPoint::Unproject, keypoints.cc:59-60)");
+  if (space != PNEC_HIP_MEM_DEVICE && space != PNEC_HIP_MEM_HOST)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad memory space");
+  if (!K_inv) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "K_inv is NULL");
+  if (n_pairs == 0) return 0;
+  if (int rc = materialize(p)) return rc;
+  const int64_t m = p->offsets[(size_t)(first_pair + n_pairs)] - p->offsets[(size_t)first_pair];
+  if (m > 0 && (!pts1 || !pts2)) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "pts1/pts2 is NULL");
+  if (m > 0 && p->nc >= 12 && !cov2) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "cov2 is NULL for a PNEC-mode problem");
+  if (m > 0 && p->nc >= 18 && !cov1) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "cov1 is NULL for a SYM-mode problem");
+  DeviceGuard guard(p->device);
+  hipStream_t stream = (hipStream_t)stream_;
+  const double *d_p1 = pts1, *d_p2 = pts2, *d_c2 = cov2, *d_c1 = cov1, *d_K = K_inv;
+  double *tmp = nullptr;
+  if (space == PNEC_HIP_MEM_HOST) {
+    const int64_t per = 4 + (p->nc >= 12 ? 3 : 0) + (p->nc >= 18 ? 3 : 0);
+    PNEC_HIP_TRY(dev_alloc(&tmp, sizeof(double) * (per * m + 9)));
+    double *w = tmp;
+    auto up = [&](const double *src, int64_t k, const double **dst) -> hipError_t {
+      *dst = w;
+      hipError_t e = k ? hipMemcpyAsync(w, src, sizeof(double) * k, hipMemcpyHostToDevice, stream) : hipSuccess;
+      w += k;
+      return e;
+    };
+    hipError_t e = up(K_inv, 9, &d_K);
+    if (e == hipSuccess) e = up(pts1, 2 * m, &d_p1);
+    if (e == hipSuccess) e = up(pts2, 2 * m, &d_p2);
+    if (e == hipSuccess && p->nc >= 12) e = up(cov2, 3 * m, &d_c2);
+    if (e == hipSuccess && p->nc >= 18) e = up(cov1, 3 * m, &d_c1);
+    if (e != hipSuccess) {
+      (void)dev_free(tmp);
+      return fail_hip(e, "hipMemcpyAsync(H2D)");
+    }
+  }
+  const int32_t n_max = std::max<int32_t>(p->n_max, 1);
+  const dim3 block(256);
+  const dim3 grid((unsigned)std::min<int64_t>((n_max + 255) / 256, 64), (unsigned)std::min<int64_t>(n_pairs, 32768));
+  switch (p->nc) {
+    case 6:
+      hipLaunchKernelGGL(ingest_keypoints_kernel<6>, grid, block, 0, stream, p->d_data, p->d_block_offset, p->d_offsets,
+                         p->d_count, first_pair, n_pairs, d_p1, d_p2, d_c2, d_c1, d_K, kappa);
+      break;
+    case 12:
+      hipLaunchKernelGGL(ingest_keypoints_kernel<12>, grid, block, 0, stream, p->d_data, p->d_block_offset, p->d_offsets,
+                         p->d_count, first_pair, n_pairs, d_p1, d_p2, d_c2, d_c1, d_K, kappa);
+      break;
+    default:
+      hipLaunchKernelGGL(ingest_keypoints_kernel<18>, grid, block, 0, stream, p->d_data, p->d_block_offset, p->d_offsets,
+                         p->d_count, first_pair, n_pairs, d_p1, d_p2, d_c2, d_c1, d_K, kappa);
+      break;
+  }
+  hipError_t e = hipGetLastError();
+  if (tmp) {
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)dev_free(tmp);
+  }
+  if (e != hipSuccess) return fail_hip(e, "ingest_keypoints_kernel");
+  return 0;
+}
+
+int64_t pnec_hip_problem_payload_doubles(const pnec_hip_problem *p) { return p ? p->data_doubles : 0; }
+
+int pnec_hip_problem_export_payload(const pnec_hip_problem *p, double *out, int space, void *stream_) {
+  if (!p || !out) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (space != PNEC_HIP_MEM_DEVICE && space != PNEC_HIP_MEM_HOST)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad memory space");
+  if (p->data_doubles == 0) return 0;
+  DeviceGuard guard(p->device);
+  hipStream_t stream = (hipStream_t)stream_;
+  PNEC_HIP_TRY(hipMemcpyAsync(out, p->d_data, sizeof(double) * p->data_doubles,
+                              space == PNEC_HIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, stream));
+  if (space == PNEC_HIP_MEM_HOST) PNEC_HIP_TRY(hipStreamSynchronize(stream));
   return 0;
 }
 

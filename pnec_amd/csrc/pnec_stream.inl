@@ -26,6 +26,7 @@ struct pnec_hip_stream {
     size_t bytes = 0;
     int64_t ticket = 0;      // ticket in flight in this slot (0: free)
     int64_t n_pairs = 0;
+    unsigned long long blocks_done = 0;  // what the slot's device counter reads once every submit so far is done
     bool staged = false;     // went through the staged route: completion is `ev`
     hipEvent_t ev = nullptr;
   };
@@ -216,7 +217,10 @@ int pnec_hip_stream_submit(pnec_hip_stream *s, int mode, int64_t n_pairs, const 
     a.done_counter = s->d_counters + (t % s->slots);
     a.host_flag = (unsigned long long *)(d + s->o_flag);
     a.flag_value = (unsigned long long)t;
-    a.n_blocks_total = (unsigned long long)n_pairs;
+    // the slot's counter only ever counts up (no reset launch between submits): this submit is complete
+    // when it reaches the number of workgroups ever launched on the slot
+    sl.blocks_done += (unsigned long long)n_pairs;
+    a.n_blocks_total = sl.blocks_done;
     a.n_hyp = 1;
     a.reg = reg;
     a.opt = opt;
@@ -229,7 +233,6 @@ int pnec_hip_stream_submit(pnec_hip_stream *s, int mode, int64_t n_pairs, const 
         default: return launch_solve_aos_mode_3(g.cpl, g.wpp, g.ldsk, aa, s->stream);
       }
     };
-    PNEC_HIP_TRY(hipMemsetAsync(a.done_counter, 0, sizeof(unsigned long long), s->stream));
     hipError_t e = hipSuccess;
     if (n_pairs == 1) {
       a.n_solves = 1;

@@ -209,3 +209,52 @@ def test_pipeline_equals_the_stage_by_stage_chain_and_never_needs_host_sizes(ora
         s = oracle.solve(oracle.MODE_TARGET, f1[sl][mo], f2[sl][mo], c2[sl][mo], None, 1e-13, oracle.quat_from_rot(Rw),
                          tw_, oracle.default_options())
         assert math.radians(oracle.rotational_difference_deg(_quat_to_R(want.q[p]), s.R)) <= 1e-6
+
+
+@pytest.mark.parametrize("mode", [capi.MODE_NEC, capi.MODE_TARGET, capi.MODE_SYM])
+def test_fused_keypoint_ingest_is_bitwise_unscented_transform_plus_fill(mode, oracle):
+    """pnec_hip_problem_fill_keypoints (KeyPoint::Unproject for both frames: keypoints.cc:49-62) against the
+    two-step path it fuses -- pnec_hip_unscented_transform, then pnec_hip_problem_fill -- plane for plane,
+    bit for bit, in both memory spaces; and against the oracle's UnscentedTransform."""
+    from pnec_amd import frontend
+    rng = np.random.default_rng(31)
+    sizes = [100, 1, 0, 513, 64]
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    M = int(offsets[-1])
+    K = np.array([[718.856, 0, 607.1928], [0, 718.856, 185.2157], [0, 0, 1.0]])
+    Kinv = np.linalg.inv(K)
+    p1 = np.stack([rng.uniform(0, 1241, M), rng.uniform(0, 376, M)], 1)
+    p2 = p1 + rng.normal(size=(M, 2)) * 5
+
+    def cov2x2():
+        A = rng.normal(size=(M, 2, 2)) * 0.4
+        return A @ np.transpose(A, (0, 2, 1)) + 0.02 * np.eye(2)
+    c2, c1 = cov2x2(), cov2x2()
+    mu = lambda p: np.concatenate([p, np.ones((M, 1))], 1)
+    c33 = lambda c: np.pad(c, ((0, 0), (0, 1), (0, 1)))
+    b2, S2 = frontend.unscented_transform(mu(p2), c33(c2), Kinv, 1.0, frontend.CAMERA_PINHOLE)
+    b1, S1 = frontend.unscented_transform(mu(p1), c33(c1), Kinv, 1.0, frontend.CAMERA_PINHOLE)
+    np.testing.assert_allclose(b1, (mu(p1) @ Kinv.T) / np.linalg.norm(mu(p1) @ Kinv.T, axis=1, keepdims=True), atol=1e-15)
+    for i in range(0, M, 41):
+        np.testing.assert_allclose(S2[i], oracle.unscented_transform(mu(p2)[i], c33(c2)[i], Kinv, 1.0, frontend.CAMERA_PINHOLE),
+                                   rtol=1e-9, atol=1e-22)
+    cov_args = {capi.MODE_NEC: (None, None), capi.MODE_TARGET: (S2, None), capi.MODE_SYM: (S2, S1)}[mode]
+    kp_args = {capi.MODE_NEC: (None, None), capi.MODE_TARGET: (c2, None), capi.MODE_SYM: (c2, c1)}[mode]
+    with Batch(mode, offsets) as two_step, Batch(mode, offsets) as fused, Batch(mode, offsets) as fused_dev:
+        two_step.fill(b1, b2, *cov_args)
+        want = two_step.export_payload()
+        fused.fill_keypoints(p1, p2, *kp_args, K_inv=Kinv)
+        np.testing.assert_array_equal(fused.export_payload(), want)
+        t = lambda a: None if a is None else torch.from_numpy(a).cuda()
+        fused_dev.fill_keypoints(t(p1), t(p2), t(kp_args[0]), t(kp_args[1]), K_inv=Kinv)
+        np.testing.assert_array_equal(fused_dev.export_payload(), want)
+        # partial re-fill of a pair range
+        fused.fill_keypoints(p1[offsets[3]:], p2[offsets[3]:], *(None if a is None else a[offsets[3]:] for a in kp_args),
+                             K_inv=Kinv, first_pair=3, n_pairs=2)
+        np.testing.assert_array_equal(fused.export_payload(), want)
+        with pytest.raises(ValueError):
+            fused.fill_keypoints(p1[:5], p2, *kp_args, K_inv=Kinv)
+        k9 = np.ascontiguousarray(Kinv.T.reshape(9))
+        with pytest.raises(capi.PnecHipError, match="pinhole"):   # KeyPoint::Unproject is pinhole only
+            capi.check(capi.lib().pnec_hip_problem_fill_keypoints(fused._h, 0, 1, p1.ctypes.data, p2.ctypes.data, None, None,
+                                                                  k9.ctypes.data, 1.0, 0, capi.MEM_HOST, None))
