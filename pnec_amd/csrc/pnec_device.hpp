@@ -208,6 +208,36 @@ __device__ __forceinline__ double swap_add16(double x, double y) {
   const auto b = __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
   return make_double((int)b[0], (int)a[0]) + make_double((int)b[1], (int)a[1]);
 }
+// single-precision twins (the direction pre-screen of the weighted stage)
+__device__ __forceinline__ float swap_add32_f(float x, float y) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float swap_add16_f(float x, float y) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm_f(float x) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_allreduce_sum_f(float x) {
+  x += dpp_perm_f<0xB1>(x);
+  x += dpp_perm_f<0x4E>(x);
+  x += dpp_perm_f<0x141>(x);
+  x += dpp_perm_f<0x140>(x);
+  return x;
+}
+__device__ __forceinline__ float wave_allreduce_min_f(float x) {
+  x = fminf(x, dpp_perm_f<0xB1>(x));
+  x = fminf(x, dpp_perm_f<0x4E>(x));
+  x = fminf(x, dpp_perm_f<0x141>(x));
+  x = fminf(x, dpp_perm_f<0x140>(x));
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fminf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fminf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 // Sum over the 16 lanes of each DPP row.  Two forms: DPP moves (VALU: 2 moves + 1 add per level)
 // or the LDS crossbar (ds_swizzle: 1 add per level on the VALU, but an LDS round trip of latency
 // per level).  Measured on the solver: with the LM step's latency chain in

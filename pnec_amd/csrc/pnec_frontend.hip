@@ -28,8 +28,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "pnec_device.hpp"
@@ -506,19 +509,42 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
 
 // ------------------------------------------------------------------------------------------
 constexpr int kFibStride = 9;  // t (3) | txx tyy tzz | 2 txy, 2 txz, 2 tyz
+// the 500 Fibonacci directions with their products, in CONSTANT memory: the search loop's index is wave-
+// uniform, and loads from the constant address space are scalar loads (s_load: no VGPRs, no vector-memory
+// latency in the loop -- through a plain global pointer the compiler issued five vector loads per
+// direction and waited for them, which was half of the stage's wall time)
+__constant__ double c_fib[500 * kFibStride];
+__constant__ float c_fib32[500 * kFibStride];  // the same table rounded to single precision (pre-screen)
+typedef float v2f __attribute__((ext_vector_type(2)));
+// 1/x to ~1e-14 (seed + one Newton step): for the direction search, whose winner is re-evaluated exactly
+__device__ __forceinline__ double rcp_search(double x) {
+  const double y = __builtin_amdgcn_rcp(x);
+  return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+}
 struct FrontArgs {
   const double *data;           // SoA payload (12 planes for the weighted stage, >= 6 for NEC)
   const int64_t *block_offset;
   const int32_t *count;
   const double *init_q;  // [n_pairs,4] xyzw
   const double *init_t;  // [n_pairs,3] (weighted stage)
-  const double *fib;     // [500, kFibStride] Fibonacci directions t and their products (fibonacci_table)
   double *out_q;         // [n_pairs,4]
   double *out_t;         // [n_pairs,3]
   int32_t *out_iterations;  // [n_pairs] Newton iterations of the (first) eigensolver call, or null
+  unsigned long long *trace;  // null, or [n_pairs, 8] clocks per phase of the weighted kernel (PNEC_HIP_TRACE_FRONT)
   double reg;
   int weighted_iterations;
 };
+// phase clocks of the weighted kernel (diagnostics): s_memtime differences accumulated per phase
+enum : int { kPhSums = 0, kPhNewton, kPhTables, kPhSearch, kPhCost, kPhScf, kPhTotal, kPhCount = 8 };
+#define PNEC_PHASE_BEGIN() unsigned long long ph_t0_ = a.trace ? __builtin_amdgcn_s_memtime() : 0ull
+#define PNEC_PHASE_END(ph)                                                  \
+  do {                                                                      \
+    if (a.trace) {                                                          \
+      const unsigned long long ph_t1_ = __builtin_amdgcn_s_memtime();       \
+      ph_clk[ph] += ph_t1_ - ph_t0_;                                        \
+      ph_t0_ = ph_t1_;                                                      \
+    }                                                                       \
+  } while (0)
 
 __device__ __forceinline__ void quat_from_rot_dev(const double (&R)[9], double (&q)[4]) {
   const double tr = R[0] + R[4] + R[8];
@@ -694,8 +720,11 @@ __device__ double obj_fun_pair(const double *base, int n, int stride, const doub
 // RES: the pair has <= 512 correspondences, so each lane keeps n and B of its (<= 8)
 // correspondences in registers for the 24 search batches and the SCF steps of a round instead of
 // re-reading the payload and rebuilding them every time (they only change with the rotation).
+#ifndef PNEC_WES_WAVES_PER_SIMD
+#define PNEC_WES_WAVES_PER_SIMD 2
+#endif
 template <bool RES>
-__global__ __launch_bounds__(kWave, 2) void weighted_eigensolver_kernel(const FrontArgs a) {
+__global__ __launch_bounds__(kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigensolver_kernel(const FrontArgs a) {
   const int64_t pair = blockIdx.x;
   const int lane = threadIdx.x;
   const int n = a.count[pair];
@@ -703,6 +732,7 @@ __global__ __launch_bounds__(kWave, 2) void weighted_eigensolver_kernel(const Fr
   const double *base = a.data + a.block_offset[pair];
   __shared__ double G[36];
   __shared__ double cand[21][3];
+  [[maybe_unused]] __shared__ float cost32[RES ? 512 : 1];  // single-precision costs of the 500 directions
   double q0[4] = {a.init_q[4 * pair], a.init_q[4 * pair + 1], a.init_q[4 * pair + 2], a.init_q[4 * pair + 3]};
   {
     const double qn = 1.0 / sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
@@ -715,8 +745,12 @@ __global__ __launch_bounds__(kWave, 2) void weighted_eigensolver_kernel(const Fr
 #pragma unroll
   for (int i = 0; i < 9; ++i) R[i] = R0[i];
   rot_to_cayley(R0, v);
+  unsigned long long ph_clk[kPhCount] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long ph_start = a.trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  PNEC_PHASE_BEGIN();
   // weights come from the INITIAL pose in every iteration (C3): the 36 weighted sums never change
   pass_sums36<true>(base, n, stride, R0, t0, a.reg, lane, G);
+  PNEC_PHASE_END(kPhSums);
 
   constexpr int KR = RES ? 8 : 1;
   double rn[KR][3], rB[KR][6];
@@ -738,33 +772,43 @@ __global__ __launch_bounds__(kWave, 2) void weighted_eigensolver_kernel(const Fr
   int fib_min_idx = -1;  // -1: no stored search yet
   int first_iterations = 0;
   bool rotation_final = false;
-  for (int it = 0; it + 1 < a.weighted_iterations; ++it) {
+  // One round of pnec.cc:295-346.  WITH_ES: the round starts with an eigensolver call (the rotation may
+  // still move) and builds the (n, B) tables after it; without, the rotation is final, the tables of the
+  // previous round are still in registers and only the translation part runs.  Returns true when the
+  // round left t bit for bit where it found it.
+  auto round = [&](int it, auto with_es) -> bool {
+    constexpr bool WITH_ES = decltype(with_es)::value;
     // The weights never change (C3), so every round minimises the same function from the previous
     // optimum: once a call has ended for any reason other than the iteration cap, the rotation is
     // final and later rounds only redo the translation (newton = 0: "did not move").
     int newton = 0;
-    if (!rotation_final) {
+    if constexpr (WITH_ES) {
       newton = es_minimise_quad<1>(G, v, (double)(n > 0 ? n : 1));
       rotation_final = newton < 50;
     }
     if (it == 0) first_iterations = newton;
+    PNEC_PHASE_END(kPhNewton);
     const bool same_rotation = (it > 0 && newton == 0 && fib_min_idx >= 0);
-    cayley_to_rot(v, R);  // bit-identical to the previous round's when the Newton iteration did not move
-    if constexpr (RES) {
-      // rebuilt every round (cheap) so that the arrays are dead across es_minimise: the Newton
-      // iteration and 144 resident registers do not fit a wavefront's register file together
+    if constexpr (WITH_ES) cayley_to_rot(v, R);
+    if constexpr (RES && WITH_ES) {
+      // built after the eigensolver call so that the arrays are dead across it (the Newton iteration
+      // and 144 resident registers do not fit a wavefront's register file together).  No branches: the
+      // loads of all eight correspondences are in flight together (clamped addresses for the lanes
+      // beyond the pair), the padding entries are patched afterwards.
 #pragma unroll
       for (int k = 0; k < KR; ++k) {
         const int idx = lane + kWave * k;
-        if (idx < n) {
-          corr_nb(base, stride, idx, R, a.reg, rn[k], rB[k]);
-        } else {  // padding: contributes exactly 0 to every sum (n = 0, B = I)
+        const bool in = idx < n;
+        corr_nb(n > 0 ? base : a.data, stride, in ? idx : 0, R, a.reg, rn[k], rB[k]);
+        if (!in) {  // padding: contributes exactly 0 to every sum (n = 0, B = I)
           rn[k][0] = rn[k][1] = rn[k][2] = 0.0;
           rB[k][0] = rB[k][3] = rB[k][5] = 1.0;
           rB[k][1] = rB[k][2] = rB[k][4] = 0.0;
         }
       }
     }
+    PNEC_PHASE_END(kPhTables);
+    const double t_in[3] = {t[0], t[1], t[2]};
     if (!same_rotation) {
       auto energy_term = [](double tx, double ty, double tz, const double(&nn)[3], const double(&B)[6]) {
         const double aa = tx * nn[0] + ty * nn[1] + tz * nn[2];
@@ -774,31 +818,101 @@ __global__ __launch_bounds__(kWave, 2) void weighted_eigensolver_kernel(const Fr
       };
       fib_min_idx = -1;
       if constexpr (RES) {
-        // 500 Fibonacci directions against the resident (n, B): one direction at a time
-#pragma unroll 2
-        for (int c = 0; c < 500; ++c) {
-          const double *fc = a.fib + kFibStride * c;  // wave-uniform: scalar loads
-          const double tx = fc[0], ty = fc[1], tz = fc[2];
-          const double txx = fc[3], tyy = fc[4], tzz = fc[5], txy = fc[6], txz = fc[7], tyz = fc[8];
-          double sacc = 0.0;
+        // 500 Fibonacci directions against the resident (n, B) in two steps:
+        //  (1) PRE-SCREEN in single precision, packed (v_pk_fma_f32: two correspondences per lane and
+        //      instruction, no Newton steps on the reciprocals): all 500 costs to ~1e-6 relative, four
+        //      directions per round (uniforms from constant memory = scalar loads; the four partial sums
+        //      are reduced together, direction c + r ending up in row r), each written to LDS;
+        //  (2) every direction whose single-precision cost is within 1e-4 of the smallest one -- the true
+        //      minimiser is among them, its single-precision cost being off by << 1e-4 -- is evaluated
+        //      again in double precision, in index order, and the minimum by (cost, index) is kept: the
+        //      sequential rule "first direction strictly better".  Usually that is one direction.
+        v2f fn[KR / 2][3], fB[KR / 2][6];
 #pragma unroll
-          for (int k = 0; k < KR; ++k) {
-            const double aa = tx * rn[k][0] + ty * rn[k][1] + tz * rn[k][2];
-            const double d = rB[k][0] * txx + rB[k][3] * tyy + rB[k][5] * tzz + rB[k][1] * txy + rB[k][2] * txz +
-                             rB[k][4] * tyz;
-            sacc = __builtin_fma(aa * aa, fast_rcp(d), sacc);
+        for (int j = 0; j < KR / 2; ++j) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) fn[j][c] = v2f{(float)rn[2 * j][c], (float)rn[2 * j + 1][c]};
+#pragma unroll
+          for (int c = 0; c < 6; ++c) fB[j][c] = v2f{(float)rB[2 * j][c], (float)rB[2 * j + 1][c]};
+        }
+        const int my_row = lane >> 4;
+        for (int c = 0; c < 500; c += 4) {
+          float s4[4];
+#pragma unroll
+          for (int jd = 0; jd < 4; ++jd) {
+            const float *fc = c_fib32 + kFibStride * (c + jd);
+            const float tx = fc[0], ty = fc[1], tz = fc[2];
+            const float txx = fc[3], tyy = fc[4], tzz = fc[5], txy = fc[6], txz = fc[7], tyz = fc[8];
+            v2f d[KR / 2], aa[KR / 2];
+#pragma unroll
+            for (int j = 0; j < KR / 2; ++j) d[j] = fB[j][0] * txx;
+#pragma unroll
+            for (int j = 0; j < KR / 2; ++j) d[j] = fB[j][3] * tyy + d[j];
+#pragma unroll
+            for (int j = 0; j < KR / 2; ++j) d[j] = fB[j][5] * tzz + d[j];
+#pragma unroll
+            for (int j = 0; j < KR / 2; ++j) d[j] = fB[j][1] * txy + d[j];
+#pragma unroll
+            for (int j = 0; j < KR / 2; ++j) d[j] = fB[j][2] * txz + d[j];
+#pragma unroll
+            for (int j = 0; j < KR / 2; ++j) d[j] = fB[j][4] * tyz + d[j];
+#pragma unroll
+            for (int j = 0; j < KR / 2; ++j) aa[j] = fn[j][0] * tx;
+#pragma unroll
+            for (int j = 0; j < KR / 2; ++j) aa[j] = fn[j][1] * ty + aa[j];
+#pragma unroll
+            for (int j = 0; j < KR / 2; ++j) aa[j] = fn[j][2] * tz + aa[j];
+            v2f acc = {0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < KR / 2; ++j) {
+              const v2f y = {__builtin_amdgcn_rcpf(d[j].x), __builtin_amdgcn_rcpf(d[j].y)};
+              acc = (aa[j] * aa[j]) * y + acc;
+            }
+            s4[jd] = acc.x + acc.y;
           }
-          const double sum = wave_allreduce_sum(sacc);
-          if (fib_min_idx < 0 || sum < fib_min_cost) {
-            fib_min_cost = sum;
-            fib_min_idx = c;
+          const float b0 = swap_add32_f(s4[0], s4[2]), b1 = swap_add32_f(s4[1], s4[3]);
+          const float sum = row_allreduce_sum_f(swap_add16_f(b0, b1));  // row r: direction c + r
+          if ((lane & 15) == 0) cost32[c + my_row] = sum;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float m32 = __builtin_inff();
+        for (int i = lane; i < 500; i += kWave) m32 = fminf(m32, cost32[i]);  // fminf skips NaN
+        m32 = wave_allreduce_min_f(m32);
+        const float thr = m32 + 1.0e-4f * fabsf(m32);
+        for (int i0 = 0; i0 < 500; i0 += kWave) {
+          const int i = i0 + lane;
+          unsigned long long cand = __builtin_amdgcn_ballot_w64(i < 500 && cost32[i < 500 ? i : 0] <= thr);
+          while (cand != 0ull) {
+            const int c = i0 + (int)__builtin_ctzll(cand);
+            cand &= cand - 1ull;
+            // this direction's cost in double precision, with the arithmetic the current translation's
+            // cost is computed with below (the comparison between the two decides whether the search
+            // result is used at all)
+            const double *fc = c_fib + kFibStride * c;
+            const double tx = fc[0], ty = fc[1], tz = fc[2];
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+              const double aa = tx * rn[k][0] + ty * rn[k][1] + tz * rn[k][2];
+              const double d = tx * (rB[k][0] * tx + rB[k][1] * ty + rB[k][2] * tz) +
+                               ty * (rB[k][1] * tx + rB[k][3] * ty + rB[k][4] * tz) +
+                               tz * (rB[k][2] * tx + rB[k][4] * ty + rB[k][5] * tz);
+              sacc = __builtin_fma(aa * aa, fast_rcp(d), sacc);
+            }
+            const double cost = wave_allreduce_sum(sacc);
+            if (fib_min_idx < 0 || cost < fib_min_cost) {  // candidates come in index order: ties keep the first
+              fib_min_cost = cost;
+              fib_min_idx = c;
+            }
           }
         }
       } else {
         // streaming: 21 directions at a time, per correspondence n, B rebuilt once per batch
         for (int b0 = 0; b0 < 500; b0 += 21) {
           const int nb = (500 - b0 < 21) ? 500 - b0 : 21;
-          if (lane < nb * 3) cand[lane / 3][lane % 3] = a.fib[kFibStride * (b0 + lane / 3) + lane % 3];
+          if (lane < nb * 3) cand[lane / 3][lane % 3] = c_fib[kFibStride * (b0 + lane / 3) + lane % 3];
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           double acc[kNumAcc];
 #pragma unroll
@@ -820,6 +934,7 @@ __global__ __launch_bounds__(kWave, 2) void weighted_eigensolver_kernel(const Fr
         }
       }
     }
+    PNEC_PHASE_END(kPhSearch);
     // best_point = current translation unless a Fibonacci direction is strictly better
     double cur_cost = 0.0;
     for_each_corr([&](const double(&nn)[3], const double(&B)[6]) {
@@ -830,10 +945,11 @@ __global__ __launch_bounds__(kWave, 2) void weighted_eigensolver_kernel(const Fr
     });
     cur_cost = wave_allreduce_sum(cur_cost);
     if (fib_min_idx >= 0 && fib_min_cost < cur_cost) {
-      t[0] = a.fib[kFibStride * fib_min_idx];
-      t[1] = a.fib[kFibStride * fib_min_idx + 1];
-      t[2] = a.fib[kFibStride * fib_min_idx + 2];
+      t[0] = c_fib[kFibStride * fib_min_idx];
+      t[1] = c_fib[kFibStride * fib_min_idx + 1];
+      t[2] = c_fib[kFibStride * fib_min_idx + 2];
     }
+    PNEC_PHASE_END(kPhCost);
     // scf: 10 steps of  t <- eigenvector of the smallest eigenvalue of sum A_i / (t' B_i t)
     for (int step = 0; step < 10; ++step) {
       double e[6] = {0, 0, 0, 0, 0, 0};
@@ -867,6 +983,26 @@ __global__ __launch_bounds__(kWave, 2) void weighted_eigensolver_kernel(const Fr
       // the reference's fixed count of 10 would only reproduce that noise
       if (moved <= 4e-15) break;
     }
+    PNEC_PHASE_END(kPhScf);
+    return t[0] == t_in[0] && t[1] == t_in[1] && t[2] == t_in[2];
+  };
+  const int rounds = a.weighted_iterations - 1;
+  int it = 0;
+  {
+    // (A) rounds that may still move the rotation (normally just the first: the call converges)
+    while (it < rounds && !rotation_final) {
+      round(it, std::true_type{});
+      ++it;
+    }
+    // (B) the rotation is final: the remaining rounds only redo the translation from the same tables.
+    // A round that returns t unchanged bit for bit has the same inputs as the next one will have, so
+    // every later round would reproduce it: stop there (exact, not a tolerance).
+    for (; it < rounds; ++it) {
+      bool unchanged;
+      if constexpr (RES) unchanged = round(it, std::false_type{});
+      else unchanged = round(it, std::true_type{}), rotation_final = true;
+      if (unchanged) break;
+    }
   }
   if (lane == 0) {
     double qo[4];
@@ -875,6 +1011,10 @@ __global__ __launch_bounds__(kWave, 2) void weighted_eigensolver_kernel(const Fr
     for (int k = 0; k < 4; ++k) a.out_q[4 * pair + k] = qo[k] * qn;
     for (int k = 0; k < 3; ++k) a.out_t[3 * pair + k] = t[k];
     if (a.out_iterations) a.out_iterations[pair] = first_iterations;
+    if (a.trace) {
+      ph_clk[kPhTotal] = __builtin_amdgcn_s_memtime() - ph_start;
+      for (int k = 0; k < kPhCount; ++k) a.trace[kPhCount * pair + k] = ph_clk[k];
+    }
   }
 }
 
@@ -1252,13 +1392,14 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
 // ------------------------------------------------------------------------------------------
 // host side: launchers called from pnec_capi.hip
 static std::mutex g_fib_mutex;
-static double *g_fib_dev[64] = {nullptr};
+static bool g_fib_ready[64] = {false};
 
-// scf.cc:53-72, including the float division (C6); computed on the host with libm, once per device
-hipError_t fibonacci_table(int device, const double **out) {
+// scf.cc:53-72, including the float division (C6); computed on the host with libm, uploaded once per
+// device into the kernel's constant table
+hipError_t fibonacci_table(int device) {
   std::lock_guard<std::mutex> lock(g_fib_mutex);
   if (device < 0 || device >= 64) return hipErrorInvalidDevice;
-  if (!g_fib_dev[device]) {
+  if (!g_fib_ready[device]) {
     std::vector<double> pts(kFibStride * 500);
     const int samples = 500;
     const double phi = M_PI * (3.0 - std::sqrt(5.0));
@@ -1274,17 +1415,13 @@ hipError_t fibonacci_table(int device, const double **out) {
       p[3] = p[0] * p[0]; p[4] = p[1] * p[1]; p[5] = p[2] * p[2];
       p[6] = 2.0 * p[0] * p[1]; p[7] = 2.0 * p[0] * p[2]; p[8] = 2.0 * p[1] * p[2];
     }
-    double *d = nullptr;
-    hipError_t e = hipMalloc(&d, sizeof(double) * pts.size());
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_fib), pts.data(), sizeof(double) * pts.size());
     if (e != hipSuccess) return e;
-    e = hipMemcpy(d, pts.data(), sizeof(double) * pts.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-      (void)hipFree(d);
-      return e;
-    }
-    g_fib_dev[device] = d;
+    std::vector<float> pts32(pts.begin(), pts.end());
+    e = hipMemcpyToSymbol(HIP_SYMBOL(c_fib32), pts32.data(), sizeof(float) * pts32.size());
+    if (e != hipSuccess) return e;
+    g_fib_ready[device] = true;
   }
-  *out = g_fib_dev[device];
   return hipSuccess;
 }
 
@@ -1311,7 +1448,7 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
                                        hipStream_t stream) {
   FrontArgs a;
   std::memset(&a, 0, sizeof(a));
-  hipError_t e = fibonacci_table(device, &a.fib);
+  hipError_t e = fibonacci_table(device);
   if (e != hipSuccess) return e;
   a.data = data;
   a.block_offset = block_offset;
@@ -1323,11 +1460,33 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
   a.out_iterations = out_iterations;
   a.reg = reg;
   a.weighted_iterations = weighted_iterations;
+  // PNEC_HIP_TRACE_FRONT=1: per-phase clocks of every pair, averaged and printed to stderr (diagnostics;
+  // synchronises, never set it for timed runs)
+  const char *tr = std::getenv("PNEC_HIP_TRACE_FRONT");
+  if (tr && *tr && n_max <= 8 * kWave) {
+    e = hipMalloc(&a.trace, sizeof(unsigned long long) * kPhCount * (size_t)n_pairs);
+    if (e != hipSuccess) return e;
+  }
   if (n_max <= 8 * kWave)
     hipLaunchKernelGGL(weighted_eigensolver_kernel<true>, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
   else
     hipLaunchKernelGGL(weighted_eigensolver_kernel<false>, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
-  return hipGetLastError();
+  e = hipGetLastError();
+  if (a.trace) {
+    std::vector<unsigned long long> h(kPhCount * (size_t)n_pairs);
+    if (hipStreamSynchronize(stream) == hipSuccess &&
+        hipMemcpy(h.data(), a.trace, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+      double m[kPhCount] = {0};
+      for (int64_t p = 0; p < n_pairs; ++p)
+        for (int k = 0; k < kPhCount; ++k) m[k] += (double)h[(size_t)(kPhCount * p + k)];
+      static const char *names[kPhCount] = {"sums36", "newton", "tables", "search", "cur_cost", "scf", "total", "-"};
+      std::fprintf(stderr, "weighted_eigensolver phases (mean s_memtime clocks per pair, %lld pairs):", (long long)n_pairs);
+      for (int k = 0; k < kPhTotal + 1; ++k) std::fprintf(stderr, " %s=%.0f", names[k], m[k] / (double)n_pairs);
+      std::fprintf(stderr, "\n");
+    }
+    (void)hipFree(a.trace);
+  }
+  return e;
 }
 
 }  // namespace pnec_hip
