@@ -1081,37 +1081,34 @@ __device__ __forceinline__ double reprojection_score(const double (&f1)[3], cons
          (1.0 - (f2[0] * p2[0] + f2[1] * p2[1] + f2[2] * p2[2]) * in2);
 }
 
-// Sum / minimum over the 16 lanes of a DPP row (a "quarter": the lanes of one frame pair)
-__device__ __forceinline__ int row_min_int(int x) {
-#pragma unroll
-  for (int off = 8; off > 0; off >>= 1) {
-    const int o = __shfl_xor(x, off);
-    x = o < x ? o : x;
-  }
+constexpr int kHypPerRound = 16;  // hypotheses evaluated per round = quads per wavefront
+
+__device__ __forceinline__ int quad_sum_int(int x) {
+  x += __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  x += __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
   return x;
 }
 
-constexpr int kHypLanes = 16;                    // hypotheses evaluated per pair and round = lanes per pair
-constexpr int kRansacPairs = kWave / kHypLanes;  // frame pairs per wavefront
-
-// One 16-lane quarter of a wavefront per frame pair, one lane per hypothesis.  The adaptive bound
-// stops the typical pair after ~15 hypotheses, so a 64-hypothesis round wasted three quarters of
-// the (dominant, divergent) per-hypothesis Newton iterations; with four pairs per wavefront the
-// one-value-per-pair work at the end (eigensolver on the inliers) is also shared four ways.
-// Everything that is one value per pair lives in registers, identical in the 16 lanes of its quarter.
-__global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacArgs a) {
+// ONE WAVEFRONT PER FRAME PAIR, ONE QUAD PER HYPOTHESIS: a round evaluates 16 hypotheses.  The four lanes
+// of a quad share the hypothesis' Newton iteration (es_minimise_quad: the finite-difference probes and the
+// Armijo step lengths of one evaluation) and split the correspondences when it is scored.  Everything
+// that is one value per pair -- the adaptive bound k, the best count, the iteration counter -- is wave-
+// uniform, so the sequential rule of the reference loop is scalar code.
+// Against the earlier shape (4 pairs per wavefront, one lane per hypothesis): a wavefront no longer runs a
+// second round because ONE of its four pairs needs it (~1.9 -> ~1.4 rounds per pair), the slowest of 16
+// instead of 64 Newton iterations sets the pace, and the register need is es_minimise_quad's, which fits
+// two wavefronts per SIMD -- the other wavefront now fills the latency gaps of this one's chains.
+__global__ __launch_bounds__(kWave, 2) void ransac_eigensolver_kernel(const RansacArgs a) {
   const int lane = threadIdx.x;
-  const int sub = lane & (kHypLanes - 1), quarter = lane / kHypLanes;
-  const int64_t pair_raw = (int64_t)blockIdx.x * kRansacPairs + quarter;
-  const bool live = pair_raw < a.n_pairs;
-  const int64_t pair = live ? pair_raw : a.n_pairs - 1;
-  const int n = live ? a.count[pair] : 0;
-  const int stride = (a.count[pair] + kWave - 1) & ~(kWave - 1);
+  const int hyp = lane >> 2, role = lane & 3;
+  const int64_t pair = blockIdx.x;
+  const int n = a.count[pair];
+  const int stride = (n + kWave - 1) & ~(kWave - 1);
   const double *base = a.data + a.block_offset[pair];
-  __shared__ double G[kRansacPairs][36];
-  __shared__ double Glane[36][kWave];  // one table of 36 sums per hypothesis (lane), interleaved
-  __shared__ double best_model[kRansacPairs][12];  // R (9) + t (3)
-  __shared__ double tile[kRansacPairs][6][kWave];   // bearings of 64 correspondences per pair (scoring)
+  __shared__ double Gh[kHypPerRound][36];  // the 36 sums of each hypothesis' sample
+  __shared__ double G[36];                 // ... of the inliers of the best model
+  __shared__ double best_model[12];        // R (9) + t (3)
+  __shared__ double tile[6][kWave];        // bearings of 64 correspondences (scoring)
   double q0[4] = {a.init_q[4 * pair], a.init_q[4 * pair + 1], a.init_q[4 * pair + 2], a.init_q[4 * pair + 3]};
   {
     const double qn = 1.0 / sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
@@ -1120,24 +1117,19 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
   double R0[9], v0[3];
   rot_from_quat(q0, R0);
   rot_to_cayley(R0, v0);
-  const int ss = a.sample_size > 16 ? 16 : a.sample_size;
-  const bool can_sample = live && (n >= ss && ss >= 1);
+  const int ss = a.sample_size;  // <= PNEC_HIP_MAX_RANSAC_SAMPLE (checked by the caller)
+  const bool can_sample = n >= ss && ss >= 1;
   int it = 0;
-
   {
     int best_count = -1;
     double k = 1.0;
     bool stop = !can_sample;
-    // rounds of 16 hypotheses per pair while any pair of the wavefront still needs one
-    while (__builtin_amdgcn_ballot_w64(!stop && (double)it < k) != 0ull) {
-      const bool active = !stop && (double)it < k;  // same in the 16 lanes of a quarter
-      double R[9], t[3] = {0.0, 0.0, 1.0};
-#pragma unroll
-      for (int i = 0; i < 9; ++i) R[i] = R0[i];
-      if (active) {
-        const unsigned long long h = (unsigned long long)(it + sub);
-        // ---- this lane's hypothesis: sample, sums, minimise, translation
-        int sel[16];
+    while (!stop && (double)it < k) {  // wave-uniform
+      const unsigned long long h = (unsigned long long)(it + hyp);
+      // ---- this quad's hypothesis: sample, sums, minimise, translation (the four lanes do the same up to
+      // the minimiser, which splits its evaluations over them)
+      int sel[PNEC_HIP_MAX_RANSAC_SAMPLE];
+      {
         int m = 0;
         unsigned long long draw = 0;
         while (m < ss) {
@@ -1147,9 +1139,11 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
           for (int j = 0; j < m; ++j) dup = dup || (sel[j] == (int)idx);
           if (!dup) sel[m++] = (int)idx;
         }
+      }
+      double ev1[3] = {0, 0, 0};  // sum f1 (for the directional evidence)
+      {
         double Gl[36];
         for (int i = 0; i < 36; ++i) Gl[i] = 0.0;
-        double ev1[3] = {0, 0, 0};  // sum f1 (for the directional evidence)
         for (int j = 0; j < ss; ++j) {
           const int idx = sel[j];
           const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
@@ -1161,94 +1155,86 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
             for (int ac = 0; ac < 6; ++ac) Gl[6 * kl + ac] += p[kl] * qq[ac];
           for (int c = 0; c < 3; ++c) ev1[c] += f1[c];
         }
-        double v[3], M[9];
-        for (int c = 0; c < 3; ++c)
-          v[c] = v0[c] + (rng_uniform(a.seed, (unsigned long long)pair, h, 1000 + c) - 0.5) * 2.0 * 0.01;
+        if (role == 0) {
 #pragma unroll
-        for (int i = 0; i < 36; ++i) Glane[i][lane] = Gl[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        es_minimise<kWave>(&Glane[0][lane], v, (double)ss);
-        es_value_grad<kWave>(&Glane[0][lane], v, nullptr, M);
-        cayley_to_rot(v, R);
-        {
-          double w[3], V[9];
-          sym_eig3(M, w, V);
-          t[0] = V[0]; t[1] = V[3]; t[2] = V[6];
-          // directional evidence sum t.(f1 - R f2) over the sample
-          double ev = t[0] * ev1[0] + t[1] * ev1[1] + t[2] * ev1[2];
-          for (int j = 0; j < ss; ++j) {
-            const int idx = sel[j];
-            const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
-                                  base[(int64_t)5 * stride + idx]};
-            const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
-                                 R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
-            ev -= t[0] * u[0] + t[1] * u[1] + t[2] * u[2];
-          }
-          if (ev < 0.0) { t[0] = -t[0]; t[1] = -t[1]; t[2] = -t[2]; }
+          for (int i = 0; i < 36; ++i) Gh[hyp][i] = Gl[i];
         }
-      }
-      // ---- inlier count of this hypothesis over its whole pair (payload reads are uniform per quarter)
-      int cnt = 0;
-      {
-        const int n_act = active ? n : 0;
-        int n_max = n_act;
-#pragma unroll
-        for (int off = 32; off >= kHypLanes; off >>= 1) {
-          const int o = __shfl_xor(n_max, off);
-          n_max = o > n_max ? o : n_max;
-        }
-        n_max = __builtin_amdgcn_readfirstlane(n_max);
-        // tiles of 64 correspondences per pair staged in LDS by the pair's 16 lanes (coalesced), then
-        // read back quarter-uniformly: an L2 round trip per correspondence was what this loop waited on
-        for (int i0 = 0; i0 < n_max; i0 += kWave) {
-#pragma unroll
-          for (int r = 0; r < kWave / kHypLanes; ++r) {
-            const int j = sub + kHypLanes * r, idx = i0 + j;
-            const bool in = idx < n_act;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) tile[quarter][c][j] = in ? base[(int64_t)c * stride + idx] : 0.0;
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          const int left = n_max - i0 < kWave ? n_max - i0 : kWave;
-#pragma unroll 4
-          for (int j = 0; j < left; ++j) {
-            const double f1[3] = {tile[quarter][0][j], tile[quarter][1][j], tile[quarter][2][j]};
-            const double f2[3] = {tile[quarter][3][j], tile[quarter][4][j], tile[quarter][5][j]};
-            // padding entries are zeros: their score is NaN and never counts
-            cnt += (i0 + j < n_act && reprojection_score(f1, f2, R, t) < a.threshold) ? 1 : 0;
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-      // ---- consume the 16 hypotheses of every pair in order with the sequential rule
-      int winner = -1;
-      bool go = active;
-      for (int j = 0; j < kHypLanes; ++j) {
-        const int cj = __shfl(cnt, quarter * kHypLanes + j);  // all lanes take part in the exchange
-        if (go && !((double)it < k)) { stop = true; go = false; }
-        if (go) {
-          if (cj > best_count) {
-            best_count = cj;
-            winner = j;
-            const double w = (double)cj / (double)n;
-            double p_no = 1.0 - pow(w, (double)ss);
-            p_no = fmax(2.220446049250313e-16, p_no);
-            p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
-            k = log(1.0 - 0.99) / log(p_no);
-          }
-          ++it;
-          if (it > a.max_iterations) { stop = true; go = false; }
-        }
-      }
-      if (winner >= 0 && sub == winner) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) best_model[quarter][i] = R[i];
-        best_model[quarter][9] = t[0]; best_model[quarter][10] = t[1]; best_model[quarter][11] = t[2];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double v[3], M[9], R[9], t[3];
+      for (int c = 0; c < 3; ++c)
+        v[c] = v0[c] + (rng_uniform(a.seed, (unsigned long long)pair, h, 1000 + c) - 0.5) * 2.0 * 0.01;
+      es_minimise_quad<1>(Gh[hyp], v, (double)ss);
+      es_value_grad<1>(Gh[hyp], v, nullptr, M);
+      cayley_to_rot(v, R);
+      {
+        double w[3], V[9];
+        sym_eig3(M, w, V);
+        t[0] = V[0]; t[1] = V[3]; t[2] = V[6];
+        // directional evidence sum t.(f1 - R f2) over the sample
+        double ev = t[0] * ev1[0] + t[1] * ev1[1] + t[2] * ev1[2];
+        for (int j = 0; j < ss; ++j) {
+          const int idx = sel[j];
+          const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
+                                base[(int64_t)5 * stride + idx]};
+          const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
+                               R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
+          ev -= t[0] * u[0] + t[1] * u[1] + t[2] * u[2];
+        }
+        if (ev < 0.0) { t[0] = -t[0]; t[1] = -t[1]; t[2] = -t[2]; }
+      }
+      // ---- inlier count of every hypothesis over the whole pair: tiles of 64 correspondences staged in
+      // LDS by the wavefront (coalesced), each quad scores its hypothesis, a quarter of the tile per lane
+      int cnt = 0;
+      for (int i0 = 0; i0 < n; i0 += kWave) {
+        {
+          const int idx = i0 + lane;  // < stride: the padding of the last tile reads zeros
+#pragma unroll
+          for (int c = 0; c < 6; ++c) tile[c][lane] = base[(int64_t)c * stride + idx];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int left = n - i0 < kWave ? n - i0 : kWave;
+#pragma unroll 4
+        for (int jj = 0; jj < kWave / 4; ++jj) {
+          const int j = 4 * jj + role;
+          const double f1[3] = {tile[0][j], tile[1][j], tile[2][j]};
+          const double f2[3] = {tile[3][j], tile[4][j], tile[5][j]};
+          // padding entries are zeros: their score is NaN and never counts
+          cnt += (j < left && reprojection_score(f1, f2, R, t) < a.threshold) ? 1 : 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      cnt = quad_sum_int(cnt);
+      // ---- consume the 16 hypotheses in order with the sequential rule (all of it wave-uniform)
+      int winner = -1;
+      for (int j = 0; j < kHypPerRound; ++j) {
+        const int cj = __builtin_amdgcn_readlane(cnt, 4 * j);
+        if (!((double)it < k)) { stop = true; break; }
+        if (cj > best_count) {
+          best_count = cj;
+          winner = j;
+          const double w = (double)cj / (double)n;
+          double p_no = 1.0 - pow(w, (double)ss);
+          p_no = fmax(2.220446049250313e-16, p_no);
+          p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
+          k = log(1.0 - 0.99) / log(p_no);
+        }
+        ++it;
+        if (it > a.max_iterations) { stop = true; break; }
+      }
+      if (winner >= 0 && hyp == winner && role == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) best_model[i] = R[i];
+        best_model[9] = t[0]; best_model[10] = t[1]; best_model[11] = t[2];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
   double bR[9], bt[3] = {0.0, 0.0, 1.0};
@@ -1256,8 +1242,8 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
   for (int i = 0; i < 9; ++i) bR[i] = R0[i];
   if (can_sample) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) bR[i] = best_model[quarter][i];
-    bt[0] = best_model[quarter][9]; bt[1] = best_model[quarter][10]; bt[2] = best_model[quarter][11];
+    for (int i = 0; i < 9; ++i) bR[i] = best_model[i];
+    bt[0] = best_model[9]; bt[1] = best_model[10]; bt[2] = best_model[11];
   }
 
   // ---- inliers of the best model (all correspondences when sampling is impossible), their 36 sums,
@@ -1267,7 +1253,7 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
   for (int i = 0; i < 36; ++i) acc[i] = 0.0;
   int my_count = 0, my_first = 0x7fffffff;
   const int64_t aos0 = a.offsets[pair];
-  for (int idx = sub; idx < n; idx += kHypLanes) {
+  for (int idx = lane; idx < n; idx += kWave) {
     const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
     const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
                           base[(int64_t)5 * stride + idx]};
@@ -1287,18 +1273,25 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
   }
 #pragma unroll
   for (int i = 0; i < 36; ++i) {
-    const double sres = row_allreduce_sum(acc[i]);
-    if (sub == 0) G[quarter][i] = sres;
+    const double sres = wave_allreduce_sum(acc[i]);
+    if (lane == 0) G[i] = sres;
   }
-  const int total = (int)row_allreduce_sum((double)my_count);
-  const int first = row_min_int(my_first);
+  const int total = (int)wave_allreduce_sum((double)my_count);
+  int first = my_first;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(first, off);
+    first = o < first ? o : first;
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   // optimizeModelCoefficients: eigensolver on the inliers from the best model's rotation
   double v[3], R[9], M[9];
   rot_to_cayley(bR, v);
-  es_minimise_quad<1>(G[quarter], v, (double)(total > 0 ? total : 1));
-  es_value_grad<1>(G[quarter], v, nullptr, M);
+  es_minimise_quad<1>(G, v, (double)(total > 0 ? total : 1));
+  es_value_grad<1>(G, v, nullptr, M);
   cayley_to_rot(v, R);
   if (total > 0) {
     const int idx = first;
@@ -1313,7 +1306,7 @@ __global__ __launch_bounds__(kWave) void ransac_eigensolver_kernel(const RansacA
   }
   double w3[3], V[9];
   sym_eig3(M, w3, V);
-  if (sub == 0 && live) {
+  if (lane == 0) {
     double qo[4];
     quat_from_rot_dev(R, qo);
     const double qn = 1.0 / sqrt(qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3]);
@@ -1384,8 +1377,7 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   a.max_iterations = max_iterations;
   a.sample_size = sample_size;
   a.threshold = threshold;
-  hipLaunchKernelGGL(ransac_eigensolver_kernel, dim3((unsigned)((n_pairs + kRansacPairs - 1) / kRansacPairs)),
-                     dim3(kWave), 0, stream, a);
+  hipLaunchKernelGGL(ransac_eigensolver_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
   return hipGetLastError();
 }
 
