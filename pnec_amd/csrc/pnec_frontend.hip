@@ -11,16 +11,25 @@
 // M(R) = sum_kl [r_k]x G_kl [r_l]x' for every R (r_k = column k of R), so the damped-Newton
 // iteration on the Cayley vector runs on 36 numbers parked in LDS.
 //
-// Work distribution (all of these stages are FP64-VALU-bound chains of one-value-per-pair work, so
-// the design question is how many lanes share one such chain):
-//   * NEC / weighted eigensolver: one wavefront per pair for the data-parallel passes; the Newton
-//     iteration is split over the four lanes of every quad (es_minimise_quad: the three
-//     finite-difference probes and four Armijo step lengths per evaluation);
+// Work distribution (these stages are chains of one-value-per-pair FP64 work around short data-parallel
+// passes, so the design question is how many lanes share one such chain):
+//   * the eigenvalue minimiser (es_minimise_quad) runs on the four lanes of a quad: one evaluation gives
+//     f, g at a point and the three finite-difference probes of the Hessian; the full Newton step is
+//     tried as such a complete evaluation (one evaluation per iteration when it passes Armijo's test),
+//     shorter steps four lengths at a time.  The smallest eigenpair of M comes from Rayleigh-quotient
+//     iteration started at the neighbouring point's eigenvector (sym_eig3_min_rqi), Jacobi as fallback;
+//   * NEC / weighted eigensolver: one wavefront per pair for the data-parallel passes, every quad
+//     running the same minimiser;
 //   * weighted stage, pairs <= 512 correspondences: per correspondence n = f1 x R f2 and
-//     B = f1hat R Sigma R' f1hat' + reg I stay in registers; 500 Fibonacci directions (table with
-//     the direction products, scalar loads) + SCF steps with warm-started 3x3 Jacobi, stopped at
-//     the fixed point; larger pairs stream the payload, 21 directions per pass (wave_reduce21);
-//   * RANSAC: 16 lanes = 16 hypotheses per pair, 4 pairs per wavefront.
+//     B = f1hat R Sigma R' f1hat' + reg I are built ONCE per rotation and stay in registers; the 500
+//     Fibonacci directions are pre-screened in packed single precision (table in constant memory,
+//     scalar loads) and every candidate within 1e-4 of the best is re-evaluated in double precision;
+//     SCF steps by Rayleigh-quotient iteration, stopped at the fixed point; once the rotation is final the
+//     remaining rounds only redo the translation, and stop when a round leaves it bitwise unchanged;
+//     larger pairs stream the payload, 21 directions per pass (wave_reduce21);
+//   * RANSAC: one wavefront per pair, one quad per hypothesis (16 per round), the quad's lanes sharing
+//     the minimiser and splitting the correspondences when the hypothesis is scored; the sequential
+//     consumption rule and the adaptive bound are wave-uniform scalar code.
 // Reference quirks reproduced: C3 (weights from the initial pose in every iteration -- hence the
 // rotation is final after the first converged eigensolver call), C4 (x1e-8), C5
 // (E = sum A_i / t'B_i t), C6 (float division in fibonacci_sphere), C7 (ComposeM skips
@@ -442,26 +451,30 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
   const double h = 1e-6, inv_h = 1.0 / h;
   double eb[3] = {0.0, 0.0, 1.0};  // eigenvector of the smallest eigenvalue at the current point
   double f, g[3], H[9];
-  // f, g at v (role 0) and the gradients at v + h e_k (role k + 1), from one evaluation
-  auto evaluate = [&](bool warm) {
-    double vp[3] = {v[0] + (role == 1 ? h : 0.0), v[1] + (role == 2 ? h : 0.0), v[2] + (role == 3 ? h : 0.0)};
-    double gp[3], ep[3] = {eb[0], eb[1], eb[2]};
-    const double fp = es_value_grad<GS>(G, vp, gp, nullptr, ep, warm);
-    f = quad_broadcast<0>(fp);
+  // f, g at `at` (role 0) and the gradients at `at` + h e_k (role k + 1), from one evaluation; on return
+  // fx, gx, Hx, ex describe the point `at`, trace_x is trace(M) there (the noise floor of Armijo's test)
+  auto evaluate_at = [&](const double (&at)[3], bool warm, double &fx, double (&gx)[3], double (&Hx)[9],
+                         double (&ex)[3], double &trace_x) {
+    double vp[3] = {at[0] + (role == 1 ? h : 0.0), at[1] + (role == 2 ? h : 0.0), at[2] + (role == 3 ? h : 0.0)};
+    double gp[3], Mp[9], ep[3] = {eb[0], eb[1], eb[2]};
+    const double fp = es_value_grad<GS>(G, vp, gp, Mp, ep, warm);
+    fx = quad_broadcast<0>(fp);
+    trace_x = quad_broadcast<0>(Mp[0] + Mp[4] + Mp[8]);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      g[r] = quad_broadcast<0>(gp[r]);
-      H[3 * r + 0] = (quad_broadcast<1>(gp[r]) - g[r]) * inv_h;
-      H[3 * r + 1] = (quad_broadcast<2>(gp[r]) - g[r]) * inv_h;
-      H[3 * r + 2] = (quad_broadcast<3>(gp[r]) - g[r]) * inv_h;
+      gx[r] = quad_broadcast<0>(gp[r]);
+      Hx[3 * r + 0] = (quad_broadcast<1>(gp[r]) - gx[r]) * inv_h;
+      Hx[3 * r + 1] = (quad_broadcast<2>(gp[r]) - gx[r]) * inv_h;
+      Hx[3 * r + 2] = (quad_broadcast<3>(gp[r]) - gx[r]) * inv_h;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) eb[i] = quad_broadcast<0>(ep[i]);
-    H[1] = H[3] = 0.5 * (H[1] + H[3]);
-    H[2] = H[6] = 0.5 * (H[2] + H[6]);
-    H[5] = H[7] = 0.5 * (H[5] + H[7]);
+    for (int i = 0; i < 3; ++i) ex[i] = quad_broadcast<0>(ep[i]);
+    Hx[1] = Hx[3] = 0.5 * (Hx[1] + Hx[3]);
+    Hx[2] = Hx[6] = 0.5 * (Hx[2] + Hx[6]);
+    Hx[5] = Hx[7] = 0.5 * (Hx[5] + Hx[7]);
   };
-  evaluate(false);
+  double trace_v;
+  evaluate_at(v, false, f, g, H, eb, trace_v);
   int it = 0;
   for (; it < 50; ++it) {
     const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
@@ -479,29 +492,53 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
     }
     if (!ok) break;
     const double slope = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];
+    // The Armijo search tries the step lengths 1, 1/2, 1/4, ... in order and takes the first that passes.
+    // Near the minimum the full step nearly always does, so it is tried on its own -- as a COMPLETE
+    // evaluation of the point it leads to (value and gradient in role 0, the Hessian probes in roles
+    // 1..3): when it passes, the next iteration's f, g, H are already there and the iteration cost one
+    // evaluation instead of two.  When it fails, the shorter lengths are tried four per evaluation as
+    // before (same sequence of lengths, same first-that-passes rule, at most 40 trials in all).
     double alpha = 1.0;
-    bool moved = false;
-    for (int ls = 0; ls < 40; ls += 4) {
-      const double scale = role == 0 ? 1.0 : (role == 1 ? 0.5 : (role == 2 ? 0.25 : 0.125));
-      const double a_mine = alpha * scale;
-      double vn[3], Mn[9], en[3] = {eb[0], eb[1], eb[2]};
-      for (int k = 0; k < 3; ++k) vn[k] = v[k] + a_mine * d[k];
-      const double fn = es_value_grad<GS>(G, vn, nullptr, Mn, en, true);
+    bool moved = false, have_next = false;
+    {
+      double vn[3] = {v[0] + d[0], v[1] + d[1], v[2] + d[2]};
+      double fn, gn[3], Hn[9], en[3], trace_n;
+      evaluate_at(vn, true, fn, gn, Hn, en, trace_n);
       // Armijo with a rounding-noise floor: lambda_min carries ~eps * trace(M) of error
-      const int pass = (fn <= f + 1e-4 * a_mine * slope + 4e-16 * (Mn[0] + Mn[4] + Mn[8])) ? 1 : 0;
-      const int p0 = quad_broadcast<0>(pass), p1 = quad_broadcast<1>(pass), p2 = quad_broadcast<2>(pass),
-                p3 = quad_broadcast<3>(pass);
-      if (p0 | p1 | p2 | p3) {
-        alpha *= p0 ? 1.0 : (p1 ? 0.5 : (p2 ? 0.25 : 0.125));
-        moved = true;
-        break;
+      if (fn <= f + 1e-4 * slope + 4e-16 * trace_n) {
+        moved = have_next = true;
+        f = fn;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { g[i] = gn[i]; eb[i] = en[i]; v[i] = vn[i]; }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) H[i] = Hn[i];
       }
-      alpha *= 0.0625;
+    }
+    if (!moved) {
+      alpha = 0.5;
+      for (int ls = 1; ls < 40; ls += 4) {
+        const double scale = role == 0 ? 1.0 : (role == 1 ? 0.5 : (role == 2 ? 0.25 : 0.125));
+        const double a_mine = alpha * scale;
+        double vn[3], Mn[9], en[3] = {eb[0], eb[1], eb[2]};
+        for (int k = 0; k < 3; ++k) vn[k] = v[k] + a_mine * d[k];
+        const double fn = es_value_grad<GS>(G, vn, nullptr, Mn, en, true);
+        const int pass = (ls + role < 40 && fn <= f + 1e-4 * a_mine * slope + 4e-16 * (Mn[0] + Mn[4] + Mn[8])) ? 1 : 0;
+        const int p0 = quad_broadcast<0>(pass), p1 = quad_broadcast<1>(pass), p2 = quad_broadcast<2>(pass),
+                  p3 = quad_broadcast<3>(pass);
+        if (p0 | p1 | p2 | p3) {
+          alpha *= p0 ? 1.0 : (p1 ? 0.5 : (p2 ? 0.25 : 0.125));
+          moved = true;
+          break;
+        }
+        alpha *= 0.0625;
+      }
     }
     if (!moved) break;
     const double smax = alpha * fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
-    for (int k = 0; k < 3; ++k) v[k] = v[k] + alpha * d[k];
-    evaluate(true);
+    if (!have_next) {
+      for (int k = 0; k < 3; ++k) v[k] = v[k] + alpha * d[k];
+      evaluate_at(v, true, f, g, H, eb, trace_v);
+    }
     if (smax < 1e-12) { ++it; break; }
   }
   return it;
@@ -535,7 +572,7 @@ struct FrontArgs {
   int weighted_iterations;
 };
 // phase clocks of the weighted kernel (diagnostics): s_memtime differences accumulated per phase
-enum : int { kPhSums = 0, kPhNewton, kPhTables, kPhSearch, kPhCost, kPhScf, kPhTotal, kPhCount = 8 };
+enum : int { kPhSums = 0, kPhNewton, kPhTables, kPhSearch, kPhCost, kPhScf, kPhTotal, kPhCount = 12 };
 #define PNEC_PHASE_BEGIN() unsigned long long ph_t0_ = a.trace ? __builtin_amdgcn_s_memtime() : 0ull
 #define PNEC_PHASE_END(ph)                                                  \
   do {                                                                      \
@@ -745,7 +782,7 @@ __global__ __launch_bounds__(kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigen
 #pragma unroll
   for (int i = 0; i < 9; ++i) R[i] = R0[i];
   rot_to_cayley(R0, v);
-  unsigned long long ph_clk[kPhCount] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ph_clk[kPhCount] = {0};
   const unsigned long long ph_start = a.trace ? __builtin_amdgcn_s_memtime() : 0ull;
   PNEC_PHASE_BEGIN();
   // weights come from the INITIAL pose in every iteration (C3): the 36 weighted sums never change
@@ -1038,6 +1075,7 @@ struct RansacArgs {
   double *out_q, *out_t;
   uint8_t *out_mask;
   int32_t *out_count, *out_iterations;
+  unsigned long long *trace;  // null, or [n_pairs, 8] clocks per phase (PNEC_HIP_TRACE_FRONT)
   unsigned long long seed;
   int64_t n_pairs;
   int max_iterations, sample_size;
@@ -1082,6 +1120,7 @@ __device__ __forceinline__ double reprojection_score(const double (&f1)[3], cons
 }
 
 constexpr int kHypPerRound = 16;  // hypotheses evaluated per round = quads per wavefront
+enum : int { kRpSample = 0, kRpNewton, kRpModel, kRpScore, kRpConsume, kRpInliers, kRpFinal, kRpTotal };
 
 __device__ __forceinline__ int quad_sum_int(int x) {
   x += __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
@@ -1098,7 +1137,10 @@ __device__ __forceinline__ int quad_sum_int(int x) {
 // second round because ONE of its four pairs needs it (~1.9 -> ~1.4 rounds per pair), the slowest of 16
 // instead of 64 Newton iterations sets the pace, and the register need is es_minimise_quad's, which fits
 // two wavefronts per SIMD -- the other wavefront now fills the latency gaps of this one's chains.
-__global__ __launch_bounds__(kWave, 2) void ransac_eigensolver_kernel(const RansacArgs a) {
+#ifndef PNEC_RANSAC_WAVES_PER_SIMD
+#define PNEC_RANSAC_WAVES_PER_SIMD 2
+#endif
+__global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eigensolver_kernel(const RansacArgs a) {
   const int lane = threadIdx.x;
   const int hyp = lane >> 2, role = lane & 3;
   const int64_t pair = blockIdx.x;
@@ -1108,7 +1150,8 @@ __global__ __launch_bounds__(kWave, 2) void ransac_eigensolver_kernel(const Rans
   __shared__ double Gh[kHypPerRound][36];  // the 36 sums of each hypothesis' sample
   __shared__ double G[36];                 // ... of the inliers of the best model
   __shared__ double best_model[12];        // R (9) + t (3)
-  __shared__ double tile[6][kWave];        // bearings of 64 correspondences (scoring)
+  __shared__ double tile[2][6][kWave];     // bearings of 64 correspondences (scoring), double-buffered
+  __shared__ int sel_lds[PNEC_HIP_MAX_RANSAC_SAMPLE][kWave];  // each lane's sample (indexed dynamically: not registers)
   double q0[4] = {a.init_q[4 * pair], a.init_q[4 * pair + 1], a.init_q[4 * pair + 2], a.init_q[4 * pair + 3]};
   {
     const double qn = 1.0 / sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
@@ -1120,6 +1163,9 @@ __global__ __launch_bounds__(kWave, 2) void ransac_eigensolver_kernel(const Rans
   const int ss = a.sample_size;  // <= PNEC_HIP_MAX_RANSAC_SAMPLE (checked by the caller)
   const bool can_sample = n >= ss && ss >= 1;
   int it = 0;
+  unsigned long long ph_clk[kPhCount] = {0};
+  const unsigned long long ph_start = a.trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  PNEC_PHASE_BEGIN();
   {
     int best_count = -1;
     double k = 1.0;
@@ -1128,7 +1174,7 @@ __global__ __launch_bounds__(kWave, 2) void ransac_eigensolver_kernel(const Rans
       const unsigned long long h = (unsigned long long)(it + hyp);
       // ---- this quad's hypothesis: sample, sums, minimise, translation (the four lanes do the same up to
       // the minimiser, which splits its evaluations over them)
-      int sel[PNEC_HIP_MAX_RANSAC_SAMPLE];
+      auto sel = [&](int j) -> int & { return sel_lds[j][lane]; };
       {
         int m = 0;
         unsigned long long draw = 0;
@@ -1136,8 +1182,8 @@ __global__ __launch_bounds__(kWave, 2) void ransac_eigensolver_kernel(const Rans
           long long idx = (long long)(rng_uniform(a.seed, (unsigned long long)pair, h, draw++) * (double)n);
           if (idx >= n) idx = n - 1;
           bool dup = false;
-          for (int j = 0; j < m; ++j) dup = dup || (sel[j] == (int)idx);
-          if (!dup) sel[m++] = (int)idx;
+          for (int j = 0; j < m; ++j) dup = dup || (sel(j) == (int)idx);
+          if (!dup) sel(m++) = (int)idx;
         }
       }
       double ev1[3] = {0, 0, 0};  // sum f1 (for the directional evidence)
@@ -1145,7 +1191,7 @@ __global__ __launch_bounds__(kWave, 2) void ransac_eigensolver_kernel(const Rans
         double Gl[36];
         for (int i = 0; i < 36; ++i) Gl[i] = 0.0;
         for (int j = 0; j < ss; ++j) {
-          const int idx = sel[j];
+          const int idx = sel(j);
           const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
           const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
                                 base[(int64_t)5 * stride + idx]};
@@ -1166,7 +1212,19 @@ __global__ __launch_bounds__(kWave, 2) void ransac_eigensolver_kernel(const Rans
       double v[3], M[9], R[9], t[3];
       for (int c = 0; c < 3; ++c)
         v[c] = v0[c] + (rng_uniform(a.seed, (unsigned long long)pair, h, 1000 + c) - 0.5) * 2.0 * 0.01;
-      es_minimise_quad<1>(Gh[hyp], v, (double)ss);
+      PNEC_PHASE_END(kRpSample);
+      const int newton_its = es_minimise_quad<1>(Gh[hyp], v, (double)ss);
+      PNEC_PHASE_END(kRpNewton);
+      if (a.trace) {  // diagnostics: Newton iterations of the round's 16 hypotheses (sum, max), rounds
+        const double its_sum = wave_allreduce_sum((double)newton_its) * 0.25;
+        int mx = newton_its;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+        ph_clk[8] += (unsigned long long)its_sum;
+        ph_clk[9] += (unsigned long long)mx;
+        ph_clk[10] += 1;
+        ph_clk[11] += (newton_its >= 50) ? 1 : 0;
+      }
       es_value_grad<1>(Gh[hyp], v, nullptr, M);
       cayley_to_rot(v, R);
       {
@@ -1176,7 +1234,7 @@ __global__ __launch_bounds__(kWave, 2) void ransac_eigensolver_kernel(const Rans
         // directional evidence sum t.(f1 - R f2) over the sample
         double ev = t[0] * ev1[0] + t[1] * ev1[1] + t[2] * ev1[2];
         for (int j = 0; j < ss; ++j) {
-          const int idx = sel[j];
+          const int idx = sel(j);
           const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
                                 base[(int64_t)5 * stride + idx]};
           const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
@@ -1185,31 +1243,40 @@ __global__ __launch_bounds__(kWave, 2) void ransac_eigensolver_kernel(const Rans
         }
         if (ev < 0.0) { t[0] = -t[0]; t[1] = -t[1]; t[2] = -t[2]; }
       }
+      PNEC_PHASE_END(kRpModel);
       // ---- inlier count of every hypothesis over the whole pair: tiles of 64 correspondences staged in
       // LDS by the wavefront (coalesced), each quad scores its hypothesis, a quarter of the tile per lane
       int cnt = 0;
-      for (int i0 = 0; i0 < n; i0 += kWave) {
-        {
-          const int idx = i0 + lane;  // < stride: the padding of the last tile reads zeros
+      {
+        double nxt[6];  // the next tile's share of this lane, in flight while the current tile is scored
 #pragma unroll
-          for (int c = 0; c < 6; ++c) tile[c][lane] = base[(int64_t)c * stride + idx];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int left = n - i0 < kWave ? n - i0 : kWave;
+        for (int c = 0; c < 6; ++c) nxt[c] = n > 0 ? base[(int64_t)c * stride + lane] : 0.0;
+        int buf = 0;
+        for (int i0 = 0; i0 < n; i0 += kWave, buf ^= 1) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) tile[buf][c][lane] = nxt[c];
+          if (i0 + kWave < n) {  // < stride: the padding of the last tile reads zeros
+#pragma unroll
+            for (int c = 0; c < 6; ++c) nxt[c] = base[(int64_t)c * stride + i0 + kWave + lane];
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const int left = n - i0 < kWave ? n - i0 : kWave;
 #pragma unroll 4
-        for (int jj = 0; jj < kWave / 4; ++jj) {
-          const int j = 4 * jj + role;
-          const double f1[3] = {tile[0][j], tile[1][j], tile[2][j]};
-          const double f2[3] = {tile[3][j], tile[4][j], tile[5][j]};
-          // padding entries are zeros: their score is NaN and never counts
-          cnt += (j < left && reprojection_score(f1, f2, R, t) < a.threshold) ? 1 : 0;
+          for (int jj = 0; jj < kWave / 4; ++jj) {
+            const int j = 4 * jj + role;
+            const double f1[3] = {tile[buf][0][j], tile[buf][1][j], tile[buf][2][j]};
+            const double f2[3] = {tile[buf][3][j], tile[buf][4][j], tile[buf][5][j]};
+            // padding entries are zeros: their score is NaN and never counts
+            cnt += (j < left && reprojection_score(f1, f2, R, t) < a.threshold) ? 1 : 0;
+          }
+          // the other buffer is written next; this one again only after the next tile has been scored
+          __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
       }
       cnt = quad_sum_int(cnt);
+      PNEC_PHASE_END(kRpScore);
       // ---- consume the 16 hypotheses in order with the sequential rule (all of it wave-uniform)
       int winner = -1;
       for (int j = 0; j < kHypPerRound; ++j) {
@@ -1235,6 +1302,7 @@ __global__ __launch_bounds__(kWave, 2) void ransac_eigensolver_kernel(const Rans
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      PNEC_PHASE_END(kRpConsume);
     }
   }
   double bR[9], bt[3] = {0.0, 0.0, 1.0};
@@ -1287,10 +1355,12 @@ __global__ __launch_bounds__(kWave, 2) void ransac_eigensolver_kernel(const Rans
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+  PNEC_PHASE_END(kRpInliers);
   // optimizeModelCoefficients: eigensolver on the inliers from the best model's rotation
   double v[3], R[9], M[9];
   rot_to_cayley(bR, v);
   es_minimise_quad<1>(G, v, (double)(total > 0 ? total : 1));
+  PNEC_PHASE_END(kRpFinal);
   es_value_grad<1>(G, v, nullptr, M);
   cayley_to_rot(v, R);
   if (total > 0) {
@@ -1317,6 +1387,10 @@ __global__ __launch_bounds__(kWave, 2) void ransac_eigensolver_kernel(const Rans
     a.out_t[3 * pair + 2] = V[6] * tn;
     if (a.out_count) a.out_count[pair] = total;
     if (a.out_iterations) a.out_iterations[pair] = it;
+    if (a.trace) {
+      ph_clk[kRpTotal] = __builtin_amdgcn_s_memtime() - ph_start;
+      for (int k = 0; k < kPhCount; ++k) a.trace[kPhCount * pair + k] = ph_clk[k];
+    }
   }
 }
 
@@ -1377,8 +1451,29 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   a.max_iterations = max_iterations;
   a.sample_size = sample_size;
   a.threshold = threshold;
+  const char *tr = std::getenv("PNEC_HIP_TRACE_FRONT");
+  if (tr && *tr) {
+    const hipError_t e0 = hipMalloc(&a.trace, sizeof(unsigned long long) * kPhCount * (size_t)n_pairs);
+    if (e0 != hipSuccess) return e0;
+  }
   hipLaunchKernelGGL(ransac_eigensolver_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
-  return hipGetLastError();
+  const hipError_t e = hipGetLastError();
+  if (a.trace) {
+    std::vector<unsigned long long> h(kPhCount * (size_t)n_pairs);
+    if (hipStreamSynchronize(stream) == hipSuccess &&
+        hipMemcpy(h.data(), a.trace, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+      double m[kPhCount] = {0};
+      for (int64_t p = 0; p < n_pairs; ++p)
+        for (int k = 0; k < kPhCount; ++k) m[k] += (double)h[(size_t)(kPhCount * p + k)];
+      static const char *names[kPhCount] = {"sample+sums", "newton", "model", "score", "consume", "inliers", "final_es", "total",
+                                            "its_sum16", "its_max_sum", "rounds", "lane0_capped"};
+      std::fprintf(stderr, "ransac_eigensolver phases (mean s_memtime clocks per pair, %lld pairs):", (long long)n_pairs);
+      for (int k = 0; k < kPhCount; ++k) std::fprintf(stderr, " %s=%.0f", names[k], m[k] / (double)n_pairs);
+      std::fprintf(stderr, "\n");
+    }
+    (void)hipFree(a.trace);
+  }
+  return e;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1471,7 +1566,7 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
       double m[kPhCount] = {0};
       for (int64_t p = 0; p < n_pairs; ++p)
         for (int k = 0; k < kPhCount; ++k) m[k] += (double)h[(size_t)(kPhCount * p + k)];
-      static const char *names[kPhCount] = {"sums36", "newton", "tables", "search", "cur_cost", "scf", "total", "-"};
+      static const char *names[kPhCount] = {"sums36", "newton", "tables", "search", "cur_cost", "scf", "total", "-", "-", "-", "-", "-"};
       std::fprintf(stderr, "weighted_eigensolver phases (mean s_memtime clocks per pair, %lld pairs):", (long long)n_pairs);
       for (int k = 0; k < kPhTotal + 1; ++k) std::fprintf(stderr, " %s=%.0f", names[k], m[k] / (double)n_pairs);
       std::fprintf(stderr, "\n");

@@ -25,9 +25,9 @@ def main():
     cpl, wpp, ldsk = (int(x) for x in args.geom.split(","))
     src = os.path.join(ROOT, "pnec_amd/csrc", f"pnec_solve_{args.mode}.hip")
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-           "-S", "--cuda-device-only", src, "-o", args.keep] + ["-D" + d for d in args.D]
+           "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-S", "--cuda-device-only", src, "-o", args.keep] + ["-D" + d for d in args.D]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
-    name = f"_ZN8pnec_hip15lm_solve_kernelILi{MODES[args.mode]}ELi{cpl}ELi{wpp}ELi{ldsk}ELb1EEEvNS_9SolveArgsE"
+    name = f"_ZN8pnec_hip15lm_solve_kernelILi{MODES[args.mode]}ELi{cpl}ELi{wpp}ELi{ldsk}ELb1ELi0EEEvNS_9SolveArgsE"
     lines = open(args.keep).read().split("\n")
     start = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
     end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
