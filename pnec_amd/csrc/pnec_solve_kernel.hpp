@@ -140,30 +140,35 @@ __host__ __device__ constexpr bool geometry_ok(int mode, int cpl, int wpp, int l
 
 
 // ---- shared by the solve kernels -------------------------------------------------------------
+// Which correspondence a lane's slot k holds (relative to the wavefront's first): the REGK register
+// slots come in pairs (2j, 2j+1) <-> 128 j + 2 lane + {0, 1} -- two neighbouring correspondences per
+// 16-byte load, the CU's load path moving ~2x the bytes per clock of 8-byte loads -- a leftover odd
+// register slot and the LDS slots hold 64 consecutive correspondences each (lane l <-> chunk + l).
+// Monotone in k for lane 0, so "slot k is empty for every lane" is a prefix property (nslots).
+template <int CPL, int REGK>
+__host__ __device__ constexpr int slot_corr(int k, int lane) {
+  if (CPL == 1) return lane;
+  if (k < (REGK & ~1)) return 2 * kWave * (k / 2) + 2 * lane + (k & 1);
+  return kWave * k + lane;  // the odd register slot (k = REGK - 1) and the LDS slots
+}
+
 // Load one wavefront's share of a pair (CPL correspondences per lane starting at first_corr) into
-// REGK register slots + (CPL - REGK) LDS slots; returns the lane's validity bits.
-// Slot k of a lane is correspondence  first_corr + 128*(k/2) + 2*lane + (k&1): two neighbouring
-// correspondences per 16-byte load (global_load_dwordx4) -- the CU's load path moves ~2x the
-// bytes per clock of 8-byte loads, which is what bounds the payload fetch.
+// REGK register slots + (CPL - REGK) LDS slots.  The LDS slots are filled by the DMA path
+// (global_load_lds_dwordx4: memory -> LDS without passing through VGPRs): with the register file full
+// of payload there are no temporaries to stage them through, and staging them a few registers at a
+// time exposed the HBM latency once per batch (the load phase was 11 % of a wavefront's life).  One
+// instruction copies 512 B = one plane of one slot (lanes 0..31, 16 B each, landing linearly).
 template <int NC, int CPL, int REGK>
-__device__ __forceinline__ unsigned load_resident(const double *__restrict__ base, int n, int stride,
-                                                  int first_corr, int lane, double (&d)[REGK][NC],
-                                                  double *lds /* [CPL-REGK][NC][64] */) {
-  unsigned vmask = 0;
-  auto put = [&](auto kc, int c, double v) {
-    constexpr int k = decltype(kc)::value;
-    if constexpr (k < REGK) d[k][c] = v;
-    else lds[((k - REGK) * NC + c) * kWave + lane] = v;
-  };
+__device__ __forceinline__ void load_resident(const double *__restrict__ base, int n, int stride,
+                                              int first_corr, int lane, double (&d)[REGK][NC],
+                                              double *lds /* [CPL-REGK][NC][64] */) {
+  (void)n;
   if constexpr (CPL == 1) {
     const int idx = first_corr + lane;
     const bool in = idx < stride;
 #pragma unroll
-    for (int c = 0; c < NC; ++c)
-      put(std::integral_constant<int, 0>{}, c, in ? base[(int64_t)c * stride + idx] : 0.0);
-    vmask = idx < n ? 1u : 0u;
+    for (int c = 0; c < NC; ++c) d[0][c] = in ? base[(int64_t)c * stride + idx] : 0.0;
   } else {
-    static_assert(CPL == 1 || CPL % 2 == 0, "correspondences per lane: 1 or even");
     using pair_t = __attribute__((ext_vector_type(2))) double;
     auto load_pair = [&](auto jc) {
       constexpr int j = decltype(jc)::value;
@@ -173,20 +178,39 @@ __device__ __forceinline__ unsigned load_resident(const double *__restrict__ bas
       for (int c = 0; c < NC; ++c) {
         pair_t v = {0.0, 0.0};
         if (in) v = *reinterpret_cast<const pair_t *>(base + (int64_t)c * stride + idx);
-        put(std::integral_constant<int, 2 * j>{}, c, v.x);
-        put(std::integral_constant<int, 2 * j + 1>{}, c, v.y);
+        d[2 * j][c] = v.x;
+        d[2 * j + 1][c] = v.y;
       }
-      vmask |= (idx < n ? 1u : 0u) << (2 * j);
-      vmask |= (idx + 1 < n ? 1u : 0u) << (2 * j + 1);
     };
-    load_pair(std::integral_constant<int, 0>{});
-    if constexpr (CPL >= 4) load_pair(std::integral_constant<int, 1>{});
-    if constexpr (CPL >= 8) {
-      load_pair(std::integral_constant<int, 2>{});
-      load_pair(std::integral_constant<int, 3>{});
+    if constexpr (REGK >= 2) load_pair(std::integral_constant<int, 0>{});
+    if constexpr (REGK >= 4) load_pair(std::integral_constant<int, 1>{});
+    if constexpr (REGK >= 6) load_pair(std::integral_constant<int, 2>{});
+    if constexpr (REGK >= 8) load_pair(std::integral_constant<int, 3>{});
+    if constexpr (REGK & 1) {
+      const int idx = first_corr + kWave * (REGK - 1) + lane;
+      const bool in = idx < stride;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) d[REGK - 1][c] = in ? base[(int64_t)c * stride + idx] : 0.0;
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void global_void;
+#pragma unroll
+    for (int k = REGK; k < CPL; ++k) {
+      const int chunk = first_corr + kWave * k;  // 64 consecutive correspondences, 64-aligned
+      if (chunk < stride) {                      // wave-uniform: the chunk is inside the plane or beyond it
+        if (lane < kWave / 2) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c)
+            __builtin_amdgcn_global_load_lds((global_void *)(base + (int64_t)c * stride + chunk + 2 * lane),
+                                             (lds_void *)(uintptr_t)(uint32_t)(uintptr_t)(lds + ((k - REGK) * NC + c) * kWave),
+                                             16, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) lds[((k - REGK) * NC + c) * kWave + lane] = 0.0;
+      }
     }
   }
-  return vmask;
 }
 
 // The same slots filled from the reference's AoS arrays (what pack_kernel + load_resident produce,
@@ -203,7 +227,7 @@ __device__ __forceinline__ void load_resident_aos(const double *__restrict__ b1,
   };
   auto load_slot = [&](auto kc) {
     constexpr int k = decltype(kc)::value;
-    const int idx = first_corr + (CPL == 1 ? lane : 2 * kWave * (k / 2) + 2 * lane + (k & 1));
+    const int idx = first_corr + slot_corr<CPL, REGK>(k, lane);
     const bool in = idx < n;
     const int64_t j = in ? idx : 0;  // a valid address for the masked lanes
 #pragma unroll
@@ -675,23 +699,18 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
 
   // ---- load this lane's correspondences once (coalesced: consecutive lanes, consecutive doubles)
   double d[REGK][NC];
-  unsigned vmask = 0;
   if constexpr (RESIDENT && SRC == SRC_AOS)
     load_resident_aos<NC, CPL, REGK>(a.aos_bvs1 + 3 * aos0, a.aos_bvs2 + 3 * aos0, NC >= 12 ? a.aos_covs + 9 * aos0 : nullptr,
                                      NC >= 18 ? a.aos_covs_host + 9 * aos0 : nullptr, n, wave * CPL * kWave, lane, d,
                                      &ldata[LDSK > 0 ? wave : 0][0][0][0]);
   else if constexpr (RESIDENT)
-    vmask = load_resident<NC, CPL, REGK>(base, n, stride, wave * CPL * kWave, lane, d, &ldata[LDSK > 0 ? wave : 0][0][0][0]);
+    load_resident<NC, CPL, REGK>(base, n, stride, wave * CPL * kWave, lane, d, &ldata[LDSK > 0 ? wave : 0][0][0][0]);
   // how many of this wavefront's CPL slots hold any correspondence of the pair (wave-uniform): slot k
   // starts at correspondence first + 128 (k / 2) + (k & 1) (load_resident), lane 0 being the first
   [[maybe_unused]] int nslots = 0;
   if constexpr (RESIDENT) {
-    (void)vmask;
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-      const int first_of_slot = wave * CPL * kWave + (CPL == 1 ? 0 : 2 * kWave * (k / 2) + (k & 1));
-      nslots += (n > first_of_slot) ? 1 : 0;
-    }
+    for (int k = 0; k < CPL; ++k) nslots += (n > wave * CPL * kWave + slot_corr<CPL, REGK>(k, 0)) ? 1 : 0;
   }
   if (a.trace) {
     // make "payload on chip" mean what it says: wait for the loads before stamping
@@ -726,6 +745,8 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
     ist[kIPark] = 0;
   }
   const double inv_max_radius = a.inv_max_radius, inv_min_radius = a.inv_min_radius;  // kernel arguments: scalar
+  // the LDS slots arrive by DMA (vmcnt-tracked): they must have landed before the first pass reads them
+  if constexpr (RESIDENT && LDSK > 0 && SRC == SRC_PLANES) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
   int term;
