@@ -237,16 +237,31 @@ def cpu_baseline(sample, n_sample, opts_hip, gpu_q):
     return base, parity
 
 
+def kernel_sources_sha256():
+    """Identity of the device code: sha256 over the kernel sources and the build recipe (stable across
+    rebuilds on another box, changes with any kernel edit)."""
+    d = os.path.join(ROOT, "pnec_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".inl")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "pnec_hip.h"), "rb").read())
+    return h.hexdigest()
+
+
 def profiled_counters(lib_path, key):
     """HBM traffic / VALU-busy of the dominant kernel from the committed rocprofv3 PMC passes -- only if
-    they were taken on THIS build of the library (sha256) and this workload + geometry; else None."""
+    they were taken on THIS device code (sha256 of the kernel sources, or of the built library) and on
+    this workload + geometry; otherwise None: a kernel change must not leave a stale counter in the line."""
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-        sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()
+        same_code = tj.get("kernel_sources_sha256") == kernel_sources_sha256() or \
+            tj.get("lib_sha256") == hashlib.sha256(open(lib_path, "rb").read()).hexdigest()
         w = tj["workload"]
-        if tj.get("lib_sha256") == sha and [w["name"], w["pairs"], w["corr"], w["iters"], w["geometry"]] == key:
+        if same_code and [w["name"], w["pairs"], w["corr"], w["iters"], w["geometry"]] == key:
             return tj["hbm_bytes_per_launch"], tj.get("valu_busy_frac"), None
-        return None, None, "profiles/traffic_latest.json was measured on another build or workload"
+        return None, None, "profiles/traffic_latest.json was measured on other device code or another workload"
     except (OSError, KeyError, ValueError):
         return None, None, "no committed PMC record"
 

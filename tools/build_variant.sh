@@ -10,7 +10,7 @@ mkdir -p $OUT
 for f in pnec_capi pnec_frontend pnec_solve_nec pnec_solve_target pnec_solve_host pnec_solve_sym pnec_stream_nec pnec_stream_target pnec_stream_host pnec_stream_sym; do
   [ -f $f.hip ] || continue
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Wall -Wno-unused-function \
-        -mllvm -amdgpu-sched-strategy=max-ilp $FLAGS -c $f.hip -o $OUT/$f.o &
+        -mllvm -amdgpu-sched-strategy=${SCHED:-max-ilp} $FLAGS -c $f.hip -o $OUT/$f.o &
 done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC $OUT/*.o -o $OUT/libpnec_hip.so
