@@ -111,3 +111,37 @@ def test_kitti_all_set_has_the_real_sequence_lengths():
     assert len(s) == 23190 and s.min() >= 64 and 450 < s.mean() < 550
     ids = tk.kitti_all_sequence_ids()
     assert np.bincount(ids).tolist() == [f - 1 for f in tk.KITTI_FRAMES]
+
+
+def test_profiled_counters_are_dropped_when_the_device_code_changed(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from a committed rocprofv3 record; it must read null unless that
+    record was measured on the device code being benchmarked (sha256 of the kernel sources) and on the same
+    workload and launch geometry."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    key = ["sim100k", 100000, 512, 10, [8, 1, 3]]
+    rec = {"kernel_sources_sha256": bench.kernel_sources_sha256(), "lib_sha256": "0" * 64, "hbm_bytes_per_launch": 4.9e9,
+           "valu_busy_frac": 0.88,
+           "workload": {"name": "sim100k", "pairs": 100000, "corr": 512, "iters": 10, "geometry": [8, 1, 3]}}
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "pnec_amd" / "csrc").mkdir(parents=True)
+    lib = tmp_path / "lib.so"
+    lib.write_bytes(b"not the library")
+    monkeypatch.setattr(bench, "kernel_sources_sha256", lambda: rec["kernel_sources_sha256"])
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles" / "traffic_latest.json").write_text(json.dumps(rec))
+    assert bench.profiled_counters(str(lib), key)[:2] == (4.9e9, 0.88)
+    assert bench.profiled_counters(str(lib), ["sim100k", 100000, 512, 10, [8, 2, 3]])[0] is None      # other geometry
+    assert bench.profiled_counters(str(lib), ["kitti_all", 23190, 0, 0, [8, 1, 3]])[0] is None         # other workload
+    rec["kernel_sources_sha256"] = "f" * 64                                                            # kernels edited since
+    (tmp_path / "profiles" / "traffic_latest.json").write_text(json.dumps(rec))
+    t, busy, why = bench.profiled_counters(str(lib), key)
+    assert t is None and busy is None and "other device code" in why
+    (tmp_path / "profiles" / "traffic_latest.json").unlink()
+    assert bench.profiled_counters(str(lib), key)[0] is None
+    # the committed record belongs to the committed kernels
+    monkeypatch.undo()
+    committed = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+    assert committed["kernel_sources_sha256"] == bench.kernel_sources_sha256(), \
+        "profiles/traffic_latest.json is stale: re-run tools/profile_bench.sh + tools/make_traffic_json.py"
