@@ -128,7 +128,8 @@ def test_profiled_counters_are_dropped_when_the_device_code_changed(tmp_path, mo
     (tmp_path / "pnec_amd" / "csrc").mkdir(parents=True)
     lib = tmp_path / "lib.so"
     lib.write_bytes(b"not the library")
-    monkeypatch.setattr(bench, "kernel_sources_sha256", lambda: rec["kernel_sources_sha256"])
+    current = rec["kernel_sources_sha256"]
+    monkeypatch.setattr(bench, "kernel_sources_sha256", lambda: current)
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     (tmp_path / "profiles" / "traffic_latest.json").write_text(json.dumps(rec))
     assert bench.profiled_counters(str(lib), key)[:2] == (4.9e9, 0.88)
