@@ -48,6 +48,14 @@
 
 namespace pnec_hip {
 
+// -DPNEC_FRONT_DEBUG: event counters of the minimiser (diagnostics builds only; tools/build_front_variant.sh)
+#ifdef PNEC_FRONT_DEBUG
+__device__ unsigned long long g_dbg[8];
+#define PNEC_DBG_COUNT(i) atomicAdd(&g_dbg[i], 1ull)
+#else
+#define PNEC_DBG_COUNT(i)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // symmetric 3x3 eigen-decomposition, cyclic Jacobi; eigenvalues ascending, eigenvectors in the
 // columns of V (row-major), largest-magnitude component of each made positive.
@@ -309,6 +317,8 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
   if (ew && warm) {
     e[0] = ew[0]; e[1] = ew[1]; e[2] = ew[2];
     have = sym_eig3_min_rqi(M, e, lam);
+    PNEC_DBG_COUNT(0);                 // warm evaluations
+    if (!have) PNEC_DBG_COUNT(1);      // ... that fell back to the Jacobi sweeps
   }
   if (!have) {
     double w[3], V[9];
@@ -438,108 +448,141 @@ __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double 
   return it;
 }
 
-// The same minimiser for a problem that is shared by (at least) the four lanes of every quad -- the
-// wave-uniform callers.  The quad splits the work that the lane-per-problem version does in
-// sequence: one evaluation yields f, g at the point (lane role 0) AND the three forward-difference
-// probes of the Hessian (roles 1..3), and one evaluation tries four step lengths of the Armijo
-// search (alpha, alpha/2, alpha/4, alpha/8; the first that passes, in that order, wins -- the
-// sequential rule).  ~2 evaluations per Newton iteration instead of ~6; same iterates up to the
-// warm-start basis of the Jacobi sweeps.
-template <int GS>
+// The same minimiser on the four lanes of a quad (the callers give every quad its own problem -- RANSAC --
+// or the same one -- NEC / weighted stage).  The quad splits what the lane-per-problem version does in
+// sequence: ONE evaluation yields f, g at a point (lane role 0) AND the three forward-difference probes
+// of the Hessian (roles 1..3), or tries four step lengths of the Armijo search at once (alpha, alpha/2,
+// alpha/4, alpha/8; the first that passes, in that order, wins -- the sequential rule).
+//
+// Written as a state machine with ONE evaluation per loop trip and a single call site of es_value_grad:
+// the quads of a wavefront are at different points of their iterations (RANSAC: 16 hypotheses), and with
+// one branch per kind of evaluation the wavefront executed every kind whenever any quad needed it -- 85 %
+// of the trips ran the short-step search although only 11 % of the iterations reject the full step.  Now a
+// trip costs one evaluation whatever the mix; a quad whose full step is rejected simply takes two more trips.
+//   kInit / kReeval : f, g, H at v                      -> convergence test, Newton direction -> kTrial
+//   kTrial          : f, g, H at v + d (the full step as a COMPLETE evaluation of the point it leads to)
+//                     passes Armijo -> v += d, the iteration cost one evaluation;  fails -> kShort
+//   kShort          : f at v + alpha d for four shorter lengths -> first that passes: v += alpha d, kReeval
+// Same iterates as es_minimise up to the warm-start vector of the eigen-iteration; same trial sequence of
+// step lengths (1, 1/2, 1/4, ..., at most 40 trials).
+//
+// TAG only separates instantiations: a non-inlined callee is compiled under the register budget of the
+// kernels that call it, so a kernel that wants a different occupancy gets its own copy.
+template <int GS, int TAG = 0>
 __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], double n_scale) {
+  enum : int { kInit = 0, kTrial, kShort, kReeval, kDone };
   const int role = (int)(threadIdx.x & 3);
   const double h = 1e-6, inv_h = 1.0 / h;
   double eb[3] = {0.0, 0.0, 1.0};  // eigenvector of the smallest eigenvalue at the current point
-  double f, g[3], H[9];
-  // f, g at `at` (role 0) and the gradients at `at` + h e_k (role k + 1), from one evaluation; on return
-  // fx, gx, Hx, ex describe the point `at`, trace_x is trace(M) there (the noise floor of Armijo's test)
-  auto evaluate_at = [&](const double (&at)[3], bool warm, double &fx, double (&gx)[3], double (&Hx)[9],
-                         double (&ex)[3], double &trace_x) {
-    double vp[3] = {at[0] + (role == 1 ? h : 0.0), at[1] + (role == 2 ? h : 0.0), at[2] + (role == 3 ? h : 0.0)};
+  double f = 0.0, g[3] = {0.0, 0.0, 0.0}, H[9], d[3] = {0.0, 0.0, 0.0};
+  double slope = 0.0, alpha = 1.0;
+  int state = kInit, it = 0, ls = 0;
+  while (state != kDone) {
+    // ---- the point this lane evaluates in this trip
+    double p[3] = {v[0], v[1], v[2]};
+    double a_mine = 0.0;
+    if (state == kShort) {
+      a_mine = alpha * (role == 0 ? 1.0 : (role == 1 ? 0.5 : (role == 2 ? 0.25 : 0.125)));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) p[k] = v[k] + a_mine * d[k];
+    } else {
+      if (state == kTrial) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = v[k] + d[k];
+      }
+      p[0] += (role == 1 ? h : 0.0);
+      p[1] += (role == 2 ? h : 0.0);
+      p[2] += (role == 3 ? h : 0.0);
+    }
     double gp[3], Mp[9], ep[3] = {eb[0], eb[1], eb[2]};
-    const double fp = es_value_grad<GS>(G, vp, gp, Mp, ep, warm);
-    fx = quad_broadcast<0>(fp);
-    trace_x = quad_broadcast<0>(Mp[0] + Mp[4] + Mp[8]);
+    const double fp = es_value_grad<GS>(G, p, gp, Mp, ep, state != kInit);
+    const double trace_p = Mp[0] + Mp[4] + Mp[8];  // Armijo's rounding-noise floor: lambda_min carries ~eps * trace(M)
+
+    bool at_new_point = false;  // f, g, H, eb below describe v: run the head of the next iteration
+    if (state == kShort) {
+      PNEC_DBG_COUNT(5);               // short-step batches
+      const int pass = (ls + role < 40 && fp <= f + 1e-4 * a_mine * slope + 4e-16 * trace_p) ? 1 : 0;
+      const int p0 = quad_broadcast<0>(pass), p1 = quad_broadcast<1>(pass), p2 = quad_broadcast<2>(pass),
+                p3 = quad_broadcast<3>(pass);
+      if (p0 | p1 | p2 | p3) {
+        alpha *= p0 ? 1.0 : (p1 ? 0.5 : (p2 ? 0.25 : 0.125));
+        const double smax = alpha * fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      gx[r] = quad_broadcast<0>(gp[r]);
-      Hx[3 * r + 0] = (quad_broadcast<1>(gp[r]) - gx[r]) * inv_h;
-      Hx[3 * r + 1] = (quad_broadcast<2>(gp[r]) - gx[r]) * inv_h;
-      Hx[3 * r + 2] = (quad_broadcast<3>(gp[r]) - gx[r]) * inv_h;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) ex[i] = quad_broadcast<0>(ep[i]);
-    Hx[1] = Hx[3] = 0.5 * (Hx[1] + Hx[3]);
-    Hx[2] = Hx[6] = 0.5 * (Hx[2] + Hx[6]);
-    Hx[5] = Hx[7] = 0.5 * (Hx[5] + Hx[7]);
-  };
-  double trace_v;
-  evaluate_at(v, false, f, g, H, eb, trace_v);
-  int it = 0;
-  for (; it < 50; ++it) {
-    const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
-    if (gmax <= 1e-14 * (1.0 + fabs(f)) * n_scale) break;
-    double mu = 0.0, d[3] = {0.0, 0.0, 0.0};
-    const double tr = fabs(H[0]) + fabs(H[4]) + fabs(H[8]);
-    bool ok = false;
-    for (int tries = 0; tries < 40; ++tries) {
-      double Hm[9];
-      for (int i = 0; i < 9; ++i) Hm[i] = H[i];
-      Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
-      const double mg[3] = {-g[0], -g[1], -g[2]};
-      if (solve3_spd(Hm, mg, d) && (d[0] * g[0] + d[1] * g[1] + d[2] * g[2]) < 0.0) { ok = true; break; }
-      mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * 10.0;
-    }
-    if (!ok) break;
-    const double slope = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];
-    // The Armijo search tries the step lengths 1, 1/2, 1/4, ... in order and takes the first that passes.
-    // Near the minimum the full step nearly always does, so it is tried on its own -- as a COMPLETE
-    // evaluation of the point it leads to (value and gradient in role 0, the Hessian probes in roles
-    // 1..3): when it passes, the next iteration's f, g, H are already there and the iteration cost one
-    // evaluation instead of two.  When it fails, the shorter lengths are tried four per evaluation as
-    // before (same sequence of lengths, same first-that-passes rule, at most 40 trials in all).
-    double alpha = 1.0;
-    bool moved = false, have_next = false;
-    {
-      double vn[3] = {v[0] + d[0], v[1] + d[1], v[2] + d[2]};
-      double fn, gn[3], Hn[9], en[3], trace_n;
-      evaluate_at(vn, true, fn, gn, Hn, en, trace_n);
-      // Armijo with a rounding-noise floor: lambda_min carries ~eps * trace(M) of error
-      if (fn <= f + 1e-4 * slope + 4e-16 * trace_n) {
-        moved = have_next = true;
-        f = fn;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { g[i] = gn[i]; eb[i] = en[i]; v[i] = vn[i]; }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) H[i] = Hn[i];
-      }
-    }
-    if (!moved) {
-      alpha = 0.5;
-      for (int ls = 1; ls < 40; ls += 4) {
-        const double scale = role == 0 ? 1.0 : (role == 1 ? 0.5 : (role == 2 ? 0.25 : 0.125));
-        const double a_mine = alpha * scale;
-        double vn[3], Mn[9], en[3] = {eb[0], eb[1], eb[2]};
-        for (int k = 0; k < 3; ++k) vn[k] = v[k] + a_mine * d[k];
-        const double fn = es_value_grad<GS>(G, vn, nullptr, Mn, en, true);
-        const int pass = (ls + role < 40 && fn <= f + 1e-4 * a_mine * slope + 4e-16 * (Mn[0] + Mn[4] + Mn[8])) ? 1 : 0;
-        const int p0 = quad_broadcast<0>(pass), p1 = quad_broadcast<1>(pass), p2 = quad_broadcast<2>(pass),
-                  p3 = quad_broadcast<3>(pass);
-        if (p0 | p1 | p2 | p3) {
-          alpha *= p0 ? 1.0 : (p1 ? 0.5 : (p2 ? 0.25 : 0.125));
-          moved = true;
-          break;
-        }
+        for (int k = 0; k < 3; ++k) v[k] = v[k] + alpha * d[k];
+        ++it;
+        state = (smax < 1e-12 || it >= 50) ? kDone : kReeval;
+      } else {
         alpha *= 0.0625;
+        ls += 4;
+        if (ls >= 40) state = kDone;  // no step length passes: the iterate stays
+      }
+    } else {
+      // value, gradient and Hessian of the evaluated point from the quad
+      const double fx = quad_broadcast<0>(fp), trace_x = quad_broadcast<0>(trace_p);
+      double gx[3], Hx[9], ex[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        gx[r] = quad_broadcast<0>(gp[r]);
+        Hx[3 * r + 0] = (quad_broadcast<1>(gp[r]) - gx[r]) * inv_h;
+        Hx[3 * r + 1] = (quad_broadcast<2>(gp[r]) - gx[r]) * inv_h;
+        Hx[3 * r + 2] = (quad_broadcast<3>(gp[r]) - gx[r]) * inv_h;
+        ex[r] = quad_broadcast<0>(ep[r]);
+      }
+      Hx[1] = Hx[3] = 0.5 * (Hx[1] + Hx[3]);
+      Hx[2] = Hx[6] = 0.5 * (Hx[2] + Hx[6]);
+      Hx[5] = Hx[7] = 0.5 * (Hx[5] + Hx[7]);
+      bool take = true;
+      if (state == kTrial) {
+        take = fx <= f + 1e-4 * slope + 4e-16 * trace_x;  // Armijo for the full step
+        if (take) {
+          const double smax = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
+#pragma unroll
+          for (int k = 0; k < 3; ++k) v[k] = v[k] + d[k];
+          ++it;
+          if (smax < 1e-12 || it >= 50) state = kDone;
+        } else {
+          PNEC_DBG_COUNT(4);           // full step rejected
+          state = kShort;
+          alpha = 0.5;
+          ls = 1;
+        }
+      }
+      if (take) {
+        f = fx;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { g[i] = gx[i]; eb[i] = ex[i]; }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) H[i] = Hx[i];
+        at_new_point = state != kDone;
       }
     }
-    if (!moved) break;
-    const double smax = alpha * fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
-    if (!have_next) {
-      for (int k = 0; k < 3; ++k) v[k] = v[k] + alpha * d[k];
-      evaluate_at(v, true, f, g, H, eb, trace_v);
+    if (at_new_point) {
+      // ---- head of a Newton iteration at v: converged?  else the damped Newton direction
+      const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+      if (gmax <= 1e-14 * (1.0 + fabs(f)) * n_scale) {
+        state = kDone;
+      } else {
+        PNEC_DBG_COUNT(2);             // Newton iterations (x4 lanes)
+        double mu = 0.0;
+        const double tr = fabs(H[0]) + fabs(H[4]) + fabs(H[8]);
+        bool ok = false;
+        for (int tries = 0; tries < 40; ++tries) {
+          double Hm[9];
+          for (int i = 0; i < 9; ++i) Hm[i] = H[i];
+          Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
+          const double mg[3] = {-g[0], -g[1], -g[2]};
+          if (solve3_spd(Hm, mg, d) && (d[0] * g[0] + d[1] * g[1] + d[2] * g[2]) < 0.0) { ok = true; break; }
+          mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * 10.0;
+          PNEC_DBG_COUNT(3);           // Levenberg shifts
+        }
+        if (ok) {
+          slope = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];
+          state = kTrial;
+        } else {
+          state = kDone;
+        }
+      }
     }
-    if (smax < 1e-12) { ++it; break; }
   }
   return it;
 }
@@ -1213,7 +1256,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
       for (int c = 0; c < 3; ++c)
         v[c] = v0[c] + (rng_uniform(a.seed, (unsigned long long)pair, h, 1000 + c) - 0.5) * 2.0 * 0.01;
       PNEC_PHASE_END(kRpSample);
-      const int newton_its = es_minimise_quad<1>(Gh[hyp], v, (double)ss);
+      const int newton_its = es_minimise_quad<1, 1>(Gh[hyp], v, (double)ss);
       PNEC_PHASE_END(kRpNewton);
       if (a.trace) {  // diagnostics: Newton iterations of the round's 16 hypotheses (sum, max), rounds
         const double its_sum = wave_allreduce_sum((double)newton_its) * 0.25;
@@ -1359,7 +1402,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
   // optimizeModelCoefficients: eigensolver on the inliers from the best model's rotation
   double v[3], R[9], M[9];
   rot_to_cayley(bR, v);
-  es_minimise_quad<1>(G, v, (double)(total > 0 ? total : 1));
+  es_minimise_quad<1, 1>(G, v, (double)(total > 0 ? total : 1));
   PNEC_PHASE_END(kRpFinal);
   es_value_grad<1>(G, v, nullptr, M);
   cayley_to_rot(v, R);
@@ -1456,8 +1499,25 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
     const hipError_t e0 = hipMalloc(&a.trace, sizeof(unsigned long long) * kPhCount * (size_t)n_pairs);
     if (e0 != hipSuccess) return e0;
   }
+#ifdef PNEC_FRONT_DEBUG
+  {
+    const unsigned long long zeros[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), zeros, sizeof(zeros));
+  }
+#endif
   hipLaunchKernelGGL(ransac_eigensolver_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
   const hipError_t e = hipGetLastError();
+#ifdef PNEC_FRONT_DEBUG
+  {
+    unsigned long long c[8] = {0};
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_dbg), sizeof(c));
+    const double per = 1.0 / (4.0 * (double)(n_pairs > 0 ? n_pairs : 1));  // lane counts / 4 = quads, per pair
+    std::fprintf(stderr, "ransac minimiser events per pair (quads): warm_evals=%.1f jacobi_fallbacks=%.2f newton_its=%.1f "
+                 "levenberg_shifts=%.2f full_step_rejected=%.2f short_step_batches=%.2f\n",
+                 c[0] * per, c[1] * per, c[2] * per, c[3] * per, c[4] * per, c[5] * per);
+  }
+#endif
   if (a.trace) {
     std::vector<unsigned long long> h(kPhCount * (size_t)n_pairs);
     if (hipStreamSynchronize(stream) == hipSuccess &&
