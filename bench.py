@@ -237,15 +237,20 @@ def cpu_baseline(sample, n_sample, opts_hip, gpu_q):
     return base, parity
 
 
+# everything that is compiled into lm_solve_kernel -- the kernel the profiled counters belong to: the kernel and
+# its device helpers, the launcher and its translation units, the build recipe (flags) and the ABI structs
+SOLVE_KERNEL_SOURCES = ("pnec_solve_kernel.hpp", "pnec_device.hpp", "pnec_solve_launch.inl", "pnec_solve_nec.hip",
+                        "pnec_solve_target.hip", "pnec_solve_host.hip", "pnec_solve_sym.hip", "Makefile")
+
+
 def kernel_sources_sha256():
-    """Identity of the device code: sha256 over the kernel sources and the build recipe (stable across
-    rebuilds on another box, changes with any kernel edit)."""
+    """Identity of the device code of the benchmarked kernel: sha256 over its sources and the build recipe
+    (stable across rebuilds on another box, changes with any edit that can change the kernel)."""
     d = os.path.join(ROOT, "pnec_amd", "csrc")
     h = hashlib.sha256()
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp", ".inl")) or f == "Makefile":
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in SOLVE_KERNEL_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "pnec_hip.h"), "rb").read())
     return h.hexdigest()
 

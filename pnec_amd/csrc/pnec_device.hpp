@@ -532,17 +532,19 @@ __device__ __forceinline__ void accumulate(double r, const double (&J)[5], doubl
 // ------------------------------------------------------------------------------------------
 // 5x5 SPD solve A y = b on the packed upper triangle (A(a,b) = P[tri(a,b)]); false if a pivot is
 // not positive or the result is not finite (-> Ceres' LINEAR_SOLVER_FAILURE).
+// The pivots are not tested one by one: a pivot <= 0 (or non-finite) makes its reciprocal square root
+// NaN / inf (rsq(-x) = NaN, rsq(0) = inf and 0 * inf = NaN, rsq(inf) = 0 and inf * 0 = NaN), every
+// later pivot and every z, y after it inherit that, and y[0] -- the last value of the back
+// substitution -- depends on all of them: "y[0] is finite" is the whole test.
 __device__ __forceinline__ bool chol_solve5(const double (&P)[15], const double (&b)[5],
                                             double (&y)[5]) {
   double L[15];  // L(i,j), i >= j, stored at tri(j,i)
   double inv[5];
-  bool ok = true;
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     double dj = P[tri(j, j)];
 #pragma unroll
     for (int k = 0; k < j; ++k) dj = __builtin_fma(-L[tri(k, j)], L[tri(k, j)], dj);
-    ok = ok && (dj > 0.0) && finite_d(dj);
     const double iv = fast_rsqrt(dj);
     inv[j] = iv;
     L[tri(j, j)] = dj * iv;
@@ -569,9 +571,7 @@ __device__ __forceinline__ bool chol_solve5(const double (&P)[15], const double 
     for (int k = i + 1; k < 5; ++k) s = __builtin_fma(-L[tri(i, k)], y[k], s);
     y[i] = s * inv[i];
   }
-#pragma unroll
-  for (int i = 0; i < 5; ++i) ok = ok && finite_d(y[i]);
-  return ok;
+  return finite_d(y[0]);
 }
 
 }  // namespace pnec_hip

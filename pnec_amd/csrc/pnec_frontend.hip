@@ -319,6 +319,15 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
     have = sym_eig3_min_rqi(M, e, lam);
     PNEC_DBG_COUNT(0);                 // warm evaluations
     if (!have) PNEC_DBG_COUNT(1);      // ... that fell back to the Jacobi sweeps
+#ifdef PNEC_FRONT_DEBUG
+    {
+      const unsigned long long act = __builtin_amdgcn_ballot_w64(true), fb = __builtin_amdgcn_ballot_w64(!have);
+      if ((int)threadIdx.x == __builtin_ctzll(act)) {
+        atomicAdd(&g_dbg[6], 4ull);              // wavefront-level evaluations (x4 to match the /4 of the print)
+        if (fb) atomicAdd(&g_dbg[7], 4ull);      // ... in which some lane fell back
+      }
+    }
+#endif
   }
   if (!have) {
     double w[3], V[9];
@@ -1450,15 +1459,31 @@ __global__ __launch_bounds__(kWave) void select_kernel(int nc, const double *src
   const double *sb = src + src_block[pair];
   double *db = dst + dst_block[pair];
   const uint8_t *mk = mask + src_offsets[pair];
+  // eight 64-chunks at a time: first where every kept correspondence goes (mask bytes and ballots only), then
+  // the copies component by component with all eight loads of a component in flight together
+  constexpr int kChunks = 8;
   int written = 0;
-  for (int c0 = 0; c0 < sstride; c0 += kWave) {
-    const int idx = c0 + lane;
-    const bool in = idx < n && mk[idx] != 0;
-    const unsigned long long b = __ballot(in);
-    const int pos = written + __popcll(b & ((1ull << lane) - 1ull));
-    if (in)
-      for (int c = 0; c < nc; ++c) db[(int64_t)c * dstride + pos] = sb[(int64_t)c * sstride + idx];
-    written += __popcll(b);
+  for (int base = 0; base < sstride; base += kChunks * kWave) {
+    bool in[kChunks];
+    int pos[kChunks];
+#pragma unroll
+    for (int j = 0; j < kChunks; ++j) {
+      const int idx = base + j * kWave + lane;
+      in[j] = idx < n && mk[idx] != 0;
+      const unsigned long long b = __ballot(in[j]);
+      pos[j] = written + __popcll(b & ((1ull << lane) - 1ull));
+      written += __popcll(b);
+    }
+    for (int c = 0; c < nc; ++c) {
+      const double *sc = sb + (int64_t)c * sstride + base + lane;
+      double *dc = db + (int64_t)c * dstride;
+      double v[kChunks];
+#pragma unroll
+      for (int j = 0; j < kChunks; ++j) v[j] = in[j] ? sc[j * kWave] : 0.0;
+#pragma unroll
+      for (int j = 0; j < kChunks; ++j)
+        if (in[j]) dc[pos[j]] = v[j];
+    }
   }
   for (int idx = m + lane; idx < dstride; idx += kWave)  // zero padding of the last 64-chunk
     for (int c = 0; c < nc; ++c) db[(int64_t)c * dstride + idx] = 0.0;
@@ -1514,8 +1539,8 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
     (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_dbg), sizeof(c));
     const double per = 1.0 / (4.0 * (double)(n_pairs > 0 ? n_pairs : 1));  // lane counts / 4 = quads, per pair
     std::fprintf(stderr, "ransac minimiser events per pair (quads): warm_evals=%.1f jacobi_fallbacks=%.2f newton_its=%.1f "
-                 "levenberg_shifts=%.2f full_step_rejected=%.2f short_step_batches=%.2f\n",
-                 c[0] * per, c[1] * per, c[2] * per, c[3] * per, c[4] * per, c[5] * per);
+                 "levenberg_shifts=%.2f full_step_rejected=%.2f short_step_batches=%.2f wave_evals=%.2f wave_evals_with_fallback=%.2f\n",
+                 c[0] * per, c[1] * per, c[2] * per, c[3] * per, c[4] * per, c[5] * per, c[6] * per, c[7] * per);
   }
 #endif
   if (a.trace) {
