@@ -90,6 +90,33 @@ int main(int argc, char **argv) {
     pnec_hip_stream_destroy(st);
     return 0;
   }
+  if (argc > 2 && std::strcmp(argv[2], "solve_latency") == 0) {
+    // one frame pair per call through the whole default chain, as the odometry front end calls it
+    // (frame2frame.cc:129-132): PNEC::Solve(bvs1, bvs2, covs, init, inliers), host arrays in, pose out
+    const int reps = argc > 3 ? std::atoi(argv[3]) : 300;
+    pnec::rel_pose_estimation::Options options;
+    pnec::rel_pose_estimation::PNEC pnec_solver(options);
+    const pnec::SE3d init(pnec::Quaterniond(0.975, 0.1, -0.14, 0.115).normalized().toRotationMatrix(),
+                          pnec::Vector3d(0.28, -0.22, 0.92).normalized());
+    std::vector<double> us;
+    double sink = 0.0;
+    size_t n_inl = 0;
+    for (int r = 0; r < reps + 20; ++r) {
+      std::vector<int> inliers;
+      const auto tic = std::chrono::steady_clock::now();
+      const pnec::SE3d sol = pnec_solver.Solve(b1, b2, covs, init, inliers);
+      const auto toc = std::chrono::steady_clock::now();
+      if (r >= 20) us.push_back(std::chrono::duration<double, std::micro>(toc - tic).count());
+      sink += sol.translation()[2];
+      n_inl = inliers.size();
+    }
+    std::sort(us.begin(), us.end());
+    std::printf("{\"call\": \"PNEC::Solve, reference-default Options (RANSAC eigensolver, weighted eigensolver + SCF, refinement), "
+                "host arrays in, pose + inliers out\", \"correspondences\": %d, \"inliers\": %zu, \"reps\": %d, "
+                "\"median_us\": %.1f, \"p10_us\": %.1f, \"p90_us\": %.1f, \"checksum\": %.6f}\n",
+                n, n_inl, reps, us[us.size() / 2], us[us.size() / 10], us[us.size() * 9 / 10], sink / reps);
+    return 0;
+  }
   // the reference's default Options: RANSAC eigensolver -> inliers -> 9 weighted eigensolver rounds +
   // SCF -> Ceres-style refinement (run_simulation.cc:74-86 calls it exactly like this)
   pnec::rel_pose_estimation::Options options;
