@@ -194,6 +194,40 @@ __device__ __forceinline__ bool sym_eig3_min_rqi(const double (&M)[9], double (&
   return true;
 }
 
+// A start vector for sym_eig3_min_rqi when there is no neighbouring eigenvector (first evaluation of a
+// minimisation) or the neighbour's led to another eigenpair: the smallest root of the characteristic
+// polynomial q(x) = x^3 - tr x^2 + c2 x - det by Newton's method from x = 0 -- the matrices here are sums of
+// n n' (positive semi-definite), so 0 is at or below the smallest eigenvalue and the iteration climbs to it
+// monotonically; four steps leave it between 0 and lambda_1, much closer to lambda_1 than to lambda_2 unless
+// the two nearly coincide -- then the adjugate of M - x I, which that shift makes (almost) the projector on the
+// wanted eigenvector: its column with the largest diagonal entry, normalised.  ~95 instructions against
+// ~900 for cold Jacobi sweeps; Rayleigh-quotient iteration polishes the pair and VERIFIES it (smallest root),
+// so a start this recipe gets wrong (indefinite or degenerate input) still ends in the sweeps.
+__device__ __forceinline__ void sym_eig3_min_start(const double (&M)[9], double (&e)[3]) {
+  const double m00 = M[0], m01 = M[1], m02 = M[2], m11 = M[4], m12 = M[5], m22 = M[8];
+  const double tr = m00 + m11 + m22;
+  const double k00 = m11 * m22 - m12 * m12, k11 = m00 * m22 - m02 * m02, k22 = m00 * m11 - m01 * m01;
+  const double c2 = k00 + k11 + k22;
+  const double det = m00 * k00 - m01 * (m01 * m22 - m12 * m02) + m02 * (m01 * m12 - m11 * m02);
+  double x = 0.0;
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    const double q = __builtin_fma(__builtin_fma(x - tr, x, c2), x, -det);
+    const double dq = __builtin_fma(__builtin_fma(3.0, x, -2.0 * tr), x, c2);
+    x = __builtin_fma(-q, fast_rcp(dq), x);
+  }
+  const double a00 = m00 - x, a11 = m11 - x, a22 = m22 - x;
+  const double c00 = a11 * a22 - m12 * m12, c01 = m02 * m12 - m01 * a22, c02 = m01 * m12 - m02 * a11;
+  const double c11 = a00 * a22 - m02 * m02, c12 = m01 * m02 - m12 * a00, c22 = a00 * a11 - m01 * m01;
+  const bool use0 = fabs(c00) >= fabs(c11) && fabs(c00) >= fabs(c22);
+  const bool use1 = !use0 && fabs(c11) >= fabs(c22);
+  const double x0 = use0 ? c00 : (use1 ? c01 : c02);
+  const double x1 = use0 ? c01 : (use1 ? c11 : c12);
+  const double x2 = use0 ? c02 : (use1 ? c12 : c22);
+  const double inv = fast_rsqrt(x0 * x0 + x1 * x1 + x2 * x2);  // 0 -> inf -> NaN: the iteration rejects it
+  e[0] = x0 * inv; e[1] = x1 * inv; e[2] = x2 * inv;
+}
+
 __device__ void cayley_to_rot(const double (&v)[3], double (&R)[9]) {
   const double x = v[0], y = v[1], z = v[2];
   const double s = fast_rcp(1.0 + x * x + y * y + z * z);
@@ -314,17 +348,27 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
   }
   double lam = 0.0, e[3] = {0.0, 0.0, 1.0};
   bool have = false;
-  if (ew && warm) {
-    e[0] = ew[0]; e[1] = ew[1]; e[2] = ew[2];
-    have = sym_eig3_min_rqi(M, e, lam);
-    PNEC_DBG_COUNT(0);                 // warm evaluations
-    if (!have) PNEC_DBG_COUNT(1);      // ... that fell back to the Jacobi sweeps
+  if (ew) {
+    // smallest eigenpair by Rayleigh-quotient iteration: from the neighbouring point's eigenvector (warm), and
+    // from the characteristic polynomial's (sym_eig3_min_start) when there is none or it led elsewhere
+    bool need_start = !warm;
+    if (warm) { e[0] = ew[0]; e[1] = ew[1]; e[2] = ew[2]; }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if (need_start) sym_eig3_min_start(M, e);
+      have = sym_eig3_min_rqi(M, e, lam);
+      if (attempt == 0) {
+        PNEC_DBG_COUNT(0);               // evaluations
+        if (!have) PNEC_DBG_COUNT(1);    // ... whose first attempt failed
+      }
+      if (have || need_start) break;
+      need_start = true;
+    }
 #ifdef PNEC_FRONT_DEBUG
     {
       const unsigned long long act = __builtin_amdgcn_ballot_w64(true), fb = __builtin_amdgcn_ballot_w64(!have);
       if ((int)threadIdx.x == __builtin_ctzll(act)) {
         atomicAdd(&g_dbg[6], 4ull);              // wavefront-level evaluations (x4 to match the /4 of the print)
-        if (fb) atomicAdd(&g_dbg[7], 4ull);      // ... in which some lane fell back
+        if (fb) atomicAdd(&g_dbg[7], 4ull);      // ... in which some lane went on to the Jacobi sweeps
       }
     }
 #endif
@@ -402,63 +446,12 @@ __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&
   return true;
 }
 
-// damped Newton on the Cayley vector; returns the number of iterations taken (0 = already converged)
-template <int GS>
-__device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double n_scale) {
-  double g[3];
-  double eb[3] = {0.0, 0.0, 1.0};  // eigenvector of the smallest eigenvalue at the current point
-  double f = es_value_grad<GS>(G, v, g, nullptr, eb, false);
-  int it = 0;
-  for (; it < 50; ++it) {
-    const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
-    if (gmax <= 1e-14 * (1.0 + fabs(f)) * n_scale) break;
-    double H[9];
-    const double h = 1e-6, inv_h = 1.0 / h;
-    for (int k = 0; k < 3; ++k) {
-      double vp[3] = {v[0], v[1], v[2]}, gp[3];
-      vp[k] += h;
-      double ep[3] = {eb[0], eb[1], eb[2]};  // the probe is 1e-6 away: its eigenvector is the current one to 1e-6
-      es_value_grad<GS>(G, vp, gp, nullptr, ep, true);
-      for (int r = 0; r < 3; ++r) H[3 * r + k] = (gp[r] - g[r]) * inv_h;
-    }
-    H[1] = H[3] = 0.5 * (H[1] + H[3]);
-    H[2] = H[6] = 0.5 * (H[2] + H[6]);
-    H[5] = H[7] = 0.5 * (H[5] + H[7]);
-    double mu = 0.0, d[3] = {0.0, 0.0, 0.0};
-    const double tr = fabs(H[0]) + fabs(H[4]) + fabs(H[8]);
-    bool ok = false;
-    for (int tries = 0; tries < 40; ++tries) {
-      double Hm[9];
-      for (int i = 0; i < 9; ++i) Hm[i] = H[i];
-      Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
-      const double mg[3] = {-g[0], -g[1], -g[2]};
-      if (solve3_spd(Hm, mg, d) && (d[0] * g[0] + d[1] * g[1] + d[2] * g[2]) < 0.0) { ok = true; break; }
-      mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * 10.0;
-    }
-    if (!ok) break;
-    double alpha = 1.0, vn[3] = {v[0], v[1], v[2]};
-    const double slope = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];
-    bool moved = false;
-    for (int ls = 0; ls < 40; ++ls) {
-      for (int k = 0; k < 3; ++k) vn[k] = v[k] + alpha * d[k];
-      double Mn[9];
-      double en[3] = {eb[0], eb[1], eb[2]};
-      const double fn = es_value_grad<GS>(G, vn, nullptr, Mn, en, true);
-      // Armijo with a rounding-noise floor: lambda_min carries ~eps * trace(M) of error
-      if (fn <= f + 1e-4 * alpha * slope + 4e-16 * (Mn[0] + Mn[4] + Mn[8])) { moved = true; break; }
-      alpha *= 0.5;
-    }
-    if (!moved) break;
-    const double smax = alpha * fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
-    for (int k = 0; k < 3; ++k) v[k] = vn[k];
-    f = es_value_grad<GS>(G, v, g, nullptr, eb, true);
-    if (smax < 1e-12) { ++it; break; }
-  }
-  return it;
-}
-
-// The same minimiser on the four lanes of a quad (the callers give every quad its own problem -- RANSAC --
-// or the same one -- NEC / weighted stage).  The quad splits what the lane-per-problem version does in
+// Damped Newton on the Cayley vector (opengv's eigensolver minimises lambda_min(M(R)) [EXT]; restated as
+// in oracle/pnec_oracle_frontend.c eigensolver_cayley): gradient analytic (es_value_grad), Hessian by forward
+// differences of the gradient (h = 1e-6), Levenberg shifts until it is positive definite, Armijo search over
+// the step lengths 1, 1/2, 1/4, ...; returns the number of iterations taken (0 = already converged).
+// Run by the four lanes of a quad (the callers give every quad its own problem -- RANSAC -- or all quads the
+// same one -- NEC / weighted stage) which split what a single thread does in
 // sequence: ONE evaluation yields f, g at a point (lane role 0) AND the three forward-difference probes
 // of the Hessian (roles 1..3), or tries four step lengths of the Armijo search at once (alpha, alpha/2,
 // alpha/4, alpha/8; the first that passes, in that order, wins -- the sequential rule).
@@ -472,8 +465,8 @@ __device__ __noinline__ int es_minimise(const double *G, double (&v)[3], double 
 //   kTrial          : f, g, H at v + d (the full step as a COMPLETE evaluation of the point it leads to)
 //                     passes Armijo -> v += d, the iteration cost one evaluation;  fails -> kShort
 //   kShort          : f at v + alpha d for four shorter lengths -> first that passes: v += alpha d, kReeval
-// Same iterates as es_minimise up to the warm-start vector of the eigen-iteration; same trial sequence of
-// step lengths (1, 1/2, 1/4, ..., at most 40 trials).
+// Same iterates as the sequential form up to the start vector of the eigen-iteration and the gradient rule
+// of the full step (below); same trial sequence of step lengths (1, 1/2, 1/4, ..., at most 40 trials).
 //
 // TAG only separates instantiations: a non-inlined callee is compiled under the register budget of the
 // kernels that call it, so a kernel that wants a different occupancy gets its own copy.
@@ -543,6 +536,18 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
       bool take = true;
       if (state == kTrial) {
         take = fx <= f + 1e-4 * slope + 4e-16 * trace_x;  // Armijo for the full step
+        // M is composed from the 36 sums with cancellation (terms of the size of the sums add up to an
+        // eigenvalue 1e-5 of it): its value carries ~50 eps trace(M) of noise, and within sqrt(noise / curvature)
+        // ~ 1e-7 of the minimum the VALUE can no longer tell a good Newton step from a bad one.  The gradient
+        // can (its noise moves the stationary point by ~1e-15): a full step that leaves the value unchanged
+        // within that noise and shrinks the gradient is taken.  (The CPU oracle composes M from the
+        // correspondences, sum of n n', without the cancellation, and needs no such rule: this is what makes
+        // the device end where it does -- without it the device stopped up to 1.3e-7 rad short.)
+        if (!take) {
+          const double gmax_old = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+          const double gmax_new = fmax(fabs(gx[0]), fmax(fabs(gx[1]), fabs(gx[2])));
+          take = (fx - f) <= 1e-13 * trace_x && gmax_new < gmax_old;
+        }
         if (take) {
           const double smax = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
 #pragma unroll
