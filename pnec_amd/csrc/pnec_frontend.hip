@@ -446,8 +446,8 @@ __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&
   return true;
 }
 
-// Damped Newton on the Cayley vector (opengv's eigensolver minimises lambda_min(M(R)) [EXT]; restated as
-// in oracle/pnec_oracle_frontend.c eigensolver_cayley): gradient analytic (es_value_grad), Hessian by forward
+// Damped Newton on the Cayley vector (opengv's eigensolver minimises lambda_min(M(R)) [EXT]; restated; the
+// CPU checker under oracle/ holds the sequential form): gradient analytic (es_value_grad), Hessian by forward
 // differences of the gradient (h = 1e-6), Levenberg shifts until it is positive definite, Armijo search over
 // the step lengths 1, 1/2, 1/4, ...; returns the number of iterations taken (0 = already converged).
 // Run by the four lanes of a quad (the callers give every quad its own problem -- RANSAC -- or all quads the
