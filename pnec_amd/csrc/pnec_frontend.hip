@@ -470,8 +470,11 @@ __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&
 //
 // TAG only separates instantiations: a non-inlined callee is compiled under the register budget of the
 // kernels that call it, so a kernel that wants a different occupancy gets its own copy.
+//
+// e_out (optional): the eigenvector of the smallest eigenvalue of M at the returned v (unit length, sign
+// arbitrary) -- every exit leaves the loop with the eigen-iteration's vector of exactly that point.
 template <int GS, int TAG = 0>
-__device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], double n_scale) {
+__device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], double n_scale, double *e_out = nullptr) {
   enum : int { kInit = 0, kTrial, kShort, kReeval, kDone };
   const int role = (int)(threadIdx.x & 3);
   const double h = 1e-6, inv_h = 1.0 / h;
@@ -479,6 +482,7 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
   double f = 0.0, g[3] = {0.0, 0.0, 0.0}, H[9], d[3] = {0.0, 0.0, 0.0};
   double slope = 0.0, alpha = 1.0;
   int state = kInit, it = 0, ls = 0;
+  bool last_eval = false;
   while (state != kDone) {
     // ---- the point this lane evaluates in this trip
     double p[3] = {v[0], v[1], v[2]};
@@ -512,7 +516,9 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
 #pragma unroll
         for (int k = 0; k < 3; ++k) v[k] = v[k] + alpha * d[k];
         ++it;
-        state = (smax < 1e-12 || it >= 50) ? kDone : kReeval;
+        // the loop ends here; with e_out the caller wants the eigenvector AT the new point: one more evaluation
+        last_eval = smax < 1e-12 || it >= 50;
+        state = (last_eval && !e_out) ? kDone : kReeval;
       } else {
         alpha *= 0.0625;
         ls += 4;
@@ -567,6 +573,7 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
         for (int i = 0; i < 3; ++i) { g[i] = gx[i]; eb[i] = ex[i]; }
 #pragma unroll
         for (int i = 0; i < 9; ++i) H[i] = Hx[i];
+        if (last_eval) state = kDone;
         at_new_point = state != kDone;
       }
     }
@@ -598,6 +605,7 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
       }
     }
   }
+  if (e_out) { e_out[0] = eb[0]; e_out[1] = eb[1]; e_out[2] = eb[2]; }
   return it;
 }
 
@@ -1266,11 +1274,12 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      double v[3], M[9], R[9], t[3];
+      double v[3], R[9], t[3];
       for (int c = 0; c < 3; ++c)
         v[c] = v0[c] + (rng_uniform(a.seed, (unsigned long long)pair, h, 1000 + c) - 0.5) * 2.0 * 0.01;
       PNEC_PHASE_END(kRpSample);
-      const int newton_its = es_minimise_quad<1, 1>(Gh[hyp], v, (double)ss);
+      // t = eigenvector of the smallest eigenvalue of M at the minimiser (sign settled by the evidence below)
+      const int newton_its = es_minimise_quad<1, 1>(Gh[hyp], v, (double)ss, t);
       PNEC_PHASE_END(kRpNewton);
       if (a.trace) {  // diagnostics: Newton iterations of the round's 16 hypotheses (sum, max), rounds
         const double its_sum = wave_allreduce_sum((double)newton_its) * 0.25;
@@ -1282,12 +1291,8 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
         ph_clk[10] += 1;
         ph_clk[11] += (newton_its >= 50) ? 1 : 0;
       }
-      es_value_grad<1>(Gh[hyp], v, nullptr, M);
       cayley_to_rot(v, R);
       {
-        double w[3], V[9];
-        sym_eig3(M, w, V);
-        t[0] = V[0]; t[1] = V[3]; t[2] = V[6];
         // directional evidence sum t.(f1 - R f2) over the sample
         double ev = t[0] * ev1[0] + t[1] * ev1[1] + t[2] * ev1[2];
         for (int j = 0; j < ss; ++j) {
