@@ -12,7 +12,7 @@ pmc = sys.argv[5] if len(sys.argv) > 5 and os.path.exists(sys.argv[5]) else None
 note = sys.argv[6] if len(sys.argv) > 6 else ""
 R1 = {"ransac_eigensolver_kernel": 7532704, "weighted_eigensolver_kernel": 5858555, "select_kernel": 530836,
       "nec_eigensolver_kernel": 1026471, "lm_solve_kernel": 428824, "pack_kernel": 99952}
-rows = [r for r in csv.DictReader(open(os.path.join(prof, "pipe_kernel_stats.csv"))) if "pnec_hip" in r["Name"] or "anonymous" in r["Name"]]
+rows = [r for r in csv.DictReader(open(os.path.join(prof, "pipe_kernel_stats.csv"))) if ("pnec_hip" in r["Name"] or "anonymous" in r["Name"]) and "at::" not in r["Name"]]
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
 p = json.load(open(pj))
 p100 = json.load(open(pj100))
