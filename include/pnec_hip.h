@@ -52,7 +52,8 @@ typedef enum pnec_hip_status {
   PNEC_HIP_OK = 0,
   PNEC_HIP_ERR_INVALID_ARGUMENT = -1,
   PNEC_HIP_ERR_HIP_RUNTIME = -2,   /* a hip* call failed (no device, OOM, launch failure ...) */
-  PNEC_HIP_ERR_UNSUPPORTED = -3
+  PNEC_HIP_ERR_UNSUPPORTED = -3,
+  PNEC_HIP_ERR_BUSY = -4           /* streaming handle: every slot holds a ticket that has not been collected */
 } pnec_hip_status;
 
 /* residual family == which reference functor the device evaluates */
@@ -260,8 +261,9 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
  *   submit  copies the caller's reference-layout arrays (as in pnec_hip_problem_fill; offsets[n_pairs+1]
  *           with offsets[0] == 0) and start poses into a free slot and launches ONE kernel that reads
  *           them over PCIe, runs InitValues + Optimize + Result on chip and writes the result records
- *           back into the slot; returns a ticket at once.  With all slots in flight it first waits for
- *           the oldest.  Pairs beyond the register-resident geometries (> 4096 correspondences; > 2048
+ *           back into the slot; returns a ticket at once.  Up to `slots` tickets may be outstanding; with
+ *           every slot holding an uncollected ticket submit returns PNEC_HIP_ERR_BUSY (collect the oldest
+ *           with wait first: nothing is ever dropped).  Pairs beyond the register-resident geometries (> 4096 correspondences; > 2048
  *           for SYM) are staged through a batch owned by the handle instead.
  *   poll    done = 1 once the ticket's results are in host memory (never blocks).
  *   wait    blocks (polling a flag the kernel raises -- no stream synchronisation), copies the results

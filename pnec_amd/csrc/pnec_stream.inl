@@ -11,8 +11,8 @@
 //   * wait = the host polling that flag (no stream synchronisation, no copy-back);
 //   * several submits may be in flight (a micro-batching window of `slots`), and one submit may carry
 //     several pairs (one workgroup each).
-// Pairs too large for the register-resident geometries take the staged route through a persistent
-// batch of the handle (upload, pack, solve, download) -- still without allocation.
+// Pairs too large for the register-resident geometries take the staged route through a batch owned by the
+// handle (pack, solve into the slot; re-shaped to the submit's sizes, so this route does allocate).
 struct pnec_hip_stream {
   int device = 0;
   int32_t max_corr = 0;   // correspondences per submit
@@ -180,8 +180,8 @@ int pnec_hip_stream_submit(pnec_hip_stream *s, int mode, int64_t n_pairs, const 
 
   const int64_t t = s->next_ticket;
   pnec_hip_stream::Slot &sl = s->slot[(size_t)(t % s->slots)];
-  if (int rc = stream_slot_wait(s, sl)) return rc;  // the ring is full: the oldest submit finishes first
-  sl.ticket = 0;
+  if (sl.ticket != 0)  // the ring is full of results nobody has collected: dropping the oldest is not ours to decide
+    return fail(PNEC_HIP_ERR_BUSY, "every slot holds an uncollected ticket: pnec_hip_stream_wait the oldest first");
 
   // ---- stage the arguments (the caller's buffers are free again when this returns)
   char *h = sl.h_base;

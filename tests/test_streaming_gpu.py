@@ -126,6 +126,17 @@ def test_stream_argument_errors_and_ticket_rules():
         st._pairs[tk] = 1
         with pytest.raises(capi.PnecHipError, match="ticket"):   # a ticket is collected once
             st.wait(tk)
+        # a full ring is an error, not a silent drop of the oldest result: slots = 2 -> the third submit must wait
+        t1 = st.submit(capi.MODE_NEC, f1[:16], f2[:16], None, None, q, t)
+        t2 = st.submit(capi.MODE_NEC, f1[:16], f2[:16], None, None, q, t)
+        with pytest.raises(capi.PnecHipError, match="uncollected"):
+            st.submit(capi.MODE_NEC, f1[:16], f2[:16], None, None, q, t)
+        r1 = st.wait(t1)
+        t3 = st.submit(capi.MODE_NEC, f1[:16], f2[:16], None, None, q, t)
+        r2, r3 = st.wait(t2), st.wait(t3)
+        np.testing.assert_array_equal(r1.q, r.q)
+        np.testing.assert_array_equal(r2.q, r.q)
+        np.testing.assert_array_equal(r3.q, r.q)
     with pytest.raises(capi.PnecHipError):
         Stream(max_corr=0)
 
