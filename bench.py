@@ -243,15 +243,27 @@ SOLVE_KERNEL_SOURCES = ("pnec_solve_kernel.hpp", "pnec_device.hpp", "pnec_solve_
                         "pnec_solve_target.hip", "pnec_solve_host.hip", "pnec_solve_sym.hip", "Makefile")
 
 
+def _strip_comments(text: str) -> str:
+    import re
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return " ".join(text.split())
+
+
 def kernel_sources_sha256():
-    """Identity of the device code of the benchmarked kernel: sha256 over its sources and the build recipe
-    (stable across rebuilds on another box, changes with any edit that can change the kernel)."""
+    """Identity of the device code of the benchmarked kernel: sha256 over its sources (comments and layout
+    stripped), the build recipe and the one ABI struct the kernel reads (pnec_hip_options) -- stable across
+    rebuilds on another box and across edits that cannot change the kernel (comments, other ABI entries)."""
+    import re
     d = os.path.join(ROOT, "pnec_amd", "csrc")
     h = hashlib.sha256()
     for f in SOLVE_KERNEL_SOURCES:
+        text = open(os.path.join(d, f), "r").read()
         h.update(f.encode())
-        h.update(open(os.path.join(d, f), "rb").read())
-    h.update(open(os.path.join(ROOT, "include", "pnec_hip.h"), "rb").read())
+        h.update((text if f == "Makefile" else _strip_comments(text)).encode())
+    header = open(os.path.join(ROOT, "include", "pnec_hip.h"), "r").read()
+    m = re.search(r"typedef struct pnec_hip_options\s*\{.*?\}\s*pnec_hip_options;", header, flags=re.S)
+    h.update(_strip_comments(m.group(0) if m else header).encode())
     return h.hexdigest()
 
 
