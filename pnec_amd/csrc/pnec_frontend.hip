@@ -50,10 +50,13 @@ namespace pnec_hip {
 
 // -DPNEC_FRONT_DEBUG: event counters of the minimiser (diagnostics builds only; tools/build_front_variant.sh)
 #ifdef PNEC_FRONT_DEBUG
-__device__ unsigned long long g_dbg[8];
+__device__ unsigned long long g_dbg[16];
+// wavefront-level event: counted once (x4, to match the per-quad print) by the first active lane
+#define PNEC_DBG_WAVE(i) do { if ((int)threadIdx.x == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_dbg[i], 4ull); } while (0)
 #define PNEC_DBG_COUNT(i) atomicAdd(&g_dbg[i], 1ull)
 #else
 #define PNEC_DBG_COUNT(i)
+#define PNEC_DBG_WAVE(i)
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -160,6 +163,7 @@ __device__ __forceinline__ bool sym_eig3_min_rqi(const double (&M)[9], double (&
   bool settled = false;
   double mu = 0.0;
   for (int step = 0; step < 8 && !settled; ++step) {
+    PNEC_DBG_WAVE(8);                  // eigen-iteration steps as the wavefront executes them
     const double mx = m00 * ex + m01 * ey + m02 * ez;
     const double my = m01 * ex + m11 * ey + m12 * ez;
     const double mz = m02 * ex + m12 * ey + m22 * ez;
@@ -354,7 +358,7 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
     bool need_start = !warm;
     if (warm) { e[0] = ew[0]; e[1] = ew[1]; e[2] = ew[2]; }
     for (int attempt = 0; attempt < 2; ++attempt) {
-      if (need_start) sym_eig3_min_start(M, e);
+      if (need_start) { PNEC_DBG_WAVE(11); sym_eig3_min_start(M, e); }
       have = sym_eig3_min_rqi(M, e, lam);
       if (attempt == 0) {
         PNEC_DBG_COUNT(0);               // evaluations
@@ -587,7 +591,9 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
         double mu = 0.0;
         const double tr = fabs(H[0]) + fabs(H[4]) + fabs(H[8]);
         bool ok = false;
+        PNEC_DBG_WAVE(10);             // iteration heads as the wavefront executes them
         for (int tries = 0; tries < 40; ++tries) {
+          PNEC_DBG_WAVE(9);            // Levenberg tries as the wavefront executes them
           double Hm[9];
           for (int i = 0; i < 9; ++i) Hm[i] = H[i];
           Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
@@ -1536,7 +1542,7 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   }
 #ifdef PNEC_FRONT_DEBUG
   {
-    const unsigned long long zeros[8] = {0};
+    const unsigned long long zeros[16] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), zeros, sizeof(zeros));
   }
 #endif
@@ -1544,13 +1550,14 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   const hipError_t e = hipGetLastError();
 #ifdef PNEC_FRONT_DEBUG
   {
-    unsigned long long c[8] = {0};
+    unsigned long long c[16] = {0};
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_dbg), sizeof(c));
     const double per = 1.0 / (4.0 * (double)(n_pairs > 0 ? n_pairs : 1));  // lane counts / 4 = quads, per pair
     std::fprintf(stderr, "ransac minimiser events per pair (quads): warm_evals=%.1f jacobi_fallbacks=%.2f newton_its=%.1f "
-                 "levenberg_shifts=%.2f full_step_rejected=%.2f short_step_batches=%.2f wave_evals=%.2f wave_evals_with_fallback=%.2f\n",
-                 c[0] * per, c[1] * per, c[2] * per, c[3] * per, c[4] * per, c[5] * per, c[6] * per, c[7] * per);
+                 "levenberg_shifts=%.2f full_step_rejected=%.2f short_step_batches=%.2f wave_evals=%.2f wave_evals_with_fallback=%.2f | as executed by the wavefront: eigen_steps=%.2f levenberg_tries=%.2f heads=%.2f poly_starts=%.2f\n",
+                 c[0] * per, c[1] * per, c[2] * per, c[3] * per, c[4] * per, c[5] * per, c[6] * per, c[7] * per,
+                 c[8] * per, c[9] * per, c[10] * per, c[11] * per);
   }
 #endif
   if (a.trace) {
