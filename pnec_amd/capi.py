@@ -128,6 +128,14 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} not found: the HIP extension is not built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C pnec_amd/csrc`. "
             "There is no CPU fallback.")
+    # PyTorch ships its own HIP runtime; a process that loads the system's first (through this library) and
+    # PyTorch's afterwards ends up with two, and the second one finds no device ("hipSetDevice failed").
+    # The package hands torch tensors to this library, so PyTorch's runtime must be the one both use:
+    # load PyTorch first whenever it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.pnec_hip_abi_version.restype = C.c_int
     if L.pnec_hip_abi_version() != ABI_VERSION:

@@ -269,3 +269,22 @@ def test_fused_keypoint_ingest_is_bitwise_unscented_transform_plus_fill(mode, or
         with pytest.raises(capi.PnecHipError, match="pinhole"):   # KeyPoint::Unproject is pinhole only
             capi.check(capi.lib().pnec_hip_problem_fill_keypoints(fused._h, 0, 1, p1.ctypes.data, p2.ctypes.data, None, None,
                                                                   k9.ctypes.data, 1.0, 0, capi.MEM_HOST, None))
+
+
+def test_loading_the_library_before_torch_keeps_one_hip_runtime():
+    """`g.build(); g.smoke()` in one process loads libpnec_hip.so before anything touched torch: the binding
+    must make PyTorch's HIP runtime the process's only one (it once ended in 'hipSetDevice failed')."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from pnec_amd import capi\n"
+            "L = capi.lib()\n"
+            "import torch\n"
+            "assert torch.cuda.is_available()\n"
+            "capi.check(L.pnec_hip_selftest(0))\n"
+            "x = torch.ones(4, device='cuda:0', dtype=torch.float64)\n"
+            "print('sum', float(x.sum()))\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "sum 4.0" in out.stdout
