@@ -48,6 +48,9 @@ t_ran, (qr, tr, mask, cnt, its) = timed(lambda: batch.ransac_eigensolver(q0, see
 t_sel, sel = timed(lambda: batch.select(mask))
 t_wes, (qw, tw) = timed(lambda: sel.weighted_eigensolver(qr, tr, 1e-13, 10))
 t_ls, res = timed(lambda: sel.solve(qw, tw))
+# the product path: the whole chain as ONE call (pnec_hip_solve_pipeline; no host synchronisation between stages)
+t_one, (q_one, t_one_t) = timed(lambda: batch.solve_pipeline(q0, t0), reps=5)
+one_call_equals_stages = bool(torch.equal(q_one, res.q) and torch.equal(t_one_t, res.t))
 Rg = torch.cat([sim.generate(min(5000, B - c), N, seed=1 + c, device=dev).R_gt for c in range(0, min(B, 5000), 5000)])
 dq = res.rotation_matrices()[: Rg.shape[0]]
 err = torch.acos(((dq.transpose(-1, -2) @ Rg).diagonal(dim1=-2, dim2=-1).sum(-1).clamp(-1, 3) - 1).clamp(-2, 2) / 2).mul(180 / np.pi)
@@ -70,6 +73,8 @@ print(json.dumps({
     "gpu_ms": {"nec_es (no ransac)": t_nec * 1e3, "ransac_es": t_ran * 1e3, "inlier_extraction": t_sel * 1e3,
                "weighted_es+scf": t_wes * 1e3, "ls_refinement": t_ls * 1e3},
     "gpu_pairs_per_s_full_pipeline": B / (t_ran + t_sel + t_wes + t_ls),
+    "gpu_ms_one_call_pipeline": t_one * 1e3, "gpu_pairs_per_s_one_call_pipeline": B / t_one,
+    "one_call_bitwise_equals_stage_by_stage": one_call_equals_stages,
     "mean_inliers": float(cnt.double().mean()), "mean_ransac_iterations": float(its.double().mean()),
     "median_rot_err_deg_vs_ground_truth": float(err.median()),
     "cpu_oracle_ms_per_pair_1_thread": {k: v / n_s * 1e3 for k, v in tc.items()},
