@@ -107,17 +107,21 @@ int fail_hip(hipError_t e, const char *what) {
   } while (0)
 
 // ---- device memory with a small cache --------------------------------------------------------
-// Batches come and go in pipelines (create -> select -> destroy every frame set), and hipMalloc /
-// hipFree of GB-sized buffers cost up to hundreds of ms on some boxes.  Freed blocks of >= 1 MiB are
-// kept (per device, up to PNEC_HIP_CACHE_MB, default 16384) and handed out again to requests of
-// [size/2, size]; pnec_hip_release_cache() returns them to the driver.  A block is only cached after
-// the device has drained (what hipFree does implicitly), so a new owner never races an old kernel.
+// Batches come and go in pipelines (create -> select -> destroy every frame set, or one batch per frame
+// when the odometry calls PNEC::Solve), and hipMalloc / hipFree cost tens of microseconds for a small
+// buffer and up to hundreds of ms for GB-sized ones on some boxes.  Freed blocks are kept (per device, up
+// to PNEC_HIP_CACHE_MB, default 16384, and kMaxCachedBlocks blocks) and handed out again to requests of
+// [size/2, size] -- requests below 1 MiB are rounded up to a power of two (>= 4 KiB) so that the small
+// arrays of same-shaped batches always match; pnec_hip_release_cache() returns them to the driver.  A
+// block is only cached after the device has drained (what hipFree does implicitly), so a new owner never
+// races an old kernel; a batch's destructor drains once for all of its blocks (dev_free_drained).
 struct DevBlock {
   void *ptr;
   size_t bytes;
   int device;
 };
-constexpr size_t kMinCachedBytes = 1u << 20;
+constexpr size_t kRoundBelowBytes = 1u << 20;  // requests below this are rounded up to a power of two
+constexpr size_t kMaxCachedBlocks = 4096;
 std::mutex g_mem_mutex;
 std::unordered_map<void *, DevBlock> g_live;  // every block handed out
 std::vector<DevBlock> g_cache;               // free blocks kept for reuse
@@ -147,7 +151,11 @@ void release_cache_locked(int device /* -1: all */) {
 template <typename T>
 hipError_t dev_alloc(T **out, size_t bytes) {
   *out = nullptr;
-  if (bytes == 0) bytes = 1;
+  if (bytes < kRoundBelowBytes) {
+    size_t r = 4096;
+    while (r < bytes) r <<= 1;
+    bytes = r;
+  }
   int device = 0;
   hipError_t e = hipGetDevice(&device);
   if (e != hipSuccess) return e;
@@ -177,19 +185,23 @@ hipError_t dev_alloc(T **out, size_t bytes) {
   return hipSuccess;
 }
 
-hipError_t dev_free(void *ptr) {
+// drained: the caller has synchronised the block's device since the last work that touched it
+hipError_t dev_free_impl(void *ptr, bool drained) {
   if (!ptr) return hipSuccess;
   std::lock_guard<std::mutex> lock(g_mem_mutex);
   auto it = g_live.find(ptr);
   if (it == g_live.end()) return hipFree(ptr);
   const DevBlock b = it->second;
   g_live.erase(it);
-  if (b.bytes >= kMinCachedBytes && g_cached_bytes + b.bytes <= cache_limit_bytes()) {
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    (void)hipSetDevice(b.device);
-    const hipError_t e = hipDeviceSynchronize();
-    if (prev >= 0) (void)hipSetDevice(prev);
+  if (g_cache.size() < kMaxCachedBlocks && g_cached_bytes + b.bytes <= cache_limit_bytes()) {
+    hipError_t e = hipSuccess;
+    if (!drained) {
+      int prev = -1;
+      (void)hipGetDevice(&prev);
+      (void)hipSetDevice(b.device);
+      e = hipDeviceSynchronize();
+      if (prev >= 0) (void)hipSetDevice(prev);
+    }
     if (e == hipSuccess) {
       g_cache.push_back(b);
       g_cached_bytes += b.bytes;
@@ -198,6 +210,8 @@ hipError_t dev_free(void *ptr) {
   }
   return hipFree(ptr);
 }
+hipError_t dev_free(void *ptr) { return dev_free_impl(ptr, false); }
+hipError_t dev_free_drained(void *ptr) { return dev_free_impl(ptr, true); }
 
 struct DeviceGuard {
   int prev = -1;
@@ -830,18 +844,22 @@ int pnec_hip_problem_create(int device, int mode, int64_t n_pairs, const int64_t
 int pnec_hip_problem_destroy(pnec_hip_problem *p) {
   if (!p) return 0;
   DeviceGuard guard(p->device);
+  // one drain for all of the batch's blocks (and its views'): nothing launched on them is still running
+  // when they go back to the cache
+  const bool drained = hipDeviceSynchronize() == hipSuccess;
+  auto release = [&](void *ptr) { (void)dev_free_impl(ptr, drained); };
   if (p->sel_view) pnec_hip_problem_destroy(p->sel_view);
   if (p->nec_view) pnec_hip_problem_destroy(p->nec_view);
-  if (p->d_mask) (void)dev_free(p->d_mask);
+  release(p->d_mask);
   if (p->owns_data) {
-    if (p->d_data) (void)dev_free(p->d_data);
-    if (p->d_block_offset) (void)dev_free(p->d_block_offset);
-    if (p->d_offsets) (void)dev_free(p->d_offsets);
-    if (p->d_count) (void)dev_free(p->d_count);
+    release(p->d_data);
+    release(p->d_block_offset);
+    release(p->d_offsets);
+    release(p->d_count);
   }
-  if (p->d_stage) (void)dev_free(p->d_stage);
-  if (p->d_stage_i) (void)dev_free(p->d_stage_i);
-  if (p->d_bucket_pairs) (void)dev_free(p->d_bucket_pairs);
+  release(p->d_stage);
+  release(p->d_stage_i);
+  release(p->d_bucket_pairs);
   delete p;
   return 0;
 }
