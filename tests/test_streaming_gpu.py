@@ -288,3 +288,35 @@ def test_loading_the_library_before_torch_keeps_one_hip_runtime():
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "sum 4.0" in out.stdout
+
+
+def test_pipeline_on_the_kitti_like_stream_matches_the_oracle_chain(oracle):
+    """BASELINE configs 3 / 5 data regime (forward motion, low parallax, ragged sizes) with 10 % gross
+    outliers: the one-call chain against the oracle's RANSAC -> weighted eigensolver + SCF -> refinement,
+    pair by pair: same inlier masks, same RANSAC iteration counts, rotations within the north-star tolerance
+    (tools/verify_pipeline_kitti.py runs 3 000 pairs: masks identical, max 8.4e-13 rad)"""
+    P = 24
+    offsets, f1, f2, c2, R_gt, t_gt, q0, t0 = sim.generate_kitti_like(P, mean_corr=400, seed=21)
+    gen = torch.Generator().manual_seed(3)
+    M = f1.shape[0]
+    bad = torch.rand(M, generator=gen) < 0.10
+    rnd = torch.randn(M, 3, dtype=torch.float64, generator=gen)
+    rnd[:, 2] = rnd[:, 2].abs() + 1.0
+    f2 = torch.where(bad[:, None], rnd / rnd.norm(dim=-1, keepdim=True), f2)
+    f1, f2, c2, q0, t0 = (x.numpy() for x in (f1, f2, c2, q0, t0))
+    off = np.asarray(offsets)
+    with Batch(capi.MODE_TARGET, off) as b:
+        b.fill(f1, f2, c2)
+        q, t, mask, cnt = b.solve_pipeline(q0, t0, want_inliers=True)
+        _, _, _, _, its = b.ransac_eigensolver(q0, seed=1)
+    mask = np.asarray(mask).astype(bool)
+    for p in range(P):
+        a, e = off[p], off[p + 1]
+        R0 = _quat_to_R(q0[p])
+        Rr, trr, m, it = oracle.ransac_eigensolver(f1[a:e], f2[a:e], R0, seed=1, pair_id=p)
+        np.testing.assert_array_equal(m, mask[a:e])
+        assert int(it) == int(its[p]) and int(m.sum()) == int(cnt[p])
+        Rw, tw = oracle.weighted_eigensolver(f1[a:e][m], f2[a:e][m], c2[a:e][m], Rr, trr)
+        s = oracle.solve(capi.MODE_TARGET, f1[a:e][m], f2[a:e][m], c2[a:e][m], None, 1e-13, oracle.quat_from_rot(Rw), tw,
+                         oracle.default_options())
+        assert math.radians(oracle.rotational_difference_deg(_quat_to_R(q[p]), s.R)) <= 1e-6, p
