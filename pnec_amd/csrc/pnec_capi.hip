@@ -31,14 +31,16 @@ hipError_t launch_solve_aos_mode_3(int, int, int, const SolveArgs &, hipStream_t
 // pnec_frontend.hip
 hipError_t launch_ransac_eigensolver(const double *, const int64_t *, const int64_t *, const int32_t *, int64_t,
                                      const double *, unsigned long long, int, int, double, double *, double *,
-                                     uint8_t *, int32_t *, int32_t *, hipStream_t);
+                                     uint8_t *, int32_t *, int32_t *, double *, int32_t *, hipStream_t);
 hipError_t launch_select(int, const double *, const int64_t *, const int64_t *, const int32_t *, const uint8_t *,
                          double *, const int64_t *, const int32_t *, int64_t, hipStream_t);
 hipError_t launch_nec_eigensolver(const double *, const int64_t *, const int32_t *, int64_t, const double *,
-                                  double *, double *, int32_t *, hipStream_t);
+                                  double *, double *, int32_t *, double *, int32_t *, hipStream_t);
 hipError_t launch_weighted_eigensolver(int, const double *, const int64_t *, const int32_t *, int64_t, int,
                                        const double *, const double *, double, int, double *, double *,
-                                       int32_t *, hipStream_t);
+                                       int32_t *, double *, int32_t *, hipStream_t);
+// scratch of the front stages, per pair (pnec_frontend.hip FrontScratch)
+constexpr int64_t kFrontDoublesPerPair = 43, kFrontIntsPerPair = 2;
 }  // namespace pnec_hip
 
 using namespace pnec_hip;
@@ -67,6 +69,10 @@ struct pnec_hip_problem {
   int64_t stage_doubles = 0;
   int32_t *d_stage_i = nullptr;
   int64_t stage_ints = 0;
+  // scratch of the front stages (sums, starts and results of the batched eigenvalue minimisation)
+  double *d_front = nullptr;
+  int32_t *d_front_i = nullptr;
+  int64_t front_pairs = 0;
   // ragged batches: pairs grouped by the smallest launch geometry that holds them (built lazily)
   struct Bucket {
     int cpl, wpp, ldsk;
@@ -737,6 +743,21 @@ int ensure_stage(pnec_hip_problem *p, int64_t doubles, int64_t ints) {
   return 0;
 }
 
+int ensure_front(pnec_hip_problem *p) {
+  const int64_t P = std::max<int64_t>(p->n_pairs, 1);
+  if (P > p->front_pairs) {
+    if (p->d_front) (void)dev_free(p->d_front);
+    if (p->d_front_i) (void)dev_free(p->d_front_i);
+    p->d_front = nullptr;
+    p->d_front_i = nullptr;
+    p->front_pairs = 0;
+    PNEC_HIP_TRY(dev_alloc(&p->d_front, sizeof(double) * kFrontDoublesPerPair * P));
+    PNEC_HIP_TRY(dev_alloc(&p->d_front_i, sizeof(int32_t) * kFrontIntsPerPair * P));
+    p->front_pairs = P;
+  }
+  return 0;
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -859,6 +880,8 @@ int pnec_hip_problem_destroy(pnec_hip_problem *p) {
   }
   release(p->d_stage);
   release(p->d_stage_i);
+  release(p->d_front);
+  release(p->d_front_i);
   release(p->d_bucket_pairs);
   delete p;
   return 0;
@@ -1303,11 +1326,13 @@ static int run_front_stage(pnec_hip_problem *p, bool weighted, const double *ini
     d_oq = w; w += 4 * P;
     d_ot = w;
   }
+  if (int rc = ensure_front(p)) return rc;
   hipError_t e = weighted
                      ? launch_weighted_eigensolver(p->device, p->d_data, p->d_block_offset, p->d_count, P, p->n_max, d_q,
-                                                   d_t, reg, weighted_iterations, d_oq, d_ot, nullptr, stream)
+                                                   d_t, reg, weighted_iterations, d_oq, d_ot, nullptr, p->d_front,
+                                                   p->d_front_i, stream)
                      : launch_nec_eigensolver(p->d_data, p->d_block_offset, p->d_count, P, d_q, d_oq, d_ot,
-                                              nullptr, stream);
+                                              nullptr, p->d_front, p->d_front_i, stream);
   if (e != hipSuccess) return fail_hip(e, weighted ? "weighted_eigensolver_kernel" : "nec_eigensolver_kernel");
   if (space == PNEC_HIP_MEM_HOST) {
     PNEC_HIP_TRY(hipMemcpyAsync(out_q, d_oq, sizeof(double) * 4 * P, hipMemcpyDeviceToHost, stream));
@@ -1364,9 +1389,13 @@ int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint6
       d_mask = tmp_mask;
     }
   }
+  if (int rc = ensure_front(p)) {
+    if (tmp_mask) (void)dev_free(tmp_mask);
+    return rc;
+  }
   hipError_t e = launch_ransac_eigensolver(p->d_data, p->d_block_offset, p->d_offsets, p->d_count, P, d_q, seed,
                                            max_iterations, sample_size, threshold, d_oq, d_ot, d_mask, d_cnt, d_it,
-                                           stream);
+                                           p->d_front, p->d_front_i, stream);
   if (e == hipSuccess && space == PNEC_HIP_MEM_HOST) {
     e = hipMemcpyAsync(out_q, d_oq, sizeof(double) * 4 * P, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_t, d_ot, sizeof(double) * 3 * P, hipMemcpyDeviceToHost, stream);

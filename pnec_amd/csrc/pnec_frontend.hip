@@ -641,6 +641,10 @@ struct FrontArgs {
   unsigned long long *trace;  // null, or [n_pairs, 8] clocks per phase of the weighted kernel (PNEC_HIP_TRACE_FRONT)
   double reg;
   int weighted_iterations;
+  // weighted stage: the 36 weighted sums [n_pairs,36], and the first round's eigenvalue minimisation
+  // (es_batch_kernel): its minimiser [n_pairs,3] and Newton iteration count [n_pairs]
+  const double *pre_G, *pre_v;
+  const int32_t *pre_its;
 };
 // phase clocks of the weighted kernel (diagnostics): s_memtime differences accumulated per phase
 enum : int { kPhSums = 0, kPhNewton, kPhTables, kPhSearch, kPhCost, kPhScf, kPhTotal, kPhCount = 12 };
@@ -721,11 +725,36 @@ __device__ void pass_sums36(const double *base, int n, int stride, const double 
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 }
 
-// ---- PNEC::Eigensolver, no RANSAC: rotation by eigenvalue minimisation, translation from
-// ComposeM (correspondences 1..n-1) -> TranslationFromM
-// two wavefronts per SIMD: these kernels alternate short data-parallel passes with long one-value
-// chains, and a second wavefront fills the gaps (weighted stage 6.7 -> 5.6 ms even with 32 spills)
-__global__ __launch_bounds__(kWave, 2) void nec_eigensolver_kernel(const FrontArgs a) {
+// ---- The eigenvalue minimisation of a pair is ONE chain of dependent evaluations that keeps one quad busy
+// (es_minimise_quad).  Run inside a kernel that owns a wavefront per pair, fifteen of the sixteen quads
+// repeat it redundantly -- 18 % of the weighted stage, 6 % of RANSAC, 90 % of the plain eigensolver went
+// there.  So the stages are split at that point: a wavefront per pair produces the pair's 36 sums
+// (sums36_kernel, or the RANSAC kernel's inlier pass), es_batch_kernel then minimises SIXTEEN pairs per
+// wavefront, one per quad, and the rest of the stage carries on from its result.  Per pair the arithmetic is
+// exactly what it was (same sums, same minimiser on the same lanes of a quad): the results do not change.
+struct FrontScratch {
+  double *G;        // [P,36] the sums of every pair
+  double *v0;       // [P,3]  Cayley vector the minimisation starts from
+  double *n_scale;  // [P]    number of correspondences in the sums (>= 1): scales the gradient tolerance
+  double *v;        // [P,3]  the minimiser
+  int32_t *its;     // [P]    Newton iterations taken
+  int32_t *first;   // [P]    correspondence ComposeM leaves out (C7), -1: none
+};
+// per pair: 36 + 3 + 1 + 3 doubles and 2 ints (pnec_capi.hip sizes the buffers: kFrontDoublesPerPair / kFrontIntsPerPair)
+FrontScratch front_scratch(double *d, int32_t *i, int64_t P) {
+  FrontScratch f;
+  f.G = d;
+  f.v0 = d + 36 * P;
+  f.n_scale = d + 39 * P;
+  f.v = d + 40 * P;
+  f.its = i;
+  f.first = i + P;
+  return f;
+}
+
+// 36 sums of every pair from its start rotation (WEIGHTED: and translation -- the weights of C3 / C4)
+template <bool WEIGHTED>
+__global__ __launch_bounds__(kWave) void sums36_kernel(const FrontArgs a, const FrontScratch out) {
   const int64_t pair = blockIdx.x;
   const int lane = threadIdx.x;
   const int n = a.count[pair];
@@ -737,37 +766,94 @@ __global__ __launch_bounds__(kWave, 2) void nec_eigensolver_kernel(const FrontAr
     const double qn = 1.0 / sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
     for (int k = 0; k < 4; ++k) q0[k] *= qn;
   }
-  double R[9];
-  rot_from_quat(q0, R);
-  const double t_dummy[3] = {0.0, 0.0, 1.0};
-  pass_sums36<false>(base, n, stride, R, t_dummy, 0.0, lane, G);
-  double v[3];
-  rot_to_cayley(R, v);
-  const int it = es_minimise_quad<1>(G, v, (double)(n > 0 ? n : 1));
-  double M[9];
-  es_value_grad<1>(G, v, nullptr, M);
-  cayley_to_rot(v, R);
-  if (n > 0) {  // ComposeM starts at i = 1 (C7): remove correspondence 0
-    const double f1[3] = {base[0], base[stride], base[2 * (int64_t)stride]};
-    const double f2[3] = {base[3 * (int64_t)stride], base[4 * (int64_t)stride], base[5 * (int64_t)stride]};
-    const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
-                         R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
-    const double nn[3] = {f1[1] * u[2] - f1[2] * u[1], f1[2] * u[0] - f1[0] * u[2], f1[0] * u[1] - f1[1] * u[0]};
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) M[3 * r + c] -= nn[r] * nn[c];
+  double R0[9];
+  rot_from_quat(q0, R0);
+  double t0[3] = {0.0, 0.0, 1.0};
+  if constexpr (WEIGHTED) {
+    t0[0] = a.init_t[3 * pair]; t0[1] = a.init_t[3 * pair + 1]; t0[2] = a.init_t[3 * pair + 2];
   }
-  double w[3], V[9];
-  sym_eig3(M, w, V);
+  pass_sums36<WEIGHTED>(base, n, stride, R0, t0, WEIGHTED ? a.reg : 0.0, lane, G);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < 36) out.G[36 * pair + lane] = G[lane];
   if (lane == 0) {
-    double qo[4];
-    quat_from_rot_dev(R, qo);
-    const double qn = 1.0 / sqrt(qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3]);
-    for (int k = 0; k < 4; ++k) a.out_q[4 * pair + k] = qo[k] * qn;
-    const double tn = 1.0 / sqrt(V[0] * V[0] + V[3] * V[3] + V[6] * V[6]);
-    a.out_t[3 * pair + 0] = V[0] * tn;
-    a.out_t[3 * pair + 1] = V[3] * tn;
-    a.out_t[3 * pair + 2] = V[6] * tn;
-    if (a.out_iterations) a.out_iterations[pair] = it;
+    double v[3];
+    rot_to_cayley(R0, v);
+    out.v0[3 * pair] = v[0]; out.v0[3 * pair + 1] = v[1]; out.v0[3 * pair + 2] = v[2];
+    out.n_scale[pair] = (double)(n > 0 ? n : 1);
+    out.first[pair] = n > 0 ? 0 : -1;  // ComposeM starts at i = 1 (C7)
+  }
+}
+
+struct EsBatchArgs {
+  FrontScratch s;
+  int64_t n_pairs;
+  // translation epilogue (PNEC::Eigensolver's tail: ComposeM without correspondence `first`, TranslationFromM)
+  const double *data;
+  const int64_t *block_offset;
+  const int32_t *count;
+  double *out_q, *out_t;
+  int32_t *out_iterations;  // Newton iterations, or null
+};
+constexpr int kEpiNone = 0, kEpiTranslation = 1;
+static unsigned es_batch_blocks(int64_t n_pairs) { return (unsigned)((n_pairs + 15) / 16); }
+
+// sixteen pairs per wavefront, one per quad: minimise lambda_min(M(R)) from v0; kEpiTranslation: then the
+// rotation as a quaternion and the translation = eigenvector of the smallest eigenvalue of M without the
+// correspondence ComposeM skips
+template <int EPI>
+__global__ __launch_bounds__(kWave, 2) void es_batch_kernel(const EsBatchArgs a) {
+  const int lane = threadIdx.x;
+  const int quad = lane >> 2;
+  __shared__ double Gs[16][36];
+  const int64_t first_pair = 16 * (int64_t)blockIdx.x;
+  for (int i = lane; i < 16 * 36; i += kWave) {
+    int64_t p = first_pair + i / 36;
+    p = p < a.n_pairs ? p : a.n_pairs - 1;  // the last wavefront's spare quads repeat the last pair (and write nothing)
+    Gs[i / 36][i % 36] = a.s.G[36 * p + i % 36];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const bool mine = first_pair + quad < a.n_pairs;
+  const int64_t pair = mine ? first_pair + quad : a.n_pairs - 1;
+  double v[3] = {a.s.v0[3 * pair], a.s.v0[3 * pair + 1], a.s.v0[3 * pair + 2]};
+  const int it = es_minimise_quad<1, 2>(Gs[quad], v, a.s.n_scale[pair]);
+  if constexpr (EPI == kEpiNone) {
+    if (mine && (lane & 3) == 0) {
+      a.s.v[3 * pair] = v[0]; a.s.v[3 * pair + 1] = v[1]; a.s.v[3 * pair + 2] = v[2];
+      a.s.its[pair] = it;
+    }
+  } else {
+    double M[9], R[9];
+    es_value_grad<1>(Gs[quad], v, nullptr, M);
+    cayley_to_rot(v, R);
+    const int f = a.s.first[pair];
+    if (f >= 0) {
+      const int n = a.count[pair];
+      const int stride = (n + kWave - 1) & ~(kWave - 1);
+      const double *base = a.data + a.block_offset[pair];
+      const double f1[3] = {base[f], base[(int64_t)stride + f], base[(int64_t)2 * stride + f]};
+      const double f2[3] = {base[(int64_t)3 * stride + f], base[(int64_t)4 * stride + f], base[(int64_t)5 * stride + f]};
+      const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
+                           R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
+      const double nn[3] = {f1[1] * u[2] - f1[2] * u[1], f1[2] * u[0] - f1[0] * u[2], f1[0] * u[1] - f1[1] * u[0]};
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) M[3 * r + c] -= nn[r] * nn[c];
+    }
+    double w[3], V[9];
+    sym_eig3(M, w, V);
+    if (mine && (lane & 3) == 0) {
+      double qo[4];
+      quat_from_rot_dev(R, qo);
+      const double qn = 1.0 / sqrt(qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3]);
+      for (int k = 0; k < 4; ++k) a.out_q[4 * pair + k] = qo[k] * qn;
+      const double tn = 1.0 / sqrt(V[0] * V[0] + V[3] * V[3] + V[6] * V[6]);
+      a.out_t[3 * pair + 0] = V[0] * tn;
+      a.out_t[3 * pair + 1] = V[3] * tn;
+      a.out_t[3 * pair + 2] = V[6] * tn;
+      if (a.out_iterations) a.out_iterations[pair] = it;
+    }
   }
 }
 
@@ -856,8 +942,13 @@ __global__ __launch_bounds__(kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigen
   unsigned long long ph_clk[kPhCount] = {0};
   const unsigned long long ph_start = a.trace ? __builtin_amdgcn_s_memtime() : 0ull;
   PNEC_PHASE_BEGIN();
-  // weights come from the INITIAL pose in every iteration (C3): the 36 weighted sums never change
-  pass_sums36<true>(base, n, stride, R0, t0, a.reg, lane, G);
+  // weights come from the INITIAL pose in every iteration (C3): the 36 weighted sums never change -- they
+  // were made by sums36_kernel<true> (the first round's minimisation, es_batch_kernel, needed them first);
+  // here they are only read again if a later round has to minimise once more
+  if (lane < 36) G[lane] = a.pre_G[36 * pair + lane];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   PNEC_PHASE_END(kPhSums);
 
   constexpr int KR = RES ? 8 : 1;
@@ -891,7 +982,12 @@ __global__ __launch_bounds__(kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigen
     // final and later rounds only redo the translation (newton = 0: "did not move").
     int newton = 0;
     if constexpr (WITH_ES) {
-      newton = es_minimise_quad<1>(G, v, (double)(n > 0 ? n : 1));
+      if (it == 0) {  // the first round's call ran in es_batch_kernel (sixteen pairs per wavefront)
+        v[0] = a.pre_v[3 * pair]; v[1] = a.pre_v[3 * pair + 1]; v[2] = a.pre_v[3 * pair + 2];
+        newton = a.pre_its[pair];
+      } else {
+        newton = es_minimise_quad<1>(G, v, (double)(n > 0 ? n : 1));
+      }
       rotation_final = newton < 50;
     }
     if (it == 0) first_iterations = newton;
@@ -1151,6 +1247,7 @@ struct RansacArgs {
   int64_t n_pairs;
   int max_iterations, sample_size;
   double threshold;
+  FrontScratch scratch;  // what es_batch_kernel needs to finish the pair (sums of the inliers, start, first inlier)
 };
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
@@ -1424,35 +1521,16 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   PNEC_PHASE_END(kRpInliers);
-  // optimizeModelCoefficients: eigensolver on the inliers from the best model's rotation
-  double v[3], R[9], M[9];
-  rot_to_cayley(bR, v);
-  es_minimise_quad<1, 1>(G, v, (double)(total > 0 ? total : 1));
-  PNEC_PHASE_END(kRpFinal);
-  es_value_grad<1>(G, v, nullptr, M);
-  cayley_to_rot(v, R);
-  if (total > 0) {
-    const int idx = first;
-    const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
-    const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
-                          base[(int64_t)5 * stride + idx]};
-    const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
-                         R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
-    const double nn[3] = {f1[1] * u[2] - f1[2] * u[1], f1[2] * u[0] - f1[0] * u[2], f1[0] * u[1] - f1[1] * u[0]};
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) M[3 * r + c] -= nn[r] * nn[c];
-  }
-  double w3[3], V[9];
-  sym_eig3(M, w3, V);
+  // optimizeModelCoefficients -- the eigensolver on the inliers from the best model's rotation, ComposeM
+  // without the first inlier, TranslationFromM -- runs in es_batch_kernel<kEpiTranslation>, sixteen pairs per
+  // wavefront: hand it the inliers' sums, the start, the count and the first inlier
+  if (lane < 36) a.scratch.G[36 * pair + lane] = G[lane];
   if (lane == 0) {
-    double qo[4];
-    quat_from_rot_dev(R, qo);
-    const double qn = 1.0 / sqrt(qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3]);
-    for (int k = 0; k < 4; ++k) a.out_q[4 * pair + k] = qo[k] * qn;
-    const double tn = 1.0 / sqrt(V[0] * V[0] + V[3] * V[3] + V[6] * V[6]);
-    a.out_t[3 * pair + 0] = V[0] * tn;
-    a.out_t[3 * pair + 1] = V[3] * tn;
-    a.out_t[3 * pair + 2] = V[6] * tn;
+    double v[3];
+    rot_to_cayley(bR, v);
+    a.scratch.v0[3 * pair] = v[0]; a.scratch.v0[3 * pair + 1] = v[1]; a.scratch.v0[3 * pair + 2] = v[2];
+    a.scratch.n_scale[pair] = (double)(total > 0 ? total : 1);
+    a.scratch.first[pair] = total > 0 ? first : -1;
     if (a.out_count) a.out_count[pair] = total;
     if (a.out_iterations) a.out_iterations[pair] = it;
     if (a.trace) {
@@ -1517,9 +1595,12 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
                                      const int32_t *count, int64_t n_pairs, const double *init_q,
                                      unsigned long long seed, int max_iterations, int sample_size,
                                      double threshold, double *out_q, double *out_t, uint8_t *out_mask,
-                                     int32_t *out_count, int32_t *out_iterations, hipStream_t stream) {
+                                     int32_t *out_count, int32_t *out_iterations, double *scratch_d,
+                                     int32_t *scratch_i, hipStream_t stream) {
+  if (n_pairs <= 0) return hipSuccess;
   RansacArgs a;
   std::memset(&a, 0, sizeof(a));
+  a.scratch = front_scratch(scratch_d, scratch_i, n_pairs);
   a.data = data;
   a.block_offset = block_offset;
   a.offsets = offsets;
@@ -1547,7 +1628,20 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   }
 #endif
   hipLaunchKernelGGL(ransac_eigensolver_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
-  const hipError_t e = hipGetLastError();
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) {
+    EsBatchArgs b;
+    std::memset(&b, 0, sizeof(b));
+    b.s = a.scratch;
+    b.n_pairs = n_pairs;
+    b.data = data;
+    b.block_offset = block_offset;
+    b.count = count;
+    b.out_q = out_q;
+    b.out_t = out_t;
+    hipLaunchKernelGGL(es_batch_kernel<kEpiTranslation>, dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, stream, b);
+    e = hipGetLastError();
+  }
 #ifdef PNEC_FRONT_DEBUG
   {
     unsigned long long c[16] = {0};
@@ -1614,19 +1708,33 @@ hipError_t fibonacci_table(int device) {
   return hipSuccess;
 }
 
+// scratch_d: kFrontScratchDoubles * n_pairs doubles, scratch_i: kFrontScratchInts * n_pairs ints (device)
 hipError_t launch_nec_eigensolver(const double *data, const int64_t *block_offset, const int32_t *count,
                                   int64_t n_pairs, const double *init_q, double *out_q, double *out_t,
-                                  int32_t *out_iterations, hipStream_t stream) {
+                                  int32_t *out_iterations, double *scratch_d, int32_t *scratch_i,
+                                  hipStream_t stream) {
+  if (n_pairs <= 0) return hipSuccess;
   FrontArgs a;
   std::memset(&a, 0, sizeof(a));
   a.data = data;
   a.block_offset = block_offset;
   a.count = count;
   a.init_q = init_q;
-  a.out_q = out_q;
-  a.out_t = out_t;
-  a.out_iterations = out_iterations;
-  hipLaunchKernelGGL(nec_eigensolver_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
+  const FrontScratch sc = front_scratch(scratch_d, scratch_i, n_pairs);
+  hipLaunchKernelGGL(sums36_kernel<false>, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a, sc);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  EsBatchArgs b;
+  std::memset(&b, 0, sizeof(b));
+  b.s = sc;
+  b.n_pairs = n_pairs;
+  b.data = data;
+  b.block_offset = block_offset;
+  b.count = count;
+  b.out_q = out_q;
+  b.out_t = out_t;
+  b.out_iterations = out_iterations;
+  hipLaunchKernelGGL(es_batch_kernel<kEpiTranslation>, dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, stream, b);
   return hipGetLastError();
 }
 
@@ -1634,7 +1742,8 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
                                        const int32_t *count, int64_t n_pairs, int n_max, const double *init_q,
                                        const double *init_t, double reg, int weighted_iterations,
                                        double *out_q, double *out_t, int32_t *out_iterations,
-                                       hipStream_t stream) {
+                                       double *scratch_d, int32_t *scratch_i, hipStream_t stream) {
+  if (n_pairs <= 0) return hipSuccess;
   FrontArgs a;
   std::memset(&a, 0, sizeof(a));
   hipError_t e = fibonacci_table(device);
@@ -1649,6 +1758,21 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
   a.out_iterations = out_iterations;
   a.reg = reg;
   a.weighted_iterations = weighted_iterations;
+  // the weighted sums of every pair, then the first round's eigenvalue minimisation sixteen pairs per wavefront
+  const FrontScratch sc = front_scratch(scratch_d, scratch_i, n_pairs);
+  hipLaunchKernelGGL(sums36_kernel<true>, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a, sc);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  {
+    EsBatchArgs b;
+    std::memset(&b, 0, sizeof(b));
+    b.s = sc;
+    b.n_pairs = n_pairs;
+    hipLaunchKernelGGL(es_batch_kernel<kEpiNone>, dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, stream, b);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  a.pre_G = sc.G;
+  a.pre_v = sc.v;
+  a.pre_its = sc.its;
   // PNEC_HIP_TRACE_FRONT=1: per-phase clocks of every pair, averaged and printed to stderr (diagnostics;
   // synchronises, never set it for timed runs)
   const char *tr = std::getenv("PNEC_HIP_TRACE_FRONT");

@@ -80,6 +80,7 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
 
   // device scratch of the chain: [in_q 4P | in_t 3P | es_q 4P | es_t 3P | w_q 4P | w_t 3P | o_q 4P | o_t 3P], ints [cnt P | its P]
   if (int rc = ensure_stage(p, 28 * P, 2 * P)) return rc;
+  if (int rc = ensure_front(p)) return rc;
   double *w = p->d_stage;
   double *in_q = w; w += 4 * P;
   double *in_t = w; w += 3 * P;
@@ -109,7 +110,7 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
     }
     e = launch_ransac_eigensolver(p->d_data, p->d_block_offset, p->d_offsets, p->d_count, P, d_iq, o.ransac_seed,
                                   o.max_ransac_iterations, o.ransac_sample_size, o.ransac_threshold, es_q, es_t,
-                                  d_mask, d_cnt, nullptr, stream);
+                                  d_mask, d_cnt, nullptr, p->d_front, p->d_front_i, stream);
     if (e != hipSuccess) return fail_hip(e, "ransac_eigensolver_kernel");
     if (!p->sel_view || p->sel_view->data_doubles != p->data_doubles || p->sel_view->n_pairs != P) {
       if (p->sel_view) pnec_hip_problem_destroy(p->sel_view);
@@ -119,7 +120,8 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
     if (int rc = select_into(p, d_mask, stream, p->sel_view)) return rc;
     stage = p->sel_view;
   } else {
-    e = launch_nec_eigensolver(p->d_data, p->d_block_offset, p->d_count, P, d_iq, es_q, es_t, nullptr, stream);
+    e = launch_nec_eigensolver(p->d_data, p->d_block_offset, p->d_count, P, d_iq, es_q, es_t, nullptr, p->d_front,
+                               p->d_front_i, stream);
     if (e != hipSuccess) return fail_hip(e, "nec_eigensolver_kernel");
     if (out_inlier_count) PNEC_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * P, stream));  // inliers.clear()
   }
@@ -136,8 +138,10 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
   } else {
     const double *ci_q = d_iq, *ci_t = d_it;  // weighted_iterations_ == 0: ceres_init = initial_pose
     if (o.weighted_iterations > 1) {
+      // (the front scratch of p is free again: the RANSAC / eigensolver stage that used it is ahead on the stream)
       e = launch_weighted_eigensolver(p->device, stage->d_data, stage->d_block_offset, stage->d_count, P, stage->n_max,
-                                      es_q, es_t, o.regularization, o.weighted_iterations, w_q, w_t, nullptr, stream);
+                                      es_q, es_t, o.regularization, o.weighted_iterations, w_q, w_t, nullptr, p->d_front,
+                                      p->d_front_i, stream);
       if (e != hipSuccess) return fail_hip(e, "weighted_eigensolver_kernel");
       ci_q = w_q; ci_t = w_t;
     } else if (o.weighted_iterations == 1) {
