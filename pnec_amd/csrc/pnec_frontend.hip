@@ -17,9 +17,12 @@
 //     f, g at a point and the three finite-difference probes of the Hessian; the full Newton step is
 //     tried as such a complete evaluation (one evaluation per iteration when it passes Armijo's test),
 //     shorter steps four lengths at a time.  The smallest eigenpair of M comes from Rayleigh-quotient
-//     iteration started at the neighbouring point's eigenvector (sym_eig3_min_rqi), Jacobi as fallback;
-//   * NEC / weighted eigensolver: one wavefront per pair for the data-parallel passes, every quad
-//     running the same minimiser;
+//     iteration started at the neighbouring point's eigenvector or, without one, from the characteristic
+//     polynomial (sym_eig3_min_rqi, sym_eig3_min_start), Jacobi sweeps only as the last resort;
+//   * one minimisation per PAIR (plain / weighted eigensolver, RANSAC's eigensolver on the inliers) would
+//     keep one quad of a wavefront busy, so those stages are split there: a wavefront per pair makes the 36
+//     sums (sums36_kernel, the RANSAC kernel's inlier pass), es_batch_kernel minimises sixteen pairs per
+//     wavefront, one per quad, and the rest of the stage starts from its result;
 //   * weighted stage, pairs <= 512 correspondences: per correspondence n = f1 x R f2 and
 //     B = f1hat R Sigma R' f1hat' + reg I are built ONCE per rotation and stay in registers; the 500
 //     Fibonacci directions are pre-screened in packed single precision (table in constant memory,
@@ -1228,11 +1231,7 @@ __global__ __launch_bounds__(kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigen
 // of the midpoint triangulation, inlier if score < threshold, adaptive bound
 // k = log(1 - 0.99) / log(1 - w^s), eigensolver re-run on the inliers; rand() replaced by a
 // counter-based hash of (seed, pair, hypothesis, draw)) ------------------------------------------
-// One 16-lane quarter of a wavefront per pair, ONE LANE PER HYPOTHESIS: a round evaluates 16
-// hypotheses of each of the wavefront's 4 pairs at once (sample, 36 sums of the sample, damped
-// Newton, translation, inlier count over all correspondences with quarter-uniform payload reads),
-// then the lanes are scanned in hypothesis order with the sequential rule (strictly better count
-// wins, adaptive bound k) so the outcome equals the sequential loop.
+// (kernel shape: see ransac_eigensolver_kernel below)
 struct RansacArgs {
   const double *data;
   const int64_t *block_offset;
