@@ -1289,6 +1289,12 @@ __device__ __forceinline__ double reprojection_score(const double (&f1)[3], cons
 constexpr int kHypPerRound = 16;  // hypotheses evaluated per round = quads per wavefront
 enum : int { kRpSample = 0, kRpNewton, kRpModel, kRpScore, kRpConsume, kRpInliers, kRpFinal, kRpTotal };
 
+// sum over the four lanes of a quad, every lane ends with it (two DPP butterflies; the same bits in all four)
+__device__ __forceinline__ double quad_sum(double x) {
+  x += dpp_perm<0xB1>(x);  // quad_perm [1,0,3,2]
+  x += dpp_perm<0x4E>(x);  // quad_perm [2,3,0,1]
+  return x;
+}
 __device__ __forceinline__ int quad_sum_int(int x) {
   x += __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
   x += __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
@@ -1355,9 +1361,11 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
       }
       double ev1[3] = {0, 0, 0};  // sum f1 (for the directional evidence)
       {
+        // the four lanes of the quad split the sample (each gather is a round trip to memory: 3 in sequence
+        // instead of 10) and add their shares up
         double Gl[36];
         for (int i = 0; i < 36; ++i) Gl[i] = 0.0;
-        for (int j = 0; j < ss; ++j) {
+        for (int j = role; j < ss; j += 4) {
           const int idx = sel(j);
           const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
           const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
@@ -1368,6 +1376,10 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
             for (int ac = 0; ac < 6; ++ac) Gl[6 * kl + ac] += p[kl] * qq[ac];
           for (int c = 0; c < 3; ++c) ev1[c] += f1[c];
         }
+#pragma unroll
+        for (int i = 0; i < 36; ++i) Gl[i] = quad_sum(Gl[i]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ev1[c] = quad_sum(ev1[c]);
         if (role == 0) {
 #pragma unroll
           for (int i = 0; i < 36; ++i) Gh[hyp][i] = Gl[i];
@@ -1396,8 +1408,8 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
       cayley_to_rot(v, R);
       {
         // directional evidence sum t.(f1 - R f2) over the sample
-        double ev = t[0] * ev1[0] + t[1] * ev1[1] + t[2] * ev1[2];
-        for (int j = 0; j < ss; ++j) {
+        double ev = 0.0;
+        for (int j = role; j < ss; j += 4) {
           const int idx = sel(j);
           const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
                                 base[(int64_t)5 * stride + idx]};
@@ -1405,6 +1417,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
                                R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
           ev -= t[0] * u[0] + t[1] * u[1] + t[2] * u[2];
         }
+        ev = (t[0] * ev1[0] + t[1] * ev1[1] + t[2] * ev1[2]) + quad_sum(ev);
         if (ev < 0.0) { t[0] = -t[0]; t[1] = -t[1]; t[2] = -t[2]; }
       }
       PNEC_PHASE_END(kRpModel);
