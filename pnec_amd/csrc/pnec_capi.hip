@@ -64,6 +64,7 @@ struct pnec_hip_problem {
   int64_t *d_block_offset = nullptr;  // [n_pairs]
   int64_t *d_offsets = nullptr;       // [n_pairs+1] AoS offsets (ingest only)
   int32_t *d_count = nullptr;         // [n_pairs]
+  void *d_meta = nullptr;             // pnec_hip_problem_create: ONE block holding the three arrays above (one upload)
   // staging for host-space solves (grown on demand, reused)
   double *d_stage = nullptr;
   int64_t stage_doubles = 0;
@@ -712,6 +713,10 @@ int ensure_buckets(pnec_hip_problem *p) {
     buckets.push_back(bk);
     flat.insert(flat.end(), lists[(size_t)b].begin(), lists[(size_t)b].end());
   }
+  if (buckets.size() == 1) {  // one geometry serves every pair: the launch indexes pairs directly, no table
+    p->buckets = std::move(buckets);
+    return 0;
+  }
   int32_t *d_pairs = nullptr;
   PNEC_HIP_TRY(dev_alloc(&d_pairs, sizeof(int32_t) * flat.size()));
   const hipError_t e = hipMemcpy(d_pairs, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice);
@@ -841,23 +846,24 @@ int pnec_hip_problem_create(int device, int mode, int64_t n_pairs, const int64_t
   hipError_t e;
   if ((e = dev_alloc(&p->d_data, sizeof(double) * std::max<int64_t>(total, 1))) != hipSuccess)
     return cleanup(e, "hipMalloc(data)");
-  if ((e = dev_alloc(&p->d_block_offset, sizeof(int64_t) * std::max<int64_t>(n_pairs, 1))) != hipSuccess)
-    return cleanup(e, "hipMalloc(block_offset)");
-  if ((e = dev_alloc(&p->d_offsets, sizeof(int64_t) * (n_pairs + 1))) != hipSuccess)
-    return cleanup(e, "hipMalloc(offsets)");
-  if ((e = dev_alloc(&p->d_count, sizeof(int32_t) * std::max<int64_t>(n_pairs, 1))) != hipSuccess)
-    return cleanup(e, "hipMalloc(count)");
-  if (n_pairs > 0) {
-    if ((e = hipMemcpy(p->d_block_offset, block_offset.data(), sizeof(int64_t) * n_pairs,
-                       hipMemcpyHostToDevice)) != hipSuccess)
-      return cleanup(e, "hipMemcpy(block_offset)");
-    if ((e = hipMemcpy(p->d_count, count.data(), sizeof(int32_t) * n_pairs,
-                       hipMemcpyHostToDevice)) != hipSuccess)
-      return cleanup(e, "hipMemcpy(count)");
+  {
+    // block_offset [P] | offsets [P+1] | count [P] in one device block, filled by one copy (a batch per frame
+    // pays every blocking copy in full: three of them were a tenth of the one-pair PNEC::Solve)
+    const size_t P1 = (size_t)std::max<int64_t>(n_pairs, 1);
+    const size_t words = P1 + (size_t)(n_pairs + 1);  // int64 entries
+    std::vector<int64_t> meta(words + (P1 + 1) / 2, 0);
+    std::copy(block_offset.begin(), block_offset.end(), meta.begin());
+    std::copy(offsets, offsets + n_pairs + 1, meta.begin() + (ptrdiff_t)P1);
+    std::memcpy(meta.data() + words, count.data(), sizeof(int32_t) * count.size());
+    int64_t *d_meta = nullptr;
+    if ((e = dev_alloc(&d_meta, sizeof(int64_t) * meta.size())) != hipSuccess) return cleanup(e, "hipMalloc(meta)");
+    p->d_meta = d_meta;
+    p->d_block_offset = d_meta;
+    p->d_offsets = d_meta + P1;
+    p->d_count = reinterpret_cast<int32_t *>(d_meta + words);
+    if ((e = hipMemcpy(d_meta, meta.data(), sizeof(int64_t) * meta.size(), hipMemcpyHostToDevice)) != hipSuccess)
+      return cleanup(e, "hipMemcpy(meta)");
   }
-  if ((e = hipMemcpy(p->d_offsets, offsets, sizeof(int64_t) * (n_pairs + 1),
-                     hipMemcpyHostToDevice)) != hipSuccess)
-    return cleanup(e, "hipMemcpy(offsets)");
   *out = p;
   return 0;
 }
@@ -874,9 +880,13 @@ int pnec_hip_problem_destroy(pnec_hip_problem *p) {
   release(p->d_mask);
   if (p->owns_data) {
     release(p->d_data);
-    release(p->d_block_offset);
-    release(p->d_offsets);
-    release(p->d_count);
+    if (p->d_meta) {
+      release(p->d_meta);
+    } else {
+      release(p->d_block_offset);
+      release(p->d_offsets);
+      release(p->d_count);
+    }
   }
   release(p->d_stage);
   release(p->d_stage_i);
