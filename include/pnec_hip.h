@@ -300,12 +300,15 @@ int pnec_hip_describe_launch(const pnec_hip_problem *p, const pnec_hip_options *
                              int32_t *lds_corr_per_lane, int32_t *threads_per_block,
                              int32_t *resident);
 
-/* Device-side unit checks of the cross-lane reduction (DPP + v_permlane*_swap), the 5x5 Cholesky
- * and the reciprocal / reciprocal-square-root refinements.  0 = all good. */
+/* Device-side unit checks of the cross-lane reduction (DPP + v_permlane*_swap), the 5x5 Cholesky,
+ * the reciprocal / reciprocal-square-root refinements, the lean trigonometry and the front stages'
+ * smallest-eigenpair route (characteristic-polynomial start + Rayleigh-quotient iteration against the
+ * Jacobi sweeps, on generic, nearly degenerate, rank-deficient and badly scaled matrices).  0 = all good. */
 int pnec_hip_selftest(int device);
 
-/* The library keeps freed device buffers of >= 1 MiB for reuse (batches are created and destroyed
- * per frame set in a pipeline; hipMalloc/hipFree of GB-sized buffers are slow).  Cap: environment
+/* The library keeps freed device buffers for reuse (batches are created and destroyed per frame or per
+ * frame set in a pipeline; hipMalloc/hipFree cost tens of microseconds for small buffers and far more for
+ * GB-sized ones).  Cap: environment
  * variable PNEC_HIP_CACHE_MB (default 16384, 0 disables).  This call returns the cached buffers
  * of `device` (-1: all devices) to the driver; returns the number of bytes released. */
 int64_t pnec_hip_release_cache(int device);

@@ -39,6 +39,7 @@ hipError_t launch_nec_eigensolver(const double *, const int64_t *, const int32_t
 hipError_t launch_weighted_eigensolver(int, const double *, const int64_t *, const int32_t *, int64_t, int,
                                        const double *, const double *, double, int, double *, double *,
                                        int32_t *, double *, int32_t *, hipStream_t);
+hipError_t launch_frontend_selftest(double *, hipStream_t);
 // scratch of the front stages, per pair (pnec_frontend.hip FrontScratch)
 constexpr int64_t kFrontDoublesPerPair = 43, kFrontIntsPerPair = 2;
 }  // namespace pnec_hip
@@ -1566,6 +1567,26 @@ int pnec_hip_unscented_transform(int64_t n, const double *mu, const double *covs
 int pnec_hip_selftest(int device) {
   DeviceGuard guard(device);
   if (!guard.ok) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "hipSetDevice failed");
+  {  // the front stages' smallest-eigenpair route against the Jacobi sweeps
+    double *d = nullptr;
+    PNEC_HIP_TRY(dev_alloc(&d, sizeof(double) * 192));
+    double h[192];
+    hipError_t e = launch_frontend_selftest(d, 0);
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)dev_free(d);
+    if (e != hipSuccess) return fail_hip(e, "eig_selftest_kernel");
+    for (int i = 0; i < kWave; ++i) {
+      char buf[160];
+      if (!(h[i] < 1e-14)) {
+        std::snprintf(buf, sizeof(buf), "smallest eigenpair: residual %.3g |M| in lane %d", h[i], i);
+        return fail(PNEC_HIP_ERR_HIP_RUNTIME, buf);
+      }
+      if (!(h[64 + i] < 1e-14)) {
+        std::snprintf(buf, sizeof(buf), "smallest eigenpair: eigenvalue %.3g |M| above the sweeps' smallest in lane %d", h[64 + i], i);
+        return fail(PNEC_HIP_ERR_HIP_RUNTIME, buf);
+      }
+    }
+  }
   double *d = nullptr;
   PNEC_HIP_TRY(dev_alloc(&d, sizeof(double) * 224));
   hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(kWave), 0, 0, d);

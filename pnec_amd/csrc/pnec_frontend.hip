@@ -197,6 +197,11 @@ __device__ __forceinline__ bool sym_eig3_min_rqi(const double (&M)[9], double (&
   const double dp = (3.0 * lambda - 2.0 * tr) * lambda + c2;
   const double tol = 1e-12 * tr * tr;
   if (!(dp >= -tol) || !(tr - 3.0 * lambda >= 0.0)) return false;
+  // and it must BE an eigenpair: with a (nearly) double smallest eigenvalue the adjugate of M - mu I is a
+  // difference of products that cancels to rounding noise, the iteration "settles" on a vector with 1e-7 of
+  // the third eigenvector in it (device self-test, kind 1), and only the residual tells
+  const double res = fmax(fabs(mx - lambda * ex), fmax(fabs(my - lambda * ey), fabs(mz - lambda * ez)));
+  if (!(res <= 1e-13 * fabs(tr))) return false;
   e[0] = ex; e[1] = ey; e[2] = ez;
   return true;
 }
@@ -487,7 +492,7 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
   const double h = 1e-6, inv_h = 1.0 / h;
   double eb[3] = {0.0, 0.0, 1.0};  // eigenvector of the smallest eigenvalue at the current point
   double f = 0.0, g[3] = {0.0, 0.0, 0.0}, H[9], d[3] = {0.0, 0.0, 0.0};
-  double slope = 0.0, alpha = 1.0;
+  double slope = 0.0, alpha = 1.0, trace_cur = 0.0;  // trace_cur: trace of M at the current point
   int state = kInit, it = 0, ls = 0;
   bool last_eval = false;
   while (state != kDone) {
@@ -576,6 +581,7 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
       }
       if (take) {
         f = fx;
+        trace_cur = trace_x;
 #pragma unroll
         for (int i = 0; i < 3; ++i) { g[i] = gx[i]; eb[i] = ex[i]; }
 #pragma unroll
@@ -587,7 +593,20 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
     if (at_new_point) {
       // ---- head of a Newton iteration at v: converged?  else the damped Newton direction
       const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
-      if (gmax <= 1e-14 * (1.0 + fabs(f)) * n_scale) {
+#ifdef PNEC_FRONT_TRACE_ITER
+      if (threadIdx.x == 0 && blockIdx.x == 0)
+        printf("it %d f %.17g gmax %.3e trace %.3e tol %.3e floor %.3e H %.3e %.3e %.3e | %.3e %.3e %.3e\n", it, f, gmax, trace_cur,
+               1e-14 * (1.0 + fabs(f)) * n_scale, 8.9e-16 * trace_cur, H[0], H[4], H[8], H[1], H[2], H[5]);
+#endif
+      // converged: the gradient tolerance of the sequential form -- or the gradient's own noise floor when that
+      // is the larger.  g = e' dM e is composed from sums of the size of trace(M); traced on the device, what is
+      // left of it bounces at 100..300 eps trace(M) once the iteration has arrived.  For ordinary problems that
+      // is far below the tolerance (RANSAC samples: trace 0.02, floor 2.5e-15 against 1e-13; weighted pairs: trace
+      // 1..10, floor <= 1e-12 against 4.5e-12).  It decides when one correspondence's weight dwarfs the rest
+      // (trace 4e4 from a nearly singular covariance): there the gradient bounced between 7e-11 and 4e-9 with
+      // steps of 1e-11 -- too large for the step-size stop -- until the cap of 50, and again in each of the nine
+      // rounds; one such pair in 20 000 set the duration of two launches.
+      if (gmax <= fmax(1e-14 * (1.0 + fabs(f)) * n_scale, 1.1e-13 * trace_cur)) {
         state = kDone;
       } else {
         PNEC_DBG_COUNT(2);             // Newton iterations (x4 lanes)
@@ -822,6 +841,14 @@ __global__ __launch_bounds__(kWave, 2) void es_batch_kernel(const EsBatchArgs a)
   const int64_t pair = mine ? first_pair + quad : a.n_pairs - 1;
   double v[3] = {a.s.v0[3 * pair], a.s.v0[3 * pair + 1], a.s.v0[3 * pair + 2]};
   const int it = es_minimise_quad<1, 2>(Gs[quad], v, a.s.n_scale[pair]);
+#ifdef PNEC_FRONT_DEBUG
+  if (mine && (lane & 3) == 0) {
+    atomicMax(&g_dbg[12], (unsigned long long)it);
+    if (it >= 50) { atomicAdd(&g_dbg[13], 1ull); atomicExch(&g_dbg[11], (unsigned long long)pair); }
+    if (it >= 20) atomicAdd(&g_dbg[14], 1ull);
+    atomicAdd(&g_dbg[15], (unsigned long long)it);
+  }
+#endif
   if constexpr (EPI == kEpiNone) {
     if (mine && (lane & 3) == 0) {
       a.s.v[3 * pair] = v[0]; a.s.v[3 * pair + 1] = v[1]; a.s.v[3 * pair + 2] = v[2];
@@ -1684,6 +1711,68 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   return e;
 }
 
+// ---- device self-test of the smallest-eigenpair route (sym_eig3_min_start -> sym_eig3_min_rqi, sweeps as the
+// last resort) against the Jacobi sweeps, on positive semi-definite 3x3 matrices of every awkward kind:
+// generic, smallest two eigenvalues 1e-6 apart (relative), rank one, rank two, scaled by 1e-12 and 1e+12.
+// out[lane]: worst residual |M e - lambda e| / |M|, out[64 + lane]: worst (lambda - lambda_jacobi) / |M|,
+// out[128 + lane]: how often the iteration could not vouch for its result (the sweeps decided)
+__global__ void eig_selftest_kernel(double *out) {
+  const int lane = threadIdx.x;
+  unsigned long long st = 0x9E3779B97F4A7C15ull * (unsigned long long)(lane + 1);
+  auto rnd = [&]() {  // uniform in (-1, 1)
+    st = st * 6364136223846793005ull + 1442695040888963407ull;
+    return (double)(st >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+  };
+  double worst_res = 0.0, worst_lam = 0.0, undecided = 0.0;
+  for (int trial = 0; trial < 256; ++trial) {
+    // an orthonormal basis from two random vectors (Gram-Schmidt), eigenvalues by kind
+    double a[3] = {rnd(), rnd(), rnd()}, b[3] = {rnd(), rnd(), rnd()};
+    double na = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) + 1e-300;
+    for (int k = 0; k < 3; ++k) a[k] /= na;
+    const double ab = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    for (int k = 0; k < 3; ++k) b[k] -= ab * a[k];
+    double nb = sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]) + 1e-300;
+    for (int k = 0; k < 3; ++k) b[k] /= nb;
+    const double c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    const int kind = (trial + lane) % 6;
+    double l1 = 1e-5 * (1.0 + rnd() * 0.5), l2 = 1.0 + 0.5 * rnd(), l3 = 2.0 + 0.5 * rnd(), scale = 1.0;
+    if (kind == 1) l2 = l1 * (1.0 + 1e-6);       // nearly double smallest eigenvalue
+    if (kind == 2) { l1 = 0.0; l2 = 0.0; }       // rank one
+    if (kind == 3) l1 = 0.0;                     // rank two
+    if (kind == 4) scale = 1e-12;
+    if (kind == 5) scale = 1e+12;
+    double M[9];
+    for (int r = 0; r < 3; ++r)
+      for (int q = 0; q < 3; ++q) M[3 * r + q] = scale * (l1 * a[r] * a[q] + l2 * b[r] * b[q] + l3 * c[r] * c[q]);
+    double w[3], V[9];
+    sym_eig3(M, w, V);
+    double e[3] = {0.0, 0.0, 1.0}, lam = 0.0;
+    sym_eig3_min_start(M, e);
+    bool have = sym_eig3_min_rqi(M, e, lam);
+    if (!have) {
+      undecided += 1.0;
+      lam = w[0];
+      e[0] = V[0]; e[1] = V[3]; e[2] = V[6];
+    }
+    const double norm = fabs(w[2]) + fabs(w[0]) + 1e-300;
+    double res = 0.0;
+    for (int r = 0; r < 3; ++r) {
+      const double me = M[3 * r] * e[0] + M[3 * r + 1] * e[1] + M[3 * r + 2] * e[2] - lam * e[r];
+      res = fmax(res, fabs(me));
+    }
+    worst_res = fmax(worst_res, res / norm);
+    worst_lam = fmax(worst_lam, (lam - w[0]) / norm);  // must not be ABOVE the smallest eigenvalue
+  }
+  out[lane] = worst_res;
+  out[64 + lane] = worst_lam;
+  out[128 + lane] = undecided;
+}
+
+hipError_t launch_frontend_selftest(double *d_out /* 192 doubles */, hipStream_t stream) {
+  hipLaunchKernelGGL(eig_selftest_kernel, dim3(1), dim3(kWave), 0, stream, d_out);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------
 // host side: launchers called from pnec_capi.hip
 static std::mutex g_fib_mutex;
@@ -1779,8 +1868,25 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
     std::memset(&b, 0, sizeof(b));
     b.s = sc;
     b.n_pairs = n_pairs;
+#ifdef PNEC_FRONT_DEBUG
+    {
+      const unsigned long long zeros[4] = {0};
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), zeros, sizeof(zeros), 12 * sizeof(unsigned long long));
+    }
+#endif
     hipLaunchKernelGGL(es_batch_kernel<kEpiNone>, dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, stream, b);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+#ifdef PNEC_FRONT_DEBUG
+    {
+      unsigned long long c[4] = {0};
+      (void)hipStreamSynchronize(stream);
+      (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_dbg), sizeof(c), 12 * sizeof(unsigned long long));
+      unsigned long long who = 0;
+      (void)hipMemcpyFromSymbol(&who, HIP_SYMBOL(g_dbg), sizeof(who), 11 * sizeof(unsigned long long));
+      std::fprintf(stderr, "weighted stage, first minimisation of %lld pairs: max Newton iterations %llu, at the cap (50): %llu (one of them: pair %llu), >= 20: %llu, mean %.2f\n",
+                   (long long)n_pairs, c[0], c[1], who, c[2], (double)c[3] / (double)n_pairs);
+    }
+#endif
   }
   a.pre_G = sc.G;
   a.pre_v = sc.v;
