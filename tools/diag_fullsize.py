@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Scratch diagnostics of the full-size batch (round 1): per-pair iteration counts and termination codes of the
+bench workload.  Runs on the GPU box."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np

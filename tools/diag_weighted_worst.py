@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Dump the inputs and both results (device, oracle twin) of the pairs whose weighted-stage rotations differ most
+(the workload of tools/verify_frontend_literal.py) into gpurun_out/diag_worst.npz, for an off-line look at the
+objective at both rotations.  Runs on the GPU box."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
