@@ -52,6 +52,10 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # vector FP64 (256 CU x 4 SIMD x 16 lanes x 2 flop
 # flop fraction (153) and the issue-slot fraction (91 slots) are reported side by side.
 VALU_INSTR_PER_CORR_PASS = 91
 FLOP_PER_CORR_PASS = 153
+# the pass that follows the last allowed iteration only needs the candidate's cost (eval_cost<TARGET>: residual and
+# weight, no Jacobian, no normal equations): 24 FMA + 17 MUL + 1 max + 1 rsq = 43 instructions, 67 flop
+VALU_INSTR_PER_CORR_COST_PASS = 43
+FLOP_PER_CORR_COST_PASS = 67
 
 
 def parse_args(argv=None):
@@ -431,8 +435,18 @@ def run(args):
             if args.workload == "kitti_all" and my_pairs:      # ragged: weight each pair's passes by its size
                 w = torch.as_tensor(np.diff(batch.offsets), dtype=torch.float64, device=iters_done.device)
                 corr_passes = float(((iters_done + 1.0) * w).sum())
-            valu_tflops = FLOP_PER_CORR_PASS * corr_passes / (kernel_ms * 1e-3) / 1e12
-            issue_tflops_equiv = 2 * VALU_INSTR_PER_CORR_PASS * corr_passes / (kernel_ms * 1e-3) / 1e12
+            # a solve that runs into the iteration cap ends with ONE cost-only pass (fixed-count mode: every solve)
+            capped = res.status == capi.TERM_MAX_ITERATIONS
+            cost_corr = 0.0
+            if my_pairs:
+                wts = (torch.as_tensor(np.diff(batch.offsets), dtype=torch.float64, device=iters_done.device)
+                       if args.workload == "kitti_all" else
+                       torch.full_like(iters_done, batch.num_correspondences / max(my_pairs, 1)))
+                cost_corr = float((capped.to(torch.float64) * wts).sum())
+            full_corr = corr_passes - cost_corr
+            valu_tflops = (FLOP_PER_CORR_PASS * full_corr + FLOP_PER_CORR_COST_PASS * cost_corr) / (kernel_ms * 1e-3) / 1e12
+            issue_tflops_equiv = 2 * (VALU_INSTR_PER_CORR_PASS * full_corr + VALU_INSTR_PER_CORR_COST_PASS * cost_corr) \
+                / (kernel_ms * 1e-3) / 1e12
             key = [args.workload, args.pairs if args.workload == "sim100k" else sh.total_pairs,
                    args.corr if args.workload == "sim100k" else 0, args.iters if args.workload == "sim100k" else 0,
                    [launch["corr_per_lane"], launch["waves_per_pair"], launch["lds_corr_per_lane"]]]
@@ -464,7 +478,10 @@ def run(args):
                 "valu": {"bound": "valu_fp64", "achieved": valu_tflops, "peak": FP64_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": valu_tflops / FP64_VALU_PEAK_TFLOPS,
                          "flop_per_corr_pass": FLOP_PER_CORR_PASS, "passes": passes,
-                         "flop_note": "62 FMA + 28 MUL + 1 rsq per correspondence per pass = 153 flop in 91 issue slots",
+                         "cost_only_passes_per_solve": (cost_corr / batch.num_correspondences) if batch.num_correspondences else 0.0,
+                         "flop_per_corr_cost_only_pass": FLOP_PER_CORR_COST_PASS,
+                         "flop_note": "62 FMA + 28 MUL + 1 rsq per correspondence per full pass = 153 flop in 91 issue slots; "
+                                      "the cost-only pass at the iteration cap: 67 flop in 43 slots",
                          # the same work priced in issue slots (every VALU instruction = one FMA-sized slot)
                          "issue_slot_frac_useful": issue_tflops_equiv / FP64_VALU_PEAK_TFLOPS,
                          # share of cycles the vector ALU was issuing (any FP64/integer/cross-lane

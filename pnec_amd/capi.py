@@ -24,6 +24,7 @@ TERM_NAMES = {
     5: "invalid_steps",
     6: "bad_initial_point",
 }
+TERM_MAX_ITERATIONS = 3  # PNEC_HIP_TERM_MAX_ITERATIONS
 NUM_COMPONENTS = {MODE_NEC: 6, MODE_TARGET: 12, MODE_HOST: 12, MODE_SYM: 18}
 
 # every symbol include/pnec_hip.h declares (tests check the library exports all of them)
