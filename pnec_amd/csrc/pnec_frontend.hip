@@ -948,7 +948,7 @@ __device__ double obj_fun_pair(const double *base, int n, int stride, const doub
 #define PNEC_WES_WAVES_PER_SIMD 2
 #endif
 template <bool RES>
-__global__ __launch_bounds__(kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigensolver_kernel(const FrontArgs a) {
+__device__ __forceinline__ void weighted_pair(const FrontArgs &a) {
   const int64_t pair = blockIdx.x;
   const int lane = threadIdx.x;
   const int n = a.count[pair];
@@ -1250,6 +1250,21 @@ __global__ __launch_bounds__(kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigen
       for (int k = 0; k < kPhCount; ++k) a.trace[kPhCount * pair + k] = ph_clk[k];
     }
   }
+}
+
+// one wavefront per pair.  A batch whose largest pair fits the resident form runs it for every pair; a ragged
+// batch with larger pairs decides PER PAIR (wave-uniform): the KITTI-like stream (265..700 correspondences) ran
+// the streaming form for all 23 190 pairs because 40 % of them exceed 512 BEFORE the inliers are extracted --
+// 8.2 of the chain's 11.6 ms
+template <bool RES>
+__global__ __launch_bounds__(kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigensolver_kernel(const FrontArgs a) {
+  weighted_pair<RES>(a);
+}
+__global__ __launch_bounds__(kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigensolver_mixed_kernel(const FrontArgs a) {
+  if (a.count[blockIdx.x] <= 8 * kWave)
+    weighted_pair<true>(a);
+  else
+    weighted_pair<false>(a);
 }
 
 // ---- RANSAC around the eigensolver (pnec.cc:239-272; opengv::sac::Ransac<EigensolverSacProblem>
@@ -1898,10 +1913,11 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
     e = hipMalloc(&a.trace, sizeof(unsigned long long) * kPhCount * (size_t)n_pairs);
     if (e != hipSuccess) return e;
   }
+  // n_max bounds the pairs' sizes (after an inlier extraction: the source's sizes)
   if (n_max <= 8 * kWave)
     hipLaunchKernelGGL(weighted_eigensolver_kernel<true>, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
   else
-    hipLaunchKernelGGL(weighted_eigensolver_kernel<false>, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
+    hipLaunchKernelGGL(weighted_eigensolver_mixed_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
   e = hipGetLastError();
   if (a.trace) {
     std::vector<unsigned long long> h(kPhCount * (size_t)n_pairs);
