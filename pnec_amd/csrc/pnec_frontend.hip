@@ -947,16 +947,53 @@ __device__ double obj_fun_pair(const double *base, int n, int stride, const doub
 #ifndef PNEC_WES_WAVES_PER_SIMD
 #define PNEC_WES_WAVES_PER_SIMD 2
 #endif
-template <bool RES>
+// WPP = 2 (resident form only): a pair of 513..1024 correspondences on TWO wavefronts, each keeping its half's
+// tables in registers; every sum over the pair is a wavefront sum + one exchange through LDS (pair_sum below),
+// everything else runs identically in both wavefronts (same bits: both add the two partial sums in the same
+// order), so their control flow never parts and the barriers inside pair_sum are always met by both.
+template <bool RES, int WPP = 1>
 __device__ __forceinline__ void weighted_pair(const FrontArgs &a) {
+  static_assert(WPP == 1 || (RES && WPP == 2), "two wavefronts per pair exist for the resident form only");
   const int64_t pair = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  [[maybe_unused]] const int wave = threadIdx.x >> 6;
   const int n = a.count[pair];
   const int stride = (n + kWave - 1) & ~(kWave - 1);
   const double *base = a.data + a.block_offset[pair];
   __shared__ double G[36];
   __shared__ double cand[21][3];
   [[maybe_unused]] __shared__ float cost32[RES ? 512 : 1];  // single-precision costs of the 500 directions
+  [[maybe_unused]] __shared__ float cost32p[WPP == 2 ? 2 : 1][WPP == 2 ? 512 : 1];  // ... each wavefront's share of them
+  // exchange between the two wavefronts of a pair: [buffer][wavefront][value]; the buffers alternate so that a
+  // wavefront that runs ahead into the next exchange cannot overwrite what the other has yet to read
+  [[maybe_unused]] __shared__ double xch[2][WPP][8];
+  [[maybe_unused]] int xpar = 0;
+  // the block's barrier (both wavefronts) or, for one wavefront, just the LDS fence
+  auto pair_sync = [&]() {
+    if constexpr (WPP == 2) {
+      __syncthreads();
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  };
+  // sums over the whole pair of K values per lane (every lane of both wavefronts ends with the same bits)
+  auto pair_sum = [&](auto &x /* double[K] */) {
+    constexpr int K = sizeof(x) / sizeof(double);
+#pragma unroll
+    for (int k = 0; k < K; ++k) x[k] = wave_allreduce_sum(x[k]);
+    if constexpr (WPP == 2) {
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) xch[xpar][wave][k] = x[k];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < K; ++k) x[k] = xch[xpar][0][k] + xch[xpar][1][k];
+      xpar ^= 1;
+    }
+  };
   double q0[4] = {a.init_q[4 * pair], a.init_q[4 * pair + 1], a.init_q[4 * pair + 2], a.init_q[4 * pair + 3]};
   {
     const double qn = 1.0 / sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
@@ -975,10 +1012,8 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a) {
   // weights come from the INITIAL pose in every iteration (C3): the 36 weighted sums never change -- they
   // were made by sums36_kernel<true> (the first round's minimisation, es_batch_kernel, needed them first);
   // here they are only read again if a later round has to minimise once more
-  if (lane < 36) G[lane] = a.pre_G[36 * pair + lane];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < 36 && (WPP == 1 || wave == 0)) G[lane] = a.pre_G[36 * pair + lane];
+  pair_sync();
   PNEC_PHASE_END(kPhSums);
 
   constexpr int KR = RES ? 8 : 1;
@@ -1031,7 +1066,7 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a) {
       // beyond the pair), the padding entries are patched afterwards.
 #pragma unroll
       for (int k = 0; k < KR; ++k) {
-        const int idx = lane + kWave * k;
+        const int idx = (WPP == 2 ? wave * KR * kWave : 0) + lane + kWave * k;
         const bool in = idx < n;
         corr_nb(n > 0 ? base : a.data, stride, in ? idx : 0, R, a.reg, rn[k], rB[k]);
         if (!in) {  // padding: contributes exactly 0 to every sum (n = 0, B = I)
@@ -1106,11 +1141,16 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a) {
           }
           const float b0 = swap_add32_f(s4[0], s4[2]), b1 = swap_add32_f(s4[1], s4[3]);
           const float sum = row_allreduce_sum_f(swap_add16_f(b0, b1));  // row r: direction c + r
-          if ((lane & 15) == 0) cost32[c + my_row] = sum;
+          if ((lane & 15) == 0) {
+            if constexpr (WPP == 2) cost32p[wave][c + my_row] = sum;
+            else cost32[c + my_row] = sum;
+          }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (WPP == 2) {  // the two wavefronts' shares of every direction's cost, added once
+          __syncthreads();
+          for (int i = (int)threadIdx.x; i < 500; i += WPP * kWave) cost32[i] = cost32p[0][i] + cost32p[1][i];
+        }
+        pair_sync();
         float m32 = __builtin_inff();
         for (int i = lane; i < 500; i += kWave) m32 = fminf(m32, cost32[i]);  // fminf skips NaN
         m32 = wave_allreduce_min_f(m32);
@@ -1135,7 +1175,9 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a) {
                                tz * (rB[k][2] * tx + rB[k][4] * ty + rB[k][5] * tz);
               sacc = __builtin_fma(aa * aa, fast_rcp(d), sacc);
             }
-            const double cost = wave_allreduce_sum(sacc);
+            double cs[1] = {sacc};
+            pair_sum(cs);
+            const double cost = cs[0];
             if (fib_min_idx < 0 || cost < fib_min_cost) {  // candidates come in index order: ties keep the first
               fib_min_cost = cost;
               fib_min_idx = c;
@@ -1177,7 +1219,11 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a) {
                        t[2] * (B[2] * t[0] + B[4] * t[1] + B[5] * t[2]);
       cur_cost = __builtin_fma(aa * aa, fast_rcp(d), cur_cost);
     });
-    cur_cost = wave_allreduce_sum(cur_cost);
+    {
+      double cs[1] = {cur_cost};
+      pair_sum(cs);
+      cur_cost = cs[0];
+    }
     if (fib_min_idx >= 0 && fib_min_cost < cur_cost) {
       t[0] = c_fib[kFibStride * fib_min_idx];
       t[1] = c_fib[kFibStride * fib_min_idx + 1];
@@ -1194,8 +1240,7 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a) {
         e[0] += w * nn[0] * nn[0]; e[1] += w * nn[0] * nn[1]; e[2] += w * nn[0] * nn[2];
         e[3] += w * nn[1] * nn[1]; e[4] += w * nn[1] * nn[2]; e[5] += w * nn[2] * nn[2];
       });
-#pragma unroll
-      for (int k = 0; k < 6; ++k) e[k] = wave_allreduce_sum(e[k]);
+      pair_sum(e);
       const double E[9] = {e[0], e[1], e[2], e[1], e[3], e[4], e[2], e[4], e[5]};
       // smallest eigenvector of E: Rayleigh-quotient iteration from the current t (the iteration is
       // near its fixed point after the first step or two), Jacobi sweeps when that cannot be vouched for
@@ -1238,7 +1283,7 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a) {
       if (unchanged) break;
     }
   }
-  if (lane == 0) {
+  if (lane == 0 && (WPP == 1 || wave == 0)) {
     double qo[4];
     quat_from_rot_dev(R, qo);
     const double qn = 1.0 / sqrt(qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3]);
@@ -1252,19 +1297,25 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a) {
   }
 }
 
-// one wavefront per pair.  A batch whose largest pair fits the resident form runs it for every pair; a ragged
-// batch with larger pairs decides PER PAIR (wave-uniform): the KITTI-like stream (265..700 correspondences) ran
-// the streaming form for all 23 190 pairs because 40 % of them exceed 512 BEFORE the inliers are extracted --
-// 8.2 of the chain's 11.6 ms
+// A batch whose largest pair fits the resident form runs it for every pair, one wavefront per pair.  A ragged
+// batch with larger pairs decides PER PAIR (the KITTI-like stream, 265..700 correspondences, ran the streaming form
+// for all 23 190 pairs because 40 % of them exceed 512 BEFORE the inliers are extracted -- 8.2 of the chain's
+// 11.6 ms): two wavefronts per block; <= 512 correspondences: the resident form on the first, the second leaves;
+// 513..1024: the resident form on both (WPP = 2); more: the streaming form on the first.
 template <bool RES>
 __global__ __launch_bounds__(kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigensolver_kernel(const FrontArgs a) {
   weighted_pair<RES>(a);
 }
-__global__ __launch_bounds__(kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigensolver_mixed_kernel(const FrontArgs a) {
-  if (a.count[blockIdx.x] <= 8 * kWave)
-    weighted_pair<true>(a);
-  else
-    weighted_pair<false>(a);
+__global__ __launch_bounds__(2 * kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigensolver_mixed_kernel(const FrontArgs a) {
+  const int n = a.count[blockIdx.x];
+  const bool first = threadIdx.x < kWave;
+  if (n <= 8 * kWave) {
+    if (first) weighted_pair<true>(a);
+  } else if (n <= 16 * kWave) {
+    weighted_pair<true, 2>(a);
+  } else {
+    if (first) weighted_pair<false>(a);
+  }
 }
 
 // ---- RANSAC around the eigensolver (pnec.cc:239-272; opengv::sac::Ransac<EigensolverSacProblem>
@@ -1917,7 +1968,7 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
   if (n_max <= 8 * kWave)
     hipLaunchKernelGGL(weighted_eigensolver_kernel<true>, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
   else
-    hipLaunchKernelGGL(weighted_eigensolver_mixed_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
+    hipLaunchKernelGGL(weighted_eigensolver_mixed_kernel, dim3((unsigned)n_pairs), dim3(2 * kWave), 0, stream, a);
   e = hipGetLastError();
   if (a.trace) {
     std::vector<unsigned long long> h(kPhCount * (size_t)n_pairs);

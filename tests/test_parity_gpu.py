@@ -519,6 +519,31 @@ def test_weighted_eigensolver_device_vs_oracle(oracle):
         assert _rot_err(oracle, _quat_to_R(res.q[p].cpu().numpy()), g.R_gt[p].numpy()) < 0.01
 
 
+def test_weighted_eigensolver_ragged_batch_forms_device_vs_oracle(oracle):
+    """a ragged batch picks the weighted stage's form PER PAIR: <= 512 correspondences resident on one wavefront,
+    513..1024 resident on two (every sum exchanged between them), more streaming -- all three against the
+    literal oracle and its early-exit twin, in one launch"""
+    sizes = [300, 512, 513, 640, 1000, 1024, 1025, 1500]
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    g = sim.generate(len(sizes), max(sizes), seed=97)
+    f1 = np.concatenate([g.bvs1[p].numpy()[:n] for p, n in enumerate(sizes)])
+    f2 = np.concatenate([g.bvs2[p].numpy()[:n] for p, n in enumerate(sizes)])
+    c2 = np.concatenate([g.covs2[p].numpy()[:n] for p, n in enumerate(sizes)])
+    with Batch(capi.MODE_TARGET, offsets) as b:
+        b.fill(f1, f2, c2)
+        qn, tn = b.nec_eigensolver(g.init_q.numpy())
+        qw, tw = b.weighted_eigensolver(qn, tn, 1e-13, 10)
+    for p, n in enumerate(sizes):
+        sl = slice(offsets[p], offsets[p + 1])
+        Rn = _quat_to_R(qn[p])
+        Ro, to = oracle.weighted_eigensolver(f1[sl], f2[sl], c2[sl], Rn, tn[p], 1e-13, 10)
+        assert _rot_err(oracle, _quat_to_R(qw[p]), Ro) <= WEIGHTED_EARLY_EXIT_BOUND, (n, "literal")
+        assert abs(abs(tw[p] @ to) - 1) < 1e-8, n
+        Rt, tt = oracle.weighted_eigensolver(f1[sl], f2[sl], c2[sl], Rn, tn[p], 1e-13, 10, device_early_exits=True)
+        assert _rot_err(oracle, _quat_to_R(qw[p]), Rt) <= 1e-8, (n, "twin")
+        assert abs(abs(tw[p] @ tt) - 1) < 1e-8, n
+
+
 def test_ransac_eigensolver_and_inlier_selection_device_vs_oracle(oracle):
     """SURVEY 8f row 2 with RANSAC (pnec.cc:239-272) + InlierExtraction (pnec.cc:210-229): same
     counter-based draws on both sides -> same inlier sets, same rotations"""
