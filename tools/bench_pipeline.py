@@ -16,7 +16,7 @@ from pnec_amd import Batch, capi
 from pnec_amd import simulation as sim
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-N = 512
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 dev = torch.device("cuda:0")
 batch = Batch.uniform(capi.MODE_TARGET, B, N)
 qs, ts, first = [], [], None
