@@ -125,6 +125,7 @@ constexpr int kUnif = 18;   // pass uniforms of the candidate: R[9] | t[3] | dt/
 enum : int { kIIter = 0, kIFirst, kIReuseDiag, kINumInvalid, kIStepOk,
               kILast,  // the published candidate is evaluated at the iteration cap: its Jacobian can never be used
               kIPark,  // which table of sums (0 / 1) belongs to the current point
+              kITerm,  // several wavefronts per solve: the termination code the advancing wavefront publishes
               kINumI = 8 };
 
 // Which (family, geometry) pairs are built: the payload must fit the 160 KB LDS and the
@@ -686,15 +687,18 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   unsigned long long t_begin = 0, t_loaded = 0;
   if (a.trace) t_begin = __builtin_amdgcn_s_memtime();
 
-  // every wavefront of the solve keeps its own copy of the LM state and advances it identically
+  // One wavefront per solve: its LM state.  Several (WPP > 1): ONE copy, advanced by the first wavefront while
+  // the others wait at the block's barrier -- their SIMDs run other solves' wavefronts meanwhile.  (Until round 2
+  // every wavefront kept a copy and advanced it identically to save that barrier: WPP x the ~400 instructions
+  // of the step per iteration, 18 % of a two-wavefront solve's issue slots, 28 % of an eight-wavefront one's.)
   __shared__ double slab_all[WPP][kSlab];
   __shared__ double unif_all[WPP][kUnif];
   __shared__ int ist_all[WPP][kINumI];
   [[maybe_unused]] __shared__ double xw[2][WPP > 1 ? WPP : 1][kSumSlots];
   [[maybe_unused]] __shared__ double ldata[LDSK > 0 ? WPP : 1][LDSK > 0 ? LDSK : 1][NC][LDSK > 0 ? kWave : 1];
-  double *slab = slab_all[wave];
-  double *unif = unif_all[wave];
-  int *ist = ist_all[wave];
+  double *slab = slab_all[WPP > 1 ? 0 : wave];
+  double *unif = unif_all[WPP > 1 ? 0 : wave];
+  int *ist = ist_all[WPP > 1 ? 0 : wave];
   [[maybe_unused]] int parity = 0;
 
   // ---- load this lane's correspondences once (coalesced: consecutive lanes, consecutive doubles)
@@ -723,7 +727,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   // Everything that is one value per solve runs in a few lanes only (here lane 0, lm_advance on
   // a quad) against the LDS slab: not faster to issue (measured), but one copy of the state and
   // plain per-lane control flow instead of wave-uniform bookkeeping in scalar registers.
-  if (lane == 0) {
+  if (lane == 0 && (WPP == 1 || wave == 0)) {
     double th, ph;
     const double *t0 = a.hyp_t ? a.hyp_t + 3 * s : a.init_t + 3 * pair;
     angles_from_vec(t0[0], t0[1], t0[2], th, ph);
@@ -748,6 +752,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   // the LDS slots arrive by DMA (vmcnt-tracked): they must have landed before the first pass reads them
   if constexpr (RESIDENT && LDSK > 0 && SRC == SRC_PLANES) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  if constexpr (WPP > 1) __syncthreads();  // the first wavefront's start state is what all of them read
 
   int term;
   for (;;) {
@@ -815,7 +820,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
           for (int i = 0; i < 6; ++i) xw[parity][wave][(lane >> 4) * 6 + i] = c[i];
         }
         __syncthreads();
-        if (lane == 0) {
+        if (wave == 0 && lane == 0) {
           double z = 0.0;
 #pragma unroll
           for (int j = 0; j < kSumSlots; ++j) {
@@ -837,11 +842,22 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
     int t = -1;
     // the chain below is latency-bound: let it win the issue arbitration against the pass of the
     // other wavefront on this SIMD, which has independent work to fill the gaps (+1.2 %)
-    __builtin_amdgcn_s_setprio(3);
-    if (lane < 4) t = lm_advance(slab, ist, unif, o, inv_max_radius, inv_min_radius);  // one quad, identical work (see the sincos exchange)
-    term = to_sgpr(t);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if constexpr (WPP == 1) {
+      __builtin_amdgcn_s_setprio(3);
+      if (lane < 4) t = lm_advance(slab, ist, unif, o, inv_max_radius, inv_min_radius);  // one quad, identical work (see the sincos exchange)
+      term = to_sgpr(t);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    } else {
+      if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        if (lane < 4) t = lm_advance(slab, ist, unif, o, inv_max_radius, inv_min_radius);
+        if (lane == 0) ist[kITerm] = t;
+        __builtin_amdgcn_s_setprio(0);
+      }
+      __syncthreads();  // the next candidate (or the verdict) is published: everybody reads it
+      term = to_sgpr(ist[kITerm]);
+    }
     if (term >= 0) break;
   }
 
