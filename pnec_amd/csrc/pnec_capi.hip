@@ -84,6 +84,11 @@ struct pnec_hip_problem {
   };
   std::vector<Bucket> buckets;
   int32_t *d_bucket_pairs = nullptr;
+  // ragged batches: the launches of the geometries in use run side by side (fork / join around them), so that
+  // the long tail of one (solves of up to 50 iterations) is filled by the others' wavefronts
+  std::vector<hipStream_t> side_streams;
+  std::vector<hipEvent_t> side_done;
+  hipEvent_t fork_event = nullptr;
   std::vector<int32_t> host_counts;
   // A batch produced by InlierExtraction on the device (pnec_hip_problem_select, the pipeline): it keeps
   // the source's block layout (capacity) and its real pair sizes exist only in d_count until somebody
@@ -893,6 +898,9 @@ int pnec_hip_problem_destroy(pnec_hip_problem *p) {
   release(p->d_stage_i);
   release(p->d_front);
   release(p->d_front_i);
+  for (hipStream_t st : p->side_streams) (void)hipStreamDestroy(st);
+  for (hipEvent_t ev : p->side_done) (void)hipEventDestroy(ev);
+  if (p->fork_event) (void)hipEventDestroy(p->fork_event);
   release(p->d_bucket_pairs);
   delete p;
   return 0;
@@ -1176,14 +1184,15 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
     a.out_status = p->d_stage_i + S;
   }
 
-  auto launch = [&](const Geometry &gg, const SolveArgs &aa) -> hipError_t {
+  auto launch_on = [&](const Geometry &gg, const SolveArgs &aa, hipStream_t st) -> hipError_t {
     switch (p->mode) {
-      case PNEC_HIP_MODE_NEC: return launch_solve_mode_0(gg.cpl, gg.wpp, gg.ldsk, gg.resident, aa, stream);
-      case PNEC_HIP_MODE_TARGET: return launch_solve_mode_1(gg.cpl, gg.wpp, gg.ldsk, gg.resident, aa, stream);
-      case PNEC_HIP_MODE_HOST: return launch_solve_mode_2(gg.cpl, gg.wpp, gg.ldsk, gg.resident, aa, stream);
-      default: return launch_solve_mode_3(gg.cpl, gg.wpp, gg.ldsk, gg.resident, aa, stream);
+      case PNEC_HIP_MODE_NEC: return launch_solve_mode_0(gg.cpl, gg.wpp, gg.ldsk, gg.resident, aa, st);
+      case PNEC_HIP_MODE_TARGET: return launch_solve_mode_1(gg.cpl, gg.wpp, gg.ldsk, gg.resident, aa, st);
+      case PNEC_HIP_MODE_HOST: return launch_solve_mode_2(gg.cpl, gg.wpp, gg.ldsk, gg.resident, aa, st);
+      default: return launch_solve_mode_3(gg.cpl, gg.wpp, gg.ldsk, gg.resident, aa, st);
     }
   };
+  auto launch = [&](const Geometry &gg, const SolveArgs &aa) -> hipError_t { return launch_on(gg, aa, stream); };
   // PNEC_HIP_TRACE=<file>: per-workgroup phase timestamps of every launch (diagnostics; adds a
   // device synchronisation, so never set it for timed runs)
   const char *trace_path = std::getenv("PNEC_HIP_TRACE");
@@ -1205,15 +1214,39 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
   if (forced || p->buckets.size() <= 1) {
     e = launch(g, a);
   } else {
-    // ragged batch: one launch per geometry in use, over the pairs that fit it
-    for (const auto &bk : p->buckets) {
+    // ragged batch: one launch per geometry in use, over the pairs that fit it -- side by side: the first on
+    // the caller's stream, the others on streams of the batch's own that fork from it and join it again
+    const size_t n_side = p->buckets.size() - 1;
+    while (e == hipSuccess && p->side_streams.size() < n_side) {
+      hipStream_t st = nullptr;
+      hipEvent_t ev = nullptr;
+      e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      if (e != hipSuccess) {
+        if (st) (void)hipStreamDestroy(st);
+        break;
+      }
+      p->side_streams.push_back(st);
+      p->side_done.push_back(ev);
+    }
+    if (e == hipSuccess && !p->fork_event) e = hipEventCreateWithFlags(&p->fork_event, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(p->fork_event, stream);
+    for (size_t b = 0; b < p->buckets.size() && e == hipSuccess; ++b) {
+      const auto &bk = p->buckets[b];
       SolveArgs ab = a;
       ab.pair_index = p->d_bucket_pairs + bk.first;
       ab.n_solves = bk.count * (int64_t)n_hyp;
       if (ab.trace) ab.trace += 4 * (size_t)(bk.first * (int64_t)n_hyp);  // records are indexed by blockIdx per launch
       const Geometry gb = {bk.cpl, bk.wpp, bk.ldsk, bk.resident};
-      e = launch(gb, ab);
-      if (e != hipSuccess) break;
+      if (b == 0) {
+        e = launch_on(gb, ab, stream);
+      } else {
+        hipStream_t st = p->side_streams[b - 1];
+        e = hipStreamWaitEvent(st, p->fork_event, 0);
+        if (e == hipSuccess) e = launch_on(gb, ab, st);
+        if (e == hipSuccess) e = hipEventRecord(p->side_done[b - 1], st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(stream, p->side_done[b - 1], 0);
+      }
     }
   }
   if (d_trace) {
