@@ -2,7 +2,7 @@
 """Parity of the whole PNEC::Solve chain (RANSAC eigensolver -> inlier extraction -> weighted eigensolver + SCF
 -> refinement, reference-default Options) against the oracle's chain, pair by pair, on P pairs of the
 pipeline benchmark's workload (512 correspondences, 10 % gross outliers).  Runs on the GPU box; the oracle
-side is ~11 ms per pair per host thread.   python tools/verify_pipeline.py [P]"""
+side is ~11 ms per pair per host thread.   python tools/verify_pipeline.py [P] [seed]"""
 import json
 import os
 import sys
@@ -17,9 +17,10 @@ from pnec_amd import Batch, capi
 from pnec_amd import simulation as sim
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 N = 512
 dev = torch.device("cuda:0")
-g = sim.generate(P, N, seed=1, device=dev)
+g = sim.generate(P, N, seed=SEED, device=dev)
 bad = torch.rand(P, N, device=dev, generator=torch.Generator(device=dev).manual_seed(0)) < 0.10
 rnd = torch.randn(P, N, 3, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
 g.bvs2 = torch.where(bad[..., None], rnd / rnd.norm(dim=-1, keepdim=True), g.bvs2)
