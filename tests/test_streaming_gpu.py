@@ -320,3 +320,36 @@ def test_pipeline_on_the_kitti_like_stream_matches_the_oracle_chain(oracle):
         s = oracle.solve(capi.MODE_TARGET, f1[a:e][m], f2[a:e][m], c2[a:e][m], None, 1e-13, oracle.quat_from_rot(Rw), tw,
                          oracle.default_options())
         assert math.radians(oracle.rotational_difference_deg(_quat_to_R(q[p]), s.R)) <= 1e-6, p
+
+
+def test_pipeline_survives_degenerate_pairs():
+    """pure rotation (no translation: a double zero eigenvalue), identical bearings, every correspondence the same
+    point, a NaN bearing, zero covariances, one covariance 1e12 times the others -- inside an ordinary batch, through
+    the whole chain in one call: it ends, the ordinary pairs are untouched by their neighbours, nothing but the NaN
+    pair may come out non-finite"""
+    P, N = 16, 512
+    g = sim.generate(P, N, seed=5)
+    f1, f2, c2 = g.bvs1.clone(), g.bvs2.clone(), g.covs2.clone()
+    f2[0] = (g.R_gt[0].T @ f1[0].T).T
+    f2[1] = f1[1]
+    f1[2] = f1[2][0:1].expand(N, 3).clone()
+    f2[2] = f2[2][0:1].expand(N, 3).clone()
+    f1[4, 7, 0] = float("nan")
+    c2[5] = 0.0
+    c2[6, 3] = c2[6, 3] * 1e12
+    q0, t0 = g.init_q.numpy(), g.init_t.numpy()
+    args = lambda a, b_, c: (a.reshape(-1, 3).numpy(), b_.reshape(-1, 3).numpy(), c.reshape(-1, 3, 3).numpy())
+    with Batch.uniform(capi.MODE_TARGET, P, N) as b:
+        b.fill(*args(f1, f2, c2))
+        q, t, mask, cnt = b.solve_pipeline(q0, t0, want_inliers=True)
+        qn, tn = b.nec_eigensolver(q0)
+    with Batch.uniform(capi.MODE_TARGET, P, N) as b:          # the same batch without the troublemakers
+        b.fill(*args(g.bvs1, g.bvs2, g.covs2))
+        q_ref, t_ref, _, cnt_ref = b.solve_pipeline(q0, t0, want_inliers=True)
+    q, t, qn = np.asarray(q), np.asarray(t), np.asarray(qn)
+    for p in range(P):
+        if p == 4:
+            continue
+        assert np.isfinite(q[p]).all() and np.isfinite(t[p]).all() and np.isfinite(qn[p]).all(), p
+    np.testing.assert_array_equal(q[7:], np.asarray(q_ref)[7:])      # pairs are independent
+    np.testing.assert_array_equal(np.asarray(cnt)[7:], np.asarray(cnt_ref)[7:])
