@@ -947,30 +947,39 @@ __device__ double obj_fun_pair(const double *base, int n, int stride, const doub
 #ifndef PNEC_WES_WAVES_PER_SIMD
 #define PNEC_WES_WAVES_PER_SIMD 2
 #endif
-// WPP = 2 (resident form only): a pair of 513..1024 correspondences on TWO wavefronts, each keeping its half's
-// tables in registers; every sum over the pair is a wavefront sum + one exchange through LDS (pair_sum below),
-// everything else runs identically in both wavefronts (same bits: both add the two partial sums in the same
-// order), so their control flow never parts and the barriers inside pair_sum are always met by both.
-template <bool RES, int WPP = 1>
-__device__ __forceinline__ void weighted_pair(const FrontArgs &a) {
-  static_assert(WPP == 1 || (RES && WPP == 2), "two wavefronts per pair exist for the resident form only");
+// WPP > 1 (resident form only): a pair of up to 512 WPP correspondences on WPP wavefronts, each keeping its
+// share's tables in registers; every sum over the pair is a wavefront sum + one exchange through LDS (pair_sum
+// below), everything else runs identically in all of them (same bits: all add the partial sums in the same
+// order), so their control flow never parts and the barriers inside pair_sum are always met by all.
+// The LDS of a block (one struct for whatever forms its kernel can run, so it is the largest, not the sum):
+template <int WMAX>
+struct WeightedLds {
+  double G[36];          // the pair's 36 weighted sums
+  double cand[21][3];    // streaming form: the directions of a batch
+  float cost32[512];     // resident form: single-precision costs of the 500 directions
+  float cost32p[WMAX > 1 ? WMAX : 1][WMAX > 1 ? 512 : 1];  // ... each wavefront's share of them
+  // exchange between the wavefronts of a pair: [buffer][wavefront][value]; the buffers alternate so that a
+  // wavefront that runs ahead into the next exchange cannot overwrite what another has yet to read
+  double xch[2][WMAX][8];
+};
+template <bool RES, int WPP, typename Lds>
+__device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
+  static_assert(WPP == 1 || RES, "several wavefronts per pair exist for the resident form only");
   const int64_t pair = blockIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
   [[maybe_unused]] const int wave = threadIdx.x >> 6;
   const int n = a.count[pair];
   const int stride = (n + kWave - 1) & ~(kWave - 1);
   const double *base = a.data + a.block_offset[pair];
-  __shared__ double G[36];
-  __shared__ double cand[21][3];
-  [[maybe_unused]] __shared__ float cost32[RES ? 512 : 1];  // single-precision costs of the 500 directions
-  [[maybe_unused]] __shared__ float cost32p[WPP == 2 ? 2 : 1][WPP == 2 ? 512 : 1];  // ... each wavefront's share of them
-  // exchange between the two wavefronts of a pair: [buffer][wavefront][value]; the buffers alternate so that a
-  // wavefront that runs ahead into the next exchange cannot overwrite what the other has yet to read
-  [[maybe_unused]] __shared__ double xch[2][WPP][8];
+  double *G = lds.G;
+  [[maybe_unused]] double (*cand)[3] = lds.cand;
+  [[maybe_unused]] float *cost32 = lds.cost32;
+  [[maybe_unused]] auto &cost32p = lds.cost32p;
+  [[maybe_unused]] auto &xch = lds.xch;
   [[maybe_unused]] int xpar = 0;
   // the block's barrier (both wavefronts) or, for one wavefront, just the LDS fence
   auto pair_sync = [&]() {
-    if constexpr (WPP == 2) {
+    if constexpr (WPP > 1) {
       __syncthreads();
     } else {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -983,14 +992,19 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a) {
     constexpr int K = sizeof(x) / sizeof(double);
 #pragma unroll
     for (int k = 0; k < K; ++k) x[k] = wave_allreduce_sum(x[k]);
-    if constexpr (WPP == 2) {
+    if constexpr (WPP > 1) {
       if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < K; ++k) xch[xpar][wave][k] = x[k];
       }
       __syncthreads();
 #pragma unroll
-      for (int k = 0; k < K; ++k) x[k] = xch[xpar][0][k] + xch[xpar][1][k];
+      for (int k = 0; k < K; ++k) {
+        double t = xch[xpar][0][k];
+#pragma unroll
+        for (int w = 1; w < WPP; ++w) t += xch[xpar][w][k];
+        x[k] = t;
+      }
       xpar ^= 1;
     }
   };
@@ -1066,7 +1080,7 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a) {
       // beyond the pair), the padding entries are patched afterwards.
 #pragma unroll
       for (int k = 0; k < KR; ++k) {
-        const int idx = (WPP == 2 ? wave * KR * kWave : 0) + lane + kWave * k;
+        const int idx = (WPP > 1 ? wave * KR * kWave : 0) + lane + kWave * k;
         const bool in = idx < n;
         corr_nb(n > 0 ? base : a.data, stride, in ? idx : 0, R, a.reg, rn[k], rB[k]);
         if (!in) {  // padding: contributes exactly 0 to every sum (n = 0, B = I)
@@ -1142,13 +1156,18 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a) {
           const float b0 = swap_add32_f(s4[0], s4[2]), b1 = swap_add32_f(s4[1], s4[3]);
           const float sum = row_allreduce_sum_f(swap_add16_f(b0, b1));  // row r: direction c + r
           if ((lane & 15) == 0) {
-            if constexpr (WPP == 2) cost32p[wave][c + my_row] = sum;
+            if constexpr (WPP > 1) cost32p[wave][c + my_row] = sum;
             else cost32[c + my_row] = sum;
           }
         }
-        if constexpr (WPP == 2) {  // the two wavefronts' shares of every direction's cost, added once
+        if constexpr (WPP > 1) {  // the wavefronts' shares of every direction's cost, added once
           __syncthreads();
-          for (int i = (int)threadIdx.x; i < 500; i += WPP * kWave) cost32[i] = cost32p[0][i] + cost32p[1][i];
+          for (int i = (int)threadIdx.x; i < 500; i += WPP * kWave) {
+            float t = cost32p[0][i];
+#pragma unroll
+            for (int w = 1; w < WPP; ++w) t += cost32p[w][i];
+            cost32[i] = t;
+          }
         }
         pair_sync();
         float m32 = __builtin_inff();
@@ -1300,21 +1319,31 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a) {
 // A batch whose largest pair fits the resident form runs it for every pair, one wavefront per pair.  A ragged
 // batch with larger pairs decides PER PAIR (the KITTI-like stream, 265..700 correspondences, ran the streaming form
 // for all 23 190 pairs because 40 % of them exceed 512 BEFORE the inliers are extracted -- 8.2 of the chain's
-// 11.6 ms): two wavefronts per block; <= 512 correspondences: the resident form on the first, the second leaves;
-// 513..1024: the resident form on both (WPP = 2); more: the streaming form on the first.
+// 11.6 ms): WMAX wavefronts per block; a pair of <= 512 correspondences runs the resident form on the first (the
+// others leave at once), up to 1024 on two, 2048 on four, 4096 on eight, and only beyond that the streaming form
+// (4 000 pairs x 2 048: 14.5 ms streaming).
 template <bool RES>
 __global__ __launch_bounds__(kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigensolver_kernel(const FrontArgs a) {
-  weighted_pair<RES>(a);
+  __shared__ WeightedLds<1> lds;
+  weighted_pair<RES, 1>(a, lds);
 }
-__global__ __launch_bounds__(2 * kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigensolver_mixed_kernel(const FrontArgs a) {
+template <int WMAX>
+__global__ __launch_bounds__(WMAX *kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigensolver_mixed_kernel(const FrontArgs a) {
+  __shared__ WeightedLds<WMAX> lds;
   const int n = a.count[blockIdx.x];
-  const bool first = threadIdx.x < kWave;
+  const int wave = threadIdx.x >> 6;
   if (n <= 8 * kWave) {
-    if (first) weighted_pair<true>(a);
+    if (wave < 1) weighted_pair<true, 1>(a, lds);
   } else if (n <= 16 * kWave) {
-    weighted_pair<true, 2>(a);
+    if (wave < 2) weighted_pair<true, 2>(a, lds);
+  } else if (WMAX >= 4 && n <= 32 * kWave) {
+    if constexpr (WMAX >= 4) {
+      if (wave < 4) weighted_pair<true, 4>(a, lds);
+    }
+  } else if (WMAX >= 8 && n <= 64 * kWave) {
+    if constexpr (WMAX >= 8) weighted_pair<true, 8>(a, lds);
   } else {
-    if (first) weighted_pair<false>(a);
+    if (wave < 1) weighted_pair<false, 1>(a, lds);
   }
 }
 
@@ -1967,8 +1996,10 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
   // n_max bounds the pairs' sizes (after an inlier extraction: the source's sizes)
   if (n_max <= 8 * kWave)
     hipLaunchKernelGGL(weighted_eigensolver_kernel<true>, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
+  else if (n_max <= 16 * kWave)
+    hipLaunchKernelGGL(weighted_eigensolver_mixed_kernel<2>, dim3((unsigned)n_pairs), dim3(2 * kWave), 0, stream, a);
   else
-    hipLaunchKernelGGL(weighted_eigensolver_mixed_kernel, dim3((unsigned)n_pairs), dim3(2 * kWave), 0, stream, a);
+    hipLaunchKernelGGL(weighted_eigensolver_mixed_kernel<8>, dim3((unsigned)n_pairs), dim3(8 * kWave), 0, stream, a);
   e = hipGetLastError();
   if (a.trace) {
     std::vector<unsigned long long> h(kPhCount * (size_t)n_pairs);

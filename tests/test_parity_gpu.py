@@ -521,9 +521,9 @@ def test_weighted_eigensolver_device_vs_oracle(oracle):
 
 def test_weighted_eigensolver_ragged_batch_forms_device_vs_oracle(oracle):
     """a ragged batch picks the weighted stage's form PER PAIR: <= 512 correspondences resident on one wavefront,
-    513..1024 resident on two (every sum exchanged between them), more streaming -- all three against the
-    literal oracle and its early-exit twin, in one launch"""
-    sizes = [300, 512, 513, 640, 1000, 1024, 1025, 1500]
+    up to 1024 on two, 2048 on four, 4096 on eight (every sum exchanged between them), more streaming -- all of
+    them against the literal oracle and its early-exit twin, in one launch"""
+    sizes = [300, 512, 513, 640, 1000, 1024, 1025, 1500, 2048, 2049, 3000, 4096, 4100]
     offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     g = sim.generate(len(sizes), max(sizes), seed=97)
     f1 = np.concatenate([g.bvs1[p].numpy()[:n] for p, n in enumerate(sizes)])
