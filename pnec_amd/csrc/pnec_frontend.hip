@@ -29,7 +29,8 @@
 //     scalar loads) and every candidate within 1e-4 of the best is re-evaluated in double precision;
 //     SCF steps by Rayleigh-quotient iteration, stopped at the fixed point; once the rotation is final the
 //     remaining rounds only redo the translation, and stop when a round leaves it bitwise unchanged;
-//     larger pairs stream the payload, 21 directions per pass (wave_reduce21);
+//     pairs of up to 1024 / 2048 / 4096 correspondences run the same form on 2 / 4 / 8 wavefronts (sums exchanged
+//     through LDS), chosen per pair in ragged batches; only larger ones stream the payload, 21 directions per pass;
 //   * RANSAC: one wavefront per pair, one quad per hypothesis (16 per round), the quad's lanes sharing
 //     the minimiser and splitting the correspondences when the hypothesis is scored; the sequential
 //     consumption rule and the adaptive bound are wave-uniform scalar code.
