@@ -31,7 +31,8 @@ hipError_t launch_solve_aos_mode_3(int, int, int, const SolveArgs &, hipStream_t
 // pnec_frontend.hip
 hipError_t launch_ransac_eigensolver(const double *, const int64_t *, const int64_t *, const int32_t *, int64_t,
                                      const double *, unsigned long long, int, int, double, double *, double *,
-                                     uint8_t *, int32_t *, int32_t *, double *, int32_t *, hipStream_t);
+                                     uint8_t *, int32_t *, int32_t *, double *, int32_t *, hipStream_t, hipStream_t,
+                                     hipEvent_t, hipEvent_t);
 hipError_t launch_select(int, const double *, const int64_t *, const int64_t *, const int32_t *, const uint8_t *,
                          double *, const int64_t *, const int32_t *, int64_t, hipStream_t);
 hipError_t launch_nec_eigensolver(const double *, const int64_t *, const int32_t *, int64_t, const double *,
@@ -754,6 +755,24 @@ int ensure_stage(pnec_hip_problem *p, int64_t doubles, int64_t ints) {
   return 0;
 }
 
+// at least `n` side streams (+ their "done" events) and the fork event of the batch
+int ensure_side_streams(pnec_hip_problem *p, size_t n) {
+  while (p->side_streams.size() < n) {
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      if (st) (void)hipStreamDestroy(st);
+      return fail_hip(e, "side stream");
+    }
+    p->side_streams.push_back(st);
+    p->side_done.push_back(ev);
+  }
+  if (!p->fork_event) PNEC_HIP_TRY(hipEventCreateWithFlags(&p->fork_event, hipEventDisableTiming));
+  return 0;
+}
+
 int ensure_front(pnec_hip_problem *p) {
   const int64_t P = std::max<int64_t>(p->n_pairs, 1);
   if (P > p->front_pairs) {
@@ -1439,7 +1458,7 @@ int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint6
   }
   hipError_t e = launch_ransac_eigensolver(p->d_data, p->d_block_offset, p->d_offsets, p->d_count, P, d_q, seed,
                                            max_iterations, sample_size, threshold, d_oq, d_ot, d_mask, d_cnt, d_it,
-                                           p->d_front, p->d_front_i, stream);
+                                           p->d_front, p->d_front_i, stream, nullptr, nullptr, nullptr);
   if (e == hipSuccess && space == PNEC_HIP_MEM_HOST) {
     e = hipMemcpyAsync(out_q, d_oq, sizeof(double) * 4 * P, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_t, d_ot, sizeof(double) * 3 * P, hipMemcpyDeviceToHost, stream);

@@ -1731,7 +1731,11 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
                                      unsigned long long seed, int max_iterations, int sample_size,
                                      double threshold, double *out_q, double *out_t, uint8_t *out_mask,
                                      int32_t *out_count, int32_t *out_iterations, double *scratch_d,
-                                     int32_t *scratch_i, hipStream_t stream) {
+                                     int32_t *scratch_i, hipStream_t stream, hipStream_t tail_stream,
+                                     hipEvent_t tail_fork, hipEvent_t tail_done) {
+  // tail_stream (optional): the eigensolver on the inliers (es_batch_kernel, which writes out_q / out_t) runs
+  // there, forked from `stream` after the RANSAC kernel -- the caller goes on with work that only needs the
+  // masks (InlierExtraction) and makes `stream` wait for tail_done before anything reads out_q / out_t
   if (n_pairs <= 0) return hipSuccess;
   RansacArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -1774,8 +1778,16 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
     b.count = count;
     b.out_q = out_q;
     b.out_t = out_t;
-    hipLaunchKernelGGL(es_batch_kernel<kEpiTranslation>, dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, stream, b);
+    hipStream_t es_stream = stream;
+    if (tail_stream) {
+      e = hipEventRecord(tail_fork, stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(tail_stream, tail_fork, 0);
+      if (e != hipSuccess) return e;
+      es_stream = tail_stream;
+    }
+    hipLaunchKernelGGL(es_batch_kernel<kEpiTranslation>, dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, es_stream, b);
     e = hipGetLastError();
+    if (e == hipSuccess && tail_stream) e = hipEventRecord(tail_done, tail_stream);
   }
 #ifdef PNEC_FRONT_DEBUG
   {

@@ -108,9 +108,13 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
       if (!p->d_mask) PNEC_HIP_TRY(dev_alloc(&p->d_mask, (size_t)M));
       d_mask = p->d_mask;
     }
+    // the eigensolver on the inliers (latency-bound: sixteen pairs per wavefront, one wavefront per SIMD) runs
+    // beside InlierExtraction (bandwidth-bound), which only needs the masks; both join before the weighted stage
+    if (int rc = ensure_side_streams(p, 1)) return rc;
     e = launch_ransac_eigensolver(p->d_data, p->d_block_offset, p->d_offsets, p->d_count, P, d_iq, o.ransac_seed,
                                   o.max_ransac_iterations, o.ransac_sample_size, o.ransac_threshold, es_q, es_t,
-                                  d_mask, d_cnt, nullptr, p->d_front, p->d_front_i, stream);
+                                  d_mask, d_cnt, nullptr, p->d_front, p->d_front_i, stream, p->side_streams[0],
+                                  p->fork_event, p->side_done[0]);
     if (e != hipSuccess) return fail_hip(e, "ransac_eigensolver_kernel");
     if (!p->sel_view || p->sel_view->data_doubles != p->data_doubles || p->sel_view->n_pairs != P) {
       if (p->sel_view) pnec_hip_problem_destroy(p->sel_view);
@@ -118,6 +122,7 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
       if (int rc = alloc_like(p, stream, &p->sel_view)) return rc;
     }
     if (int rc = select_into(p, d_mask, stream, p->sel_view)) return rc;
+    PNEC_HIP_TRY(hipStreamWaitEvent(stream, p->side_done[0], 0));  // es_q / es_t are there from here on
     stage = p->sel_view;
   } else {
     e = launch_nec_eigensolver(p->d_data, p->d_block_offset, p->d_count, P, d_iq, es_q, es_t, nullptr, p->d_front,
