@@ -486,15 +486,17 @@ __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&
 //
 // e_out (optional): the eigenvector of the smallest eigenvalue of M at the returned v (unit length, sign
 // arbitrary) -- every exit leaves the loop with the eigen-iteration's vector of exactly that point.
+// active = false: this quad has no problem (its lanes only keep the wavefront's calls convergent): it is done at once.
 template <int GS, int TAG = 0>
-__device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], double n_scale, double *e_out = nullptr) {
+__device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], double n_scale, double *e_out = nullptr,
+                                             bool active = true) {
   enum : int { kInit = 0, kTrial, kShort, kReeval, kDone };
   const int role = (int)(threadIdx.x & 3);
   const double h = 1e-6, inv_h = 1.0 / h;
   double eb[3] = {0.0, 0.0, 1.0};  // eigenvector of the smallest eigenvalue at the current point
   double f = 0.0, g[3] = {0.0, 0.0, 0.0}, H[9], d[3] = {0.0, 0.0, 0.0};
   double slope = 0.0, alpha = 1.0, trace_cur = 0.0;  // trace_cur: trace of M at the current point
-  int state = kInit, it = 0, ls = 0;
+  int state = active ? kInit : kDone, it = 0, ls = 0;
   bool last_eval = false;
   while (state != kDone) {
     // ---- the point this lane evaluates in this trip
@@ -1468,10 +1470,16 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
     bool stop = !can_sample;
     while (!stop && (double)it < k) {  // wave-uniform
       const unsigned long long h = (unsigned long long)(it + hyp);
+      // The first round evaluates all 16 hypotheses before any bound is known.  A later round knows k: hypothesis
+      // j of the round is consumed only if it + j < k, and k can only shrink while the round is consumed -- the
+      // quads beyond ceil(k - it) would never be looked at, so they stay out (exact; it shortens the slowest-of-
+      // the-quads Newton phase of the ~40 % of pairs that need a second round, typically for two or three more)
+      const int needed = it == 0 ? kHypPerRound : (int)ceil(k - (double)it);
+      const bool active = hyp < needed;
       // ---- this quad's hypothesis: sample, sums, minimise, translation (the four lanes do the same up to
       // the minimiser, which splits its evaluations over them)
       auto sel = [&](int j) -> int & { return sel_lds[j][lane]; };
-      {
+      if (active) {
         int m = 0;
         unsigned long long draw = 0;
         while (m < ss) {
@@ -1488,7 +1496,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
         // instead of 10) and add their shares up
         double Gl[36];
         for (int i = 0; i < 36; ++i) Gl[i] = 0.0;
-        for (int j = role; j < ss; j += 4) {
+        for (int j = role; j < (active ? ss : 0); j += 4) {
           const int idx = sel(j);
           const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
           const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
@@ -1516,7 +1524,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
         v[c] = v0[c] + (rng_uniform(a.seed, (unsigned long long)pair, h, 1000 + c) - 0.5) * 2.0 * 0.01;
       PNEC_PHASE_END(kRpSample);
       // t = eigenvector of the smallest eigenvalue of M at the minimiser (sign settled by the evidence below)
-      const int newton_its = es_minimise_quad<1, 1>(Gh[hyp], v, (double)ss, t);
+      const int newton_its = es_minimise_quad<1, 1>(Gh[hyp], v, (double)ss, t, active);
       PNEC_PHASE_END(kRpNewton);
       if (a.trace) {  // diagnostics: Newton iterations of the round's 16 hypotheses (sum, max), rounds
         const double its_sum = wave_allreduce_sum((double)newton_its) * 0.25;
@@ -1532,7 +1540,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
       {
         // directional evidence sum t.(f1 - R f2) over the sample
         double ev = 0.0;
-        for (int j = role; j < ss; j += 4) {
+        for (int j = role; j < (active ? ss : 0); j += 4) {
           const int idx = sel(j);
           const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
                                 base[(int64_t)5 * stride + idx]};
@@ -1564,7 +1572,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           const int left = n - i0 < kWave ? n - i0 : kWave;
 #pragma unroll 4
-          for (int jj = 0; jj < kWave / 4; ++jj) {
+          for (int jj = 0; jj < (active ? kWave / 4 : 0); ++jj) {
             const int j = 4 * jj + role;
             const double f1[3] = {tile[buf][0][j], tile[buf][1][j], tile[buf][2][j]};
             const double f2[3] = {tile[buf][3][j], tile[buf][4][j], tile[buf][5][j]};
