@@ -23,6 +23,14 @@ Workloads:
             come from --tracks <file.npz> (format: pnec_amd/tracks.py); without it a labelled
             SYNTHETIC KITTI-like stand-in with the real sequence lengths is generated.
 
+  kitti_all --chain   the same pairs (10 % gross mismatches added) through the WHOLE chain of PNEC::Solve
+            (pnec.cc:77-124, reference-default Options) in one pnec_hip_solve_pipeline call per step: ~10x the
+            device time per pair of the refinement alone, i.e. the config-5 workload that has something to scale.
+
+--share-gpu puts every rank on cuda:0 (boxes with one GPU): real solver, real partition, the gather's device
+side (events, side stream, double buffering, per-rank sizes) with world > 1; the collective itself is gloo over
+pinned host records, because RCCL does not accept two ranks on one device.  Its line says so ("shared_gpu").
+
 --dry-run-cpu replaces the device solve by a stub that fabricates records (gloo on CPU): it exists so
 that the spawn / partition / gather path can be exercised where there is no GPU (tests); its JSON
 line says so and carries no throughput claim.
@@ -75,6 +83,14 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
     ap.add_argument("--sync-gather", action="store_true", help="gather on the solve's stream (A/B of the overlap)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="gloo + stubbed solve: exercises spawn/partition/gather without a GPU")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="all ranks on cuda:0 (single-GPU boxes): the real solver and the device side of the gather "
+                         "(events, side stream, per-rank sizes) with world > 1; the collective is gloo over pinned "
+                         "host records because RCCL refuses two ranks on one device")
+    ap.add_argument("--chain", action="store_true",
+                    help="kitti_all: the whole PNEC::Solve chain per pair (pnec_hip_solve_pipeline: RANSAC eigensolver, "
+                         "inlier extraction, weighted eigensolver + SCF, refinement) instead of the refinement alone")
+    ap.add_argument("--outliers", type=float, default=0.10, help="--chain: share of gross mismatches in the synthetic set")
     return ap.parse_args(argv)
 
 
@@ -175,6 +191,9 @@ def build_kitti_all(args, rank, world, device):
     sh.workload = ("configs[4]: all KITTI 00-10 frame pairs (23 190 ragged pairs) sharded as independent "
                    "batches, contiguous ranges balanced by correspondence count")
     sh.data = f"tracks:{os.path.basename(args.tracks)}" if args.tracks else "synthetic"
+    if args.chain:
+        sh.workload += (f"; whole PNEC::Solve chain per pair (reference-default Options"
+                        + ("" if args.tracks else f", {args.outliers:.0%} gross mismatches added") + ")")
     sh.pair_sizes = sizes
     if args.dry_run_cpu:
         sh.batch, sh.q0, sh.t0, sh.sample = None, None, None, None
@@ -183,7 +202,8 @@ def build_kitti_all(args, rank, world, device):
 
     from pnec_amd import Batch, capi
     a, b = int(bounds[rank]), int(bounds[rank + 1])
-    tr = tk.load_tracks(args.tracks, a, b) if args.tracks else tk.kitti_all_shard(a, b, device=device)
+    tr = tk.load_tracks(args.tracks, a, b) if args.tracks else \
+        tk.kitti_all_shard(a, b, device=device, outlier_frac=args.outliers if args.chain else 0.0)
     as_dev = lambda x: x if hasattr(x, "is_cuda") and x.is_cuda else torch.as_tensor(np.asarray(x), device=device)
     batch = Batch(capi.MODE_TARGET, tr.offsets, device=device.index)
     if tr.n_pairs:
@@ -301,6 +321,8 @@ def run(args):
     if not cpu:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the solver has no CPU fallback")
+        if args.share_gpu:
+            local_rank = 0
         if torch.cuda.device_count() <= local_rank:
             raise SystemExit(f"rank {rank}: no GPU {local_rank} ({torch.cuda.device_count()} visible)")
         device = torch.device("cuda", local_rank)
@@ -309,7 +331,7 @@ def run(args):
         device = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if cpu:
+        if cpu or args.share_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
@@ -320,7 +342,11 @@ def run(args):
     sh = (build_kitti_all if args.workload == "kitti_all" else build_sim100k)(args, rank, world, device)
     my_pairs = sh.sizes[rank]
     first_global = sum(sh.sizes[:rank])
-    gather = RecordGather(world, rank, sizes=sh.sizes, device=None if (cpu or args.sync_gather) else device)
+    if args.chain and args.workload != "kitti_all":
+        raise SystemExit("--chain goes with --workload kitti_all")
+    gather = RecordGather(world, rank, sizes=sh.sizes, device=None if (cpu or args.sync_gather) else device,
+                          host_staged=args.share_gpu)
+    host_collective = world > 1 and not cpu and (args.share_gpu and args.sync_gather)
     outs = [None, None]
 
     if cpu:
@@ -345,9 +371,23 @@ def run(args):
                                     lds_corr_per_lane=args.ldsk, **sh.opts)
         launch = sh.batch.describe_launch(opts)
 
-        def solve(slot):
-            outs[slot] = sh.batch.solve(sh.q0, sh.t0, reg=1e-13, options=opts, out=outs[slot])
-            return outs[slot]
+        if args.chain:
+            from pnec_amd.batch import SolveResult
+
+            # pair p of this shard draws its RANSAC samples as pair first_global + p of the whole set: the records do
+            # not depend on the number of ranks
+            popts = capi.default_pipeline_options(first_pair_id=first_global)
+
+            def solve(slot):
+                # one pnec_hip_solve_pipeline call; the record's "iterations" column carries the inlier count
+                q, t, _, cnt = sh.batch.solve_pipeline(sh.q0, sh.t0, options=popts, want_inliers=True)
+                outs[slot] = SolveResult(q, t, torch.zeros(my_pairs, dtype=torch.float64, device=device), cnt,
+                                         torch.zeros(my_pairs, dtype=torch.int32, device=device))
+                return outs[slot]
+        else:
+            def solve(slot):
+                outs[slot] = sh.batch.solve(sh.q0, sh.t0, reg=1e-13, options=opts, out=outs[slot])
+                return outs[slot]
 
     ev0 = ev1 = None
     if not cpu:
@@ -361,7 +401,11 @@ def run(args):
         res = solve(slot)
         if i is not None and ev1:
             ev1[i].record()
-        gather.submit(slot, res)
+        if host_collective:   # --share-gpu --sync-gather: gloo moves host tensors only
+            from pnec_amd.batch import SolveResult as _SR
+            gather.submit(slot, _SR(*(x.cpu() for x in (res.q, res.t, res.cost, res.iterations, res.status))))
+        else:
+            gather.submit(slot, res)
         return res
 
     def fence():
@@ -392,7 +436,7 @@ def run(args):
     fence()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -402,18 +446,30 @@ def run(args):
         assert bool(torch.isfinite(gathered[:, :8]).all())
         line = {
             "metric": "PNEC pose solves/sec (512 corr, 10 GN iters)" if args.workload == "sim100k"
-                      else "PNEC pose solves/sec (all KITTI 00-10 pairs, ragged, Ceres-default termination)",
-            "value": value, "unit": "solves/s", "n_gpus": n_ranks, "steps": args.steps,
+                      else ("PNEC::Solve frame pairs/sec, whole chain (all KITTI 00-10 pairs, ragged, reference-default Options)"
+                            if args.chain else
+                            "PNEC pose solves/sec (all KITTI 00-10 pairs, ragged, Ceres-default termination)"),
+            "value": value, "unit": "pairs/s" if args.chain else "solves/s",
+            "n_gpus": 1 if (args.share_gpu and not cpu) else n_ranks, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": sh.scaling, "vs_baseline": None, "dtype": "f64",
             "data": sh.data,
             "config": {"workload": sh.workload, "pairs_total": sh.total_pairs, "pairs_per_rank": sh.sizes,
                        "launcher": "torch.distributed.run" if not os.environ.get("PNEC_BENCH_SPAWNED") and world > 1
                                    else ("self-spawned ranks" if world > 1 else "single process"),
-                       "sharding": f"independent pairs, {n_ranks} rank(s), one {'gloo' if cpu else 'RCCL'} gather of "
+                       "sharding": f"independent pairs, {n_ranks} rank(s), one "
+                                   f"{'gloo' if (cpu or args.share_gpu) else 'RCCL'} gather of "
                                    f"80-B result records per step" + ("" if args.sync_gather or cpu else
                                                                       ", on a side stream (overlaps the next step)")},
         }
+        # digest of the gathered records of the last step (q, t, cost, iterations, status per pair, in pair order):
+        # equal across rank counts for the strong-scaling workloads, whose pairs do not depend on the sharding
+        line["records_sha256"] = hashlib.sha256(gathered.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+        if args.share_gpu and not cpu:
+            line["shared_gpu"] = {"ranks": n_ranks, "note": "every rank on cuda:0 (plumbing run on a one-GPU box: real "
+                                  "solver, partition and device-side gather with world > 1; gloo over pinned host records "
+                                  "because RCCL refuses two ranks on one device) -- NOT a scaling measurement",
+                                  "collectives_issued": gather.collectives}
         if cpu:
             # the gathered "cost" column must be the global pair index, in order, from the LAST step
             assert torch.equal(gathered[:, 7], torch.arange(sh.total_pairs, dtype=torch.float64))
@@ -424,6 +480,20 @@ def run(args):
                          "value": None, "dry_run": True, "records_in_order": True})
             if args.workload == "kitti_all":
                 line["config"]["corr_per_rank"] = sh.shard_corr
+        elif args.chain:
+            # the chain is five kernels of different character; no single roofline describes it.
+            # Reported: the device time of this rank's shard per step and the inlier statistics of the last step.
+            dev_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+            inl = gathered[:, 8]
+            line["config"].update({"corr_per_rank": sh.shard_corr,
+                                   "corr_min_mean_max": [int(sh.pair_sizes.min()), float(sh.pair_sizes.mean()),
+                                                         int(sh.pair_sizes.max())],
+                                   "options": "reference defaults: RANSAC eigensolver (5000 its max, 10-point samples), "
+                                              "weighted_iterations 10 + SCF, Ceres-default refinement"})
+            line["chain"] = {"device_ms_per_step_rank0": dev_ms,
+                             "inlier_share_mean": float((inl / torch.as_tensor(sh.pair_sizes, dtype=torch.float64)).mean()),
+                             "note": "one pnec_hip_solve_pipeline call per step and rank; stage kernels and their bounds: "
+                                     "profiles/r03_full_pipeline_kernels.md"}
         else:
             kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
             batch = sh.batch
@@ -464,7 +534,11 @@ def run(args):
                                        "corr_min_mean_max": [int(sh.pair_sizes.min()), float(sh.pair_sizes.mean()),
                                                              int(sh.pair_sizes.max())]})
             line["roofline"] = {
-                "bound": "hbm", "kernel": "lm_solve_kernel<TARGET>", "rank": 0,
+                # the contract's block prices the kernel against HBM (bytes it must read once / its duration);
+                # the roof that BINDS this register-resident kernel is FP64 VALU issue: see bound_binding / 'valu'
+                "bound": "hbm", "bound_binding": "valu_fp64",
+                "binding_frac": valu_tflops / FP64_VALU_PEAK_TFLOPS,
+                "kernel": "lm_solve_kernel<TARGET>", "rank": 0,
                 "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": why,
                 "kernel_ms": kernel_ms,

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define PNEC_HIP_ABI_VERSION 2
+#define PNEC_HIP_ABI_VERSION 3
 #define PNEC_HIP_MAX_RANSAC_SAMPLE 16 /* largest Options::ransac_sample_size_ the RANSAC kernel is built for */
 
 typedef enum pnec_hip_status {
@@ -232,7 +232,9 @@ typedef struct pnec_hip_pipeline_options {
   int32_t weighted_iterations;   /* 10    Options::weighted_iterations_ */
   int32_t max_ransac_iterations; /* 5000  Options::max_ransac_iterations_ */
   int32_t ransac_sample_size;    /* 10    Options::ransac_sample_size_ (<= PNEC_HIP_MAX_RANSAC_SAMPLE) */
-  int32_t reserved[2];           /* must be 0 */
+  int64_t first_pair_id;         /* 0     RANSAC draws: pair p of the batch samples as pair first_pair_id + p, so a
+                                          rank that solves pairs [a, b) of a larger set passes a and the results do
+                                          not depend on how the set was sharded (>= 0; ABI 2 had reserved[2] here) */
   double regularization;         /* 1e-13 Options::regularization_ */
   double ransac_threshold;       /* 1e-6  pnec.cc:248 */
   uint64_t ransac_seed;          /* 1     counter-based draws (see pnec_hip_ransac_eigensolver) */

@@ -201,6 +201,18 @@ void pnec_oracle_weighted_eigensolver(int64_t n, const double *bvs1, const doubl
                                       double reg, int weighted_iterations, double R_out[9],
                                       double t_out[3]);
 
+/* PNEC::Solve with the reference's default Options (pnec.cc:77-124: RANSAC eigensolver -> InlierExtraction ->
+ * WeightedEigensolver -> CeresSolver) for a ragged batch, OpenMP over pairs; covs [M,9] column-major; pair p
+ * draws as pair_id = first_pair_id + p; quaternions xyzw.  All outputs required. */
+void pnec_oracle_solve_chain_batch(int64_t n_pairs, const int64_t *offsets, const double *bvs1,
+                                   const double *bvs2, const double *covs, const double *init_q,
+                                   uint64_t seed, uint64_t first_pair_id, int max_ransac_iterations,
+                                   int sample_size, double threshold, double reg, int weighted_iterations,
+                                   int num_threads, double *es_q, double *es_t, uint8_t *inlier_mask,
+                                   int32_t *inlier_count, int32_t *ransac_iterations, double *w_q,
+                                   double *w_t, double *out_q, double *out_t, int32_t *ls_iterations,
+                                   int32_t *ls_status);
+
 #ifdef __cplusplus
 }
 #endif

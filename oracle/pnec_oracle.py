@@ -133,6 +133,10 @@ def lib() -> C.CDLL:
                                                                 C.c_int, C.c_int, C.c_int, _dp, _dp]
         _lib.pnec_oracle_weighted_eigensolver_ex.argtypes = [C.c_int64, _dp, _dp, _dp, _dp, _dp, C.c_double,
                                                              C.c_int, C.c_int, _dp, _dp]
+        _u8 = C.POINTER(C.c_uint8)
+        _lib.pnec_oracle_solve_chain_batch.argtypes = [C.c_int64, _lp, _dp, _dp, _dp, _dp, C.c_uint64, C.c_uint64,
+                                                       C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                                                       _dp, _dp, _u8, _ip, _ip, _dp, _dp, _dp, _dp, _ip, _ip]
     return _lib
 
 
@@ -335,6 +339,34 @@ def weighted_eigensolver_batch(offsets, bvs1, bvs2, covs, R_init, t_init, reg=1e
                                                  num_threads or max_threads(), R.ctypes.data_as(_dp),
                                                  t.ctypes.data_as(_dp))
     return R.reshape(P, 3, 3), t
+
+
+def solve_chain_batch(offsets, bvs1, bvs2, covs, init_q, seed=1, first_pair_id=0, max_ransac_iterations=5000,
+                      sample_size=10, threshold=1e-6, reg=1e-13, weighted_iterations=10, num_threads=0):
+    """PNEC::Solve with the reference's default Options (pnec.cc:77-124) for a ragged batch, OpenMP over pairs:
+    RANSAC eigensolver (pair p draws as pair_id first_pair_id + p) -> InlierExtraction -> WeightedEigensolver
+    (literal) -> CeresSolver (central differences, default solver options).  covs [M,3,3].
+    -> dict(es_q, es_t, mask [M] bool, inlier_count, ransac_iterations, w_q, w_t, q, t, ls_iterations, ls_status)"""
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    P, M = len(off) - 1, int(off[-1])
+    b1, b1p = _d(bvs1)
+    b2, b2p = _d(bvs2)
+    c, cp = _d(covs_to_colmajor9(covs))
+    q0, q0p = _d(np.asarray(init_q).reshape(P, 4))
+    f = lambda *shape: np.zeros(shape)
+    i = lambda n: np.zeros(n, dtype=np.int32)
+    es_q, es_t, w_q, w_t, q, t = f(P, 4), f(P, 3), f(P, 4), f(P, 3), f(P, 4), f(P, 3)
+    mask = np.zeros(max(M, 1), dtype=np.uint8)
+    cnt, rit, lit, lst = i(P), i(P), i(P), i(P)
+    dp = lambda a: a.ctypes.data_as(_dp)
+    ip = lambda a: a.ctypes.data_as(_ip)
+    lib().pnec_oracle_solve_chain_batch(P, off.ctypes.data_as(_lp), b1p, b2p, cp, q0p, seed, first_pair_id,
+                                        max_ransac_iterations, sample_size, threshold, reg, weighted_iterations,
+                                        num_threads or max_threads(), dp(es_q), dp(es_t),
+                                        mask.ctypes.data_as(C.POINTER(C.c_uint8)), ip(cnt), ip(rit), dp(w_q), dp(w_t),
+                                        dp(q), dp(t), ip(lit), ip(lst))
+    return dict(es_q=es_q, es_t=es_t, mask=mask[:M].astype(bool), inlier_count=cnt, ransac_iterations=rit, w_q=w_q,
+                w_t=w_t, q=q, t=t, ls_iterations=lit, ls_status=lst)
 
 
 def angles_from_vec(v):

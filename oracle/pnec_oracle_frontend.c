@@ -625,3 +625,67 @@ int pnec_oracle_ransac_eigensolver(int64_t n, const double *bvs1, const double *
   if (iterations) *iterations = it;
   return 0;
 }
+
+/* ---- PNEC::Solve with the reference's default Options, for a ragged batch: pnec.cc:77-124 ---------
+ * ES_solution = Eigensolver(bvs1, bvs2, initial_pose, inliers) with use_ransac_ (pnec.cc:231-272)
+ * InlierExtraction (pnec.cc:210-229)
+ * weighted_iterations_ > 1: WeightedEigensolver on the inliers from ES_solution (pnec.cc:283-348)
+ * use_ceres_: CeresSolver on the inliers from that (pnec.cc:350-370: default options, Target frame,
+ * central numeric differences)
+ * OpenMP over pairs (test tooling: the device's one-call chain against this at tens of thousands of
+ * pairs).  Pair p draws its RANSAC samples as pair_id = first_pair_id + p.  Every intermediate the
+ * parity tests look at comes back: the stage outputs, the mask, the iteration counts. */
+void pnec_oracle_solve_chain_batch(int64_t n_pairs, const int64_t *offsets, const double *bvs1,
+                                   const double *bvs2, const double *covs, const double *init_q,
+                                   uint64_t seed, uint64_t first_pair_id, int max_ransac_iterations,
+                                   int sample_size, double threshold, double reg, int weighted_iterations,
+                                   int num_threads, double *es_q, double *es_t, uint8_t *inlier_mask,
+                                   int32_t *inlier_count, int32_t *ransac_iterations, double *w_q,
+                                   double *w_t, double *out_q, double *out_t, int32_t *ls_iterations,
+                                   int32_t *ls_status) {
+  pnec_oracle_options opt;
+  pnec_oracle_default_options(&opt); /* PNEC::CeresSolver default-constructs its optimiser (pnec.cc:355) */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads > 0 ? num_threads : 1)
+  for (int64_t p = 0; p < n_pairs; ++p) {
+    const int64_t a = offsets[p], n = offsets[p + 1] - offsets[p];
+    double R0[9], Rr[9], tr[3], Rw[9], tw[3], qw[4];
+    pnec_oracle_rot_from_quat(init_q + 4 * p, R0);
+    int32_t cnt = 0, its = 0;
+    pnec_oracle_ransac_eigensolver(n, bvs1 + 3 * a, bvs2 + 3 * a, R0, seed, first_pair_id + (uint64_t)p,
+                                   max_ransac_iterations, sample_size, threshold, Rr, tr, inlier_mask + a, &cnt,
+                                   &its);
+    inlier_count[p] = cnt;
+    ransac_iterations[p] = its;
+    pnec_oracle_quat_from_rot(Rr, es_q + 4 * p);
+    memcpy(es_t + 3 * p, tr, sizeof(tr));
+    const size_t m = (size_t)(cnt > 0 ? cnt : 1);
+    double *i1 = (double *)malloc(sizeof(double) * 3 * m), *i2 = (double *)malloc(sizeof(double) * 3 * m);
+    double *ic = (double *)malloc(sizeof(double) * 9 * m);
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; ++i)
+      if (inlier_mask[a + i]) {
+        memcpy(i1 + 3 * k, bvs1 + 3 * (a + i), 3 * sizeof(double));
+        memcpy(i2 + 3 * k, bvs2 + 3 * (a + i), 3 * sizeof(double));
+        memcpy(ic + 9 * k, covs + 9 * (a + i), 9 * sizeof(double));
+        ++k;
+      }
+    if (weighted_iterations > 1) {
+      pnec_oracle_weighted_eigensolver_ex(k, i1, i2, ic, Rr, tr, reg, weighted_iterations, 0, Rw, tw);
+    } else { /* == 1: the eigensolver's pose goes on (pnec.cc:109-111); 0 is not this function's business */
+      memcpy(Rw, Rr, sizeof(Rw));
+      memcpy(tw, tr, sizeof(tw));
+    }
+    pnec_oracle_quat_from_rot(Rw, qw);
+    memcpy(w_q + 4 * p, qw, sizeof(qw));
+    memcpy(w_t + 3 * p, tw, sizeof(tw));
+    double cost = 0.0;
+    int32_t it_ls = 0;
+    const int st = pnec_oracle_solve(PNEC_ORACLE_MODE_TARGET, k, i1, i2, ic, NULL, reg, qw, tw, &opt, out_q + 4 * p,
+                                     out_t + 3 * p, NULL, &cost, &it_ls);
+    ls_iterations[p] = it_ls;
+    ls_status[p] = st;
+    free(i1);
+    free(i2);
+    free(ic);
+  }
+}

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PNEC_HIP_LIB: load an alternative build of the same ABI (kernel A/B experiments only)
 LIB_PATH = os.environ.get("PNEC_HIP_LIB") or os.path.join(_HERE, "libpnec_hip.so")
 
-ABI_VERSION = 2  # PNEC_HIP_ABI_VERSION of include/pnec_hip.h this binding was written against
+ABI_VERSION = 3  # PNEC_HIP_ABI_VERSION of include/pnec_hip.h this binding was written against
 MODE_NEC, MODE_TARGET, MODE_HOST, MODE_SYM = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 TERM_NAMES = {
@@ -101,7 +101,7 @@ class PipelineOptions(C.Structure):
         ("weighted_iterations", C.c_int32),
         ("max_ransac_iterations", C.c_int32),
         ("ransac_sample_size", C.c_int32),
-        ("reserved", C.c_int32 * 2),
+        ("first_pair_id", C.c_int64),
         ("regularization", C.c_double),
         ("ransac_threshold", C.c_double),
         ("ransac_seed", C.c_uint64),

@@ -117,6 +117,26 @@ int main(int argc, char **argv) {
                 n, n_inl, reps, us[us.size() / 2], us[us.size() / 10], us[us.size() * 9 / 10], sink / reps);
     return 0;
   }
+  if (argc > 2 && std::strcmp(argv[2], "timing") == 0) {
+    // the odometry's bookkeeping around the solver (pnec_vo.cc:220-261,273-276): one FrameTiming per frame,
+    // filled by the timed PNEC::Solve overload, collected in a Timing and written to timing.txt
+    const int frames = argc > 3 ? std::atoi(argv[3]) : 5;
+    const char *path = argc > 4 ? argv[4] : "timing.txt";
+    pnec::rel_pose_estimation::Options options;
+    pnec::rel_pose_estimation::PNEC pnec_solver(options);
+    const pnec::SE3d init(pnec::Quaterniond(0.975, 0.1, -0.14, 0.115).normalized().toRotationMatrix(),
+                          pnec::Vector3d(0.28, -0.22, 0.92).normalized());
+    pnec::common::Timing timing;
+    for (int f = 1; f <= frames; ++f) {
+      pnec::common::FrameTiming frame_timing(f);
+      std::vector<int> inliers;
+      pnec_solver.Solve(b1, b2, covs, init, inliers, frame_timing);
+      timing.push_back(frame_timing);
+    }
+    if (!timing.Save(path)) { std::printf("cannot write %s\n", path); return 1; }
+    std::printf("wrote %zu rows to %s\n", timing.size(), path);
+    return 0;
+  }
   // the reference's default Options: RANSAC eigensolver -> inliers -> 9 weighted eigensolver rounds +
   // SCF -> Ceres-style refinement (run_simulation.cc:74-86 calls it exactly like this)
   pnec::rel_pose_estimation::Options options;
@@ -131,5 +151,28 @@ int main(int argc, char **argv) {
   const double cost = pnec::common::CostFunction(b1, b2, covs, sol);
   std::printf("n=%d inliers=%zu rot_err_init_deg=%.6f rot_err_deg=%.6f t_err_deg=%.6f cost=%.6f\n", n,
               inliers.size(), e0, e1, te, cost);
+  if (argc > 3 && std::strcmp(argv[2], "dump") == 0) {
+    // everything a checker needs to repeat this call elsewhere: inputs, start pose, result, inliers
+    // (text, %.17g: doubles round-trip exactly)
+    std::FILE *f = std::fopen(argv[3], "w");
+    if (!f) { std::printf("cannot write %s\n", argv[3]); return 1; }
+    std::fprintf(f, "%d\n", n);
+    for (int i = 0; i < n; ++i) {
+      for (int k = 0; k < 3; ++k) std::fprintf(f, "%.17g ", b1[i][k]);
+      for (int k = 0; k < 3; ++k) std::fprintf(f, "%.17g ", b2[i][k]);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) std::fprintf(f, "%.17g ", covs[i](r, c));
+      std::fprintf(f, "\n");
+    }
+    const pnec::Quaterniond qi(init.rotationMatrix()), qs(sol.rotationMatrix());
+    std::fprintf(f, "%.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", qi.coeffs()[0], qi.coeffs()[1], qi.coeffs()[2],
+                 qi.coeffs()[3], init.translation()[0], init.translation()[1], init.translation()[2]);
+    std::fprintf(f, "%.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", qs.coeffs()[0], qs.coeffs()[1], qs.coeffs()[2],
+                 qs.coeffs()[3], sol.translation()[0], sol.translation()[1], sol.translation()[2]);
+    std::fprintf(f, "%zu", inliers.size());
+    for (int i : inliers) std::fprintf(f, " %d", i);
+    std::fprintf(f, "\n");
+    std::fclose(f);
+  }
   return (e1 < e0 && e1 < 0.1) ? 0 : 1;
 }

@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <fstream>
 
 namespace pnec {
 namespace {
@@ -215,6 +216,31 @@ double CostFunction(const bearingVectors_t &bvs_1, const bearingVectors_t &bvs_2
   Check(pnec_hip_cost_function(prob.p, q.coeffs(), camera_pose.translation().data(), &out,
                                PNEC_HIP_MEM_HOST, nullptr));
   return out;
+}
+
+std::ostream &operator<<(std::ostream &os, const FrameTiming &ft) {
+  const long fields[] = {(long)ft.id_,    ft.frame_loading_, ft.feature_creation_,      ft.nec_es_,
+                         ft.it_es_,       ft.avg_it_es_,     ft.ceres_,
+                         (long)ft.OptimizationTime(),        (long)ft.TotalTime()};
+  const char *sep = "";
+  for (long v : fields) {
+    os << sep << v;
+    sep = " ";
+  }
+  return os;
+}
+
+std::ostream &operator<<(std::ostream &os, const Timing &timing) {
+  os << FrameTiming::TimingHeader() << std::endl;
+  for (const FrameTiming &ft : timing.frame_timings_) os << ft << std::endl;
+  return os;
+}
+
+bool Timing::Save(const std::string &path) const {
+  std::ofstream out(path, std::ios_base::trunc);
+  if (!out) return false;
+  out << *this;
+  return (bool)out;
 }
 
 }  // namespace common

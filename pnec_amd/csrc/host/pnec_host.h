@@ -15,6 +15,7 @@
 #pragma once
 
 #include <cstdint>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -56,6 +57,26 @@ struct FrameTiming {
   int id_;
   long frame_loading_ = 0, feature_creation_ = 0, nec_es_ = 0, it_es_ = 0, avg_it_es_ = 0, ceres_ = 0;  // ms
 };
+// src/common/timing.cc:49-58: one row of timing.txt -- "id loading features nec-es it-es avg-it-es ceres
+// optimization total", blank separated.  Every field is an integral millisecond count there
+// (std::chrono::milliseconds::count() and two int sums), so the std::scientific / setprecision(8) the
+// reference sets on the stream never shows in a row: the fields print as plain integers.
+std::ostream &operator<<(std::ostream &os, const FrameTiming &frame_timing);
+
+// include/common/timing.h:69-80, src/common/timing.cc:60-66: the rows of a run; streams as the header line
+// followed by one row per frame (what pnec_vo.cc:273-276 writes to <results>/timing.txt)
+class Timing {
+ public:
+  void push_back(const FrameTiming &frame_timing) { frame_timings_.push_back(frame_timing); }
+  size_t size() const { return frame_timings_.size(); }
+  friend std::ostream &operator<<(std::ostream &os, const Timing &timing);
+  // pnec_vo.cc:273-276: open <path> truncating, stream the table; false if the file cannot be written
+  bool Save(const std::string &path) const;
+
+ private:
+  std::vector<FrameTiming> frame_timings_;
+};
+std::ostream &operator<<(std::ostream &os, const Timing &timing);
 
 // common.cc:237-259, evaluated on the device
 double CostFunction(const bearingVectors_t &bvs_1, const bearingVectors_t &bvs_2,

@@ -30,7 +30,7 @@ hipError_t launch_solve_aos_mode_3(int, int, int, const SolveArgs &, hipStream_t
 
 // pnec_frontend.hip
 hipError_t launch_ransac_eigensolver(const double *, const int64_t *, const int64_t *, const int32_t *, int64_t,
-                                     const double *, unsigned long long, int, int, double, double *, double *,
+                                     const double *, unsigned long long, unsigned long long, int, int, double, double *, double *,
                                      uint8_t *, int32_t *, int32_t *, double *, int32_t *, hipStream_t, hipStream_t,
                                      hipEvent_t, hipEvent_t);
 hipError_t launch_select(int, const double *, const int64_t *, const int64_t *, const int32_t *, const uint8_t *,
@@ -1457,7 +1457,7 @@ int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint6
     return rc;
   }
   hipError_t e = launch_ransac_eigensolver(p->d_data, p->d_block_offset, p->d_offsets, p->d_count, P, d_q, seed,
-                                           max_iterations, sample_size, threshold, d_oq, d_ot, d_mask, d_cnt, d_it,
+                                           /*first_pair_id*/ 0ull, max_iterations, sample_size, threshold, d_oq, d_ot, d_mask, d_cnt, d_it,
                                            p->d_front, p->d_front_i, stream, nullptr, nullptr, nullptr);
   if (e == hipSuccess && space == PNEC_HIP_MEM_HOST) {
     e = hipMemcpyAsync(out_q, d_oq, sizeof(double) * 4 * P, hipMemcpyDeviceToHost, stream);

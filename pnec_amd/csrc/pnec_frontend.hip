@@ -1368,6 +1368,7 @@ struct RansacArgs {
   int32_t *out_count, *out_iterations;
   unsigned long long *trace;  // null, or [n_pairs, 8] clocks per phase (PNEC_HIP_TRACE_FRONT)
   unsigned long long seed;
+  unsigned long long pair_id_base;  // pair p draws as pair pair_id_base + p (shards of a larger set)
   int64_t n_pairs;
   int max_iterations, sample_size;
   double threshold;
@@ -1474,7 +1475,8 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
       // j of the round is consumed only if it + j < k, and k can only shrink while the round is consumed -- the
       // quads beyond ceil(k - it) would never be looked at, so they stay out (exact; it shortens the slowest-of-
       // the-quads Newton phase of the ~40 % of pairs that need a second round, typically for two or three more)
-      const int needed = it == 0 ? kHypPerRound : (int)ceil(k - (double)it);
+      // (clamped in floating point: with no inlier yet k is ~2e16 or inf, outside int's range)
+      const int needed = it == 0 ? kHypPerRound : (int)fmin(ceil(k - (double)it), (double)kHypPerRound);
       const bool active = hyp < needed;
       // ---- this quad's hypothesis: sample, sums, minimise, translation (the four lanes do the same up to
       // the minimiser, which splits its evaluations over them)
@@ -1483,7 +1485,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
         int m = 0;
         unsigned long long draw = 0;
         while (m < ss) {
-          long long idx = (long long)(rng_uniform(a.seed, (unsigned long long)pair, h, draw++) * (double)n);
+          long long idx = (long long)(rng_uniform(a.seed, a.pair_id_base + (unsigned long long)pair, h, draw++) * (double)n);
           if (idx >= n) idx = n - 1;
           bool dup = false;
           for (int j = 0; j < m; ++j) dup = dup || (sel(j) == (int)idx);
@@ -1521,7 +1523,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       double v[3], R[9], t[3];
       for (int c = 0; c < 3; ++c)
-        v[c] = v0[c] + (rng_uniform(a.seed, (unsigned long long)pair, h, 1000 + c) - 0.5) * 2.0 * 0.01;
+        v[c] = v0[c] + (rng_uniform(a.seed, a.pair_id_base + (unsigned long long)pair, h, 1000 + c) - 0.5) * 2.0 * 0.01;
       PNEC_PHASE_END(kRpSample);
       // t = eigenvector of the smallest eigenvalue of M at the minimiser (sign settled by the evidence below)
       const int newton_its = es_minimise_quad<1, 1>(Gh[hyp], v, (double)ss, t, active);
@@ -1736,8 +1738,8 @@ hipError_t launch_select(int nc, const double *src, const int64_t *src_block, co
 
 hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_offset, const int64_t *offsets,
                                      const int32_t *count, int64_t n_pairs, const double *init_q,
-                                     unsigned long long seed, int max_iterations, int sample_size,
-                                     double threshold, double *out_q, double *out_t, uint8_t *out_mask,
+                                     unsigned long long seed, unsigned long long pair_id_base, int max_iterations,
+                                     int sample_size, double threshold, double *out_q, double *out_t, uint8_t *out_mask,
                                      int32_t *out_count, int32_t *out_iterations, double *scratch_d,
                                      int32_t *scratch_i, hipStream_t stream, hipStream_t tail_stream,
                                      hipEvent_t tail_fork, hipEvent_t tail_done) {
@@ -1759,6 +1761,7 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   a.out_count = out_count;
   a.out_iterations = out_iterations;
   a.seed = seed;
+  a.pair_id_base = pair_id_base;
   a.n_pairs = n_pairs;
   a.max_iterations = max_iterations;
   a.sample_size = sample_size;

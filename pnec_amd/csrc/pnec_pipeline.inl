@@ -63,6 +63,7 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
     return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad memory space");
   pnec_hip_pipeline_options o;
   if (opt_in) o = *opt_in; else pnec_hip_default_pipeline_options(&o);
+  if (o.first_pair_id < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "first_pair_id < 0");
   if (o.weighted_iterations < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "weighted_iterations < 0");
   if (!o.use_nec && p->mode != PNEC_HIP_MODE_TARGET)
     return fail(PNEC_HIP_ERR_UNSUPPORTED, "the PNEC chain needs a TARGET-mode problem (bearings + frame-2 covariances)");
@@ -112,7 +113,7 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
     // beside InlierExtraction (bandwidth-bound), which only needs the masks; both join before the weighted stage
     if (int rc = ensure_side_streams(p, 1)) return rc;
     e = launch_ransac_eigensolver(p->d_data, p->d_block_offset, p->d_offsets, p->d_count, P, d_iq, o.ransac_seed,
-                                  o.max_ransac_iterations, o.ransac_sample_size, o.ransac_threshold, es_q, es_t,
+                                  (unsigned long long)o.first_pair_id, o.max_ransac_iterations, o.ransac_sample_size, o.ransac_threshold, es_q, es_t,
                                   d_mask, d_cnt, nullptr, p->d_front, p->d_front_i, stream, p->side_streams[0],
                                   p->fork_event, p->side_done[0]);
     if (e != hipSuccess) return fail_hip(e, "ransac_eigensolver_kernel");

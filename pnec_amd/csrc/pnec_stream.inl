@@ -132,6 +132,20 @@ static bool aos_geometry_for(int mode, int n, Geometry *g) {
   return false;
 }
 
+// After a failed launch or a failed wait the slot's device counter and the host's idea of it may have drifted
+// apart (some workgroups of a multi-launch submit counted in, others never ran).  Bring both back to zero: drain
+// the stream so that nothing still counts, clear the counter, forget the ticket.  The slot is usable again; the
+// error that brought us here is what the caller sees.
+static void stream_slot_reset(pnec_hip_stream *s, pnec_hip_stream::Slot &sl) {
+  const size_t i = (size_t)(&sl - s->slot.data());
+  (void)hipStreamSynchronize(s->stream);
+  (void)hipGetLastError();
+  (void)hipMemset(s->d_counters + i, 0, sizeof(unsigned long long));
+  sl.blocks_done = 0;
+  sl.ticket = 0;
+  __atomic_store_n((unsigned long long *)(sl.h_base + s->o_flag), 0ull, __ATOMIC_RELEASE);
+}
+
 static int stream_slot_wait(pnec_hip_stream *s, pnec_hip_stream::Slot &sl) {
   if (sl.ticket == 0) return 0;
   if (sl.staged) {
@@ -176,6 +190,11 @@ int pnec_hip_stream_submit(pnec_hip_stream *s, int mode, int64_t n_pairs, const 
   pnec_hip_options opt;
   if (opt_in) opt = *opt_in; else pnec_hip_default_options(&opt);
   if (opt.max_num_iterations < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "max_num_iterations < 0");
+  // the handle picks each pair's geometry from the auto-tuner's ladder (the only AoS-source kernels built), so a
+  // forced geometry cannot be honoured here: refuse it rather than silently run something else
+  if (opt.corr_per_lane != 0 || opt.waves_per_pair != 0 || opt.lds_corr_per_lane != 0)
+    return fail(PNEC_HIP_ERR_UNSUPPORTED, "forced launch tunings (corr_per_lane / waves_per_pair / lds_corr_per_lane) "
+                                          "are not available on the streaming handle");
   DeviceGuard guard(s->device);
 
   const int64_t t = s->next_ticket;
@@ -219,8 +238,9 @@ int pnec_hip_stream_submit(pnec_hip_stream *s, int mode, int64_t n_pairs, const 
     a.flag_value = (unsigned long long)t;
     // the slot's counter only ever counts up (no reset launch between submits): this submit is complete
     // when it reaches the number of workgroups ever launched on the slot
-    sl.blocks_done += (unsigned long long)n_pairs;
-    a.n_blocks_total = sl.blocks_done;
+    // (the host's count advances only once every launch of this submit has been accepted)
+    const unsigned long long blocks_total = sl.blocks_done + (unsigned long long)n_pairs;
+    a.n_blocks_total = blocks_total;
     a.n_hyp = 1;
     a.reg = reg;
     a.opt = opt;
@@ -260,7 +280,15 @@ int pnec_hip_stream_submit(pnec_hip_stream *s, int mode, int64_t n_pairs, const 
         e = launch(g, ab);
       }
     }
-    if (e != hipSuccess) return fail_hip(e, "streaming solve launch");
+    if (e != hipSuccess) {
+      // some launches of this submit may be running and will count into the slot: drain and re-zero it
+      const int rc = fail_hip(e, "streaming solve launch");
+      const std::string msg = g_last_error;
+      stream_slot_reset(s, sl);
+      g_last_error = msg;
+      return rc;
+    }
+    sl.blocks_done = blocks_total;
   } else {
     // staged route: a persistent batch of the handle, re-shaped to this submit's sizes
     if (s->big) pnec_hip_problem_destroy(s->big);
@@ -310,7 +338,13 @@ int pnec_hip_stream_wait(pnec_hip_stream *s, int64_t ticket, double *out_q, doub
   pnec_hip_stream::Slot *sl = stream_find(s, ticket);
   if (!sl) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "unknown or already collected ticket");
   DeviceGuard guard(s->device);
-  if (int rc = stream_slot_wait(s, *sl)) return rc;
+  if (int rc = stream_slot_wait(s, *sl)) {
+    // the ticket is lost, the slot is not: release it (counter and flag re-zeroed) instead of leaving it BUSY
+    const std::string msg = g_last_error;
+    stream_slot_reset(s, *sl);
+    g_last_error = msg;
+    return rc;
+  }
   const size_t P = (size_t)sl->n_pairs;
   const char *h = sl->h_base;
   if (out_q) std::memcpy(out_q, h + s->o_oq, sizeof(double) * 4 * P);

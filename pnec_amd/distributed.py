@@ -87,42 +87,84 @@ class RecordGather:
                         g.submit(slot, out)           # pack + gather on the side stream
     and once at the end g.drain() -> the last step's gathered records on `dst` (None elsewhere).
     On CPU tensors (gloo; the tests) the same calls run synchronously.
+
+    Device forms (device = a CUDA device):
+      * default: the collective itself takes the device records (backend "nccl" = RCCL over xGMI) and is
+        enqueued on the side stream -- the production path, one GPU per rank;
+      * host_staged=True: the side stream packs the records and copies them into a pinned host buffer; the
+        collective (any backend that moves host tensors, i.e. gloo) runs when the slot comes round again or at
+        drain().  Same events, same double buffering, same `sizes=` trimming -- it exists so that several ranks
+        can share ONE GPU (RCCL refuses two ranks on one device), which is how this path is exercised on the
+        single-GPU test boxes (`bench.py --share-gpu`, tests/test_distributed_gpu.py).
+    force_collective=True issues the collective even for world == 1 (a one-rank RCCL communicator: the
+    device call path of the production form, on a box with one GPU).
     """
 
     SLOTS = 2
 
-    def __init__(self, world: int, rank: int, sizes=None, dst: int = 0, device=None):
+    def __init__(self, world: int, rank: int, sizes=None, dst: int = 0, device=None, host_staged: bool = False,
+                 force_collective: bool = False):
         self.world, self.rank, self.sizes, self.dst = world, rank, sizes, dst
         self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.host_staged = bool(host_staged) and self.cuda
+        self.force = bool(force_collective)
         self.next_slot = 0
         self.last = None
+        self.collectives = 0      # collectives issued (bookkeeping for the tests)
         if self.cuda:
             self.device = torch.device(device)
             self.side = torch.cuda.Stream(device=self.device)
             self.solved = [torch.cuda.Event() for _ in range(self.SLOTS)]
             self.gathered = [None] * self.SLOTS
+            self.pinned = [None] * self.SLOTS     # host_staged: the slot's records on the host
+            self.pending = [False] * self.SLOTS   # host_staged: copy enqueued, collective not yet run
+
+    def _collective(self, rec: torch.Tensor):
+        self.collectives += 1
+        if self.world == 1 and self.force:
+            bufs = [torch.empty_like(rec)]
+            dist.gather(rec.contiguous(), bufs, dst=0)
+            return bufs[0]
+        return gather_records(rec, self.world, self.rank, self.sizes, self.dst)
+
+    def _complete(self, slot: int) -> None:
+        """host_staged: run the collective of a slot whose device-to-host copy was enqueued earlier."""
+        if self.host_staged and self.pending[slot]:
+            self.gathered[slot].synchronize()      # the copy into pinned memory has landed
+            self.last = self._collective(self.pinned[slot])
+            self.pending[slot] = False
 
     def acquire(self) -> int:
         slot = self.next_slot
         self.next_slot = (slot + 1) % self.SLOTS
         if self.cuda and self.gathered[slot] is not None:
+            self._complete(slot)
             torch.cuda.current_stream(self.device).wait_event(self.gathered[slot])
         return slot
 
     def submit(self, slot: int, res) -> None:
         if not self.cuda:
-            self.last = gather_records(pack_records(res), self.world, self.rank, self.sizes, self.dst)
+            self.last = self._collective(pack_records(res))
             return
         self.solved[slot].record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.solved[slot])
             rec = pack_records(res)
-            self.last = gather_records(rec, self.world, self.rank, self.sizes, self.dst)
+            if self.host_staged:
+                if self.pinned[slot] is None or self.pinned[slot].shape != rec.shape:
+                    self.pinned[slot] = torch.empty(rec.shape, dtype=rec.dtype, pin_memory=True)
+                self.pinned[slot].copy_(rec, non_blocking=True)
+                self.pending[slot] = True
+            else:
+                self.last = self._collective(rec)
             ev = torch.cuda.Event()
             ev.record(self.side)
             self.gathered[slot] = ev
 
     def drain(self):
         if self.cuda:
+            if self.host_staged:   # in submission order: the slot after the most recent one is the older
+                for k in range(self.SLOTS):
+                    self._complete((self.next_slot + k) % self.SLOTS)
             self.side.synchronize()
         return self.last

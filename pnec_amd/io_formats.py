@@ -12,7 +12,10 @@ simulator's experiment folders.
       r_error.csv / t_error.csv / cost.csv: header "index,<method>,..." then one row per experiment
   pose stream             pnec::out::SavePose               src/io/odometry_output.cc:43-54
       "<timestamp fixed> tx ty tz qx qy qz qw" with 8-digit scientific notation
-  timing                  FrameTiming::TimingHeader         include/common/timing.h:52-55
+  timing                  FrameTiming / Timing operator<<   include/common/timing.h:52-55, src/common/timing.cc:49-67
+      timing.txt (pnec_vo.cc:273-276): the header line, then per frame
+      "id loading features nec-es it-es avg-it-es ceres optimization total" -- integral milliseconds
+      (the reference sets std::scientific on the stream, but every field is an integer count)
 """
 from __future__ import annotations
 
@@ -119,3 +122,37 @@ def read_pose_file(path):
     """-> (timestamps [M], t [M,3], q_xyzw [M,4])"""
     a = np.loadtxt(path, ndmin=2)
     return a[:, 0], a[:, 1:4], a[:, 4:8]
+
+
+TIMING_FIELDS = ("id", "frame_loading", "feature_creation", "nec_es", "it_es", "avg_it_es", "ceres")
+
+
+def format_timing_row(id, frame_loading=0, feature_creation=0, nec_es=0, it_es=0, avg_it_es=0, ceres=0) -> str:
+    """FrameTiming's operator<< (timing.cc:49-58): the six stage times in whole milliseconds, then
+    OptimizationTime() = nec_es + it_es + ceres and TotalTime() = loading + features + optimisation
+    (timing.cc:40-47).  Durations are truncated to whole milliseconds like duration_cast does."""
+    v = [int(id)] + [int(x) for x in (frame_loading, feature_creation, nec_es, it_es, avg_it_es, ceres)]
+    optimization = v[3] + v[4] + v[6]
+    return " ".join(str(x) for x in v + [optimization, v[1] + v[2] + optimization])
+
+
+def write_timing_file(path, rows) -> None:
+    """Timing's operator<< (timing.cc:60-66) into a truncated file (pnec_vo.cc:273-276).
+    rows: dicts with TIMING_FIELDS keys (missing stage times are 0) or 7-sequences in that order."""
+    with open(path, "w") as f:
+        f.write(TIMING_HEADER + "\n")
+        for r in rows:
+            f.write((format_timing_row(**r) if isinstance(r, dict) else format_timing_row(*r)) + "\n")
+
+
+def read_timing_file(path):
+    """-> int64 [M,9] (the columns of TIMING_HEADER); checks the header and the two derived columns."""
+    with open(path) as f:
+        header = f.readline().rstrip("\n")
+        if header != TIMING_HEADER:
+            raise ValueError(f"not a timing file: header {header!r}")
+        a = np.array([[int(c) for c in line.split()] for line in f if line.strip()], dtype=np.int64).reshape(-1, 9)
+    if len(a) and not (np.array_equal(a[:, 7], a[:, 3] + a[:, 4] + a[:, 6])
+                       and np.array_equal(a[:, 8], a[:, 1] + a[:, 2] + a[:, 7])):
+        raise ValueError("timing rows whose OPTIMIZATION / TOTAL columns are not the sums of their stages")
+    return a

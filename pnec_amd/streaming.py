@@ -21,6 +21,7 @@ class Stream:
         capi.check(self._lib.pnec_hip_stream_create(self.device, self.max_corr, self.max_pairs, self.slots, None,
                                                     C.byref(h)))
         self._h = h
+        self._pairs = {}   # ticket -> pairs it carries (sizes the result arrays of wait)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -41,7 +42,10 @@ class Stream:
 
     def submit(self, mode: int, bvs1, bvs2, covs=None, covs_host=None, init_q=None, init_t=None, reg: float = 1e-13,
                options: capi.Options | None = None, offsets=None) -> int:
-        """One frame pair (or, with `offsets`, several) -> ticket.  Arrays as in Batch.fill."""
+        """One frame pair (or, with `offsets`, several) -> ticket.  Arrays as in Batch.fill; a start pose
+        (init_q xyzw, init_t) per pair is required."""
+        if init_q is None or init_t is None:
+            raise ValueError("init_q and init_t are required: one start pose per pair")
         b1 = np.ascontiguousarray(bvs1, dtype=np.float64).reshape(-1, 3)
         b2 = np.ascontiguousarray(bvs2, dtype=np.float64).reshape(-1, 3)
         M = len(b1)
@@ -71,7 +75,6 @@ class Stream:
                                                     q.ctypes.data, t.ctypes.data, float(reg),
                                                     C.byref(options) if options is not None else None,
                                                     C.byref(ticket)))
-        self._pairs = getattr(self, "_pairs", {})
         self._pairs[ticket.value] = P
         return ticket.value
 
@@ -81,7 +84,11 @@ class Stream:
         return bool(done.value)
 
     def wait(self, ticket: int) -> SolveResult:
-        P = self._pairs.pop(int(ticket))
+        P = self._pairs.get(int(ticket))
+        if P is None:   # let the library name the problem (INVALID_ARGUMENT: unknown or already collected ticket)
+            capi.check(self._lib.pnec_hip_stream_wait(self._h, int(ticket), None, None, None, None, None))
+            raise capi.PnecHipError(-1, "unknown or already collected ticket")
+        del self._pairs[int(ticket)]
         out = SolveResult(np.empty((P, 4)), np.empty((P, 3)), np.empty(P), np.empty(P, dtype=np.int32),
                           np.empty(P, dtype=np.int32))
         capi.check(self._lib.pnec_hip_stream_wait(self._h, int(ticket), out.q.ctypes.data, out.t.ctypes.data,

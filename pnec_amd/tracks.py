@@ -143,8 +143,10 @@ def kitti_all_sizes(mean_corr: int = 500, seed: int = 1, frames=KITTI_FRAMES) ->
 
 
 def kitti_all_shard(first_pair: int, last_pair: int, mean_corr: int = 500, seed: int = 1,
-                    device="cpu", frames=KITTI_FRAMES) -> Tracks:
-    """Pairs [first_pair, last_pair) of the synthetic KITTI-00..10-sized set, generated on `device`."""
+                    device="cpu", frames=KITTI_FRAMES, outlier_frac: float = 0.0) -> Tracks:
+    """Pairs [first_pair, last_pair) of the synthetic KITTI-00..10-sized set, generated on `device`.
+    outlier_frac > 0 replaces that share of frame-2 bearings by random directions in front of the camera
+    (gross mismatches, what RANSAC is there for) -- drawn per chunk, so still a function of (seed, pair)."""
     import torch
 
     from . import simulation as sim
@@ -160,6 +162,13 @@ def kitti_all_shard(first_pair: int, last_pair: int, mean_corr: int = 500, seed:
         off, f1, f2, cv, _, _, q, t = sim.generate_kitti_like(hi - lo, mean_corr=mean_corr,
                                                               seed=seed * 100_003 + c, device=device,
                                                               counts=counts)
+        if outlier_frac > 0.0:
+            g = torch.Generator(device=f1.device)
+            g.manual_seed(seed * 7_919 + 31 * c + 5)
+            bad = torch.rand(f2.shape[0], device=f1.device, generator=g) < outlier_frac
+            rnd = torch.randn(f2.shape[0], 3, dtype=torch.float64, device=f1.device, generator=g)
+            rnd[:, 2] = rnd[:, 2].abs() + 1.0
+            f2 = torch.where(bad[:, None], rnd / rnd.norm(dim=-1, keepdim=True), f2)
         a, b = max(first_pair, lo) - lo, min(last_pair, hi) - lo
         parts.append((off[a:b + 1] - off[a], f1[off[a]:off[b]], f2[off[a]:off[b]], cv[off[a]:off[b]], q[a:b], t[a:b]))
     dev = torch.device(device)

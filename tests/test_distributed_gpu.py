@@ -60,3 +60,147 @@ def test_two_ranks_solve_their_shards_and_gather_the_whole_batch():
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-2000:]
     assert "GATHERED_EQUALS_WHOLE_BATCH" in outs[0][0]
+
+
+def test_config5_full_set_as_eight_shards_equals_one_batch_and_the_oracle(oracle):
+    """BASELINE config 5 at its size: all 23 190 ragged pairs of the KITTI-00..10-sized set (the labelled synthetic
+    stand-in: no KITTI data exists here), (a) solved as ONE batch, (b) solved as the 8 contiguous, correspondence-
+    balanced shards `partition` hands to 8 ranks -- each shard built from scratch the way its rank would build it
+    (tracks.kitti_all_shard(a, b)) -- with the records concatenated in rank order, which is what the one gather
+    delivers (scripts/parallel_kitti.sh:60-69 is the reference's fan-out).  The two must be equal bit for bit,
+    and 256 sampled pairs must match the reference-faithful oracle (central differences, Ceres-default
+    termination): iteration counts equal, rotations <= 1e-6 rad."""
+    import numpy as np
+    import torch
+    from pnec_amd import Batch, capi
+    from pnec_amd import tracks as tk
+    from pnec_amd.distributed import pack_records, partition
+    dev = torch.device("cuda:0")
+    sizes = tk.kitti_all_sizes()
+    P = len(sizes)
+    assert P == 23190 and sizes.min() >= 64 and sizes.max() > 512          # ragged, beyond one wavefront's 512
+    whole = tk.kitti_all_shard(0, P, device=dev)
+    assert np.array_equal(np.diff(whole.offsets), sizes)
+    with Batch(capi.MODE_TARGET, whole.offsets) as b:
+        b.fill(whole.bvs1, whole.bvs2, whole.covs)
+        ref = pack_records(b.solve(whole.init_q.contiguous(), whole.init_t.contiguous())).cpu()
+    bounds = partition(sizes, 8)
+    shard_corr = [int(sizes[bounds[r]:bounds[r + 1]].sum()) for r in range(8)]
+    assert max(shard_corr) - min(shard_corr) <= 2 * sizes.max()            # balanced by correspondences
+    parts = []
+    for r in range(8):
+        a, c = int(bounds[r]), int(bounds[r + 1])
+        tr = tk.kitti_all_shard(a, c, device=dev)                           # what rank r builds for itself
+        with Batch(capi.MODE_TARGET, tr.offsets) as b:
+            b.fill(tr.bvs1, tr.bvs2, tr.covs)
+            parts.append(pack_records(b.solve(tr.init_q.contiguous(), tr.init_t.contiguous())).cpu())
+    got = torch.cat(parts)
+    assert got.shape == ref.shape == (P, 10)
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    # sampled parity against the oracle (the reference's execution: numeric central differences)
+    rng = np.random.default_rng(5)
+    pick = np.sort(rng.choice(P, 256, replace=False))
+    off = whole.offsets
+    idx = np.concatenate([np.arange(off[p], off[p + 1]) for p in pick])
+    f1, f2, cv = (x[torch.as_tensor(idx, device=dev)].cpu().numpy() for x in (whole.bvs1, whole.bvs2, whole.covs))
+    soff = np.concatenate([[0], np.cumsum(sizes[pick])])
+    q, t, cost, its, st = oracle.solve_batch(oracle.MODE_TARGET, soff, f1, f2, oracle.covs_to_colmajor9(cv), None, 1e-13,
+                                             whole.init_q[pick].cpu().numpy(), whole.init_t[pick].cpu().numpy(),
+                                             options=oracle.default_options(jacobian_mode=oracle.JAC_NUMERIC_CENTRAL))
+    rec = ref.numpy()[pick]
+    dots = np.abs(np.sum(rec[:, :4] * q, axis=1)).clip(0, 1)
+    ang = 2.0 * np.arccos(dots)
+    # arccos loses half the digits near 1: recompute small angles from the vector part
+    v = np.stack([rec[:, 3] * q[:, 0] - rec[:, 0] * q[:, 3] - rec[:, 1] * q[:, 2] + rec[:, 2] * q[:, 1],
+                  rec[:, 3] * q[:, 1] + rec[:, 0] * q[:, 2] - rec[:, 1] * q[:, 3] - rec[:, 2] * q[:, 0],
+                  rec[:, 3] * q[:, 2] - rec[:, 0] * q[:, 1] + rec[:, 1] * q[:, 0] - rec[:, 2] * q[:, 3]], 1)
+    ang = 2.0 * np.arctan2(np.linalg.norm(v, axis=1), dots)
+    assert ang.max() <= 1e-6, ang.max()
+    assert (rec[:, 8].astype(np.int64) == its).mean() >= 0.99, (rec[:, 8], its)   # a stopping test inside rounding: <= 2 of 256
+    assert np.abs(rec[:, 8] - its).max() <= 1
+
+
+def _run_bench(args, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                       timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    import json
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_share_the_gpu_config5_device_side_gather():
+    """`bench.py --gpus 2 --share-gpu --workload kitti_all`: two ranks, both on cuda:0, the REAL solver on each
+    rank's `partition` shard of the 23 190-pair set, RecordGather's device form with world > 1 (solve-done event,
+    pack + copy on the side stream, double buffering, per-rank `sizes=` trimming; gloo carries the pinned host
+    records because RCCL refuses two ranks on one device).  bench.py itself asserts the gathered shape and
+    finiteness; here: the line, the sizes, and that the gathered records equal a one-rank run's bit for bit."""
+    two = _run_bench(["--gpus", "2", "--share-gpu", "--workload", "kitti_all", "--steps", "3", "--warmup", "1",
+                      "--no-cpu-baseline"])
+    assert two["shared_gpu"]["ranks"] == 2 and two["n_gpus"] == 1 and two["scaling"] == "strong"
+    assert two["config"]["pairs_total"] == 23190 and sum(two["config"]["pairs_per_rank"]) == 23190
+    assert len(two["config"]["pairs_per_rank"]) == 2 and min(two["config"]["pairs_per_rank"]) > 10000
+    assert two["shared_gpu"]["collectives_issued"] == 3 + 1 + 1              # steps + warm-up + communicator set-up step
+    assert two["value"] > 0 and "gloo" in two["config"]["sharding"]
+    it2 = two["config"]["lm_iterations_done_min_mean_max"]
+    one = _run_bench(["--gpus", "1", "--workload", "kitti_all", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert one["n_gpus"] == 1 and one["config"]["pairs_total"] == 23190
+    # rank 0's shard is the first half: its iteration statistics are a subset's; the whole-set check is the digest
+    assert two["records_sha256"] == one["records_sha256"], (two["records_sha256"], one["records_sha256"])
+    assert it2[0] >= one["config"]["lm_iterations_done_min_mean_max"][0]
+
+
+def test_bench_chain_workload_two_ranks_share_the_gpu():
+    """config 5 with something to scale: the whole PNEC::Solve chain per pair (`--chain`), two ranks on one GPU
+    against one rank: same gathered records"""
+    two = _run_bench(["--gpus", "2", "--share-gpu", "--workload", "kitti_all", "--chain", "--steps", "2", "--warmup", "1"])
+    one = _run_bench(["--gpus", "1", "--workload", "kitti_all", "--chain", "--steps", "2", "--warmup", "1"])
+    assert two["unit"] == one["unit"] == "pairs/s" and "chain" in two and "roofline" not in two
+    assert 0.8 < two["chain"]["inlier_share_mean"] < 0.95                    # 10 % gross mismatches rejected
+    assert two["records_sha256"] == one["records_sha256"]
+
+
+RCCL_ONE_RANK = r'''
+import os, sys
+sys.path.insert(0, os.environ["PNEC_ROOT"])
+import torch, torch.distributed as dist
+from pnec_amd import Batch, capi
+from pnec_amd import simulation as sim
+from pnec_amd.distributed import RecordGather, pack_records
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)       # backend "nccl" IS RCCL on ROCm
+g = sim.generate(300, 200, seed=9, device=dev)
+gather = RecordGather(1, 0, sizes=[300], device=dev, force_collective=True)
+outs = [None, None]
+with Batch.uniform(capi.MODE_TARGET, 300, 200) as b:
+    b.fill(g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3))
+    for step in range(5):
+        slot = gather.acquire()
+        outs[slot] = b.solve(g.init_q, g.init_t, out=outs[slot])
+        gather.submit(slot, outs[slot])
+    got = gather.drain()
+    torch.cuda.synchronize()
+    want = pack_records(b.solve(g.init_q, g.init_t))
+assert gather.collectives == 5
+assert got.is_cuda and torch.equal(got, want)
+print("RCCL_GATHER_ON_SIDE_STREAM_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_gather_of_device_records_on_the_side_stream_one_rank_communicator():
+    """The production form of RecordGather -- dist.gather on DEVICE tensors through backend "nccl" (= RCCL),
+    enqueued on the side stream behind the solve-done event -- on the one GPU this box has: a one-rank RCCL
+    communicator with the collective forced.  What it cannot show is a second device; what it does show is the
+    RCCL call path, stream ordering and buffer lifetime of the code the multi-GPU run executes."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PNEC_ROOT=ROOT)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", RCCL_ONE_RANK], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    assert "RCCL_GATHER_ON_SIDE_STREAM_OK" in r.stdout

@@ -80,12 +80,59 @@ def test_pyceresnec_and_batch_match_oracle(oracle):
 
 
 @pytest.mark.gpu
-def test_cpp_facade_demo_runs_run_simulation_call_pattern():
-    """pnec::rel_pose_estimation::PNEC::Solve + CostFunction + RotationalDifference from C++"""
+def test_cpp_facade_demo_runs_run_simulation_call_pattern(tmp_path, oracle):
+    """BASELINE config 1 through the C++ facade with no Python in the product path: the demo executable makes
+    run_simulation's call (run_simulation.cc:74-86: PNEC::Solve(bvs1, bvs2, covs, init, inliers) with the
+    reference's default Options) on ONE pair of 100 isotropic-covariance correspondences, dumps its inputs and
+    its result, and the oracle's chain on those very inputs must give the same inliers and the same pose."""
     exe = os.path.join(ROOT, "pnec_amd", "pnec_host_demo")
-    r = subprocess.run([exe, "100"], capture_output=True, text=True, timeout=120)
+    dump = tmp_path / "pair.txt"
+    r = subprocess.run([exe, "100", "dump", str(dump)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "rot_err_deg" in r.stdout
+    rows = open(dump).read().splitlines()
+    n = int(rows[0])
+    assert n == 100
+    a = np.array([[float(v) for v in row.split()] for row in rows[1:1 + n]])
+    b1, b2 = np.ascontiguousarray(a[:, 0:3]), np.ascontiguousarray(a[:, 3:6])
+    cv = np.ascontiguousarray(a[:, 6:15].reshape(n, 3, 3))
+    assert np.allclose(cv, cv[0, 0, 0] * np.eye(3))                      # isotropic, the same for every point
+    init = np.array([float(v) for v in rows[1 + n].split()])
+    sol = np.array([float(v) for v in rows[2 + n].split()])
+    inl = [int(v) for v in rows[3 + n].split()]
+    assert inl[0] == len(inl) - 1
+    R0 = oracle.rot_from_quat(init[:4])
+    Ro, to, mo, _ = oracle.ransac_eigensolver(b1, b2, R0, seed=1, pair_id=0)
+    assert inl[1:] == list(np.flatnonzero(mo))
+    Rw, tw = oracle.weighted_eigensolver(b1[mo], b2[mo], cv[mo], Ro, to, 1e-13, 10)
+    s = oracle.solve(oracle.MODE_TARGET, b1[mo], b2[mo], cv[mo], None, 1e-13, oracle.quat_from_rot(Rw), tw,
+                     oracle.default_options())
+    R = oracle.rot_from_quat(sol[:4])
+    assert math.radians(oracle.rotational_difference_deg(R, s.R)) <= 1e-6          # the north star's tolerance
+    assert abs(sol[4:7] @ s.t) > 1 - 1e-10
+    # the line the demo prints carries the facade's metric helpers: same numbers from the oracle's
+    f = dict(kv.split("=") for kv in r.stdout.split())
+    assert int(f["inliers"]) == inl[0]
+    assert float(f["cost"]) == pytest.approx(oracle.cost_function(b1, b2, cv, R, sol[4:7]), rel=1e-5, abs=1e-6)
+    assert float(f["rot_err_deg"]) < float(f["rot_err_init_deg"])
+
+
+@pytest.mark.gpu
+def test_cpp_facade_demo_writes_timing_txt_like_the_odometry(tmp_path):
+    """pnec_vo.cc:220-261,273-276: a FrameTiming per frame filled by the timed PNEC::Solve overload, collected in
+    a Timing, streamed into timing.txt -- header line, then one row of integral milliseconds per frame whose
+    OPTIMIZATION / TOTAL columns are the sums timing.cc:40-47 define."""
+    from pnec_amd import io_formats as io
+    exe = os.path.join(ROOT, "pnec_amd", "pnec_host_demo")
+    path = tmp_path / "timing.txt"
+    r = subprocess.run([exe, "200", "timing", "6", str(path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    text = open(path).read()
+    assert text.splitlines()[0] == io.TIMING_HEADER and text.endswith("\n")
+    a = io.read_timing_file(path)                       # checks the derived columns
+    assert a.shape == (6, 9) and a[:, 0].tolist() == [1, 2, 3, 4, 5, 6]
+    assert (a[:, 1:3] == 0).all()                       # no frame loading / feature creation on this path
+    assert (a >= 0).all() and (a[:, 5] == a[:, 4] // 10).all()          # avg-it-es = it-es / weighted_iterations
+    assert all(len(line.split(" ")) == 9 and all(c.isdigit() for c in line.split(" ")) for line in text.splitlines()[1:])
 
 
 def test_common_helpers_of_the_facade_match_oracle(oracle):

@@ -119,3 +119,64 @@ def test_run_simulation_start_poses_and_metrics():
     assert rs.translational_difference_deg(t, -t)[0] < 1e-6
     assert abs(rs.translational_difference_deg(t, np.array([[1.0, 0, 0]]))[0] - 90.0) < 1e-12
     assert rs.translational_difference_deg(np.zeros((1, 3)), t)[0] == 90.0                 # degenerate input
+
+
+# what the reference's `out << timing` (pnec_vo.cc:273-276, timing.cc:49-66) puts into timing.txt for two frames
+# with (loading, features, nec-es, it-es, avg-it-es, ceres) = (3, 12, 40, 27, 3, 5) and (0, 0, 1, 0, 0, 2):
+# integral millisecond counts, blank separated, OPTIMIZATION = nec + it + ceres, TOTAL = loading + features + that
+TIMING_TXT = ("ID FrameLoading FeatureCreation NEC-ES IT-ES AVG-IT-ES CERES OPTIMIZATION TOTAL\n"
+              "1 3 12 40 27 3 5 72 87\n"
+              "2 0 0 1 0 0 2 3 3\n")
+
+
+def test_timing_file_is_the_references_table_literally(tmp_path):
+    rows = [dict(id=1, frame_loading=3, feature_creation=12, nec_es=40, it_es=27, avg_it_es=3, ceres=5),
+            (2, 0, 0, 1, 0, 0, 2)]
+    io.write_timing_file(tmp_path / "timing.txt", rows)
+    assert open(tmp_path / "timing.txt").read() == TIMING_TXT
+    a = io.read_timing_file(tmp_path / "timing.txt")
+    assert a.tolist() == [[1, 3, 12, 40, 27, 3, 5, 72, 87], [2, 0, 0, 1, 0, 0, 2, 3, 3]]
+    assert io.format_timing_row(7, nec_es=2.9) == "7 0 0 2 0 0 0 2 2"      # duration_cast truncates
+    io.write_timing_file(tmp_path / "empty.txt", [])                        # a run without frames: header only
+    assert open(tmp_path / "empty.txt").read() == TIMING_TXT.splitlines(True)[0]
+    assert io.read_timing_file(tmp_path / "empty.txt").shape == (0, 9)
+    (tmp_path / "bad.txt").write_text(TIMING_TXT.replace("72 87", "73 87"))
+    with pytest.raises(ValueError):
+        io.read_timing_file(tmp_path / "bad.txt")
+
+
+def test_cpp_facade_timing_streams_the_same_table(tmp_path):
+    """pnec::common::FrameTiming / Timing of the host facade (pnec_host.h) stream exactly the reference's
+    timing.txt; compiled here against libpnec_host.so (no device call is made)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "pnec_amd")
+    if not os.path.exists(os.path.join(pkg, "libpnec_host.so")):
+        pytest.skip("libpnec_host.so not built")
+    src = tmp_path / "t.cc"
+    src.write_text(r'''
+#include <iostream>
+#include <sstream>
+#include "pnec_host.h"
+int main(int argc, char **argv) {
+  pnec::common::Timing timing;
+  pnec::common::FrameTiming a(1);
+  a.frame_loading_ = 3; a.feature_creation_ = 12; a.nec_es_ = 40; a.it_es_ = 27; a.avg_it_es_ = 3; a.ceres_ = 5;
+  pnec::common::FrameTiming b(2);
+  b.nec_es_ = 1; b.ceres_ = 2;
+  timing.push_back(a);
+  timing.push_back(b);
+  std::cout << timing;
+  std::ostringstream one;
+  one << a;
+  if (one.str() != "1 3 12 40 27 3 5 72 87" || a.OptimizationTime() != 72 || a.TotalTime() != 87) return 2;
+  return timing.Save(argv[1]) ? 0 : 3;
+}
+''')
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(root, "include"), "-I" + os.path.join(pkg, "csrc", "host"),
+                    str(src), "-o", str(exe), "-L" + pkg, "-lpnec_host", "-lpnec_hip", "-Wl,-rpath," + pkg], check=True)
+    out = subprocess.run([str(exe), str(tmp_path / "timing.txt")], check=True, capture_output=True, text=True).stdout
+    assert out == TIMING_TXT
+    assert open(tmp_path / "timing.txt").read() == TIMING_TXT
+    assert io.read_timing_file(tmp_path / "timing.txt").shape == (2, 9)

@@ -7,6 +7,7 @@ path (central-difference Jacobian + Ceres LM policy).  Against the oracle's anal
 variant (the same algorithm the kernel runs) the bar is 1e-9 rad.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -608,6 +609,12 @@ def test_device_buffer_cache_reuses_and_releases():
     assert L.pnec_hip_release_cache(-1) == 0
 
 
+# how often the "one stopping decision inside rounding per batch" allowance below is actually used: filled by the
+# trials, written out by test_randomised_batches_allowance_bookkeeping (gpurun_out/iteration_allowance.json; the
+# committed copy of a run is profiles/r03_iteration_allowance.json)
+_ALLOWANCE = {"trials": 0, "solves": 0, "fired": []}
+
+
 @pytest.mark.parametrize("trial", range(8))
 def test_randomised_batches_against_oracle(oracle, trial):
     """random residual family, batch size, ragged counts up to a random maximum (all launch geometries incl.
@@ -640,7 +647,31 @@ def test_randomised_batches_against_oracle(oracle, trial):
     # acceptance test decided inside rounding of its threshold, which shows as both runs ending in the
     # same tolerance ball -- every such pair is checked, and there may be at most one per batch
     diff = np.flatnonzero((res.iterations != it) | (res.status != st))
+    _ALLOWANCE["trials"] += 1
+    _ALLOWANCE["solves"] += int(B)
+    for p in diff:
+        _ALLOWANCE["fired"].append({"trial": int(trial), "mode": int(mode), "pair": int(p), "corr": int(counts[p]),
+                                    "iterations_device_oracle": [int(res.iterations[p]), int(it[p])],
+                                    "status_device_oracle": [int(res.status[p]), int(st[p])]})
     assert len(diff) <= 1, (diff, res.iterations[diff], it[diff])
     for p in diff:
         assert abs(int(res.iterations[p]) - int(it[p])) == 1, (p, res.iterations[p], it[p])
         assert abs(res.cost[p] - cost[p]) <= 2e-6 * abs(cost[p]), (p, res.cost[p], cost[p])
+
+
+def test_randomised_batches_allowance_bookkeeping():
+    """Record of how often test_randomised_batches_against_oracle's allowance (at most one solve per batch whose
+    iteration count or termination code differs by a stopping test decided inside rounding) was used in this run."""
+    import json
+    if _ALLOWANCE["trials"] == 0:
+        pytest.skip("the randomised trials did not run in this session")
+    rec = dict(_ALLOWANCE, fired_count=len(_ALLOWANCE["fired"]))
+    print("iteration allowance:", json.dumps(rec))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "iteration_allowance.json"), "w") as f:
+            json.dump(rec, f)
+    except OSError:
+        pass
+    assert len(_ALLOWANCE["fired"]) <= _ALLOWANCE["trials"]
