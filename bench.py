@@ -284,6 +284,17 @@ def kernel_sources_sha256():
     for f in SOLVE_KERNEL_SOURCES:
         text = open(os.path.join(d, f), "r").read()
         h.update(f.encode())
+        if f == "Makefile":
+            # the build recipe of the kernels: compiler, target and flags (incl. their continuation lines) -- not the
+            # lists of sources / headers / host targets, which cannot change the device code of this kernel
+            keep, cont = [], False
+            for ln in text.splitlines():
+                if cont or re.match(r"\s*(HIPCC|ARCH|CXXFLAGS)\s*[?:+]?=", ln):
+                    keep.append(" ".join(ln.split()))
+                    cont = ln.rstrip().endswith("\\")
+                else:
+                    cont = False
+            text = "\n".join(keep)
         h.update((text if f == "Makefile" else _strip_comments(text)).encode())
     header = open(os.path.join(ROOT, "include", "pnec_hip.h"), "r").read()
     m = re.search(r"typedef struct pnec_hip_options\s*\{.*?\}\s*pnec_hip_options;", header, flags=re.S)
@@ -484,7 +495,7 @@ def run(args):
             # the chain is five kernels of different character; no single roofline describes it.
             # Reported: the device time of this rank's shard per step and the inlier statistics of the last step.
             dev_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
-            inl = gathered[:, 8]
+            inl = gathered[:, 8].detach().cpu()
             line["config"].update({"corr_per_rank": sh.shard_corr,
                                    "corr_min_mean_max": [int(sh.pair_sizes.min()), float(sh.pair_sizes.mean()),
                                                          int(sh.pair_sizes.max())],

@@ -116,6 +116,16 @@ int pnec_hip_problem_create(int device, int mode, int64_t n_pairs, const int64_t
                             pnec_hip_problem **out);
 int pnec_hip_problem_destroy(pnec_hip_problem *p);
 
+/* A batch that is shaped again and again without allocating: room for up to max_pairs pairs holding up to
+ * max_corr correspondences in total; created empty (0 pairs).  pnec_hip_problem_reshape gives it a shape --
+ * offsets as in pnec_hip_problem_create -- on `stream` (the index arrays are uploaded asynchronously; work
+ * queued earlier on that stream still sees the old shape); the planes then hold garbage until filled.  Shapes
+ * beyond the capacity return PNEC_HIP_ERR_INVALID_ARGUMENT.  What the per-frame callers of the reference need
+ * (one PNEC::Solve per frame pair, frame2frame.cc:122-141): see pnec_hip_frame_* below, which is built on it. */
+int pnec_hip_problem_create_capacity(int device, int mode, int64_t max_pairs, int64_t max_corr,
+                                     pnec_hip_problem **out);
+int pnec_hip_problem_reshape(pnec_hip_problem *p, int64_t n_pairs, const int64_t *offsets, void *stream);
+
 /* Fill pairs [first_pair, first_pair+n_pairs) from arrays in the REFERENCE layout (AoS: bvs
  * 3 doubles, covs 9 doubles column-major per correspondence), pointing at the first
  * correspondence of `first_pair`.  `covs` is the single array of Optimize(bvs1,bvs2,covs,..)
@@ -283,6 +293,29 @@ int pnec_hip_stream_submit(pnec_hip_stream *s, int mode, int64_t n_pairs, const 
 int pnec_hip_stream_poll(pnec_hip_stream *s, int64_t ticket, int32_t *done);
 int pnec_hip_stream_wait(pnec_hip_stream *s, int64_t ticket, double *out_q, double *out_t, double *out_cost,
                          int32_t *out_iterations, int32_t *out_status);
+
+/* ---- per-frame PNEC::Solve: the WHOLE chain for one frame pair per call, nothing allocated per call ----
+ * (Frame2Frame::PNECAlign -> PNEC::Solve, src/rel_pose_estimation/frame2frame.cc:122-141 -> pnec.cc:77-124.)
+ * A handle owns a pinned, device-mapped staging block, a capacity-shaped batch of one pair (TARGET family) with
+ * its cached scratch / InlierExtraction target / side stream, and one HIP stream.
+ *   solve   bvs1, bvs2 [n,3], covs [n,9] column-major (may be NULL with use_nec), start pose (q xyzw, t) in HOST
+ *           memory -> pose out, inlier mask [n] and count (either may be NULL; zeros without RANSAC).  Runs
+ *           pnec_hip_solve_pipeline on the handle's batch -- the same launches as the batch call, so the result
+ *           is bit-identical to pnec_hip_solve_pipeline on a one-pair batch -- and returns when it is done.
+ *   load    only the ingest (arrays -> SoA planes of the handle's batch, asynchronous on the handle's stream);
+ *           *problem is the handle's batch, valid until the next load / solve / destroy, for callers that run the
+ *           stages one by one (the timed PNEC::Solve overloads, pnec.cc:135-208) on pnec_hip_frame_stream().
+ * n <= max_corr (pnec_hip_frame_capacity).  Not thread-safe: one handle per thread. */
+typedef struct pnec_hip_frame pnec_hip_frame;
+int pnec_hip_frame_create(int device, int64_t max_corr, void *stream, pnec_hip_frame **out);
+int pnec_hip_frame_destroy(pnec_hip_frame *f);
+int64_t pnec_hip_frame_capacity(const pnec_hip_frame *f);
+void *pnec_hip_frame_stream(const pnec_hip_frame *f);
+int pnec_hip_frame_load(pnec_hip_frame *f, int64_t n, const double *bvs1, const double *bvs2, const double *covs,
+                        pnec_hip_problem **problem);
+int pnec_hip_frame_solve(pnec_hip_frame *f, int64_t n, const double *bvs1, const double *bvs2, const double *covs,
+                         const double *init_q, const double *init_t, const pnec_hip_pipeline_options *opt,
+                         double *out_q, double *out_t, uint8_t *out_inlier_mask, int32_t *out_inlier_count);
 
 /* Input side of the path: pnec::common::UnscentedTransform (src/common/common.cc:467-525) and
  * pnec::common::Unproject (:460-465) for n keypoints at once -- what KeyPoint::Unproject

@@ -57,6 +57,14 @@ SYMBOLS = [
     "pnec_hip_solve_pipeline",
     "pnec_hip_stream_create",
     "pnec_hip_stream_destroy",
+    "pnec_hip_problem_create_capacity",
+    "pnec_hip_problem_reshape",
+    "pnec_hip_frame_create",
+    "pnec_hip_frame_destroy",
+    "pnec_hip_frame_capacity",
+    "pnec_hip_frame_stream",
+    "pnec_hip_frame_load",
+    "pnec_hip_frame_solve",
     "pnec_hip_stream_submit",
     "pnec_hip_stream_poll",
     "pnec_hip_stream_wait",
@@ -174,6 +182,17 @@ def lib() -> C.CDLL:
     L.pnec_hip_default_pipeline_options.argtypes = [C.POINTER(PipelineOptions)]
     L.pnec_hip_default_pipeline_options.restype = None
     L.pnec_hip_solve_pipeline.argtypes = [_vp, _vp, _vp, C.POINTER(PipelineOptions), _vp, _vp, _vp, _vp, C.c_int, _vp]
+    L.pnec_hip_problem_create_capacity.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.POINTER(_vp)]
+    L.pnec_hip_problem_reshape.argtypes = [_vp, C.c_int64, _vp, _vp]
+    L.pnec_hip_frame_create.argtypes = [C.c_int, C.c_int64, _vp, C.POINTER(_vp)]
+    L.pnec_hip_frame_destroy.argtypes = [_vp]
+    L.pnec_hip_frame_capacity.argtypes = [_vp]
+    L.pnec_hip_frame_capacity.restype = C.c_int64
+    L.pnec_hip_frame_stream.argtypes = [_vp]
+    L.pnec_hip_frame_stream.restype = _vp
+    L.pnec_hip_frame_load.argtypes = [_vp, C.c_int64, _vp, _vp, _vp, C.POINTER(_vp)]
+    L.pnec_hip_frame_solve.argtypes = [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.POINTER(PipelineOptions), _vp, _vp,
+                                       _vp, _vp]
     L.pnec_hip_stream_create.argtypes = [C.c_int, C.c_int32, C.c_int32, C.c_int32, _vp, C.POINTER(_vp)]
     L.pnec_hip_stream_destroy.argtypes = [_vp]
     L.pnec_hip_stream_submit.argtypes = [_vp, C.c_int, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_double,

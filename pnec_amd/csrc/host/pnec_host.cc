@@ -370,17 +370,41 @@ SE3d PNEC::Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
 }
 
 namespace {
-// one pair resident on the device, shared by the stages of Solve
+// The per-thread frame handle of a device (pnec_hip_frame: pinned staging, a capacity-shaped one-pair batch with
+// its cached scratch, one HIP stream -- all created once): PNEC::Solve is called once per frame pair by the
+// odometry (frame2frame.cc:122-141), and a batch object per call cost more than the chain's kernels take.
+// Grown (re-created) when a pair exceeds its capacity.
+struct ThreadFrame {
+  pnec_hip_frame *f = nullptr;
+  int device = -1;
+  ~ThreadFrame() { pnec_hip_frame_destroy(f); }
+  pnec_hip_frame *Get(int dev, int64_t n) {
+    if (!f || dev != device || n > pnec_hip_frame_capacity(f)) {
+      pnec_hip_frame_destroy(f);
+      f = nullptr;
+      int64_t cap = 2048;
+      while (cap < n) cap *= 2;
+      Check(pnec_hip_frame_create(dev, cap, nullptr, &f));
+      device = dev;
+    }
+    return f;
+  }
+};
+thread_local ThreadFrame g_frame;
+
+// one pair resident on the device (the thread's frame handle's batch), shared by the stages of Solve
 struct PairOnDevice {
-  Problem prob;
+  struct {
+    pnec_hip_problem *p = nullptr;
+  } prob;
+  pnec_hip_frame *frame = nullptr;
   PairOnDevice(int device, const bearingVectors_t &b1, const bearingVectors_t &b2,
-               const std::vector<Matrix3d> &covs)
-      : prob(device, PNEC_HIP_MODE_TARGET, std::vector<int64_t>{0, (int64_t)b1.size()}) {
+               const std::vector<Matrix3d> &covs) {
     if (b1.size() != b2.size() || b1.size() != covs.size())
       throw std::invalid_argument("bvs1, bvs2 and projected_covs differ in size");
-    if (!b1.empty())
-      Check(pnec_hip_problem_fill(prob.p, 0, 1, b1[0].data(), b2[0].data(), covs[0].data(), nullptr,
-                                  PNEC_HIP_MEM_HOST, nullptr));
+    frame = g_frame.Get(device, (int64_t)b1.size());
+    Check(pnec_hip_frame_load(frame, (int64_t)b1.size(), b1.empty() ? nullptr : b1[0].data(),
+                              b2.empty() ? nullptr : b2[0].data(), covs.empty() ? nullptr : covs[0].data(), &prob.p));
   }
 };
 
@@ -431,15 +455,20 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
     return (long)std::chrono::duration_cast<std::chrono::milliseconds>(clock::now() - t0).count();
   };
   auto tic = clock::now();
-  PairOnDevice dev(optimization::SolverOptions().device, bvs1, bvs2, projected_covs);
   const Quaterniond q0(initial_pose.rotationMatrix());
   double q[4], t[3];
   if (!timing) {
-    // the untimed overloads: the whole chain in one call, stages chained on the device
+    // the untimed overloads: the whole chain in one call on the thread's frame handle -- arrays in through
+    // pinned staging, stages chained on the device, pose and inlier mask written straight back
+    if (bvs1.size() != bvs2.size() || bvs1.size() != projected_covs.size())
+      throw std::invalid_argument("bvs1, bvs2 and projected_covs differ in size");
     const pnec_hip_pipeline_options po = ToPipeline(options_);
     std::vector<uint8_t> mask(bvs1.size() ? bvs1.size() : 1, 0);
-    Check(pnec_hip_solve_pipeline(dev.prob.p, q0.coeffs(), initial_pose.translation().data(), &po, q, t,
-                                  mask.data(), nullptr, PNEC_HIP_MEM_HOST, nullptr));
+    pnec_hip_frame *frame = g_frame.Get(optimization::SolverOptions().device, (int64_t)bvs1.size());
+    Check(pnec_hip_frame_solve(frame, (int64_t)bvs1.size(), bvs1.empty() ? nullptr : bvs1[0].data(),
+                               bvs2.empty() ? nullptr : bvs2[0].data(),
+                               projected_covs.empty() ? nullptr : projected_covs[0].data(), q0.coeffs(),
+                               initial_pose.translation().data(), &po, q, t, mask.data(), nullptr));
     inliers.clear();
     if (options_.use_ransac_)
       for (size_t i = 0; i < bvs1.size(); ++i)
@@ -447,6 +476,8 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
     return PoseFromQT(q, t);
   }
   // the timed overloads run stage by stage (each stage's wall time is what FrameTiming reports)
+  PairOnDevice dev(optimization::SolverOptions().device, bvs1, bvs2, projected_covs);
+  void *const st = pnec_hip_frame_stream(dev.frame);   // the ingest is queued there: the stages follow it
   pnec_hip_problem *stage = dev.prob.p;   // the batch the later stages run on (inliers under RANSAC)
   pnec_hip_problem *selected = nullptr;
   struct Guard {
@@ -459,14 +490,14 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
     std::vector<uint8_t> mask(bvs1.size() ? bvs1.size() : 1);
     Check(pnec_hip_ransac_eigensolver(dev.prob.p, q0.coeffs(), /*seed*/ 1, options_.max_ransac_iterations_,
                                       options_.ransac_sample_size_, /*threshold pnec.cc:248*/ 1.0e-6, q, t,
-                                      mask.data(), nullptr, nullptr, PNEC_HIP_MEM_HOST, nullptr));
+                                      mask.data(), nullptr, nullptr, PNEC_HIP_MEM_HOST, st));
     for (size_t i = 0; i < bvs1.size(); ++i)
       if (mask[i]) inliers.push_back((int)i);
     // InlierExtraction (pnec.cc:210-229)
-    Check(pnec_hip_problem_select(dev.prob.p, mask.data(), PNEC_HIP_MEM_HOST, nullptr, &selected));
+    Check(pnec_hip_problem_select(dev.prob.p, mask.data(), PNEC_HIP_MEM_HOST, st, &selected));
     stage = selected;
   } else {
-    Check(pnec_hip_nec_eigensolver(dev.prob.p, q0.coeffs(), q, t, PNEC_HIP_MEM_HOST, nullptr));
+    Check(pnec_hip_nec_eigensolver(dev.prob.p, q0.coeffs(), q, t, PNEC_HIP_MEM_HOST, st));
   }
   if (timing) timing->nec_es_ = ms_since(tic);
   const pnec_hip_options o = optimization::SolverOptions().ToHip();
@@ -494,7 +525,7 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
     tic = clock::now();
     Check(pnec_hip_weighted_eigensolver(stage, q, t, options_.regularization_,
                                         (int32_t)options_.weighted_iterations_, qi, ti, PNEC_HIP_MEM_HOST,
-                                        nullptr));
+                                        st));
     if (timing) {
       timing->it_es_ = ms_since(tic);
       timing->avg_it_es_ = timing->it_es_ / (long)options_.weighted_iterations_;
@@ -511,7 +542,7 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
   // CeresSolver: default-constructed optimiser, Target frame (pnec.cc:355,366)
   tic = clock::now();
   Check(pnec_hip_solve(stage, qi, ti, 1, nullptr, options_.regularization_, &o, oq, ot, nullptr, nullptr,
-                       nullptr, PNEC_HIP_MEM_HOST, nullptr));
+                       nullptr, PNEC_HIP_MEM_HOST, st));
   if (timing) timing->ceres_ = ms_since(tic);
   return PoseFromQT(oq, ot);
 }
@@ -547,7 +578,7 @@ SE3d PNEC::WeightedEigensolver(const bearingVectors_t &bvs1, const bearingVector
   double q[4], t[3];
   Check(pnec_hip_weighted_eigensolver(dev.prob.p, q0.coeffs(), initial_pose.translation().data(),
                                       options_.regularization_, (int32_t)options_.weighted_iterations_, q, t,
-                                      PNEC_HIP_MEM_HOST, nullptr));
+                                      PNEC_HIP_MEM_HOST, pnec_hip_frame_stream(dev.frame)));
   return PoseFromQT(q, t);
 }
 

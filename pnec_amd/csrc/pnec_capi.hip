@@ -61,6 +61,13 @@ struct pnec_hip_problem {
   int64_t n_corr = 0;
   int32_t n_max = 0;
   int64_t data_doubles = 0;
+  // A batch made with pnec_hip_problem_create_capacity is re-shaped in place (pnec_hip_problem_reshape): room for
+  // cap_pairs pairs / cap_doubles doubles of planes, the index arrays laid out for cap_pairs.  0 = the shape it
+  // was created with is all it can hold.  layout_gen counts the shapes it has had (views cache by it).
+  int64_t cap_pairs = 0, cap_doubles = 0;
+  uint64_t layout_gen = 0, view_src_gen = ~0ull;
+  std::vector<int64_t> meta_host;      // reshape: the index arrays as uploaded (alive until the copy has run)
+  hipEvent_t meta_uploaded = nullptr;  // reshape: recorded behind the upload
   std::vector<int64_t> offsets;       // host copy, [n_pairs+1]
   double *d_data = nullptr;           // SoA payload
   int64_t *d_block_offset = nullptr;  // [n_pairs]
@@ -101,6 +108,7 @@ struct pnec_hip_problem {
   pnec_hip_problem *sel_view = nullptr;  // pipeline: cached InlierExtraction target (same capacity, reused)
   pnec_hip_problem *nec_view = nullptr;  // pipeline: this batch's bearings as a NEC-family batch (no copy)
   uint8_t *d_mask = nullptr;             // pipeline: inlier mask [n_corr]
+  int64_t mask_bytes = 0;
 };
 
 namespace {
@@ -226,6 +234,98 @@ hipError_t dev_free_impl(void *ptr, bool drained) {
 }
 hipError_t dev_free(void *ptr) { return dev_free_impl(ptr, false); }
 hipError_t dev_free_drained(void *ptr) { return dev_free_impl(ptr, true); }
+
+// ---- side streams and events with a pool -----------------------------------------------------
+// hipStreamCreate / hipStreamDestroy cost milliseconds on some boxes (measured: a batch per frame that forked one
+// side stream spent 2.7 of its 3.1 ms creating and destroying it).  Streams and events a batch no longer needs
+// go back to a per-device pool (the owner drains before it lets go, like the memory blocks) and are handed out
+// again; pnec_hip_release_cache() destroys them.
+struct PooledStream {
+  hipStream_t st;
+  int device;
+};
+struct PooledEvent {
+  hipEvent_t ev;
+  int device;
+};
+std::vector<PooledStream> g_stream_pool;
+std::vector<PooledEvent> g_event_pool;
+constexpr size_t kMaxPooledStreams = 64, kMaxPooledEvents = 256;
+
+hipError_t pool_stream_get(hipStream_t *out) {
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) return e;
+  {
+    std::lock_guard<std::mutex> lock(g_mem_mutex);
+    for (size_t i = 0; i < g_stream_pool.size(); ++i)
+      if (g_stream_pool[i].device == device) {
+        *out = g_stream_pool[i].st;
+        g_stream_pool[i] = g_stream_pool.back();
+        g_stream_pool.pop_back();
+        return hipSuccess;
+      }
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+void pool_stream_put(hipStream_t st, int device) {
+  if (!st) return;
+  {
+    std::lock_guard<std::mutex> lock(g_mem_mutex);
+    if (g_stream_pool.size() < kMaxPooledStreams) {
+      g_stream_pool.push_back({st, device});
+      return;
+    }
+  }
+  (void)hipStreamDestroy(st);
+}
+hipError_t pool_event_get(hipEvent_t *out) {
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) return e;
+  {
+    std::lock_guard<std::mutex> lock(g_mem_mutex);
+    for (size_t i = 0; i < g_event_pool.size(); ++i)
+      if (g_event_pool[i].device == device) {
+        *out = g_event_pool[i].ev;
+        g_event_pool[i] = g_event_pool.back();
+        g_event_pool.pop_back();
+        return hipSuccess;
+      }
+  }
+  return hipEventCreateWithFlags(out, hipEventDisableTiming);
+}
+void pool_event_put(hipEvent_t ev, int device) {
+  if (!ev) return;
+  {
+    std::lock_guard<std::mutex> lock(g_mem_mutex);
+    if (g_event_pool.size() < kMaxPooledEvents) {
+      g_event_pool.push_back({ev, device});
+      return;
+    }
+  }
+  (void)hipEventDestroy(ev);
+}
+void release_stream_pool_locked(int device /* -1: all */) {
+  for (size_t i = 0; i < g_stream_pool.size();) {
+    if (device < 0 || g_stream_pool[i].device == device) {
+      (void)hipStreamDestroy(g_stream_pool[i].st);
+      g_stream_pool[i] = g_stream_pool.back();
+      g_stream_pool.pop_back();
+    } else {
+      ++i;
+    }
+  }
+  for (size_t i = 0; i < g_event_pool.size();) {
+    if (device < 0 || g_event_pool[i].device == device) {
+      (void)hipEventDestroy(g_event_pool[i].ev);
+      g_event_pool[i] = g_event_pool.back();
+      g_event_pool.pop_back();
+    } else {
+      ++i;
+    }
+  }
+}
 
 struct DeviceGuard {
   int prev = -1;
@@ -760,16 +860,16 @@ int ensure_side_streams(pnec_hip_problem *p, size_t n) {
   while (p->side_streams.size() < n) {
     hipStream_t st = nullptr;
     hipEvent_t ev = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    hipError_t e = pool_stream_get(&st);
+    if (e == hipSuccess) e = pool_event_get(&ev);
     if (e != hipSuccess) {
-      if (st) (void)hipStreamDestroy(st);
+      pool_stream_put(st, p->device);
       return fail_hip(e, "side stream");
     }
     p->side_streams.push_back(st);
     p->side_done.push_back(ev);
   }
-  if (!p->fork_event) PNEC_HIP_TRY(hipEventCreateWithFlags(&p->fork_event, hipEventDisableTiming));
+  if (!p->fork_event) PNEC_HIP_TRY(pool_event_get(&p->fork_event));
   return 0;
 }
 
@@ -828,17 +928,13 @@ void pnec_hip_default_options(pnec_hip_options *o) {
   o->max_lm_diagonal = 1e32;
 }
 
-int pnec_hip_problem_create(int device, int mode, int64_t n_pairs, const int64_t *offsets,
-                            pnec_hip_problem **out) {
-  if (!out) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "out is NULL");
-  *out = nullptr;
-  if (mode < PNEC_HIP_MODE_NEC || mode > PNEC_HIP_MODE_SYM)
-    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "unknown mode");
+// the block layout of a shape: block_offset / count per pair, total doubles, the largest pair
+static int shape_layout(int nc, int64_t n_pairs, const int64_t *offsets, std::vector<int64_t> &block_offset,
+                        std::vector<int32_t> &count, int64_t *total_out, int32_t *n_max_out) {
   if (n_pairs < 0 || !offsets) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad n_pairs/offsets");
   if (offsets[0] != 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "offsets[0] must be 0");
-  std::vector<int64_t> block_offset((size_t)n_pairs);
-  std::vector<int32_t> count((size_t)n_pairs);
-  const int nc = num_components(mode);
+  block_offset.resize((size_t)n_pairs);
+  count.resize((size_t)n_pairs);
   int64_t total = 0;
   int32_t n_max = 0;
   for (int64_t p = 0; p < n_pairs; ++p) {
@@ -851,6 +947,72 @@ int pnec_hip_problem_create(int device, int mode, int64_t n_pairs, const int64_t
     total += stride * nc;
     n_max = std::max<int32_t>(n_max, (int32_t)n);
   }
+  *total_out = total;
+  *n_max_out = n_max;
+  return 0;
+}
+
+// block_offset [C] | offsets [C+1] | count [C] (C = the pair capacity) in one device block, filled by one copy (a
+// batch per frame pays every blocking copy in full: three of them were a tenth of the one-pair PNEC::Solve)
+static int upload_meta(pnec_hip_problem *p, const std::vector<int64_t> &block_offset, const int64_t *offsets,
+                       const std::vector<int32_t> &count, hipStream_t stream, bool blocking) {
+  const int64_t n_pairs = (int64_t)count.size();
+  const size_t C1 = (size_t)std::max<int64_t>(std::max(p->cap_pairs, n_pairs), 1);
+  const size_t words = C1 + (C1 + 1);  // int64 entries
+  // an asynchronous upload reads this buffer when the stream gets there: it lives in the batch, and the next
+  // upload waits for the previous one before it overwrites it
+  if (p->meta_uploaded) PNEC_HIP_TRY(hipEventSynchronize(p->meta_uploaded));
+  std::vector<int64_t> &meta = p->meta_host;
+  meta.assign(words + (C1 + 1) / 2, 0);
+  std::copy(block_offset.begin(), block_offset.end(), meta.begin());
+  std::copy(offsets, offsets + n_pairs + 1, meta.begin() + (ptrdiff_t)C1);
+  std::memcpy(meta.data() + words, count.data(), sizeof(int32_t) * count.size());
+  if (!p->d_meta) {
+    int64_t *d_meta = nullptr;
+    hipError_t e = dev_alloc(&d_meta, sizeof(int64_t) * meta.size());
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(meta)");
+    p->d_meta = d_meta;
+    p->d_block_offset = d_meta;
+    p->d_offsets = d_meta + C1;
+    p->d_count = reinterpret_cast<int32_t *>(d_meta + words);
+  }
+  // the used prefix of each array is what changes; for the small capacities of per-frame handles one copy
+  // of the whole block is cheaper than three
+  hipError_t e;
+  if (blocking) {
+    e = hipMemcpy(p->d_meta, meta.data(), sizeof(int64_t) * meta.size(), hipMemcpyHostToDevice);
+  } else if (C1 <= 4096) {
+    e = hipMemcpyAsync(p->d_meta, meta.data(), sizeof(int64_t) * meta.size(), hipMemcpyHostToDevice, stream);
+  } else {
+    e = hipMemcpyAsync(p->d_block_offset, meta.data(), sizeof(int64_t) * (size_t)std::max<int64_t>(n_pairs, 1),
+                       hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(p->d_offsets, meta.data() + C1, sizeof(int64_t) * (size_t)(n_pairs + 1), hipMemcpyHostToDevice,
+                         stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(p->d_count, meta.data() + words, sizeof(int32_t) * (size_t)std::max<int64_t>(n_pairs, 1),
+                         hipMemcpyHostToDevice, stream);
+  }
+  if (e != hipSuccess) return fail_hip(e, "hipMemcpy(meta)");
+  if (!blocking) {
+    if (!p->meta_uploaded) PNEC_HIP_TRY(pool_event_get(&p->meta_uploaded));
+    PNEC_HIP_TRY(hipEventRecord(p->meta_uploaded, stream));
+  }
+  return 0;
+}
+
+static int problem_create_impl(int device, int mode, int64_t cap_pairs, int64_t cap_doubles, int64_t n_pairs,
+                               const int64_t *offsets, pnec_hip_problem **out) {
+  if (!out) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  if (mode < PNEC_HIP_MODE_NEC || mode > PNEC_HIP_MODE_SYM)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "unknown mode");
+  std::vector<int64_t> block_offset;
+  std::vector<int32_t> count;
+  const int nc = num_components(mode);
+  int64_t total = 0;
+  int32_t n_max = 0;
+  if (int rc = shape_layout(nc, n_pairs, offsets, block_offset, count, &total, &n_max)) return rc;
   DeviceGuard guard(device);
   if (!guard.ok) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "hipSetDevice failed (no such device?)");
   pnec_hip_problem *p = new (std::nothrow) pnec_hip_problem();
@@ -863,33 +1025,75 @@ int pnec_hip_problem_create(int device, int mode, int64_t n_pairs, const int64_t
   p->n_max = n_max;
   p->host_counts = count;
   p->data_doubles = total;
+  p->cap_pairs = cap_pairs;
+  p->cap_doubles = cap_doubles;
   p->offsets.assign(offsets, offsets + n_pairs + 1);
-  auto cleanup = [&](hipError_t e, const char *what) {
-    pnec_hip_problem_destroy(p);
-    return fail_hip(e, what);
-  };
   hipError_t e;
-  if ((e = dev_alloc(&p->d_data, sizeof(double) * std::max<int64_t>(total, 1))) != hipSuccess)
-    return cleanup(e, "hipMalloc(data)");
-  {
-    // block_offset [P] | offsets [P+1] | count [P] in one device block, filled by one copy (a batch per frame
-    // pays every blocking copy in full: three of them were a tenth of the one-pair PNEC::Solve)
-    const size_t P1 = (size_t)std::max<int64_t>(n_pairs, 1);
-    const size_t words = P1 + (size_t)(n_pairs + 1);  // int64 entries
-    std::vector<int64_t> meta(words + (P1 + 1) / 2, 0);
-    std::copy(block_offset.begin(), block_offset.end(), meta.begin());
-    std::copy(offsets, offsets + n_pairs + 1, meta.begin() + (ptrdiff_t)P1);
-    std::memcpy(meta.data() + words, count.data(), sizeof(int32_t) * count.size());
-    int64_t *d_meta = nullptr;
-    if ((e = dev_alloc(&d_meta, sizeof(int64_t) * meta.size())) != hipSuccess) return cleanup(e, "hipMalloc(meta)");
-    p->d_meta = d_meta;
-    p->d_block_offset = d_meta;
-    p->d_offsets = d_meta + P1;
-    p->d_count = reinterpret_cast<int32_t *>(d_meta + words);
-    if ((e = hipMemcpy(d_meta, meta.data(), sizeof(int64_t) * meta.size(), hipMemcpyHostToDevice)) != hipSuccess)
-      return cleanup(e, "hipMemcpy(meta)");
+  if ((e = dev_alloc(&p->d_data, sizeof(double) * std::max<int64_t>(std::max(total, cap_doubles), 1))) != hipSuccess) {
+    pnec_hip_problem_destroy(p);
+    return fail_hip(e, "hipMalloc(data)");
+  }
+  if (int rc = upload_meta(p, block_offset, offsets, count, nullptr, /*blocking*/ true)) {
+    const std::string msg = g_last_error;
+    pnec_hip_problem_destroy(p);
+    g_last_error = msg;
+    return rc;
   }
   *out = p;
+  return 0;
+}
+
+int pnec_hip_problem_create(int device, int mode, int64_t n_pairs, const int64_t *offsets,
+                            pnec_hip_problem **out) {
+  return problem_create_impl(device, mode, 0, 0, n_pairs, offsets, out);
+}
+
+int pnec_hip_problem_create_capacity(int device, int mode, int64_t max_pairs, int64_t max_corr,
+                                     pnec_hip_problem **out) {
+  if (!out) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  if (mode < PNEC_HIP_MODE_NEC || mode > PNEC_HIP_MODE_SYM) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "unknown mode");
+  if (max_pairs < 1 || max_corr < 0 || max_corr > (int64_t)1 << 40)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "need max_pairs >= 1, max_corr >= 0");
+  // every pair's planes are padded to a multiple of 64 correspondences: at most 63 extra per pair
+  const int64_t cap_doubles = (int64_t)num_components(mode) * ((max_corr + 63 * max_pairs + kWave - 1) & ~(int64_t)(kWave - 1));
+  const int64_t zero = 0;
+  return problem_create_impl(device, mode, max_pairs, cap_doubles, 0, &zero, out);
+}
+
+static int problem_reshape_impl(pnec_hip_problem *p, int64_t n_pairs, const int64_t *offsets, hipStream_t stream,
+                                bool upload);
+int pnec_hip_problem_reshape(pnec_hip_problem *p, int64_t n_pairs, const int64_t *offsets, void *stream_) {
+  return problem_reshape_impl(p, n_pairs, offsets, (hipStream_t)stream_, true);
+}
+// upload = false: the caller's next kernel on the stream writes the device-side index arrays itself (the frame
+// handle's ingest kernel does, for its single pair)
+static int problem_reshape_impl(pnec_hip_problem *p, int64_t n_pairs, const int64_t *offsets, hipStream_t stream,
+                                bool upload) {
+  if (!p) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "problem is NULL");
+  if (p->cap_pairs <= 0 || !p->owns_data)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "not a capacity-shaped batch (pnec_hip_problem_create_capacity)");
+  std::vector<int64_t> block_offset;
+  std::vector<int32_t> count;
+  int64_t total = 0;
+  int32_t n_max = 0;
+  if (int rc = shape_layout(p->nc, n_pairs, offsets, block_offset, count, &total, &n_max)) return rc;
+  if (n_pairs > p->cap_pairs || total > p->cap_doubles)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "shape exceeds the batch's capacity");
+  DeviceGuard guard(p->device);
+  if (upload)
+    if (int rc = upload_meta(p, block_offset, offsets, count, stream, /*blocking*/ false)) return rc;
+  p->n_pairs = n_pairs;
+  p->n_corr = offsets[n_pairs];
+  p->n_max = n_max;
+  p->host_counts = count;
+  p->data_doubles = total;
+  p->offsets.assign(offsets, offsets + n_pairs + 1);
+  p->lazy = false;
+  p->buckets.clear();
+  if (p->d_bucket_pairs) (void)dev_free(p->d_bucket_pairs);  // (drains: only ragged multi-geometry shapes have one)
+  p->d_bucket_pairs = nullptr;
+  ++p->layout_gen;
   return 0;
 }
 
@@ -917,9 +1121,19 @@ int pnec_hip_problem_destroy(pnec_hip_problem *p) {
   release(p->d_stage_i);
   release(p->d_front);
   release(p->d_front_i);
-  for (hipStream_t st : p->side_streams) (void)hipStreamDestroy(st);
-  for (hipEvent_t ev : p->side_done) (void)hipEventDestroy(ev);
-  if (p->fork_event) (void)hipEventDestroy(p->fork_event);
+  // (the device has drained: nothing is pending on these, so the next owner starts clean)
+  for (hipStream_t st : p->side_streams) {
+    if (drained) pool_stream_put(st, p->device); else (void)hipStreamDestroy(st);
+  }
+  for (hipEvent_t ev : p->side_done) {
+    if (drained) pool_event_put(ev, p->device); else (void)hipEventDestroy(ev);
+  }
+  if (p->fork_event) {
+    if (drained) pool_event_put(p->fork_event, p->device); else (void)hipEventDestroy(p->fork_event);
+  }
+  if (p->meta_uploaded) {
+    if (drained) pool_event_put(p->meta_uploaded, p->device); else (void)hipEventDestroy(p->meta_uploaded);
+  }
   release(p->d_bucket_pairs);
   delete p;
   return 0;
@@ -1236,20 +1450,11 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
     // ragged batch: one launch per geometry in use, over the pairs that fit it -- side by side: the first on
     // the caller's stream, the others on streams of the batch's own that fork from it and join it again
     const size_t n_side = p->buckets.size() - 1;
-    while (e == hipSuccess && p->side_streams.size() < n_side) {
-      hipStream_t st = nullptr;
-      hipEvent_t ev = nullptr;
-      e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-      if (e != hipSuccess) {
-        if (st) (void)hipStreamDestroy(st);
-        break;
-      }
-      p->side_streams.push_back(st);
-      p->side_done.push_back(ev);
+    if (int rc = ensure_side_streams(p, n_side)) {
+      if (d_trace) (void)dev_free(d_trace);
+      return rc;
     }
-    if (e == hipSuccess && !p->fork_event) e = hipEventCreateWithFlags(&p->fork_event, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventRecord(p->fork_event, stream);
+    e = hipEventRecord(p->fork_event, stream);
     for (size_t b = 0; b < p->buckets.size() && e == hipSuccess; ++b) {
       const auto &bk = p->buckets[b];
       SolveArgs ab = a;
@@ -1489,14 +1694,18 @@ static int alloc_like(pnec_hip_problem *src, hipStream_t stream, pnec_hip_proble
   d->host_counts = src->host_counts;
   d->offsets = src->offsets;
   d->data_doubles = src->data_doubles;
-  const int64_t P = std::max<int64_t>(src->n_pairs, 1);
-  hipError_t e = dev_alloc(&d->d_data, sizeof(double) * std::max<int64_t>(src->data_doubles, 1));
+  // as roomy as the source can ever get, so that a cached view survives the source's re-shaping
+  d->cap_pairs = std::max(src->cap_pairs, src->n_pairs);
+  d->cap_doubles = std::max(src->cap_doubles, src->data_doubles);
+  const int64_t P = std::max<int64_t>(d->cap_pairs, 1);
+  hipError_t e = dev_alloc(&d->d_data, sizeof(double) * std::max<int64_t>(d->cap_doubles, 1));
   if (e == hipSuccess) e = dev_alloc(&d->d_block_offset, sizeof(int64_t) * P);
   if (e == hipSuccess) e = dev_alloc(&d->d_offsets, sizeof(int64_t) * (P + 1));
   if (e == hipSuccess) e = dev_alloc(&d->d_count, sizeof(int32_t) * P);
   if (e == hipSuccess && src->n_pairs > 0)
     e = hipMemcpyAsync(d->d_block_offset, src->d_block_offset, sizeof(int64_t) * src->n_pairs,
                        hipMemcpyDeviceToDevice, stream);
+  d->view_src_gen = src->layout_gen;
   if (e != hipSuccess) {
     pnec_hip_problem_destroy(d);
     return fail_hip(e, "InlierExtraction target allocation");
@@ -1509,6 +1718,19 @@ static int alloc_like(pnec_hip_problem *src, hipStream_t stream, pnec_hip_proble
 // correspondences compacted pair by pair into dst (which has src's capacity).  All on `stream`.
 static int select_into(pnec_hip_problem *src, const uint8_t *d_mask, hipStream_t stream, pnec_hip_problem *dst) {
   const int64_t P = src->n_pairs;
+  if (dst->view_src_gen != src->layout_gen) {  // the source has been re-shaped since dst copied its block layout
+    if (P > 0)
+      PNEC_HIP_TRY(hipMemcpyAsync(dst->d_block_offset, src->d_block_offset, sizeof(int64_t) * P, hipMemcpyDeviceToDevice,
+                                  stream));
+    dst->view_src_gen = src->layout_gen;
+    dst->n_pairs = P;
+    dst->data_doubles = src->data_doubles;
+    dst->buckets.clear();
+    if (dst->d_bucket_pairs) (void)dev_free(dst->d_bucket_pairs);
+    dst->d_bucket_pairs = nullptr;
+    dst->lazy = false;  // (so that the block below re-installs the source's bounds)
+    dst->offsets = src->offsets;
+  }
   if (P > 0) {
     hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)P), dim3(kWave), 0, stream, d_mask, src->d_offsets,
                        src->d_count, dst->d_count);
@@ -1548,7 +1770,8 @@ int pnec_hip_problem_select(pnec_hip_problem *src, const uint8_t *mask, int spac
   if (int rc = alloc_like(src, stream, &dst)) return rc;
   const uint8_t *d_mask = mask;
   if (space == PNEC_HIP_MEM_HOST) {
-    hipError_t e = dev_alloc(&dst->d_mask, (size_t)std::max<int64_t>(src->n_corr, 1));
+    dst->mask_bytes = std::max<int64_t>(src->n_corr, 1);
+    hipError_t e = dev_alloc(&dst->d_mask, (size_t)dst->mask_bytes);
     if (e == hipSuccess && src->n_corr > 0)
       e = hipMemcpyAsync(dst->d_mask, mask, (size_t)src->n_corr, hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) {
@@ -1680,11 +1903,13 @@ int pnec_hip_selftest(int device) {
 
 #include "pnec_pipeline.inl"
 #include "pnec_stream.inl"
+#include "pnec_frame.inl"
 
 int64_t pnec_hip_release_cache(int device) {
   std::lock_guard<std::mutex> lock(g_mem_mutex);
   const size_t before = g_cached_bytes;
   release_cache_locked(device);
+  release_stream_pool_locked(device);
   return (int64_t)(before - g_cached_bytes);
 }
 

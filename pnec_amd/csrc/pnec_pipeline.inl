@@ -106,7 +106,14 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
   // ---- ES_solution = Eigensolver(bvs1, bvs2, initial_pose, inliers); InlierExtraction
   if (o.use_ransac) {
     if (!d_mask) {
-      if (!p->d_mask) PNEC_HIP_TRY(dev_alloc(&p->d_mask, (size_t)M));
+      if (p->mask_bytes < M) {  // (a re-shaped batch may have grown)
+        if (p->d_mask) (void)dev_free(p->d_mask);
+        p->d_mask = nullptr;
+        p->mask_bytes = 0;
+        const int64_t want = std::max<int64_t>(M, p->cap_doubles / std::max(p->nc, 1));
+        PNEC_HIP_TRY(dev_alloc(&p->d_mask, (size_t)want));
+        p->mask_bytes = want;
+      }
       d_mask = p->d_mask;
     }
     // the eigensolver on the inliers (latency-bound: sixteen pairs per wavefront, one wavefront per SIMD) runs
@@ -117,7 +124,9 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
                                   d_mask, d_cnt, nullptr, p->d_front, p->d_front_i, stream, p->side_streams[0],
                                   p->fork_event, p->side_done[0]);
     if (e != hipSuccess) return fail_hip(e, "ransac_eigensolver_kernel");
-    if (!p->sel_view || p->sel_view->data_doubles != p->data_doubles || p->sel_view->n_pairs != P) {
+    // (the cached InlierExtraction target has the capacity of the source; a re-shaped source is re-synced into it
+    // by select_into, by layout generation)
+    if (!p->sel_view || p->sel_view->cap_doubles < p->data_doubles || p->sel_view->cap_pairs < P) {
       if (p->sel_view) pnec_hip_problem_destroy(p->sel_view);
       p->sel_view = nullptr;
       if (int rc = alloc_like(p, stream, &p->sel_view)) return rc;

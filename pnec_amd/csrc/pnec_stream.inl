@@ -11,8 +11,9 @@
 //   * wait = the host polling that flag (no stream synchronisation, no copy-back);
 //   * several submits may be in flight (a micro-batching window of `slots`), and one submit may carry
 //     several pairs (one workgroup each).
-// Pairs too large for the register-resident geometries take the staged route through a batch owned by the
-// handle (pack, solve into the slot; re-shaped to the submit's sizes, so this route does allocate).
+// Pairs too large for the register-resident geometries take the staged route through a capacity-shaped batch
+// owned by the handle (re-shaped to the submit's sizes, pack, solve into the slot: nothing allocated per submit
+// once the batch exists).
 struct pnec_hip_stream {
   int device = 0;
   int32_t max_corr = 0;   // correspondences per submit
@@ -290,10 +291,15 @@ int pnec_hip_stream_submit(pnec_hip_stream *s, int mode, int64_t n_pairs, const 
     }
     sl.blocks_done = blocks_total;
   } else {
-    // staged route: a persistent batch of the handle, re-shaped to this submit's sizes
-    if (s->big) pnec_hip_problem_destroy(s->big);
-    s->big = nullptr;
-    if (int rc = pnec_hip_problem_create(s->device, mode, n_pairs, offsets, &s->big)) return rc;
+    // staged route: a persistent batch of the handle at the handle's capacity, re-shaped (no allocation, no
+    // device-wide drain) to this submit's sizes; it is re-made only when the residual family changes
+    if (s->big && s->big->mode != mode) {
+      pnec_hip_problem_destroy(s->big);
+      s->big = nullptr;
+    }
+    if (!s->big)
+      if (int rc = pnec_hip_problem_create_capacity(s->device, mode, s->max_pairs, s->max_corr, &s->big)) return rc;
+    if (int rc = pnec_hip_problem_reshape(s->big, n_pairs, offsets, s->stream)) return rc;
     if (int rc = pnec_hip_problem_fill(s->big, 0, n_pairs, (const double *)(d + s->o_b1), (const double *)(d + s->o_b2),
                                        nc >= 12 ? (const double *)(d + s->o_cv) : nullptr,
                                        nc >= 18 ? (const double *)(d + s->o_ch) : nullptr, PNEC_HIP_MEM_DEVICE, s->stream))
