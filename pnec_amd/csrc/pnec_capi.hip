@@ -66,6 +66,7 @@ struct pnec_hip_problem {
   // was created with is all it can hold.  layout_gen counts the shapes it has had (views cache by it).
   int64_t cap_pairs = 0, cap_doubles = 0;
   uint64_t layout_gen = 0, view_src_gen = ~0ull;
+  std::vector<int64_t> block_offset_host;  // reshape: the block layout of the current shape
   std::vector<int64_t> meta_host;      // reshape: the index arrays as uploaded (alive until the copy has run)
   hipEvent_t meta_uploaded = nullptr;  // reshape: recorded behind the upload
   std::vector<int64_t> offsets;       // host copy, [n_pairs+1]
@@ -624,13 +625,22 @@ __global__ __launch_bounds__(256) void ingest_keypoints_kernel(double *__restric
 __global__ __launch_bounds__(kWave) void mask_count_kernel(const uint8_t *__restrict__ mask,
                                                            const int64_t *__restrict__ offsets,
                                                            const int32_t *__restrict__ count,
-                                                           int32_t *__restrict__ out) {
+                                                           int32_t *__restrict__ out,
+                                                           int64_t *__restrict__ single_offsets /* null, or the
+                                                           new batch's offsets when it has ONE pair: the scan of one
+                                                           count is the count (a launch less per frame) */) {
   const int64_t p = blockIdx.x;
   const int n = count[p];
   int c = 0;
   for (int i = threadIdx.x; i < n; i += kWave) c += mask[offsets[p] + i] != 0;
   c = (int)wave_allreduce_sum((double)c);
-  if (threadIdx.x == 0) out[p] = c;
+  if (threadIdx.x == 0) {
+    out[p] = c;
+    if (single_offsets) {
+      single_offsets[0] = 0;
+      single_offsets[1] = c;
+    }
+  }
 }
 
 // exclusive prefix sum of the pair sizes -> AoS offsets [n+1] (one workgroup; n is at most a few 1e5)
@@ -1093,7 +1103,12 @@ static int problem_reshape_impl(pnec_hip_problem *p, int64_t n_pairs, const int6
   p->buckets.clear();
   if (p->d_bucket_pairs) (void)dev_free(p->d_bucket_pairs);  // (drains: only ragged multi-geometry shapes have one)
   p->d_bucket_pairs = nullptr;
-  ++p->layout_gen;
+  // views cache the block layout by generation: a new one only when it really changed (the frame handle's single
+  // pair always starts at 0, so its InlierExtraction target never re-copies anything)
+  if (block_offset != p->block_offset_host) {
+    p->block_offset_host = block_offset;
+    ++p->layout_gen;
+  }
   return 0;
 }
 
@@ -1733,8 +1748,8 @@ static int select_into(pnec_hip_problem *src, const uint8_t *d_mask, hipStream_t
   }
   if (P > 0) {
     hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)P), dim3(kWave), 0, stream, d_mask, src->d_offsets,
-                       src->d_count, dst->d_count);
-    hipLaunchKernelGGL(offsets_scan_kernel, dim3(1), dim3(1024), 0, stream, dst->d_count, dst->d_offsets, P);
+                       src->d_count, dst->d_count, P == 1 ? dst->d_offsets : (int64_t *)nullptr);
+    if (P > 1) hipLaunchKernelGGL(offsets_scan_kernel, dim3(1), dim3(1024), 0, stream, dst->d_count, dst->d_offsets, P);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
       e = launch_select(src->nc, src->d_data, src->d_block_offset, src->d_offsets, src->d_count, d_mask, dst->d_data,
@@ -1751,7 +1766,13 @@ static int select_into(pnec_hip_problem *src, const uint8_t *d_mask, hipStream_t
   dst->lazy_stream = stream;
   dst->n_corr = src->n_corr;
   dst->n_max = src->n_max;
-  dst->host_counts = src->host_counts;
+  if (dst->host_counts != src->host_counts) {  // a re-shaped source: the launch geometries follow its new bounds
+    dst->host_counts = src->host_counts;
+    dst->offsets = src->offsets;
+    dst->buckets.clear();
+    if (dst->d_bucket_pairs) (void)dev_free(dst->d_bucket_pairs);
+    dst->d_bucket_pairs = nullptr;
+  }
   return 0;
 }
 

@@ -106,7 +106,7 @@ def test_capacity_shaped_batch_reshapes_without_reallocating_and_matches_fresh_b
             assert np.array_equal(got.iterations, want.iterations) and np.array_equal(got.cost, want.cost)
         too_many = np.arange(42, dtype=np.int64)
         assert L.pnec_hip_problem_reshape(h, 41, too_many.ctypes.data, None) == -1
-        too_big = np.array([0, 13000], dtype=np.int64)
+        too_big = np.array([0, 20000], dtype=np.int64)       # > 12000 + 63 * 40 (padding room)
         assert L.pnec_hip_problem_reshape(h, 1, too_big.ctypes.data, None) == -1
         assert L.pnec_hip_problem_num_pairs(h) == P          # unchanged by the refused shapes
         fixed = C.c_void_p()

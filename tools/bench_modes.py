@@ -3,7 +3,7 @@
 B pairs x 512 correspondences x 10 LM iterations, plus the rotation difference against the oracle on a
 sample.  Runs on the GPU box; prints one JSON object per family.  (HOST and SYM reuse the frame-2
 covariances as frame-1 covariances: the arithmetic, not the data model, is what is timed.)
-   python tools/bench_modes.py [B]"""
+   python tools/bench_modes.py [B] [family: nec|target|host|sym|all] [cpl wpp ldsk]   (forced launch geometry: A/B runs)"""
 import json
 import os
 import sys
@@ -18,9 +18,12 @@ from pnec_amd import Batch, capi
 from pnec_amd import simulation as sim
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+ONLY = sys.argv[2].lower() if len(sys.argv) > 2 else "all"
+GEOM = [int(x) for x in sys.argv[3:6]] if len(sys.argv) > 5 else [0, 0, 0]
 N = 512
 dev = torch.device("cuda:0")
-opts = capi.default_options(max_num_iterations=10, check_convergence=0)
+opts = capi.default_options(max_num_iterations=10, check_convergence=0, corr_per_lane=GEOM[0], waves_per_pair=GEOM[1],
+                            lds_corr_per_lane=GEOM[2])
 oo = po.default_options(jacobian_mode=po.JAC_NUMERIC_CENTRAL, max_num_iterations=10, check_convergence=0)
 
 
@@ -32,6 +35,8 @@ def quat_angle(a, b):
 
 for name, mode, omode in (("NEC", capi.MODE_NEC, po.MODE_NEC), ("PNEC target", capi.MODE_TARGET, po.MODE_TARGET),
                           ("PNEC host", capi.MODE_HOST, po.MODE_HOST), ("PNEC symmetric", capi.MODE_SYM, po.MODE_SYM)):
+    if ONLY != "all" and ONLY not in name.lower():
+        continue
     batch = Batch.uniform(mode, B, N)
     qs, ts, first = [], [], None
     for c0 in range(0, B, 10_000):
