@@ -700,6 +700,38 @@ __global__ void selftest_kernel(double *out) {
     out[65] = fast_rsqrt(2.0) - 0.70710678118654752440;
     out[66] = fast_rcp(3.0) - 0.33333333333333333333;
   }
+  {
+    // the same system solved across lanes (gj_solve5_rows: lane i of every 16-lane row owns row i) with a damped
+    // diagonal, against chol_solve5 on the damped matrix; and the 64-bit row broadcast on its own
+    double P[15], bb[5], y[5];
+    double M[5][5];
+    for (int i = 0; i < 5; ++i)
+      for (int j = 0; j < 5; ++j) M[i][j] = sin(1.0 + i * 1.7 + j * 0.9);
+    for (int i = 0; i < 5; ++i)
+      for (int j = i; j < 5; ++j) {
+        double sacc = (i == j) ? 1.0 : 0.0;
+        for (int k = 0; k < 5; ++k) sacc += M[i][k] * M[j][k];
+        P[tri(i, j)] = sacc;
+      }
+    for (int i = 0; i < 5; ++i) bb[i] = 1.0 + i;
+    const int li = lane & 15;
+    double A[5], rhs = 0.0, damp = 0.0;
+    for (int k = 0; k < 5; ++k) A[k] = 0.0;
+    for (int i = 0; i < 5; ++i)
+      if (li == i) {
+        for (int k = 0; k < 5; ++k) A[k] = P[sym(i, k)];
+        rhs = bb[i];
+        damp = 0.25 * (i + 1);
+      }
+    for (int i = 0; i < 5; ++i) P[tri(i, i)] += 0.25 * (i + 1);
+    const bool ok_rows = gj_solve5_rows(A, damp, rhs, li);
+    const bool ok_chol = chol_solve5(P, bb, y);
+    double dev = 0.0;
+    for (int i = 0; i < 5; ++i)
+      if (li == i) dev = fabs(rhs - y[i]) / fabs(y[i]);
+    out[216 + lane] = (ok_rows && ok_chol && li < 5) ? dev : ((ok_rows && ok_chol) ? 0.0 : -1.0);
+    out[280 + lane] = bcast_row<11>(1000.0 + lane);  // must be 1011 + 16 * (lane / 16)
+  }
   // 21-way swap-halving reduction: acc[j] = (lane+1)(j+1) + j  ->  2080 (j+1) + 64 j
   double acc[kNumAcc], sums[kNumAcc];
   for (int j = 0; j < kNumAcc; ++j) acc[j] = (double)((lane + 1) * (j + 1) + j);
@@ -1884,11 +1916,11 @@ int pnec_hip_selftest(int device) {
     }
   }
   double *d = nullptr;
-  PNEC_HIP_TRY(dev_alloc(&d, sizeof(double) * 224));
+  PNEC_HIP_TRY(dev_alloc(&d, sizeof(double) * 352));
   hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(kWave), 0, 0, d);
-  double h[224];
+  double h[352];
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(double) * 216, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(double) * 344, hipMemcpyDeviceToHost);
   (void)dev_free(d);
   if (e != hipSuccess) return fail_hip(e, "selftest_kernel");
   for (int i = 0; i < kWave; ++i)
@@ -1898,6 +1930,17 @@ int pnec_hip_selftest(int device) {
       return fail(PNEC_HIP_ERR_HIP_RUNTIME, buf);
     }
   if (!(h[64] >= 0.0 && h[64] < 1e-12)) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "chol_solve5 residual too large");
+  for (int i = 0; i < kWave; ++i) {
+    char buf[160];
+    if (!(h[216 + i] >= 0.0 && h[216 + i] < 1e-13)) {
+      std::snprintf(buf, sizeof(buf), "gj_solve5_rows: lane %d deviates from chol_solve5 by %.3g (relative)", i, h[216 + i]);
+      return fail(PNEC_HIP_ERR_HIP_RUNTIME, buf);
+    }
+    if (h[280 + i] != 1011.0 + 16.0 * (i / 16)) {
+      std::snprintf(buf, sizeof(buf), "bcast_row<11>: lane %d holds %.17g", i, h[280 + i]);
+      return fail(PNEC_HIP_ERR_HIP_RUNTIME, buf);
+    }
+  }
   if (!(std::abs(h[65]) < 1e-15)) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "fast_rsqrt inaccurate");
   if (!(std::abs(h[66]) < 1e-15)) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "fast_rcp inaccurate");
   for (int j = 0; j < kNumAcc; ++j)

@@ -154,6 +154,33 @@ template <int K>
 __device__ __forceinline__ int quad_broadcast(int x) {
   return __builtin_amdgcn_mov_dpp(x, K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true);
 }
+// 64-bit DPP.  The DP ALU of gfx90a / gfx94x / gfx950 supports exactly one DPP control, row_newbcast:N -- "every lane
+// of a 16-lane row reads lane N of its row" -- on its VOP1 / VOP2 encodings (v_mov_b64, v_fmac_f64, ...).  That is a
+// 64-bit broadcast FUSED into the consuming multiply-add: no separate cross-lane instruction (a 64-bit value moved
+// with the 32-bit DPP moves costs two VALU slots).  The compiler has no builtin that selects these (its update_dpp
+// builtin is 32-bit), so they are spelled in assembly; "s_nop 1" in front covers the DPP read-after-VALU-write hazard
+// (2 wait states) the hazard recogniser cannot see through inline assembly.  The source lane must be active.
+// (tools/dpp_probe.hip is the hardware probe of these semantics; pnec_hip_selftest repeats it.)
+//   acc += src[lane N of this row] * y
+template <int N>
+__device__ __forceinline__ void fmac_row(double &acc, double src, double y) {
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc) : "v"(src), "v"(y), "n"(N));
+}
+//   acc -= src[lane N of this row] * y
+template <int N>
+__device__ __forceinline__ void fnmac_row(double &acc, double src, double y) {
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc) : "v"(src), "v"(y), "n"(N));
+}
+//   src[lane N of this row]
+template <int N>
+__device__ __forceinline__ double bcast_row(double src) {
+  double r;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(N));
+  return r;
+}
+
 // lane ^ XOR inside a group of 32 through the LDS crossbar (ds_swizzle_b32, bit-mask mode): the
 // exchange runs on the LDS pipe, not the VALU the solver is bound by
 template <int XOR>
@@ -572,6 +599,40 @@ __device__ __forceinline__ bool chol_solve5(const double (&P)[15], const double 
     y[i] = s * inv[i];
   }
   return finite_d(y[0]);
+}
+
+// The same 5x5 SPD system solved ACROSS LANES: lane i (i = 0..4) of every 16-lane row holds row i of A in the
+// registers A[0..4] and the right-hand side b_i; on return b_i is x_i (lanes >= 5 hold garbage and are never read).
+// Gauss-Jordan without pivoting (the pivots are those of the LDL' / Cholesky factorisation of an SPD matrix, so
+// "every pivot > 0" is exactly "the Cholesky factorisation exists"): step j broadcasts row j -- fused into the
+// multiply-adds (fmac_row) -- every other row eliminates its column j, and row j scales itself by 1 / pivot
+// (multiplier 1 - 1/pivot on its own row), so no back substitution follows.  ~70 VALU slots against the ~125 of the
+// replicated Cholesky + two triangular solves (the reciprocals dominate: 5 x 6).
+// `damp` is added to the diagonal: lane i's damp to A(i,i).  A diagonal entry is only ever used as the pivot of its
+// own step (until then it is updated like any other entry of its column), so the damping is added where the pivot
+// is read -- one add per step instead of a per-lane select of "my diagonal register" up front.
+// Returns the wave-uniform "all pivots positive".
+__device__ __forceinline__ bool gj_solve5_rows(double (&A)[5], double damp, double &b, int li) {
+  bool ok = true;
+  auto step = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const double piv = bcast_row<j>(A[j] + damp);
+    ok = ok && (piv > 0.0);
+    const double inv = fast_rcp(piv);
+    double f = A[j] * inv;
+    f = (li == j) ? (1.0 - inv) : f;
+    if constexpr (j < 1) fnmac_row<j>(A[1], A[1], f);
+    if constexpr (j < 2) fnmac_row<j>(A[2], A[2], f);
+    if constexpr (j < 3) fnmac_row<j>(A[3], A[3], f);
+    if constexpr (j < 4) fnmac_row<j>(A[4], A[4], f);
+    fnmac_row<j>(b, b, f);
+  };
+  step(std::integral_constant<int, 0>{});
+  step(std::integral_constant<int, 1>{});
+  step(std::integral_constant<int, 2>{});
+  step(std::integral_constant<int, 3>{});
+  step(std::integral_constant<int, 4>{});
+  return ok;
 }
 
 }  // namespace pnec_hip

@@ -118,7 +118,9 @@ enum : int {
   // equations of the current (accepted) point, the pass writes the candidate's into the other; accepting
   // a step flips which is which (ist[kIPark]) instead of copying 20 doubles
   kSums = 36,    // 2 x 24
-  kSlab = 84
+  kTcur = 84,    // 3  translation of the current point: the candidate's pass uniforms t = unif[9..11], copied when the
+                 //    candidate becomes the current point, so Result() needs no sine / cosine of (theta, phi) again
+  kSlab = 88
 };
 constexpr int kUnif = 18;   // pass uniforms of the candidate: R[9] | t[3] | dt/dtheta[3] | dt/dphi[2] | pad
 // per-solve integer state (LDS)
@@ -133,7 +135,8 @@ enum : int { kIIter = 0, kIFirst, kIReuseDiag, kINumInvalid, kIStepOk,
 // per SIMD; the (8,W,0) shape runs one wavefront per SIMD with AGPR parking).
 __host__ __device__ constexpr bool geometry_ok(int mode, int cpl, int wpp, int ldsk) {
   const int nc = num_components(mode);
-  const long lds = (long)wpp * (ldsk * nc * kWave * 8 + (kSlab + kUnif) * 8 + kINumI * 4) + (wpp > 1 ? 2L * wpp * kSumSlots * 8 : 0);
+  const long lds = (long)wpp * (ldsk * nc * kWave * 8 + (kSlab + kUnif) * 8 + kINumI * 4) + (wpp > 1 ? 2L * wpp * kSumSlots * 8 : 0) +
+                   16 * 8 * 4 /* gather offsets of lm_advance_rows (A/B build) */;
   if (lds > 160 * 1024) return false;
   if (cpl == 8 && ldsk == 0) return nc <= 18;
   return nc * (cpl - ldsk) <= 72;
@@ -367,7 +370,7 @@ __device__ __forceinline__ void pose_uniforms_sc(double st, double ct, double sp
   for (int i = 0; i < 9; ++i) u[i] = R[i];
   u[9] = st * cp;   u[10] = st * sp;  u[11] = ct;
   u[12] = ct * cp;  u[13] = ct * sp;  u[14] = -st;
-  u[15] = -st * sp; u[16] = st * cp;
+  // (dt/dphi = (-u[10], u[9], 0): the pass derives it from t)
 }
 __device__ __forceinline__ void pose_uniforms(double theta, double phi, const double (&q)[4], double *u) {
   double st, ct, sp, cp;
@@ -388,12 +391,11 @@ __device__ __forceinline__ void write_result(const SolveArgs &a, int64_t s, cons
     a.out_q[4 * s + 3] = q3 * qn;
   }
   if (a.out_t) {
-    double st, ct, sp, cp;
-    sincos_bounded(slab[kTheta], st, ct);
-    sincos_bounded(slab[kPhi], sp, cp);
-    a.out_t[3 * s + 0] = st * cp;
-    a.out_t[3 * s + 1] = st * sp;
-    a.out_t[3 * s + 2] = ct;
+    // t(theta, phi) = (sin th cos ph, sin th sin ph, cos th) of the current point: the very products its pass
+    // evaluated with (pose_uniforms_sc), parked by lm_advance when the point was accepted
+    a.out_t[3 * s + 0] = slab[kTcur + 0];
+    a.out_t[3 * s + 1] = slab[kTcur + 1];
+    a.out_t[3 * s + 2] = slab[kTcur + 2];
   }
   if (a.out_cost) a.out_cost[s] = slab[kCost];
   if (a.out_iterations) a.out_iterations[s] = iteration;
@@ -443,6 +445,7 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
       slab[kQ + 0] = qc0; slab[kQ + 1] = qc1; slab[kQ + 2] = qc2; slab[kQ + 3] = qc3;
       slab[kTheta] = thc0;
       slab[kPhi] = phc0;
+        slab[kTcur + 0] = unif[9]; slab[kTcur + 1] = unif[10]; slab[kTcur + 2] = unif[11];
       slab[kCost] = cost_c;
       term = PNEC_HIP_TERM_BAD_INITIAL;
     } else {
@@ -491,6 +494,7 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
       slab[kQ + 0] = qc0; slab[kQ + 1] = qc1; slab[kQ + 2] = qc2; slab[kQ + 3] = qc3;
       slab[kTheta] = thc0;
       slab[kPhi] = phc0;
+        slab[kTcur + 0] = unif[9]; slab[kTcur + 1] = unif[10]; slab[kTcur + 2] = unif[11];
       slab[kCost] = cost_c;
     }
     term = PNEC_HIP_TERM_MAX_ITERATIONS;
@@ -524,6 +528,7 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
       for (int k = 0; k < 4; ++k) slab[kQ + k] = x[k];
       slab[kTheta] = x[4];
       slab[kPhi] = x[5];
+        slab[kTcur + 0] = unif[9]; slab[kTcur + 1] = unif[10]; slab[kTcur + 2] = unif[11];
       slab[kCost] = cost_c;
       if (o.check_convergence) {  // |x| is only read by the parameter-tolerance test
         slab[kXNorm] = fast_sqrt(x[4] * x[4] + x[5] * x[5] + x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
@@ -650,6 +655,291 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
   return term;
 }
 
+// ---- the same step, ACROSS THE LANES OF A ROW: an A/B build (-DPNEC_ADVANCE_ROWS), NOT the default.  Measured on the
+// benchmark (same box, same call): SQ_INSTS_VALU 14 202 -> 13 936 per solve (-1.9 %), 33.8 -> 33.1 M solves/s (-2 %).
+// The kernel sits where two limits meet -- the VALU issue slots of two wavefronts per SIMD and the latency of this
+// chain against the other wavefront's pass -- and this form buys its fewer slots with a longer chain (the gather is
+// two dependent LDS round trips instead of one, every fused broadcast waits out the DPP hazard).  Kept because it is
+// the measured answer to "run the 5x5 solve across lanes" and the home of the DP-ALU DPP primitives.
+// lm_advance runs one solve's step identically in four lanes: a wavefront instruction costs its four issue
+// clocks whether four or sixty-four lanes are live, so everything that is a 5-vector or a 5x5 matrix is paid for
+// five (or fifteen) times over.  Here the WHOLE wavefront executes the step (EXEC full: the 64-bit DPP broadcasts
+// need their source lanes active) and lane i (i = 0..4) of every 16-lane row owns component i: row i of the normal
+// equations, g_i, the LM diagonal, the Jacobi scale, the step p_i.  Cross-lane traffic is the DP ALU's
+// row_newbcast fused into v_fmac_f64 (pnec_device.hpp: fmac_row / fnmac_row / bcast_row), i.e. free of its own
+// instruction: the 5x5 system is a Gauss-Jordan elimination across lanes (gj_solve5_rows, ~70 slots against ~125),
+// the clamped diagonal, the scaled step and the model decrease are one lane-parallel expression each, and the six
+// sines / cosines of the step reach the quaternion and the pose uniforms through one 64-bit broadcast each instead
+// of two 32-bit DPP moves.  Scalars of the solve (cost, radius, iteration counters, the quaternion) stay replicated in
+// every lane exactly as before; the control flow is the same code, statement for statement.
+//
+// Lane i finds its row in the 24-slot tables of sums through `gidx` (LDS, 8 ints per lane, written once per
+// kernel): byte offsets of H(i,0..4) and g_i inside a table (lanes >= 5: offset 0, harmless).  The four rows of
+// the wavefront do the same thing on the same data; stores are made by lane 0 (or lanes 0..4) only.
+constexpr int kGatherInts = 8;  // per lane: H(i,0) .. H(i,4), g_i, H(i,i), pad   (byte offsets into a table of sums)
+__device__ __forceinline__ void gather_index_init(int *gidx, int lane) {
+  if (lane < 16) {
+    int v[kGatherInts];
+#pragma unroll
+    for (int k = 0; k < kGatherInts; ++k) v[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if (lane == i) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = 8 * sum_slot(6 + tri(i < k ? i : k, i < k ? k : i));
+        v[5] = 8 * sum_slot(1 + i);
+        v[6] = 8 * sum_slot(6 + tri(i, i));
+      }
+#pragma unroll
+    for (int k = 0; k < kGatherInts; ++k) gidx[lane * kGatherInts + k] = v[k];
+  }
+}
+
+__device__ __forceinline__ int lm_advance_rows(double *slab, int *ist, double *unif, const int *gidx,
+                                               const pnec_hip_options &o, double inv_max_radius,
+                                               double inv_min_radius, int lane) {
+  const int li = lane & 15;
+  const bool own = li < 5;          // this lane owns a component
+  const bool writer = lane == 0;    // the one lane that stores scalars
+  const bool cwriter = lane < 5;    // the lanes that store 5-vectors
+  int iteration = ist[kIIter], reuse_diagonal = ist[kIReuseDiag];
+  int num_invalid = ist[kINumInvalid], step_ok = ist[kIStepOk];
+  const int first = ist[kIFirst];
+  const bool last = ist[kILast] != 0;  // the pass was the cost-only one: sums 1..20 do not exist
+  int park = ist[kIPark];
+  int term = -1;
+
+  // ---- loads: the scalars (broadcast reads) and this lane's gather offsets
+  const char *cand_tab = reinterpret_cast<const char *>(slab + kSums + (park ^ 1) * kSumSlots);
+  const double S0 = *reinterpret_cast<const double *>(cand_tab + 8 * sum_slot(0));
+  const bool rest_ok = slab[kSumsFinite] != 0.0;
+  const double qc0 = slab[kQc + 0], qc1 = slab[kQc + 1], qc2 = slab[kQc + 2], qc3 = slab[kQc + 3];
+  const double thc0 = slab[kThetaC], phc0 = slab[kPhiC];
+  const double cost = slab[kCost], model = slab[kModel], xnorm = slab[kXNorm];
+  double inv_radius = slab[kInvRadius], dec = slab[kDec], gmax = slab[kGmax];
+  int go[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) go[k] = gidx[li * kGatherInts + k];
+  auto row_of = [&](const char *tab, double (&A)[5], double &gi) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) A[k] = *reinterpret_cast<const double *>(tab + go[k]);
+    gi = *reinterpret_cast<const double *>(tab + go[5]);
+  };
+  // this lane's own diagonal entry H(i,i) is column i of its row: its own gather offset, not a register select
+  auto diag_of = [&](const char *tab) { return *reinterpret_cast<const double *>(tab + go[6]); };
+  const double fcol = li >= 2 ? 2.0 : 1.0;  // the rotation columns of Ceres' tangent Jacobian are 2 x the pass's
+  double x[6];
+
+  double cost_c = 0.5 * S0;
+  const bool cost_ok = finite_d(cost_c);
+  bool accept = false;
+  double rho = 0.0;
+  if (first) {
+    if (!(cost_ok && rest_ok)) {
+      if (writer) {
+        slab[kQ + 0] = qc0; slab[kQ + 1] = qc1; slab[kQ + 2] = qc2; slab[kQ + 3] = qc3;
+        slab[kTheta] = thc0;
+        slab[kPhi] = phc0;
+        slab[kTcur + 0] = unif[9]; slab[kTcur + 1] = unif[10]; slab[kTcur + 2] = unif[11];
+        slab[kCost] = cost_c;
+      }
+      term = PNEC_HIP_TERM_BAD_INITIAL;
+    } else {
+      // jacobi_scaling: s = 1 / (1 + sqrt(diag(J'J))) on the Ceres-tangent Jacobian; frozen after iteration zero.
+      // Parked: (f s)^2 and its inverse, f = 2 for the rotation columns.  One component per lane.
+      const double hii = diag_of(cand_tab) * (fcol * fcol);
+      const double a = (o.jacobi_scaling ? 1.0 + fast_sqrt(hii) : 1.0) * (li >= 2 ? 0.5 : 1.0);  // 1 / (f s)
+      if (cwriter) {
+        slab[kInvScaleSq + li] = a * a;
+        slab[kScaleSq + li] = fast_rcp(a * a);
+      }
+      accept = true;
+    }
+  } else {
+    if (!cost_ok) cost_c = 1.7976931348623157e308;
+    if (o.check_convergence) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = slab[kQ + k];
+      x[4] = slab[kTheta];
+      x[5] = slab[kPhi];
+      double dn = (x[4] - thc0) * (x[4] - thc0) + (x[5] - phc0) * (x[5] - phc0);
+      dn = __builtin_fma(x[0] - qc0, x[0] - qc0, dn);
+      dn = __builtin_fma(x[1] - qc1, x[1] - qc1, dn);
+      dn = __builtin_fma(x[2] - qc2, x[2] - qc2, dn);
+      dn = __builtin_fma(x[3] - qc3, x[3] - qc3, dn);
+      const double step_norm = fast_sqrt(dn);
+      if (step_norm <= o.parameter_tolerance * (xnorm + o.parameter_tolerance))
+        term = PNEC_HIP_TERM_PARAMETER_TOL;
+      else if (fabs(cost - cost_c) <= o.function_tolerance * cost)
+        term = PNEC_HIP_TERM_FUNCTION_TOL;
+    }
+    if (term < 0) {
+      rho = (cost - cost_c) * fast_rcp(model);
+      accept = rho > o.min_relative_decrease;
+      if (accept && !rest_ok) term = PNEC_HIP_TERM_BAD_INITIAL;  // finite cost, non-finite Jacobian: Ceres fails here
+    }
+  }
+
+  if (term < 0 && last) {
+    // at the iteration cap the solve ends here whatever the verdict on the step
+    if (accept && writer) {
+      slab[kQ + 0] = qc0; slab[kQ + 1] = qc1; slab[kQ + 2] = qc2; slab[kQ + 3] = qc3;
+      slab[kTheta] = thc0;
+      slab[kPhi] = phc0;
+        slab[kTcur + 0] = unif[9]; slab[kTcur + 1] = unif[10]; slab[kTcur + 2] = unif[11];
+      slab[kCost] = cost_c;
+    }
+    term = PNEC_HIP_TERM_MAX_ITERATIONS;
+  }
+  if (term < 0) {
+    double Hr[5], gi, diag = 0.0;   // this lane's row of J'J, its g_i, its LM diagonal entry
+    const char *cur_tab;            // the table of the point the next step starts from
+    if (accept) {
+      // x <- candidate; its normal equations are the sums of the pass just made
+      x[0] = qc0; x[1] = qc1; x[2] = qc2; x[3] = qc3; x[4] = thc0; x[5] = phc0;
+      cur_tab = cand_tab;
+      row_of(cur_tab, Hr, gi);
+      if (o.check_convergence) {  // only the gradient-tolerance test reads it: max_i |g_i| f_i over the five lanes
+        const double ga = fabs(gi) * fcol;
+        gmax = fmax(fmax(fmax(bcast_row<0>(ga), bcast_row<1>(ga)), fmax(bcast_row<2>(ga), bcast_row<3>(ga))), bcast_row<4>(ga));
+      }
+      if (first) {
+        inv_radius = fast_rcp(o.initial_trust_region_radius);
+      } else {
+        const double c1 = 2.0 * rho - 1.0;
+        inv_radius = fmax(inv_max_radius, inv_radius * fmax(1.0 / 3.0, 1.0 - c1 * c1 * c1));
+      }
+      dec = 2.0;
+      park ^= 1;  // the candidate's table is the current point's from now on (nothing is copied)
+      step_ok = 1;
+      reuse_diagonal = 0;
+      if (writer) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) slab[kQ + k] = x[k];
+        slab[kTheta] = x[4];
+        slab[kPhi] = x[5];
+        slab[kTcur + 0] = unif[9]; slab[kTcur + 1] = unif[10]; slab[kTcur + 2] = unif[11];
+        slab[kCost] = cost_c;
+        if (o.check_convergence) {  // |x| is only read by the parameter-tolerance test
+          slab[kXNorm] = fast_sqrt(x[4] * x[4] + x[5] * x[5] + x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+          slab[kGmax] = gmax;
+        }
+      }
+    } else {
+      // rejected: back to the parked point (its normal equations are still in its table), smaller region
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = slab[kQ + k];
+      x[4] = slab[kTheta];
+      x[5] = slab[kPhi];
+      cur_tab = reinterpret_cast<const char *>(slab + kSums + park * kSumSlots);
+      row_of(cur_tab, Hr, gi);
+      inv_radius = inv_radius * dec;
+      dec = 2.0 * dec;
+      reuse_diagonal = 1;
+    }
+    const double hii = diag_of(cur_tab);
+    if (reuse_diagonal) diag = slab[kDiag + (own ? li : 0)];
+    const double scale_sq = slab[kScaleSq + (own ? li : 0)], inv_scale_sq = slab[kInvScaleSq + (own ? li : 0)];
+    const double xang = li == 0 ? x[4] : x[5];   // lane 0 steps theta, lane 1 phi
+
+    // ---- FinalizeIterationAndCheckIfMinimizerCanContinue + the next trust-region step
+    for (;;) {
+      if (iteration >= o.max_num_iterations) { term = PNEC_HIP_TERM_MAX_ITERATIONS; break; }
+      if (o.check_convergence && step_ok && gmax <= o.gradient_tolerance) {
+        term = PNEC_HIP_TERM_GRADIENT_TOL; break;
+      }
+      if (inv_radius > inv_min_radius) { term = PNEC_HIP_TERM_MIN_RADIUS; break; }  // radius < min_radius
+      ++iteration;
+      step_ok = 0;
+
+      // LevenbergMarquardtStrategy::ComputeStep in parameter scale (see lm_advance): (H + D'/radius) p = -g,
+      // D'_i = clamp(s_i^2 H_ii) / s_i^2 -- one component per lane
+      if (!reuse_diagonal) {
+        diag = fmin(fmax(hii * scale_sq, o.min_lm_diagonal), o.max_lm_diagonal) * inv_scale_sq;
+        if (cwriter) slab[kDiag + li] = diag;
+      }
+      const double dr = diag * inv_radius;
+      double A[5];   // the elimination works in place: a retry starts from the row again
+#pragma unroll
+      for (int k = 0; k < 5; ++k) A[k] = Hr[k];
+      double p = -gi;
+      bool valid = gj_solve5_rows(A, dr, p, li);   // p_i = step component i (parameter scale), lanes 0..4
+      // model cost change (-g'p + p'(D'/radius)p) / 2: the lanes' terms summed through broadcasts; a non-finite
+      // step component makes the sum NaN (0 x inf), and NaN > 0 is false
+      double e = __builtin_fma(dr * p, p, -(p * gi));
+      e = __builtin_fma(p, 0.0, e);
+      double msum = 0.0;
+      fmac_row<0>(msum, e, 0.5);
+      fmac_row<1>(msum, e, 0.5);
+      fmac_row<2>(msum, e, 0.5);
+      fmac_row<3>(msum, e, 0.5);
+      fmac_row<4>(msum, e, 0.5);
+      const double model_change = msum;
+      valid = valid && (model_change > 0.0);
+      if (!valid) {
+        if (++num_invalid >= o.max_num_consecutive_invalid_steps) { term = PNEC_HIP_TERM_INVALID_STEPS; break; }
+        inv_radius = inv_radius * dec;
+        dec = 2.0 * dec;
+        reuse_diagonal = 1;
+        continue;
+      }
+      num_invalid = 0;
+
+      // candidate = Plus(x, p): theta + p_0 (lane 0), phi + p_1 (lane 1); EigenQuaternionManifold::Plus on q with
+      // delta = (p_2, p_3, p_4) / 2 (lanes 2, 3, 4)
+      const double hp = 0.5 * p;
+      const double hp2 = hp * hp;
+      double nd2 = 0.0;
+      fmac_row<2>(nd2, hp2, 1.0);
+      fmac_row<3>(nd2, hp2, 1.0);
+      fmac_row<4>(nd2, hp2, 1.0);
+      const double ind = nd2 > 0.0 ? fast_rsqrt(nd2) : 0.0, nd = nd2 * ind;
+      // the three sine / cosine pairs of the step in ONE evaluation: lane 0 theta, lane 1 phi, lane 2 |delta|
+      const double angle = li == 2 ? nd : xang + p;
+      double sa, ca;
+      sincos_bounded(angle, sa, ca);
+      const double st = bcast_row<0>(sa), ct = bcast_row<0>(ca);
+      const double sp = bcast_row<1>(sa), cp = bcast_row<1>(ca);
+      const double aw = bcast_row<2>(ca);
+      double sbd = 0.0;                 // sin|delta| / |delta| (0 for a zero step: qc = x)
+      fmac_row<2>(sbd, sa, ind);
+      double ax = 0.0, ay = 0.0, az = 0.0;
+      fmac_row<2>(ax, hp, sbd);
+      fmac_row<3>(ay, hp, sbd);
+      fmac_row<4>(az, hp, sbd);
+      double qc[4];
+      qc[0] = aw * x[0] + ax * x[3] + ay * x[2] - az * x[1];
+      qc[1] = aw * x[1] - ax * x[2] + ay * x[3] + az * x[0];
+      qc[2] = aw * x[2] + ax * x[1] - ay * x[0] + az * x[3];
+      qc[3] = aw * x[3] - ax * x[0] - ay * x[1] - az * x[2];
+      const double thc = bcast_row<0>(angle), phc = bcast_row<1>(angle);
+      if (writer) {
+        pose_uniforms_sc(st, ct, sp, cp, qc, unif);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) slab[kQc + k] = qc[k];
+        slab[kThetaC] = thc;
+        slab[kPhiC] = phc;
+        slab[kModel] = model_change;
+        ist[kILast] = iteration >= o.max_num_iterations ? 1 : 0;
+      }
+      break;
+    }
+    if (writer) {
+      slab[kInvRadius] = inv_radius;
+      slab[kDec] = dec;
+    }
+  }
+  if (writer) {
+    ist[kIPark] = park;
+    ist[kIIter] = iteration;
+    ist[kIFirst] = (term < 0 || !first) ? 0 : 1;
+    ist[kIReuseDiag] = reuse_diagonal;
+    ist[kINumInvalid] = num_invalid;
+    ist[kIStepOk] = step_ok;
+  }
+  return term;
+}
+
 // region markers for tools/isa_mix.py --regions (assembly comments; compiled in only on request)
 #ifdef PNEC_ISA_MARKS
 #define PNEC_MARK(name) asm volatile("; PNEC_MARK " name)
@@ -694,6 +984,9 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   __shared__ double slab_all[WPP][kSlab];
   __shared__ double unif_all[WPP][kUnif];
   __shared__ int ist_all[WPP][kINumI];
+#ifdef PNEC_ADVANCE_ROWS
+  __shared__ int gidx_all[1][16 * kGatherInts];  // lm_advance_rows: each lane's row of the tables of sums
+#endif
   [[maybe_unused]] __shared__ double xw[2][WPP > 1 ? WPP : 1][kSumSlots];
   [[maybe_unused]] __shared__ double ldata[LDSK > 0 ? WPP : 1][LDSK > 0 ? LDSK : 1][NC][LDSK > 0 ? kWave : 1];
   double *slab = slab_all[WPP > 1 ? 0 : wave];
@@ -727,6 +1020,9 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   // Everything that is one value per solve runs in a few lanes only (here lane 0, lm_advance on
   // a quad) against the LDS slab: not faster to issue (measured), but one copy of the state and
   // plain per-lane control flow instead of wave-uniform bookkeeping in scalar registers.
+#ifdef PNEC_ADVANCE_ROWS
+  if (WPP == 1 || wave == 0) gather_index_init(gidx_all[0], lane);
+#endif
   if (lane == 0 && (WPP == 1 || wave == 0)) {
     double th, ph;
     const double *t0 = a.hyp_t ? a.hyp_t + 3 * s : a.init_t + 3 * pair;
@@ -767,8 +1063,10 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
       for (int i = 0; i < 3; ++i) U.t[i] = to_sgpr(unif[9 + i]);
 #pragma unroll
       for (int i = 0; i < 3; ++i) U.bth[i] = to_sgpr(unif[12 + i]);
-      U.bph[0] = to_sgpr(unif[15]);
-      U.bph[1] = to_sgpr(unif[16]);
+      // dt/dphi = (-sin th sin ph, sin th cos ph, 0) = (-t_y, t_x, 0): the same products, a sign flip on the scalar
+      // side -- four readfirstlanes fewer per pass
+      U.bph[0] = -U.t[1];
+      U.bph[1] = U.t[0];
       U.bph[2] = 0.0;
       double c[6];
       bool cost_only = false;
@@ -844,14 +1142,22 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
     // other wavefront on this SIMD, which has independent work to fill the gaps (+1.2 %)
     if constexpr (WPP == 1) {
       __builtin_amdgcn_s_setprio(3);
+#ifndef PNEC_ADVANCE_ROWS
       if (lane < 4) t = lm_advance(slab, ist, unif, o, inv_max_radius, inv_min_radius);  // one quad, identical work (see the sincos exchange)
+#else
+      t = lm_advance_rows(slab, ist, unif, gidx_all[0], o, inv_max_radius, inv_min_radius, lane);  // every lane: one component per lane
+#endif
       term = to_sgpr(t);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     } else {
       if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);
+#ifndef PNEC_ADVANCE_ROWS
         if (lane < 4) t = lm_advance(slab, ist, unif, o, inv_max_radius, inv_min_radius);
+#else
+        t = lm_advance_rows(slab, ist, unif, gidx_all[0], o, inv_max_radius, inv_min_radius, lane);
+#endif
         if (lane == 0) ist[kITerm] = t;
         __builtin_amdgcn_s_setprio(0);
       }
