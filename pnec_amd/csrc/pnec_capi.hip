@@ -781,7 +781,19 @@ bool geometry_exists(int mode, int cpl, int wpp, int ldsk) {
 }
 
 // The auto-tuner's ladder for a residual family (smallest capacity first).
-int geometry_ladder(int mode, const int (**order)[3]) {
+// planes = true: the batch path, which reads the SoA planes in HBM and has the tail form (12, 1, 3) for pairs of
+// 513..768 -- one wavefront, 512 correspondences resident, the tail re-read from L2 every pass -- whose results are
+// bit for bit those of (8, 2, 3); the AoS-source kernels of the streaming handle (planes = false) are not built for it
+// and run such pairs on (8, 2, 3), to the same bits.
+int geometry_ladder(int mode, const int (**order)[3], bool planes = true) {
+  static const int order12t[][3] = {{1, 1, 0}, {2, 1, 0}, {4, 1, 0}, {8, 1, 3}, {12, 1, 3},
+                                    {8, 2, 3}, {8, 4, 3}, {8, 8, 3}};
+  static const int order6t[][3] = {{1, 1, 0}, {2, 1, 0}, {4, 1, 0}, {8, 1, 0}, {12, 1, 3},
+                                   {8, 2, 3}, {8, 4, 3}, {8, 8, 3}};
+  if (planes && mode != PNEC_HIP_MODE_SYM) {
+    *order = (mode == PNEC_HIP_MODE_NEC) ? order6t : order12t;
+    return 8;
+  }
   static const int order12[][3] = {{1, 1, 0}, {2, 1, 0}, {4, 1, 0}, {8, 1, 3},
                                    {8, 2, 3}, {8, 4, 3}, {8, 8, 3}};
   // 18-plane payload: 512 correspondences fit ONE wavefront at one wavefront per SIMD (288 payload

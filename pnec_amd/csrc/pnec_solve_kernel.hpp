@@ -42,7 +42,11 @@
 // SYM payload; (8,1,0), (4,2,0) and (1,8,0) also serve the A/B measurements in DESIGN.md.
 #define PNEC_FOR_EACH_GEOMETRY(X) \
   X(1, 1, 0) X(2, 1, 0) X(4, 1, 0) X(4, 2, 0) X(4, 4, 0) X(4, 8, 0) \
-  X(8, 1, 3) X(8, 2, 3) X(8, 4, 3) X(8, 8, 3) X(8, 1, 0) X(1, 8, 0)
+  X(8, 1, 3) X(12, 1, 3) X(8, 2, 3) X(8, 4, 3) X(8, 8, 3) X(8, 1, 0) X(1, 8, 0)
+// (12, 1, 3) is (8, 1, 3) + a TAIL: 512 correspondences resident on chip and up to 256 more re-read from L2 in every
+// pass -- pairs of 513..768 on ONE wavefront instead of (8, 2, 3)'s two wavefronts and two barriers per pass for a
+// tail of a few dozen correspondences.  See the tail pass in lm_solve_kernel: its sums are, bit for bit, those of
+// (8, 2, 3)'s second wavefront.
 // the geometries the auto-tuner's ladders can pick (pnec_capi.hip geometry_ladder): what the AoS-source
 // kernels of the streaming handle are built for
 #define PNEC_FOR_EACH_AOS_GEOMETRY(X) \
@@ -135,6 +139,7 @@ enum : int { kIIter = 0, kIFirst, kIReuseDiag, kINumInvalid, kIStepOk,
 // per SIMD; the (8,W,0) shape runs one wavefront per SIMD with AGPR parking).
 __host__ __device__ constexpr bool geometry_ok(int mode, int cpl, int wpp, int ldsk) {
   const int nc = num_components(mode);
+  if (cpl == 12) return wpp == 1 && ldsk == 3 && nc <= 12;  // (8, 1, 3) + tail: the 6- and 12-plane payloads
   const long lds = (long)wpp * (ldsk * nc * kWave * 8 + (kSlab + kUnif) * 8 + kINumI * 4) + (wpp > 1 ? 2L * wpp * kSumSlots * 8 : 0) +
                    16 * 8 * 4 /* gather offsets of lm_advance_rows (A/B build) */;
   if (lds > 160 * 1024) return false;
@@ -947,6 +952,32 @@ __device__ __forceinline__ int lm_advance_rows(double *slab, int *ist, double *u
 #define PNEC_MARK(name)
 #endif
 
+// One correspondence per lane of the tail (geometry (12, 1, 3)) from the planes in memory: plane c of the pair starts at
+// sbase + c * plane_bytes (scalar registers), the lane's correspondence sits `lo` + IMM bytes into it.  Spelled as
+// the scalar-base form of global_load (saddr + 32-bit voffset + immediate) because the compiler, left to itself,
+// keeps a 64-bit vector address per plane alive across the whole LM loop (24 registers this kernel does not have).
+// Lanes beyond the planes (`in` false) keep the zeros they came with.  The s_waitcnt carries the values as operands,
+// so nothing that reads them can be scheduled in front of it.
+template <int NC, int IMM>
+__device__ __forceinline__ void tail_load(double (&e)[NC], const char *sbase, size_t plane_bytes, unsigned lo, bool in) {
+  static_assert(NC == 6 || NC == 12, "tail form: 6- and 12-plane payloads");
+#pragma unroll
+  for (int c = 0; c < NC; ++c) e[c] = 0.0;
+  if (in) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const char *pl = sbase + (size_t)c * plane_bytes;
+      asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "+v"(e[c]) : "v"(lo), "s"(pl), "n"(IMM) : "memory");
+    }
+    if constexpr (NC == 12)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]),
+                     "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]));
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]));
+  }
+}
+
 constexpr int SRC_PLANES = 0;  // the batch's SoA planes in HBM (pnec_hip_problem)
 constexpr int SRC_AOS = 1;     // the caller's arrays in the reference layout (streaming handle)
 template <int MODE, int CPL, int WPP, int LDSK, bool RESIDENT, int SRC = SRC_PLANES>
@@ -954,7 +985,10 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
     const SolveArgs a) {
   static_assert(SRC == SRC_PLANES || RESIDENT, "the AoS source is only built for the on-chip-resident geometries");
   constexpr int NC = num_components(MODE);
-  constexpr int REGK = RESIDENT ? CPL - LDSK : 1;  // correspondences per lane kept in registers
+  constexpr int RCPL = CPL > 8 ? 8 : CPL;          // correspondences per lane resident on chip
+  constexpr int TAILK = CPL - RCPL;                // ... and re-read from memory in every pass (one wavefront only)
+  static_assert(TAILK == 0 || (TAILK == 4 && WPP == 1 && RESIDENT && SRC == SRC_PLANES), "the tail form is (12, 1, 3) on the batch's planes");
+  constexpr int REGK = RESIDENT ? RCPL - LDSK : 1;  // correspondences per lane kept in registers
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int64_t slot = xcd_contiguous_index(blockIdx.x, a.n_solves);
@@ -997,17 +1031,37 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   // ---- load this lane's correspondences once (coalesced: consecutive lanes, consecutive doubles)
   double d[REGK][NC];
   if constexpr (RESIDENT && SRC == SRC_AOS)
-    load_resident_aos<NC, CPL, REGK>(a.aos_bvs1 + 3 * aos0, a.aos_bvs2 + 3 * aos0, NC >= 12 ? a.aos_covs + 9 * aos0 : nullptr,
-                                     NC >= 18 ? a.aos_covs_host + 9 * aos0 : nullptr, n, wave * CPL * kWave, lane, d,
+    load_resident_aos<NC, RCPL, REGK>(a.aos_bvs1 + 3 * aos0, a.aos_bvs2 + 3 * aos0, NC >= 12 ? a.aos_covs + 9 * aos0 : nullptr,
+                                     NC >= 18 ? a.aos_covs_host + 9 * aos0 : nullptr, n, wave * RCPL * kWave, lane, d,
                                      &ldata[LDSK > 0 ? wave : 0][0][0][0]);
   else if constexpr (RESIDENT)
-    load_resident<NC, CPL, REGK>(base, n, stride, wave * CPL * kWave, lane, d, &ldata[LDSK > 0 ? wave : 0][0][0][0]);
+    load_resident<NC, RCPL, REGK>(base, n, stride, wave * RCPL * kWave, lane, d, &ldata[LDSK > 0 ? wave : 0][0][0][0]);
   // how many of this wavefront's CPL slots hold any correspondence of the pair (wave-uniform): slot k
   // starts at correspondence first + 128 (k / 2) + (k & 1) (load_resident), lane 0 being the first
   [[maybe_unused]] int nslots = 0;
   if constexpr (RESIDENT) {
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) nslots += (n > wave * CPL * kWave + slot_corr<CPL, REGK>(k, 0)) ? 1 : 0;
+    for (int k = 0; k < RCPL; ++k) nslots += (n > wave * RCPL * kWave + slot_corr<RCPL, REGK>(k, 0)) ? 1 : 0;
+  }
+  // The tail (TAILK = 4): correspondences 512 .. 767 as the SECOND wavefront of (8, 2, 3) would hold them in its first
+  // four register slots -- tail slot t <-> 512 + 128 (t / 2) + 2 lane + (t & 1) -- accumulated from zero in that order,
+  // reduced through the same tree and added to the resident part's sums the way the two wavefronts' sums are added.
+  // Same operations in the same order: the result is bit for bit (8, 2, 3)'s.  ntail = tail slots that hold a
+  // correspondence (wave-uniform; like (8, 2, 3)'s second wavefront, slots 0, 1 are evaluated together and 2, 3 together).
+  [[maybe_unused]] int ntail = 0;
+  [[maybe_unused]] const char *tail_base = nullptr;  // first tail correspondence of plane 0, in scalar registers
+  [[maybe_unused]] size_t tail_plane_bytes = 0;
+  if constexpr (TAILK > 0) {
+#pragma unroll
+    for (int t = 0; t < TAILK; ++t) ntail += (n > RCPL * kWave + 2 * kWave * (t / 2) + (t & 1)) ? 1 : 0;
+    // the pair's block and its plane stride are one value per wavefront: say so, and the tail's loads address as
+    // scalar base + 32-bit lane offset + immediate
+    const unsigned long long b64 = reinterpret_cast<unsigned long long>(base) + (unsigned long long)RCPL * kWave * sizeof(double);
+    const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
+    const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
+    tail_base = reinterpret_cast<const char *>(((unsigned long long)bhi << 32) | blo);
+    tail_plane_bytes = (size_t)(unsigned)__builtin_amdgcn_readfirstlane(stride) * sizeof(double);
+    ntail = __builtin_amdgcn_readfirstlane(ntail);
   }
   if (a.trace) {
     // make "payload on chip" mean what it says: wait for the loads before stamping
@@ -1081,6 +1135,37 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
           // the finite-Jacobian witness as a wave-uniform 0 / NaN in the place of sum 1
           c[1] = __builtin_amdgcn_ballot_w64(!(z == 0.0)) == 0ull ? 0.0 : __builtin_nan("");
           c[2] = c[3] = c[4] = c[5] = 0.0;
+          if constexpr (TAILK > 0) {
+            if (ntail > 0) {  // wave-uniform
+              double a1 = 0.0, z1 = 0.0;
+              const char *tb = tail_base;
+              const size_t plane_bytes = tail_plane_bytes;
+              const unsigned voff = 16u * (unsigned)lane;
+              auto tail_cost = [&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr unsigned imm = 2u * kWave * 8u * (t / 2) + 8u * (t & 1);
+                const bool in = RCPL * kWave + 2 * kWave * (t / 2) + 2 * lane < stride;
+                double e[NC];
+                tail_load<NC, (int)imm>(e, tb, plane_bytes, voff, in);
+                double r, kk;
+                eval_cost<MODE>(e, U, reg, r, kk);
+                a1 = __builtin_fma(r, r, a1);
+                z1 = __builtin_fma(kk, 0.0, z1);
+              };
+              tail_cost(std::integral_constant<int, 0>{});
+              __builtin_amdgcn_sched_barrier(0);
+              tail_cost(std::integral_constant<int, 1>{});
+              __builtin_amdgcn_sched_barrier(0);
+              if (ntail > 2) {
+                tail_cost(std::integral_constant<int, 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+                tail_cost(std::integral_constant<int, 3>{});
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              c[0] += wave_reduce_acc0_row0(a1);
+              c[1] += __builtin_amdgcn_ballot_w64(!(z1 == 0.0)) == 0ull ? 0.0 : __builtin_nan("");
+            }
+          }
         }
       } else {
         double acc[kNumAcc];
@@ -1101,6 +1186,55 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
         }
         PNEC_MARK("reduce");
         wave_reduce21_rows(acc, c);
+        if constexpr (TAILK > 0) {
+          if (ntail > 0) {  // wave-uniform
+            // the resident part's sums wait in the table (the registers are needed: payload + accumulators + a
+            // correspondence in flight fill the file), where the tail's are added to them below
+            double *park_sums = slab + kSums + (to_sgpr(ist[kIPark]) ^ 1) * kSumSlots;
+            if ((lane & 15) == 0) {
+#pragma unroll
+              for (int i = 0; i < 6; ++i) park_sums[(lane >> 4) * 6 + i] = c[i];
+            }
+            // the tail, from memory (L2: it was read moments ago by the previous pass), into fresh accumulators
+#pragma unroll
+            for (int j = 0; j < kNumAcc; ++j) acc[j] = 0.0;
+            // addresses as (scalar plane base) + (one 32-bit per-lane offset) + (an immediate per slot): nothing to
+            // keep in 64-bit vector registers across the loop (24 precomputed pointers did not fit and spilled)
+            const char *tb = tail_base;
+            const size_t plane_bytes = tail_plane_bytes;
+            const unsigned voff = 16u * (unsigned)lane;
+            auto tail_slot = [&](auto tc) {
+              constexpr int t = decltype(tc)::value;
+              constexpr unsigned imm = 2u * kWave * 8u * (t / 2) + 8u * (t & 1);
+              const bool in = RCPL * kWave + 2 * kWave * (t / 2) + 2 * lane < stride;
+              double e[NC];
+              tail_load<NC, (int)imm>(e, tb, plane_bytes, voff, in);
+              double r, J[5];
+              eval_corr<MODE>(e, U, reg, r, J);
+              accumulate(r, J, acc);
+            };
+            // (one correspondence in flight at a time: the scheduler must not hoist the later slots' loads -- there
+            // are no registers for them)
+            tail_slot(std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            tail_slot(std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (ntail > 2) {
+              tail_slot(std::integral_constant<int, 2>{});
+              __builtin_amdgcn_sched_barrier(0);
+              tail_slot(std::integral_constant<int, 3>{});
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            double c2[6];
+            wave_reduce21_rows(acc, c2);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // resident + tail, the order in which (8, 2, 3) adds its two wavefronts' sums
+#pragma unroll
+            for (int i = 0; i < 6; ++i) c[i] = park_sums[(lane >> 4) * 6 + i] + c2[i];
+          }
+        }
       }
       // the four row leaders store the sums they own (sum_slot layout) into the table the current
       // point does not own

@@ -124,7 +124,7 @@ int pnec_hip_stream_destroy(pnec_hip_stream *s) {
 // the ladder entry that holds a pair of n correspondences (same choice the batch path makes)
 static bool aos_geometry_for(int mode, int n, Geometry *g) {
   const int (*order)[3];
-  const int count = geometry_ladder(mode, &order);
+  const int count = geometry_ladder(mode, &order, /*planes*/ false);
   for (int i = 0; i < count; ++i)
     if ((int64_t)kWave * order[i][0] * order[i][1] >= std::max(n, 1)) {
       *g = {order[i][0], order[i][1], order[i][2], true};

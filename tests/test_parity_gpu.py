@@ -675,3 +675,37 @@ def test_randomised_batches_allowance_bookkeeping():
     except OSError:
         pass
     assert len(_ALLOWANCE["fired"]) <= _ALLOWANCE["trials"]
+
+
+@pytest.mark.parametrize("mode", [capi.MODE_TARGET, capi.MODE_HOST, capi.MODE_NEC])
+def test_tail_geometry_is_bitwise_the_two_wavefront_geometry(oracle, mode):
+    """Pairs of 513..768 correspondences run on ONE wavefront -- geometry (12, 1, 3): 512 correspondences resident on
+    chip, the tail re-read from L2 in every pass -- instead of (8, 2, 3)'s two wavefronts and two barriers per pass.
+    The tail's sums are accumulated, reduced and added exactly the way the second wavefront's are, so every output
+    (pose, cost, iteration count, termination code) must equal the forced (8, 2, 3) solve BIT FOR BIT -- which is also
+    what the streaming handle's AoS kernels (not built for the tail form) produce for such pairs.  Sizes on every
+    boundary of the tail's slot pairs; Ceres-default termination and a fixed iteration count; sampled oracle parity."""
+    sizes = [513, 514, 575, 576, 577, 639, 640, 641, 642, 700, 703, 704, 705, 767, 768, 520, 600, 650, 750, 768]
+    B = len(sizes)
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    g = sim.generate(B, 768, seed=4242)
+    f1 = np.concatenate([g.bvs1[p].numpy()[:n] for p, n in enumerate(sizes)])
+    f2 = np.concatenate([g.bvs2[p].numpy()[:n] for p, n in enumerate(sizes)])
+    S2 = np.concatenate([g.covs2[p].numpy()[:n] for p, n in enumerate(sizes)])
+    c2, c1 = _covs_for(mode, S2)
+    reg = 0.0 if mode == capi.MODE_NEC else 1e-13
+    for kw in (dict(), dict(max_num_iterations=7, check_convergence=0)):
+        with Batch(mode, offsets) as b:
+            b.fill(f1, f2, c2, c1)
+            auto = capi.default_options(**kw)
+            assert b.describe_launch(auto)["corr_per_lane"] == 12 and b.describe_launch(auto)["waves_per_pair"] == 1
+            res = b.solve(g.init_q.numpy(), g.init_t.numpy(), reg=reg, options=auto)
+            two = b.solve(g.init_q.numpy(), g.init_t.numpy(), reg=reg,
+                          options=capi.default_options(corr_per_lane=8, waves_per_pair=2, lds_corr_per_lane=3, **kw))
+        for name in ("q", "t", "cost", "iterations", "status"):
+            assert np.array_equal(getattr(res, name), getattr(two, name)), (name, kw)
+        q, t, cost, it, st = _oracle_batch(oracle, mode, offsets, f1, f2, c2, c1, reg, g.init_q.numpy(),
+                                           g.init_t.numpy(), _oracle_opts(oracle, auto, oracle.JAC_NUMERIC_CENTRAL))
+        worst = max(_rot_err(oracle, _quat_to_R(res.q[p]), _quat_to_R(q[p])) for p in range(B))
+        assert worst <= ROT_TOL_REFERENCE, worst
+        np.testing.assert_array_equal(res.iterations, it)
