@@ -214,6 +214,27 @@ __device__ __forceinline__ double wave_allreduce_sum(double x) {
   return x;
 }
 
+// smallest value over the 64 lanes (fmin: a NaN loses against a number); every lane ends with it
+__device__ __forceinline__ double wave_allreduce_min(double x) {
+  x = fmin(x, dpp_perm<0xB1>(x));
+  x = fmin(x, dpp_perm<0x4E>(x));
+  x = fmin(x, dpp_perm<0x141>(x));
+  x = fmin(x, dpp_perm<0x140>(x));
+  {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    x = fmin(make_double((int)b[0], (int)a[0]), make_double((int)b[1], (int)a[1]));
+  }
+  {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    x = fmin(make_double((int)b[0], (int)a[0]), make_double((int)b[1], (int)a[1]));
+  }
+  return x;
+}
+
 // Sum each of the 21 accumulators over the 64 lanes and return the sums in scalar registers.
 // v_permlane32_swap / v_permlane16_swap exchange half of one register with the other half of
 // a second one, so one swap + one add reduces TWO accumulators at once with no selects:
@@ -337,6 +358,61 @@ __device__ __forceinline__ bool rows_all_finite(const double (&c)[6]) {
 #pragma unroll
   for (int i = 0; i < 6; ++i) z = __builtin_fma(c[i], 0.0, z);  // 0 for finite, NaN otherwise
   return __builtin_amdgcn_ballot_w64(!(z == 0.0)) == 0ull;
+}
+
+// One correspondence per lane from a pair's SoA planes in memory: plane c of the pair starts at sbase + c * plane_bytes
+// (scalar registers), the lane's correspondence sits `lo` + IMM bytes into it.  (The solver's tail pass, geometry
+// (12, 1, 3), and the weighted stage's table build.)  Spelled as
+// the scalar-base form of global_load (saddr + 32-bit voffset + immediate) because the compiler, left to itself,
+// keeps a 64-bit vector address per plane and slot alive across its loops -- registers these kernels do not have: the
+// solver spilled them, the weighted stage reloaded 96 of them from scratch one by one, each in front of its load.
+// Lanes beyond the planes (`in` false) keep the zeros they came with.  The s_waitcnt carries the values as operands,
+// so nothing that reads them can be scheduled in front of it.
+template <int NC, int IMM>
+__device__ __forceinline__ void load_planes_saddr(double (&e)[NC], const char *sbase, size_t plane_bytes, unsigned lo, bool in) {
+  static_assert(NC == 6 || NC == 12, "tail form: 6- and 12-plane payloads");
+#pragma unroll
+  for (int c = 0; c < NC; ++c) e[c] = 0.0;
+  if (in) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const char *pl = sbase + (size_t)c * plane_bytes;
+      asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "+v"(e[c]) : "v"(lo), "s"(pl), "n"(IMM) : "memory");
+    }
+    if constexpr (NC == 12)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]),
+                     "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]));
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]));
+  }
+}
+
+// The same loads without the wait, for callers that want several correspondences per lane in flight together:
+// issue them all (load_planes_issue), then planes_arrived() on the FIRST set -- s_waitcnt vmcnt(0): everything issued
+// before has landed -- and planes_after() on every other set, which ties its values to a point after that wait
+// (volatile statements keep their order; readers of the values depend on these statements' outputs).
+template <int NC, int IMM>
+__device__ __forceinline__ void load_planes_issue(double (&e)[NC], const char *sbase, size_t plane_bytes, unsigned lo, bool in) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) e[c] = 0.0;
+  if (in) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const char *pl = sbase + (size_t)c * plane_bytes;
+      asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "+v"(e[c]) : "v"(lo), "s"(pl), "n"(IMM) : "memory");
+    }
+  }
+}
+__device__ __forceinline__ void planes_arrived(double (&e)[12]) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]),
+                 "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]));
+}
+__device__ __forceinline__ void planes_after(double (&e)[12]) {
+  asm volatile(""
+               : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]),
+                 "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]));
 }
 
 // ------------------------------------------------------------------------------------------

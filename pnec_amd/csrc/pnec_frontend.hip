@@ -647,7 +647,25 @@ constexpr int kFibStride = 9;  // t (3) | txx tyy tzz | 2 txy, 2 txz, 2 tyz
 // latency in the loop -- through a plain global pointer the compiler issued five vector loads per
 // direction and waited for them, which was half of the stage's wall time)
 __constant__ double c_fib[500 * kFibStride];
-__constant__ float c_fib32[500 * kFibStride];  // the same table rounded to single precision (pre-screen)
+__constant__ float c_fib32[500 * kFibStride];  // the same table rounded to single precision (pre-screen of the rare pair)
+// the directions' products txx tyy tzz | 2 txy 2 txz 2 tyz, one PLANE per product (the bound test of the weighted stage
+// reads them one direction per lane: 64 consecutive doubles per load instead of 64 lines); entries 500..511 are zero
+__device__ double c_fib_prod[6][512];
+// this lane's direction 64 J + lane: its six products from the planes above, in the scalar-base form of global_load
+// (see pnec_device.hpp load_planes_saddr for why), without a wait; fib_prod_arrived(first = true) is the wait for
+// everything issued so far, (first = false) ties a later set to a point after it
+template <int J>
+__device__ __forceinline__ void fib_prod_issue(double (&p)[6], const char *planes, unsigned voff) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const char *pl = planes + (size_t)k * 512 * sizeof(double);
+    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(p[k]) : "v"(voff), "s"(pl), "n"(J * 64 * 8) : "memory");
+  }
+}
+__device__ __forceinline__ void fib_prod_arrived(double (&p)[6], bool first) {
+  if (first) asm volatile("s_waitcnt vmcnt(0)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]));
+  else asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]));
+}
 typedef float v2f __attribute__((ext_vector_type(2)));
 // 1/x to ~1e-14 (seed + one Newton step): for the direction search, whose winner is re-evaluated exactly
 __device__ __forceinline__ double rcp_search(double x) {
@@ -891,14 +909,21 @@ __global__ __launch_bounds__(kWave, 2) void es_batch_kernel(const EsBatchArgs a)
 }
 
 // per-correspondence n = f1 x R f2 and B = f1hat R Sigma R' f1hat' + reg I (packed symmetric)
+// (n, B) of one correspondence from its twelve payload values e = f1 | f2 | Sigma (xx xy xz yy yz zz)
+__device__ __forceinline__ void corr_nb_of(const double (&e)[12], const double (&R)[9], double reg, double (&nn)[3],
+                                           double (&B)[6]);
 __device__ __forceinline__ void corr_nb(const double *base, int stride, int idx, const double (&R)[9],
                                         double reg, double (&nn)[3], double (&B)[6]) {
-  const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
-  const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
-                        base[(int64_t)5 * stride + idx]};
-  const double S[6] = {base[(int64_t)6 * stride + idx], base[(int64_t)7 * stride + idx],
-                       base[(int64_t)8 * stride + idx], base[(int64_t)9 * stride + idx],
-                       base[(int64_t)10 * stride + idx], base[(int64_t)11 * stride + idx]};
+  double e[12];
+#pragma unroll
+  for (int c = 0; c < 12; ++c) e[c] = base[(int64_t)c * stride + idx];
+  corr_nb_of(e, R, reg, nn, B);
+}
+__device__ __forceinline__ void corr_nb_of(const double (&e)[12], const double (&R)[9], double reg, double (&nn)[3],
+                                           double (&B)[6]) {
+  const double f1[3] = {e[0], e[1], e[2]};
+  const double f2[3] = {e[3], e[4], e[5]};
+  const double S[6] = {e[6], e[7], e[8], e[9], e[10], e[11]};
   const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
                        R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
   nn[0] = f1[1] * u[2] - f1[2] * u[1];
@@ -959,11 +984,15 @@ template <int WMAX>
 struct WeightedLds {
   double G[36];          // the pair's 36 weighted sums
   double cand[21][3];    // streaming form: the directions of a batch
-  float cost32[512];     // resident form: single-precision costs of the 500 directions
-  float cost32p[WMAX > 1 ? WMAX : 1][WMAX > 1 ? 512 : 1];  // ... each wavefront's share of them
   // exchange between the wavefronts of a pair: [buffer][wavefront][value]; the buffers alternate so that a
   // wavefront that runs ahead into the next exchange cannot overwrite what another has yet to read
   double xch[2][WMAX][8];
+  // resident form: each wavefront's lower bounds of the 500 directions' costs for the current tables
+  // (direction 64 j + lane at [j][lane])
+  double lb[WMAX][8][kWave];
+  unsigned long long cmask[8];   // directions that can still be chosen (bit l of word j: direction 64 j + l)
+  float cost32[512];             // the rare pair with many of them: their single-precision costs
+  float cost32p[WMAX > 1 ? WMAX : 1][WMAX > 1 ? 512 : 1];  // ... each wavefront's share of those
 };
 template <bool RES, int WPP, typename Lds>
 __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
@@ -976,8 +1005,6 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
   const double *base = a.data + a.block_offset[pair];
   double *G = lds.G;
   [[maybe_unused]] double (*cand)[3] = lds.cand;
-  [[maybe_unused]] float *cost32 = lds.cost32;
-  [[maybe_unused]] auto &cost32p = lds.cost32p;
   [[maybe_unused]] auto &xch = lds.xch;
   [[maybe_unused]] int xpar = 0;
   // the block's barrier (both wavefronts) or, for one wavefront, just the LDS fence
@@ -1050,7 +1077,13 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
   };
 
   double fib_min_cost = 0.0;
-  int fib_min_idx = -1;  // -1: no stored search yet
+  int fib_min_idx = -1;  // -1: no stored search yet (streaming form) / no direction can beat the translation
+  [[maybe_unused]] bool mlo_valid = false;  // resident form: lds.lb belongs to the current tables
+  // resident form: what the stored search (fib_min_*) is good for while the tables stand.  search_global: it is the
+  // smallest cost of ALL 500 directions (nothing left to find out); otherwise no direction costs less than
+  // search_thr, the current translation's cost it was run against (nothing to find out while the cost stays below)
+  [[maybe_unused]] bool search_global = false;
+  [[maybe_unused]] double search_thr = -1.0;
   int first_iterations = 0;
   bool rotation_final = false;
   // One round of pnec.cc:295-346.  WITH_ES: the round starts with an eigensolver call (the rotation may
@@ -1074,18 +1107,44 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
     }
     if (it == 0) first_iterations = newton;
     PNEC_PHASE_END(kPhNewton);
-    const bool same_rotation = (it > 0 && newton == 0 && fib_min_idx >= 0);
+    [[maybe_unused]] const bool same_rotation = (it > 0 && newton == 0 && fib_min_idx >= 0);
     if constexpr (WITH_ES) cayley_to_rot(v, R);
     if constexpr (RES && WITH_ES) {
       // built after the eigensolver call so that the arrays are dead across it (the Newton iteration
       // and 144 resident registers do not fit a wavefront's register file together).  No branches: the
       // loads of all eight correspondences are in flight together (clamped addresses for the lanes
       // beyond the pair), the padding entries are patched afterwards.
+      mlo_valid = false;
+      search_global = false;
+      search_thr = -1.0;
+      // (loads in the scalar-base form, pnec_device.hpp load_planes_issue: the compiler's own version of this
+      // loop kept 96 precomputed 64-bit addresses in scratch and reloaded each in front of its load, one memory
+      // round trip after the other -- this phase took 170 k clocks of the stage's 375 k)
+      const unsigned long long b64 = reinterpret_cast<unsigned long long>(base) +
+                                     (unsigned long long)(WPP > 1 ? wave : 0) * KR * kWave * sizeof(double);
+      const char *sbase = reinterpret_cast<const char *>(
+          ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32)) << 32) |
+          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64));
+      const size_t plane_bytes = (size_t)(unsigned)__builtin_amdgcn_readfirstlane(stride) * sizeof(double);
+      const unsigned voff = 8u * (unsigned)lane;
+      double pe[KR][12];
+      auto issue = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const int idx = (WPP > 1 ? wave * KR * kWave : 0) + lane + kWave * k;
+        load_planes_issue<12, k * kWave * 8>(pe[k], sbase, plane_bytes, voff, idx < n);
+      };
+      issue(std::integral_constant<int, 0>{}); issue(std::integral_constant<int, 1>{});
+      issue(std::integral_constant<int, 2>{}); issue(std::integral_constant<int, 3>{});
+      issue(std::integral_constant<int, 4>{}); issue(std::integral_constant<int, 5>{});
+      issue(std::integral_constant<int, 6>{}); issue(std::integral_constant<int, 7>{});
+      planes_arrived(pe[0]);
+#pragma unroll
+      for (int k = 1; k < KR; ++k) planes_after(pe[k]);
 #pragma unroll
       for (int k = 0; k < KR; ++k) {
         const int idx = (WPP > 1 ? wave * KR * kWave : 0) + lane + kWave * k;
         const bool in = idx < n;
-        corr_nb(n > 0 ? base : a.data, stride, in ? idx : 0, R, a.reg, rn[k], rB[k]);
+        corr_nb_of(pe[k], R, a.reg, rn[k], rB[k]);
         if (!in) {  // padding: contributes exactly 0 to every sum (n = 0, B = I)
           rn[k][0] = rn[k][1] = rn[k][2] = 0.0;
           rB[k][0] = rB[k][3] = rB[k][5] = 1.0;
@@ -1095,118 +1154,220 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
     }
     PNEC_PHASE_END(kPhTables);
     const double t_in[3] = {t[0], t[1], t[2]};
-    if (!same_rotation) {
-      auto energy_term = [](double tx, double ty, double tz, const double(&nn)[3], const double(&B)[6]) {
-        const double aa = tx * nn[0] + ty * nn[1] + tz * nn[2];
-        const double d = tx * (B[0] * tx + B[1] * ty + B[2] * tz) + ty * (B[1] * tx + B[3] * ty + B[4] * tz) +
-                         tz * (B[2] * tx + B[4] * ty + B[5] * tz);
-        return aa * aa * fast_rcp(d);
-      };
-      fib_min_idx = -1;
-      if constexpr (RES) {
-        // 500 Fibonacci directions against the resident (n, B) in two steps:
-        //  (1) PRE-SCREEN in single precision, packed (v_pk_fma_f32: two correspondences per lane and
-        //      instruction, no Newton steps on the reciprocals): all 500 costs to ~1e-6 relative, four
-        //      directions per round (uniforms from constant memory = scalar loads; the four partial sums
-        //      are reduced together, direction c + r ending up in row r), each written to LDS;
-        //  (2) every direction whose single-precision cost is within 1e-4 of the smallest one -- the true
-        //      minimiser is among them, its single-precision cost being off by << 1e-4 -- is evaluated
-        //      again in double precision, in index order, and the minimum by (cost, index) is kept: the
-        //      sequential rule "first direction strictly better".  Usually that is one direction.
-        v2f fn[KR / 2][3], fB[KR / 2][6];
+    // the current translation's cost: what a Fibonacci direction has to beat (pnec.cc:318-325)
+    double cur_cost = 0.0;
+    for_each_corr([&](const double(&nn)[3], const double(&B)[6]) {
+      const double aa = t[0] * nn[0] + t[1] * nn[1] + t[2] * nn[2];
+      const double d = t[0] * (B[0] * t[0] + B[1] * t[1] + B[2] * t[2]) + t[1] * (B[1] * t[0] + B[3] * t[1] + B[4] * t[2]) +
+                       t[2] * (B[2] * t[0] + B[4] * t[1] + B[5] * t[2]);
+      cur_cost = __builtin_fma(aa * aa, fast_rcp(d), cur_cost);
+    });
+    {
+      double cs[1] = {cur_cost};
+      pair_sum(cs);
+      cur_cost = cs[0];
+    }
+    PNEC_PHASE_END(kPhCost);
+    [[maybe_unused]] auto energy_term = [](double tx, double ty, double tz, const double(&nn)[3], const double(&B)[6]) {
+      const double aa = tx * nn[0] + ty * nn[1] + tz * nn[2];
+      const double d = tx * (B[0] * tx + B[1] * ty + B[2] * tz) + ty * (B[1] * tx + B[3] * ty + B[4] * tz) +
+                       tz * (B[2] * tx + B[4] * ty + B[5] * tz);
+      return aa * aa * fast_rcp(d);
+    };
+    if constexpr (RES) {
+      // The 500 Fibonacci directions (scf.cc:43-66, pnec.cc:313-325) through an EXACT bound instead of 500
+      // evaluations.  The search only matters through "the first direction whose cost is the smallest AND strictly
+      // below the current translation's" -- and every term of a direction's cost is
+      //     (t.n_i)^2 / (t' B_i t)  >=  (t.n_i)^2 / trace(B_i)          (B_i is positive semi-definite, |t| = 1),
+      // so  cost(t) >= t' M t  with  M = sum_i n_i n_i' / trace(B_i): one 3x3 matrix per rotation, six
+      // multiply-adds per direction.  A direction whose bound is not below the current translation's cost
+      // cannot be chosen, whatever its cost; the others (on the simulated and the KITTI-like data: none in
+      // almost every pair -- the translation handed over by the eigensolver stage is already far better than
+      // any grid point nine degrees from its neighbours) are evaluated in double precision, in index order, as
+      // before.  Same decisions, same bits: until round 3 this was a packed single-precision pre-screen of all
+      // 500 directions over the resident tables -- 28 k of the stage's 44 k instructions per pair, and 72
+      // registers of single-precision tables.
+      if (!mlo_valid) {
+        double m[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < KR / 2; ++j) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) fn[j][c] = v2f{(float)rn[2 * j][c], (float)rn[2 * j + 1][c]};
-#pragma unroll
-          for (int c = 0; c < 6; ++c) fB[j][c] = v2f{(float)rB[2 * j][c], (float)rB[2 * j + 1][c]};
+        for (int k = 0; k < KR; ++k) {
+          const double w = fast_rcp(rB[k][0] + rB[k][3] + rB[k][5]);
+          const double wx = w * rn[k][0], wy = w * rn[k][1], wz = w * rn[k][2];
+          m[0] = __builtin_fma(wx, rn[k][0], m[0]); m[1] = __builtin_fma(wx, rn[k][1], m[1]);
+          m[2] = __builtin_fma(wx, rn[k][2], m[2]); m[3] = __builtin_fma(wy, rn[k][1], m[3]);
+          m[4] = __builtin_fma(wy, rn[k][2], m[4]); m[5] = __builtin_fma(wz, rn[k][2], m[5]);
         }
-        const int my_row = lane >> 4;
-        for (int c = 0; c < 500; c += 4) {
-          float s4[4];
+        pair_sum(m);
+        // t' M t for this lane's directions from the planes of products (all 48 loads in flight together), a hair
+        // below the bound: the costs it is compared with carry their own rounding.  The bounds belong to the
+        // tables: later rounds on the same rotation compare them with their own current cost without a load.
+        // (the loads in the scalar-base form, like the tables'; half of the grid at a time: 48 doubles in flight on
+        // top of the 144 table registers do not fit the file -- left to the compiler, the 48 addresses were computed
+        // at kernel entry, parked in scratch and fetched back one by one)
+        {
+          const char *pb = reinterpret_cast<const char *>(&c_fib_prod[0][0]);
+          const unsigned voff = 8u * (unsigned)lane;
+          auto half = [&](auto hc) {
+            constexpr int j0 = 4 * decltype(hc)::value;
+            double fp[4][6];
+            fib_prod_issue<j0 + 0>(fp[0], pb, voff); fib_prod_issue<j0 + 1>(fp[1], pb, voff);
+            fib_prod_issue<j0 + 2>(fp[2], pb, voff); fib_prod_issue<j0 + 3>(fp[3], pb, voff);
+            fib_prod_arrived(fp[0], true);
 #pragma unroll
-          for (int jd = 0; jd < 4; ++jd) {
-            const float *fc = c_fib32 + kFibStride * (c + jd);
-            const float tx = fc[0], ty = fc[1], tz = fc[2];
-            const float txx = fc[3], tyy = fc[4], tzz = fc[5], txy = fc[6], txz = fc[7], tyz = fc[8];
-            v2f d[KR / 2], aa[KR / 2];
+            for (int j = 1; j < 4; ++j) fib_prod_arrived(fp[j], false);
 #pragma unroll
-            for (int j = 0; j < KR / 2; ++j) d[j] = fB[j][0] * txx;
-#pragma unroll
-            for (int j = 0; j < KR / 2; ++j) d[j] = fB[j][3] * tyy + d[j];
-#pragma unroll
-            for (int j = 0; j < KR / 2; ++j) d[j] = fB[j][5] * tzz + d[j];
-#pragma unroll
-            for (int j = 0; j < KR / 2; ++j) d[j] = fB[j][1] * txy + d[j];
-#pragma unroll
-            for (int j = 0; j < KR / 2; ++j) d[j] = fB[j][2] * txz + d[j];
-#pragma unroll
-            for (int j = 0; j < KR / 2; ++j) d[j] = fB[j][4] * tyz + d[j];
-#pragma unroll
-            for (int j = 0; j < KR / 2; ++j) aa[j] = fn[j][0] * tx;
-#pragma unroll
-            for (int j = 0; j < KR / 2; ++j) aa[j] = fn[j][1] * ty + aa[j];
-#pragma unroll
-            for (int j = 0; j < KR / 2; ++j) aa[j] = fn[j][2] * tz + aa[j];
-            v2f acc = {0.0f, 0.0f};
-#pragma unroll
-            for (int j = 0; j < KR / 2; ++j) {
-              const v2f y = {__builtin_amdgcn_rcpf(d[j].x), __builtin_amdgcn_rcpf(d[j].y)};
-              acc = (aa[j] * aa[j]) * y + acc;
-            }
-            s4[jd] = acc.x + acc.y;
-          }
-          const float b0 = swap_add32_f(s4[0], s4[2]), b1 = swap_add32_f(s4[1], s4[3]);
-          const float sum = row_allreduce_sum_f(swap_add16_f(b0, b1));  // row r: direction c + r
-          if ((lane & 15) == 0) {
-            if constexpr (WPP > 1) cost32p[wave][c + my_row] = sum;
-            else cost32[c + my_row] = sum;
-          }
+            for (int j = 0; j < 4; ++j)
+              lds.lb[WPP > 1 ? wave : 0][j0 + j][lane] = (m[0] * fp[j][0] + m[3] * fp[j][1] + m[5] * fp[j][2] + m[1] * fp[j][3] +
+                                                          m[2] * fp[j][4] + m[4] * fp[j][5]) * (1.0 - 1.0e-9);
+          };
+          half(std::integral_constant<int, 0>{});
+          half(std::integral_constant<int, 1>{});
         }
-        if constexpr (WPP > 1) {  // the wavefronts' shares of every direction's cost, added once
-          __syncthreads();
-          for (int i = (int)threadIdx.x; i < 500; i += WPP * kWave) {
-            float t = cost32p[0][i];
+        mlo_valid = true;
+      }
+      // The stored search stands while the tables do: either it found the smallest of all 500 costs, or it showed
+      // that none is below search_thr and the current translation still costs no more than that.  (A NaN cost:
+      // no comparison with it is true, the search result cannot be used -- nothing to do either.)
+      const bool need_search = !search_global && !(cur_cost <= search_thr) && cur_cost == cur_cost;
+      if (need_search) {
+        fib_min_idx = -1;
+        // which directions can still be chosen (written so that a NaN bound keeps its direction: nothing is pruned
+        // on garbage); the masks are the same in every wavefront of the pair
+        int n_cand = 0;
+        bool full_grid = false;  // the search below went over all 500 directions
 #pragma unroll
-            for (int w = 1; w < WPP; ++w) t += cost32p[w][i];
-            cost32[i] = t;
-          }
+        for (int j = 0; j < 8; ++j) {
+          const unsigned long long cm =
+              __builtin_amdgcn_ballot_w64(kWave * j + lane < 500 && !(lds.lb[WPP > 1 ? wave : 0][j][lane] >= cur_cost));
+          n_cand += __builtin_popcountll(cm);
+          if (lane == 0 && (WPP == 1 || wave == 0)) lds.cmask[j] = cm;
+        }
+        if (a.trace) {  // diagnostics: searches run, candidates they started with
+          ph_clk[8] += 1;
+          ph_clk[9] += (unsigned long long)n_cand;
         }
         pair_sync();
-        float m32 = __builtin_inff();
-        for (int i = lane; i < 500; i += kWave) m32 = fminf(m32, cost32[i]);  // fminf skips NaN
-        m32 = wave_allreduce_min_f(m32);
-        const float thr = m32 + 1.0e-4f * fabsf(m32);
-        for (int i0 = 0; i0 < 500; i0 += kWave) {
-          const int i = i0 + lane;
-          unsigned long long cand = __builtin_amdgcn_ballot_w64(i < 500 && cost32[i < 500 ? i : 0] <= thr);
-          while (cand != 0ull) {
-            const int c = i0 + (int)__builtin_ctzll(cand);
-            cand &= cand - 1ull;
-            // this direction's cost in double precision, with the arithmetic the current translation's
-            // cost is computed with below (the comparison between the two decides whether the search
-            // result is used at all)
-            const double *fc = c_fib + kFibStride * c;
-            const double tx = fc[0], ty = fc[1], tz = fc[2];
-            double sacc = 0.0;
+        // one direction's cost in double precision, with the arithmetic of the current translation's cost (the
+        // comparison between the two decides whether the search result is used at all); candidates come in index
+        // order: ties keep the first
+        auto exact = [&](int c) {
+          const double *fc = c_fib + kFibStride * c;
+          const double tx = fc[0], ty = fc[1], tz = fc[2];
+          double sacc = 0.0;
 #pragma unroll
-            for (int k = 0; k < KR; ++k) {
-              const double aa = tx * rn[k][0] + ty * rn[k][1] + tz * rn[k][2];
-              const double d = tx * (rB[k][0] * tx + rB[k][1] * ty + rB[k][2] * tz) +
-                               ty * (rB[k][1] * tx + rB[k][3] * ty + rB[k][4] * tz) +
-                               tz * (rB[k][2] * tx + rB[k][4] * ty + rB[k][5] * tz);
-              sacc = __builtin_fma(aa * aa, fast_rcp(d), sacc);
-            }
-            double cs[1] = {sacc};
-            pair_sum(cs);
-            const double cost = cs[0];
-            if (fib_min_idx < 0 || cost < fib_min_cost) {  // candidates come in index order: ties keep the first
-              fib_min_cost = cost;
-              fib_min_idx = c;
+          for (int k = 0; k < KR; ++k) {
+            const double aa = tx * rn[k][0] + ty * rn[k][1] + tz * rn[k][2];
+            const double d = tx * (rB[k][0] * tx + rB[k][1] * ty + rB[k][2] * tz) +
+                             ty * (rB[k][1] * tx + rB[k][3] * ty + rB[k][4] * tz) +
+                             tz * (rB[k][2] * tx + rB[k][4] * ty + rB[k][5] * tz);
+            sacc = __builtin_fma(aa * aa, fast_rcp(d), sacc);
+          }
+          double cs[1] = {sacc};
+          pair_sum(cs);
+          if (fib_min_idx < 0 || cs[0] < fib_min_cost) {
+            fib_min_cost = cs[0];
+            fib_min_idx = c;
+          }
+          if (a.trace) ph_clk[10] += 1;  // diagnostics: double-precision evaluations
+        };
+#ifdef PNEC_WES_NO_PRESCREEN   // A/B: every candidate straight to double precision (what the common path costs alone)
+        if (n_cand > 0) {
+#else
+        if (n_cand > 0 && n_cand <= 12) {
+#endif
+          // the usual case when there are any: a handful -- straight to double precision, in index order
+          for (int j = 0; j < 8; ++j) {
+            unsigned long long cand = lds.cmask[j];
+            while (cand != 0ull) {
+              exact(kWave * j + (int)__builtin_ctzll(cand));
+              cand &= cand - 1ull;
             }
           }
         }
-      } else {
+#ifndef PNEC_WES_NO_PRESCREEN
+        else if (n_cand > 0) {
+          full_grid = true;
+          // The rare pair whose translation is barely observable (its cost is nearly flat over the sphere, so the
+          // bound prunes little; 1-2 % of the simulated pairs, none of the KITTI-like ones): ALL 500 directions go
+          // through the packed single-precision pre-screen this stage used for every pair until round 3
+          // (v_pk_fma_f32: two correspondences per lane and instruction, no Newton steps on the reciprocals, ~1e-6
+          // relative; direction c + r ends up in row r), and every direction within 1e-4 of the smallest single-
+          // precision cost is evaluated again in double precision, in index order.  All of them, not just the
+          // candidates: what comes out is the smallest cost of the whole grid, which stands whatever the translation
+          // does in later rounds (such a pair's cost wanders up and down, and a search per round took the longest
+          // pair of a 20 000-pair launch to 4 M clocks -- the launch's whole duration).
+          const int my_row = lane >> 4;
+          for (int c = 0; c < 500; c += 4) {
+            // (the single-precision copies of the tables are made here, two correspondences at a time, and die here:
+            // kept resident they cost the common path 72 registers it does not have)
+            v2f acc4[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+#pragma unroll
+            for (int j = 0; j < KR / 2; ++j) {
+              v2f fn[3], fB[6];
+#pragma unroll
+              for (int cc = 0; cc < 3; ++cc) fn[cc] = v2f{(float)rn[2 * j][cc], (float)rn[2 * j + 1][cc]};
+#pragma unroll
+              for (int cc = 0; cc < 6; ++cc) fB[cc] = v2f{(float)rB[2 * j][cc], (float)rB[2 * j + 1][cc]};
+#pragma unroll
+              for (int jd = 0; jd < 4; ++jd) {
+                const float *fc = c_fib32 + kFibStride * (c + jd);
+                v2f d = fB[0] * fc[3];
+                d = fB[3] * fc[4] + d;
+                d = fB[5] * fc[5] + d;
+                d = fB[1] * fc[6] + d;
+                d = fB[2] * fc[7] + d;
+                d = fB[4] * fc[8] + d;
+                v2f aa = fn[0] * fc[0];
+                aa = fn[1] * fc[1] + aa;
+                aa = fn[2] * fc[2] + aa;
+                const v2f y = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                acc4[jd] = (aa * aa) * y + acc4[jd];
+              }
+            }
+            float s4[4];
+#pragma unroll
+            for (int jd = 0; jd < 4; ++jd) s4[jd] = acc4[jd].x + acc4[jd].y;
+            const float b0 = swap_add32_f(s4[0], s4[2]), b1 = swap_add32_f(s4[1], s4[3]);
+            const float sum = row_allreduce_sum_f(swap_add16_f(b0, b1));  // row r: direction c + r
+            if ((lane & 15) == 0) {
+              if constexpr (WPP > 1) lds.cost32p[wave][c + my_row] = sum;
+              else lds.cost32[c + my_row] = sum;
+            }
+          }
+          if constexpr (WPP > 1) {  // the wavefronts' shares of every direction's cost, added once
+            __syncthreads();
+            for (int i = (int)threadIdx.x; i < 500; i += WPP * kWave) {
+              float t32 = lds.cost32p[0][i];
+#pragma unroll
+              for (int w = 1; w < WPP; ++w) t32 += lds.cost32p[w][i];
+              lds.cost32[i] = t32;
+            }
+          }
+          pair_sync();
+          float m32 = __builtin_inff();
+          for (int i = lane; i < 500; i += kWave) m32 = fminf(m32, lds.cost32[i]);  // fminf skips NaN
+          m32 = wave_allreduce_min_f(m32);
+          const float thr32 = m32 + 1.0e-4f * fabsf(m32);
+          for (int i0 = 0; i0 < 500; i0 += kWave) {
+            const int i = i0 + lane;
+            unsigned long long cand = __builtin_amdgcn_ballot_w64(i < 500 && lds.cost32[i < 500 ? i : 0] <= thr32);
+            while (cand != 0ull) {
+              exact(i0 + (int)__builtin_ctzll(cand));
+              cand &= cand - 1ull;
+            }
+          }
+        }
+#endif
+        // what this search is good for from here on (see above)
+        if (fib_min_idx >= 0 && (fib_min_cost < cur_cost || full_grid)) {
+          search_global = true;
+        } else {
+          fib_min_idx = -1;
+          search_thr = cur_cost;
+        }
+      }
+    } else if (!same_rotation) {
+      fib_min_idx = -1;
         // streaming: 21 directions at a time, per correspondence n, B rebuilt once per batch
         for (int b0 = 0; b0 < 500; b0 += 21) {
           const int nb = (500 - b0 < 21) ? 500 - b0 : 21;
@@ -1230,28 +1391,13 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
-      }
     }
     PNEC_PHASE_END(kPhSearch);
-    // best_point = current translation unless a Fibonacci direction is strictly better
-    double cur_cost = 0.0;
-    for_each_corr([&](const double(&nn)[3], const double(&B)[6]) {
-      const double aa = t[0] * nn[0] + t[1] * nn[1] + t[2] * nn[2];
-      const double d = t[0] * (B[0] * t[0] + B[1] * t[1] + B[2] * t[2]) + t[1] * (B[1] * t[0] + B[3] * t[1] + B[4] * t[2]) +
-                       t[2] * (B[2] * t[0] + B[4] * t[1] + B[5] * t[2]);
-      cur_cost = __builtin_fma(aa * aa, fast_rcp(d), cur_cost);
-    });
-    {
-      double cs[1] = {cur_cost};
-      pair_sum(cs);
-      cur_cost = cs[0];
-    }
     if (fib_min_idx >= 0 && fib_min_cost < cur_cost) {
       t[0] = c_fib[kFibStride * fib_min_idx];
       t[1] = c_fib[kFibStride * fib_min_idx + 1];
       t[2] = c_fib[kFibStride * fib_min_idx + 2];
     }
-    PNEC_PHASE_END(kPhCost);
     // scf: 10 steps of  t <- eigenvector of the smallest eigenvalue of sum A_i / (t' B_i t)
     for (int step = 0; step < 10; ++step) {
       double e[6] = {0, 0, 0, 0, 0, 0};
@@ -1923,6 +2069,11 @@ hipError_t fibonacci_table(int device) {
     std::vector<float> pts32(pts.begin(), pts.end());
     e = hipMemcpyToSymbol(HIP_SYMBOL(c_fib32), pts32.data(), sizeof(float) * pts32.size());
     if (e != hipSuccess) return e;
+    std::vector<double> prod(6 * 512, 0.0);
+    for (int i = 0; i < samples; ++i)
+      for (int k = 0; k < 6; ++k) prod[(size_t)512 * k + i] = pts[(size_t)kFibStride * i + 3 + k];
+    e = hipMemcpyToSymbol(HIP_SYMBOL(c_fib_prod), prod.data(), sizeof(double) * prod.size());
+    if (e != hipSuccess) return e;
     g_fib_ready[device] = true;
   }
   return hipSuccess;
@@ -2036,6 +2187,26 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
       std::fprintf(stderr, "weighted_eigensolver phases (mean s_memtime clocks per pair, %lld pairs):", (long long)n_pairs);
       for (int k = 0; k < kPhTotal + 1; ++k) std::fprintf(stderr, " %s=%.0f", names[k], m[k] / (double)n_pairs);
       std::fprintf(stderr, "\n");
+      // where the launch's duration comes from: the distribution over the pairs (a launch ends with its slowest)
+      {
+        int64_t worst = 0;
+        for (int64_t p = 1; p < n_pairs; ++p)
+          if (h[(size_t)(kPhCount * p + kPhTotal)] > h[(size_t)(kPhCount * worst + kPhTotal)]) worst = p;
+        const unsigned long long *w = &h[(size_t)(kPhCount * worst)];
+        std::fprintf(stderr, "  slowest pair %lld: newton %llu tables %llu search %llu scf %llu total %llu | searches %llu candidates %llu "
+                     "double-precision evaluations %llu\n", (long long)worst, w[kPhNewton], w[kPhTables], w[kPhSearch], w[kPhScf],
+                     w[kPhTotal], w[8], w[9], w[10]);
+        std::fprintf(stderr, "  means: searches %.3f candidates %.3f double-precision evaluations %.3f\n", m[8] / (double)n_pairs,
+                     m[9] / (double)n_pairs, m[10] / (double)n_pairs);
+      }
+      for (int k : {(int)kPhSearch, (int)kPhScf, (int)kPhNewton, (int)kPhTotal}) {
+        std::vector<unsigned long long> v((size_t)n_pairs);
+        for (int64_t p = 0; p < n_pairs; ++p) v[(size_t)p] = h[(size_t)(kPhCount * p + k)];
+        std::sort(v.begin(), v.end());
+        auto q = [&](double f) { return (double)v[(size_t)std::min<double>((double)n_pairs - 1, f * (double)n_pairs)]; };
+        std::fprintf(stderr, "  %-8s p50 %.0f  p90 %.0f  p99 %.0f  p99.9 %.0f  max %.0f\n", names[k], q(0.5), q(0.9), q(0.99),
+                     q(0.999), (double)v.back());
+      }
     }
     (void)hipFree(a.trace);
   }

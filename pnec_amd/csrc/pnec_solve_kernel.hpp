@@ -952,32 +952,6 @@ __device__ __forceinline__ int lm_advance_rows(double *slab, int *ist, double *u
 #define PNEC_MARK(name)
 #endif
 
-// One correspondence per lane of the tail (geometry (12, 1, 3)) from the planes in memory: plane c of the pair starts at
-// sbase + c * plane_bytes (scalar registers), the lane's correspondence sits `lo` + IMM bytes into it.  Spelled as
-// the scalar-base form of global_load (saddr + 32-bit voffset + immediate) because the compiler, left to itself,
-// keeps a 64-bit vector address per plane alive across the whole LM loop (24 registers this kernel does not have).
-// Lanes beyond the planes (`in` false) keep the zeros they came with.  The s_waitcnt carries the values as operands,
-// so nothing that reads them can be scheduled in front of it.
-template <int NC, int IMM>
-__device__ __forceinline__ void tail_load(double (&e)[NC], const char *sbase, size_t plane_bytes, unsigned lo, bool in) {
-  static_assert(NC == 6 || NC == 12, "tail form: 6- and 12-plane payloads");
-#pragma unroll
-  for (int c = 0; c < NC; ++c) e[c] = 0.0;
-  if (in) {
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const char *pl = sbase + (size_t)c * plane_bytes;
-      asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "+v"(e[c]) : "v"(lo), "s"(pl), "n"(IMM) : "memory");
-    }
-    if constexpr (NC == 12)
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]),
-                     "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]));
-    else
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]));
-  }
-}
-
 constexpr int SRC_PLANES = 0;  // the batch's SoA planes in HBM (pnec_hip_problem)
 constexpr int SRC_AOS = 1;     // the caller's arrays in the reference layout (streaming handle)
 template <int MODE, int CPL, int WPP, int LDSK, bool RESIDENT, int SRC = SRC_PLANES>
@@ -1146,7 +1120,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
                 constexpr unsigned imm = 2u * kWave * 8u * (t / 2) + 8u * (t & 1);
                 const bool in = RCPL * kWave + 2 * kWave * (t / 2) + 2 * lane < stride;
                 double e[NC];
-                tail_load<NC, (int)imm>(e, tb, plane_bytes, voff, in);
+                load_planes_saddr<NC, (int)imm>(e, tb, plane_bytes, voff, in);
                 double r, kk;
                 eval_cost<MODE>(e, U, reg, r, kk);
                 a1 = __builtin_fma(r, r, a1);
@@ -1208,7 +1182,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
               constexpr unsigned imm = 2u * kWave * 8u * (t / 2) + 8u * (t & 1);
               const bool in = RCPL * kWave + 2 * kWave * (t / 2) + 2 * lane < stride;
               double e[NC];
-              tail_load<NC, (int)imm>(e, tb, plane_bytes, voff, in);
+              load_planes_saddr<NC, (int)imm>(e, tb, plane_bytes, voff, in);
               double r, J[5];
               eval_corr<MODE>(e, U, reg, r, J);
               accumulate(r, J, acc);
