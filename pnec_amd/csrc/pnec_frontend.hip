@@ -489,16 +489,17 @@ __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&
 // active = false: this quad has no problem (its lanes only keep the wavefront's calls convergent): it is done at once.
 template <int GS, int TAG = 0>
 __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], double n_scale, double *e_out = nullptr,
-                                             bool active = true) {
+                                             bool active = true, int *evals_out = nullptr) {
   enum : int { kInit = 0, kTrial, kShort, kReeval, kDone };
   const int role = (int)(threadIdx.x & 3);
   const double h = 1e-6, inv_h = 1.0 / h;
   double eb[3] = {0.0, 0.0, 1.0};  // eigenvector of the smallest eigenvalue at the current point
   double f = 0.0, g[3] = {0.0, 0.0, 0.0}, H[9], d[3] = {0.0, 0.0, 0.0};
   double slope = 0.0, alpha = 1.0, trace_cur = 0.0;  // trace_cur: trace of M at the current point
-  int state = active ? kInit : kDone, it = 0, ls = 0;
+  int state = active ? kInit : kDone, it = 0, ls = 0, evals = 0;
   bool last_eval = false;
   while (state != kDone) {
+    ++evals;  // diagnostics: evaluations of this quad's problem
     // ---- the point this lane evaluates in this trip
     double p[3] = {v[0], v[1], v[2]};
     double a_mine = 0.0;
@@ -637,6 +638,7 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
     }
   }
   if (e_out) { e_out[0] = eb[0]; e_out[1] = eb[1]; e_out[2] = eb[2]; }
+  if (evals_out) *evals_out = evals;
   return it;
 }
 
@@ -1672,7 +1674,8 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
         v[c] = v0[c] + (rng_uniform(a.seed, a.pair_id_base + (unsigned long long)pair, h, 1000 + c) - 0.5) * 2.0 * 0.01;
       PNEC_PHASE_END(kRpSample);
       // t = eigenvector of the smallest eigenvalue of M at the minimiser (sign settled by the evidence below)
-      const int newton_its = es_minimise_quad<1, 1>(Gh[hyp], v, (double)ss, t, active);
+      int evals = 0;
+      const int newton_its = es_minimise_quad<1, 1>(Gh[hyp], v, (double)ss, t, active, a.trace ? &evals : nullptr);
       PNEC_PHASE_END(kRpNewton);
       if (a.trace) {  // diagnostics: Newton iterations of the round's 16 hypotheses (sum, max), rounds
         const double its_sum = wave_allreduce_sum((double)newton_its) * 0.25;
@@ -1682,7 +1685,10 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
         ph_clk[8] += (unsigned long long)its_sum;
         ph_clk[9] += (unsigned long long)mx;
         ph_clk[10] += 1;
-        ph_clk[11] += (newton_its >= 50) ? 1 : 0;
+        int me = evals;   // evaluations as the wavefront executes them = those of its slowest quad
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(me, off); me = o > me ? o : me; }
+        ph_clk[11] += (unsigned long long)me;
       }
       cayley_to_rot(v, R);
       {
@@ -1831,6 +1837,462 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
   }
 }
 
+// ---- The same RANSAC, TWO PAIRS PER WAVEFRONT with the hypotheses of both in one queue (round 3) -----------------
+// In the kernel above a round's Newton phase runs at the pace of the slowest of its sixteen minimisations (phase
+// counters: 131 iterations summed over the sixteen quads, 18 for the slowest -- the quads idle half of the phase, which is
+// 60 % of the kernel).  Here a wavefront owns two pairs: a round prepares up to 32 hypotheses (sample, 36 sums, jittered
+// start: per hypothesis in LDS), the sixteen quads PULL them from one queue (es_minimise_queue: a quad that has finished
+// a minimisation re-arms on the next hypothesis of the list, whichever pair it belongs to), and the rest of the round --
+// model, scoring, the sequential consume rule -- runs per pair with quad j on hypothesis j as before.  A hypothesis'
+// arithmetic does not depend on which quad minimises it or when: masks, iteration counts and models are bit for bit
+// those of the one-pair kernel (and of the oracle's restatement).
+struct Ransac2Lds {
+  double Gh[2 * kHypPerRound][36];   // the 36 sums of each hypothesis' sample
+  double tv[2 * kHypPerRound][3];    // its start (in) / minimiser (out) in Cayley coordinates
+  double te[2 * kHypPerRound][3];    // eigenvector of the smallest eigenvalue at the minimiser (the translation)
+  double tev1[2 * kHypPerRound][3];  // sum of the sample's f1 (directional evidence)
+  int tsel[2 * kHypPerRound][PNEC_HIP_MAX_RANSAC_SAMPLE];  // the sample
+  int tits[2 * kHypPerRound];
+  int tlist[2 * kHypPerRound];       // the round's queue: slots of the active hypotheses
+  double tile[6][kWave];             // bearings of 64 correspondences (scoring)
+  double best_model[2][12];          // R (9) + t (3) per pair
+  double G[2][36];                   // sums of the inliers of the best model
+};
+
+// es_minimise_quad<1> for a QUEUE of problems: problem slot s has its sums at Gtab[s], its start at tv[s]; on return
+// tv[s] is the minimiser, te[s] the eigenvector there, tits[s] the Newton iterations.  Quad q starts on tlist[q]; a quad
+// that is done stores its result and takes the next entry of tlist (in quad order when several finish in one trip).
+// One trip of the loop is ONE evaluation for every quad that is busy, exactly the trip of es_minimise_quad -- the same
+// arithmetic per problem, hence the same bits.
+__device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, const double (*Gtab)[36], double (*tv)[3],
+                                              double (*te)[3], int *tits, double n_scale) {
+  enum : int { kInit = 0, kTrial, kShort, kReeval, kDone };
+  const int lane = (int)threadIdx.x, quad = lane >> 2, role = lane & 3;
+  const double h = 1e-6, inv_h = 1.0 / h;
+  double v[3] = {0.0, 0.0, 0.0}, eb[3] = {0.0, 0.0, 1.0};
+  double f = 0.0, g[3] = {0.0, 0.0, 0.0}, H[9], d[3] = {0.0, 0.0, 0.0};
+  double slope = 0.0, alpha = 1.0, trace_cur = 0.0;
+  int state = kDone, it = 0, ls = 0, slot = -1;
+  bool last_eval = false;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) H[i] = 0.0;
+  auto arm = [&](int s) {
+    slot = s;
+    v[0] = tv[s][0]; v[1] = tv[s][1]; v[2] = tv[s][2];
+    eb[0] = 0.0; eb[1] = 0.0; eb[2] = 1.0;
+    f = 0.0; g[0] = g[1] = g[2] = 0.0; d[0] = d[1] = d[2] = 0.0;
+    slope = 0.0; alpha = 1.0; trace_cur = 0.0;
+    it = 0; ls = 0; last_eval = false;
+    state = kInit;
+  };
+  if (quad < n_tasks) arm(tlist[quad]);
+  int next = kHypPerRound;  // wave-uniform: the next entry of tlist to hand out
+  int trips = 0;            // evaluations as the wavefront executes them (diagnostics)
+  for (;;) {
+    ++trips;
+    if (state != kDone) {
+      const double *G = Gtab[slot];
+      // ---- the point this lane evaluates in this trip
+      double p[3] = {v[0], v[1], v[2]};
+      double a_mine = 0.0;
+      if (state == kShort) {
+        a_mine = alpha * (role == 0 ? 1.0 : (role == 1 ? 0.5 : (role == 2 ? 0.25 : 0.125)));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) p[k] = v[k] + a_mine * d[k];
+      } else {
+        if (state == kTrial) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) p[k] = v[k] + d[k];
+        }
+        p[0] += (role == 1 ? h : 0.0);
+        p[1] += (role == 2 ? h : 0.0);
+        p[2] += (role == 3 ? h : 0.0);
+      }
+      double gp[3], Mp[9], ep[3] = {eb[0], eb[1], eb[2]};
+      const double fp = es_value_grad<1>(G, p, gp, Mp, ep, state != kInit);
+      const double trace_p = Mp[0] + Mp[4] + Mp[8];
+      bool at_new_point = false;
+      if (state == kShort) {
+        const int pass = (ls + role < 40 && fp <= f + 1e-4 * a_mine * slope + 4e-16 * trace_p) ? 1 : 0;
+        const int p0 = quad_broadcast<0>(pass), p1 = quad_broadcast<1>(pass), p2 = quad_broadcast<2>(pass),
+                  p3 = quad_broadcast<3>(pass);
+        if (p0 | p1 | p2 | p3) {
+          alpha *= p0 ? 1.0 : (p1 ? 0.5 : (p2 ? 0.25 : 0.125));
+          const double smax = alpha * fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
+#pragma unroll
+          for (int k = 0; k < 3; ++k) v[k] = v[k] + alpha * d[k];
+          ++it;
+          last_eval = smax < 1e-12 || it >= 50;
+          state = kReeval;  // the eigenvector AT the new point is wanted: one more evaluation even at the end
+        } else {
+          alpha *= 0.0625;
+          ls += 4;
+          if (ls >= 40) state = kDone;
+        }
+      } else {
+        const double fx = quad_broadcast<0>(fp), trace_x = quad_broadcast<0>(trace_p);
+        double gx[3], Hx[9], ex[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          gx[r] = quad_broadcast<0>(gp[r]);
+          Hx[3 * r + 0] = (quad_broadcast<1>(gp[r]) - gx[r]) * inv_h;
+          Hx[3 * r + 1] = (quad_broadcast<2>(gp[r]) - gx[r]) * inv_h;
+          Hx[3 * r + 2] = (quad_broadcast<3>(gp[r]) - gx[r]) * inv_h;
+          ex[r] = quad_broadcast<0>(ep[r]);
+        }
+        Hx[1] = Hx[3] = 0.5 * (Hx[1] + Hx[3]);
+        Hx[2] = Hx[6] = 0.5 * (Hx[2] + Hx[6]);
+        Hx[5] = Hx[7] = 0.5 * (Hx[5] + Hx[7]);
+        bool take = true;
+        if (state == kTrial) {
+          take = fx <= f + 1e-4 * slope + 4e-16 * trace_x;
+          if (!take) {  // the gradient judges the full step when the value cannot (see es_minimise_quad)
+            const double gmax_old = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+            const double gmax_new = fmax(fabs(gx[0]), fmax(fabs(gx[1]), fabs(gx[2])));
+            take = (fx - f) <= 1e-13 * trace_x && gmax_new < gmax_old;
+          }
+          if (take) {
+            const double smax = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = v[k] + d[k];
+            ++it;
+            if (smax < 1e-12 || it >= 50) state = kDone;
+          } else {
+            state = kShort;
+            alpha = 0.5;
+            ls = 1;
+          }
+        }
+        if (take) {
+          f = fx;
+          trace_cur = trace_x;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) { g[i] = gx[i]; eb[i] = ex[i]; }
+#pragma unroll
+          for (int i = 0; i < 9; ++i) H[i] = Hx[i];
+          if (last_eval) state = kDone;
+          at_new_point = state != kDone;
+        }
+      }
+      if (at_new_point) {
+        const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+        if (gmax <= fmax(1e-14 * (1.0 + fabs(f)) * n_scale, 1.1e-13 * trace_cur)) {
+          state = kDone;
+        } else {
+          double mu = 0.0;
+          const double tr = fabs(H[0]) + fabs(H[4]) + fabs(H[8]);
+          bool ok = false;
+          for (int tries = 0; tries < 40; ++tries) {
+            double Hm[9];
+            for (int i = 0; i < 9; ++i) Hm[i] = H[i];
+            Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
+            const double mg[3] = {-g[0], -g[1], -g[2]};
+            if (solve3_spd(Hm, mg, d) && (d[0] * g[0] + d[1] * g[1] + d[2] * g[2]) < 0.0) { ok = true; break; }
+            mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * 10.0;
+          }
+          if (ok) {
+            slope = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];
+            state = kTrial;
+          } else {
+            state = kDone;
+          }
+        }
+      }
+    }
+    // ---- quads that have finished: park the result, take the next problem of the queue (in quad order)
+    const bool fin = state == kDone && slot >= 0;
+    if (fin && role == 0) {
+      tv[slot][0] = v[0]; tv[slot][1] = v[1]; tv[slot][2] = v[2];
+      te[slot][0] = eb[0]; te[slot][1] = eb[1]; te[slot][2] = eb[2];
+      tits[slot] = it;
+    }
+    const unsigned long long fb = __builtin_amdgcn_ballot_w64(fin && role == 0);
+    if (fin) {
+      const int rank = __builtin_popcountll(fb & ((1ull << (lane & ~3)) - 1ull));
+      const int idx = next + rank;
+      slot = -1;
+      if (idx < n_tasks) arm(tlist[idx]);
+    }
+    next += __builtin_popcountll(fb);
+    if (__builtin_amdgcn_ballot_w64(state != kDone) == 0ull) break;
+  }
+  return trips;
+}
+
+__global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eigensolver_kernel(const RansacArgs a) {
+  const int lane = threadIdx.x;
+  const int hyp = lane >> 2, role = lane & 3;
+  __shared__ Ransac2Lds lds;
+  const int ss = a.sample_size;  // <= PNEC_HIP_MAX_RANSAC_SAMPLE (checked by the caller)
+  // ---- the two pairs' wave-uniform state
+  int64_t pair[2];
+  int n[2], stride[2], it[2] = {0, 0}, best_count[2] = {-1, -1};
+  const double *base[2];
+  double k[2] = {1.0, 1.0}, v0[2][3], R0[2][9];
+  bool stop[2], can_sample[2];
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    pair[pp] = 2 * (int64_t)blockIdx.x + pp;
+    const bool exists = pair[pp] < a.n_pairs;
+    const int64_t pq = exists ? pair[pp] : 0;
+    n[pp] = exists ? a.count[pq] : 0;
+    stride[pp] = (n[pp] + kWave - 1) & ~(kWave - 1);
+    base[pp] = a.data + a.block_offset[pq];
+    double q0[4] = {a.init_q[4 * pq], a.init_q[4 * pq + 1], a.init_q[4 * pq + 2], a.init_q[4 * pq + 3]};
+    const double qn = 1.0 / sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
+    for (int c = 0; c < 4; ++c) q0[c] *= qn;
+    rot_from_quat(q0, R0[pp]);
+    rot_to_cayley(R0[pp], v0[pp]);
+    can_sample[pp] = exists && n[pp] >= ss && ss >= 1;
+    stop[pp] = !can_sample[pp];
+  }
+  unsigned long long ph_clk[kPhCount] = {0};
+  const unsigned long long ph_start = a.trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  PNEC_PHASE_BEGIN();
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  for (;;) {
+    bool go[2];
+    int needed[2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      go[pp] = !stop[pp] && (double)it[pp] < k[pp];
+      if (!go[pp]) stop[pp] = true;
+      // the first round evaluates all 16 hypotheses; a later round only those that can still be consumed (see the
+      // one-pair kernel)
+      needed[pp] = !go[pp] ? 0 : (it[pp] == 0 ? kHypPerRound : (int)fmin(ceil(k[pp] - (double)it[pp]), (double)kHypPerRound));
+    }
+    if (!go[0] && !go[1]) break;  // wave-uniform
+    // ---- prepare the round's hypotheses: quad j samples hypothesis j of each pair that goes on
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const int slot = kHypPerRound * pp + hyp;
+      const bool active = hyp < needed[pp];
+      const unsigned long long hh = (unsigned long long)(it[pp] + hyp);
+      const unsigned long long pid = a.pair_id_base + (unsigned long long)pair[pp];
+      if (active) {
+        // (all four lanes of the quad draw the same sample; lane `role == 0` records it)
+        int m = 0;
+        unsigned long long draw = 0;
+        while (m < ss) {
+          long long idx = (long long)(rng_uniform(a.seed, pid, hh, draw++) * (double)n[pp]);
+          if (idx >= n[pp]) idx = n[pp] - 1;
+          bool dup = false;
+          for (int j = 0; j < m; ++j) dup = dup || (lds.tsel[slot][j] == (int)idx);
+          if (!dup) {
+            if (role == 0) lds.tsel[slot][m] = (int)idx;
+            // the quad's other lanes read the entry back in the duplicate test: make it visible
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            ++m;
+          }
+        }
+      }
+      lds_sync();
+      double ev1[3] = {0, 0, 0};
+      double Gl[36];
+      for (int i = 0; i < 36; ++i) Gl[i] = 0.0;
+      const double *bs = base[pp];
+      const int st = stride[pp];
+      for (int j = role; j < (active ? ss : 0); j += 4) {
+        const int idx = lds.tsel[slot][j];
+        const double f1[3] = {bs[idx], bs[(int64_t)st + idx], bs[(int64_t)2 * st + idx]};
+        const double f2[3] = {bs[(int64_t)3 * st + idx], bs[(int64_t)4 * st + idx], bs[(int64_t)5 * st + idx]};
+        const double p[6] = {f2[0] * f2[0], f2[0] * f2[1], f2[0] * f2[2], f2[1] * f2[1], f2[1] * f2[2], f2[2] * f2[2]};
+        const double qq[6] = {f1[0] * f1[0], f1[0] * f1[1], f1[0] * f1[2], f1[1] * f1[1], f1[1] * f1[2], f1[2] * f1[2]};
+        for (int kl = 0; kl < 6; ++kl)
+          for (int ac = 0; ac < 6; ++ac) Gl[6 * kl + ac] += p[kl] * qq[ac];
+        for (int c = 0; c < 3; ++c) ev1[c] += f1[c];
+      }
+#pragma unroll
+      for (int i = 0; i < 36; ++i) Gl[i] = quad_sum(Gl[i]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ev1[c] = quad_sum(ev1[c]);
+      if (role == 0 && active) {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) lds.Gh[slot][i] = Gl[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          lds.tev1[slot][c] = ev1[c];
+          lds.tv[slot][c] = v0[pp][c] + (rng_uniform(a.seed, pid, hh, 1000 + c) - 0.5) * 2.0 * 0.01;
+        }
+      }
+    }
+    // the round's queue: pair 0's active hypotheses, then pair 1's
+    const int n_tasks = needed[0] + needed[1];
+    if (lane < 2 * kHypPerRound) {
+      const int pp = lane >= needed[0] ? 1 : 0;
+      const int j = pp ? lane - needed[0] : lane;
+      if (lane < n_tasks) lds.tlist[lane] = kHypPerRound * pp + j;
+    }
+    lds_sync();
+    PNEC_PHASE_END(kRpSample);
+    const int trips = es_minimise_queue(n_tasks, lds.tlist, lds.Gh, lds.tv, lds.te, lds.tits, (double)ss);
+    lds_sync();
+    PNEC_PHASE_END(kRpNewton);
+    if (a.trace) {  // diagnostics (per wavefront = two pairs; halved on the way out): Newton iterations of the round's
+                    // hypotheses (sum), evaluations as executed (in the slot the one-pair kernel uses for the slowest
+                    // quad's iterations), rounds
+      int its = (lane < 2 * kHypPerRound && ((lane < kHypPerRound) ? lane < needed[0] : lane - kHypPerRound < needed[1]))
+                    ? lds.tits[lane] : 0;
+      ph_clk[8] += 2ull * (unsigned long long)wave_allreduce_sum((double)its);
+      ph_clk[9] += 2ull * (unsigned long long)trips;
+      ph_clk[10] += 2;
+    }
+    // ---- per pair: model of hypothesis `hyp`, scoring, the sequential rule
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      if (!go[pp]) continue;  // wave-uniform
+      const int slot = kHypPerRound * pp + hyp;
+      const bool active = hyp < needed[pp];
+      const double *bs = base[pp];
+      const int st = stride[pp], nn = n[pp];
+      double v[3] = {0, 0, 0}, R[9], t[3] = {0, 0, 1};
+      if (active) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { v[c] = lds.tv[slot][c]; t[c] = lds.te[slot][c]; }
+      }
+      cayley_to_rot(v, R);
+      {
+        // directional evidence sum t.(f1 - R f2) over the sample
+        double ev = 0.0;
+        for (int j = role; j < (active ? ss : 0); j += 4) {
+          const int idx = lds.tsel[slot][j];
+          const double f2[3] = {bs[(int64_t)3 * st + idx], bs[(int64_t)4 * st + idx], bs[(int64_t)5 * st + idx]};
+          const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
+                               R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
+          ev -= t[0] * u[0] + t[1] * u[1] + t[2] * u[2];
+        }
+        const double e1[3] = {active ? lds.tev1[slot][0] : 0.0, active ? lds.tev1[slot][1] : 0.0, active ? lds.tev1[slot][2] : 0.0};
+        ev = (t[0] * e1[0] + t[1] * e1[1] + t[2] * e1[2]) + quad_sum(ev);
+        if (ev < 0.0) { t[0] = -t[0]; t[1] = -t[1]; t[2] = -t[2]; }
+      }
+      PNEC_PHASE_END(kRpModel);
+      // inlier count of every hypothesis over the whole pair: tiles of 64 correspondences staged in LDS by the
+      // wavefront (coalesced, the next tile's loads in flight while this one is scored), a quarter of the tile per lane
+      int cnt = 0;
+      {
+        double nxt[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) nxt[c] = nn > 0 ? bs[(int64_t)c * st + lane] : 0.0;
+        for (int i0 = 0; i0 < nn; i0 += kWave) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) lds.tile[c][lane] = nxt[c];
+          if (i0 + kWave < nn) {  // < stride: the padding of the last tile reads zeros
+#pragma unroll
+            for (int c = 0; c < 6; ++c) nxt[c] = bs[(int64_t)c * st + i0 + kWave + lane];
+          }
+          lds_sync();
+          const int left = nn - i0 < kWave ? nn - i0 : kWave;
+#pragma unroll 4
+          for (int jj = 0; jj < (active ? kWave / 4 : 0); ++jj) {
+            const int j = 4 * jj + role;
+            const double f1[3] = {lds.tile[0][j], lds.tile[1][j], lds.tile[2][j]};
+            const double f2[3] = {lds.tile[3][j], lds.tile[4][j], lds.tile[5][j]};
+            cnt += (j < left && reprojection_score(f1, f2, R, t) < a.threshold) ? 1 : 0;
+          }
+          lds_sync();  // one buffer: everybody has read the tile before the next one is written
+        }
+      }
+      cnt = quad_sum_int(cnt);
+      PNEC_PHASE_END(kRpScore);
+      int winner = -1;
+      for (int j = 0; j < kHypPerRound; ++j) {
+        const int cj = __builtin_amdgcn_readlane(cnt, 4 * j);
+        if (!((double)it[pp] < k[pp])) { stop[pp] = true; break; }
+        if (cj > best_count[pp]) {
+          best_count[pp] = cj;
+          winner = j;
+          const double w = (double)cj / (double)nn;
+          double p_no = 1.0 - pow(w, (double)ss);
+          p_no = fmax(2.220446049250313e-16, p_no);
+          p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
+          k[pp] = log(1.0 - 0.99) / log(p_no);
+        }
+        ++it[pp];
+        if (it[pp] > a.max_iterations) { stop[pp] = true; break; }
+      }
+      if (winner >= 0 && hyp == winner && role == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) lds.best_model[pp][i] = R[i];
+        lds.best_model[pp][9] = t[0]; lds.best_model[pp][10] = t[1]; lds.best_model[pp][11] = t[2];
+      }
+      lds_sync();
+      PNEC_PHASE_END(kRpConsume);
+    }
+  }
+  // ---- per pair: inliers of the best model (all correspondences when sampling is impossible), their 36 sums, the
+  // first inlier; handed to es_batch_kernel<kEpiTranslation> as in the one-pair kernel
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    if (pair[pp] >= a.n_pairs) continue;
+    const double *bs = base[pp];
+    const int st = stride[pp], nn = n[pp];
+    double bR[9], bt[3] = {0.0, 0.0, 1.0};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) bR[i] = R0[pp][i];
+    if (can_sample[pp]) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) bR[i] = lds.best_model[pp][i];
+      bt[0] = lds.best_model[pp][9]; bt[1] = lds.best_model[pp][10]; bt[2] = lds.best_model[pp][11];
+    }
+    double acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+    int my_count = 0, my_first = 0x7fffffff;
+    const int64_t aos0 = a.offsets[pair[pp]];
+    for (int idx = lane; idx < nn; idx += kWave) {
+      const double f1[3] = {bs[idx], bs[(int64_t)st + idx], bs[(int64_t)2 * st + idx]};
+      const double f2[3] = {bs[(int64_t)3 * st + idx], bs[(int64_t)4 * st + idx], bs[(int64_t)5 * st + idx]};
+      bool in = true;
+      if (can_sample[pp]) in = reprojection_score(f1, f2, bR, bt) < a.threshold;
+      if (a.out_mask) a.out_mask[aos0 + idx] = in ? 1 : 0;
+      if (in) {
+        ++my_count;
+        if (idx < my_first) my_first = idx;
+        const double p[6] = {f2[0] * f2[0], f2[0] * f2[1], f2[0] * f2[2], f2[1] * f2[1], f2[1] * f2[2], f2[2] * f2[2]};
+        const double qq[6] = {f1[0] * f1[0], f1[0] * f1[1], f1[0] * f1[2], f1[1] * f1[1], f1[1] * f1[2], f1[2] * f1[2]};
+#pragma unroll
+        for (int kl = 0; kl < 6; ++kl)
+#pragma unroll
+          for (int ac = 0; ac < 6; ++ac) acc[6 * kl + ac] = __builtin_fma(p[kl], qq[ac], acc[6 * kl + ac]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+      const double sres = wave_allreduce_sum(acc[i]);
+      if (lane == 0) lds.G[pp][i] = sres;
+    }
+    const int total = (int)wave_allreduce_sum((double)my_count);
+    int first = my_first;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int o = __shfl_xor(first, off);
+      first = o < first ? o : first;
+    }
+    lds_sync();
+    PNEC_PHASE_END(kRpInliers);
+    if (lane < 36) a.scratch.G[36 * pair[pp] + lane] = lds.G[pp][lane];
+    if (lane == 0) {
+      double vv[3];
+      rot_to_cayley(bR, vv);
+      a.scratch.v0[3 * pair[pp]] = vv[0]; a.scratch.v0[3 * pair[pp] + 1] = vv[1]; a.scratch.v0[3 * pair[pp] + 2] = vv[2];
+      a.scratch.n_scale[pair[pp]] = (double)(total > 0 ? total : 1);
+      a.scratch.first[pair[pp]] = total > 0 ? first : -1;
+      if (a.out_count) a.out_count[pair[pp]] = total;
+      if (a.out_iterations) a.out_iterations[pair[pp]] = it[pp];
+      if (a.trace) {
+        ph_clk[kRpTotal] = (__builtin_amdgcn_s_memtime() - ph_start) / 2;  // two pairs shared this wavefront
+        for (int kk = 0; kk < kPhCount; ++kk) a.trace[kPhCount * pair[pp] + kk] = kk == kRpTotal ? ph_clk[kk] : ph_clk[kk] / 2;
+      }
+    }
+  }
+}
+
 // ---- InlierExtraction (pnec.cc:210-229): compact the masked correspondences of every pair into a
 // new batch, order preserved.  One wavefront per pair; positions by ballot prefix counts.
 __global__ __launch_bounds__(kWave) void select_kernel(int nc, const double *src, const int64_t *src_block,
@@ -1923,7 +2385,18 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), zeros, sizeof(zeros));
   }
 #endif
-  hipLaunchKernelGGL(ransac_eigensolver_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
+  // Two pairs per wavefront with the hypotheses of both in one queue (ransac2_eigensolver_kernel) once there are
+  // enough pairs to fill the GPU either way; a handful of pairs (the per-frame handle: one) keep a wavefront each --
+  // half the latency.  Same results, bit for bit.  PNEC_RANSAC_FORM=1|2 forces a form (A/B runs).
+  static const int forced_form = [] {
+    const char *ev = std::getenv("PNEC_RANSAC_FORM");
+    return ev && *ev ? std::atoi(ev) : 0;
+  }();
+  const bool two = forced_form ? forced_form == 2 : n_pairs >= 4096;
+  if (two)
+    hipLaunchKernelGGL(ransac2_eigensolver_kernel, dim3((unsigned)((n_pairs + 1) / 2)), dim3(kWave), 0, stream, a);
+  else
+    hipLaunchKernelGGL(ransac_eigensolver_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) {
     EsBatchArgs b;
@@ -1966,7 +2439,7 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
       for (int64_t p = 0; p < n_pairs; ++p)
         for (int k = 0; k < kPhCount; ++k) m[k] += (double)h[(size_t)(kPhCount * p + k)];
       static const char *names[kPhCount] = {"sample+sums", "newton", "model", "score", "consume", "inliers", "final_es", "total",
-                                            "its_sum16", "its_max_sum", "rounds", "lane0_capped"};
+                                            "its_sum16", "its_max_sum (two-pair form: evaluations executed)", "rounds", "evaluations_executed (one-pair form)"};
       std::fprintf(stderr, "ransac_eigensolver phases (mean s_memtime clocks per pair, %lld pairs):", (long long)n_pairs);
       for (int k = 0; k < kPhCount; ++k) std::fprintf(stderr, " %s=%.0f", names[k], m[k] / (double)n_pairs);
       std::fprintf(stderr, "\n");

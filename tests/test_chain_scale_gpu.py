@@ -108,3 +108,44 @@ def test_one_call_chain_matches_the_oracle_chain_over_20000_pairs(oracle):
     except OSError:
         pass
     print(json.dumps(report))
+
+
+def test_two_pairs_per_wavefront_ransac_is_bitwise_the_one_pair_form():
+    """From 4 096 pairs up the RANSAC stage runs two pairs per wavefront with the hypotheses of both in one queue
+    (ransac2_eigensolver_kernel: a quad that has finished a minimisation takes the next hypothesis, whichever pair it
+    belongs to); smaller batches keep one wavefront per pair.  A hypothesis' arithmetic does not depend on which quad
+    minimises it or when, so the whole chain over 6 001 ragged pairs (odd: the last wavefront holds one pair; sizes
+    from below the sample size to beyond one wavefront's 512; gross mismatches) in ONE call must equal, bit for bit,
+    the same pairs solved as three batches of <= 2 048 (one-pair form) whose RANSAC draws are offset to the pairs'
+    global indices (`first_pair_id`)."""
+    dev = torch.device("cuda:0")
+    P = 6001
+    rng = np.random.default_rng(77)
+    counts = rng.integers(60, 640, size=P).astype(np.int64)
+    counts[:8] = [5, 9, 10, 11, 64, 512, 513, 639]          # below / at the 10-point sample, slot boundaries
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    nmax = int(counts.max())
+    parts = []
+    for c0 in range(0, P, 1000):                              # generated in chunks: [m, nmax] boxes, then ragged
+        m = min(1000, P - c0)
+        g = sim.generate(m, nmax, seed=900 + c0, device=dev)
+        keep = torch.arange(nmax, device=dev)[None, :] < torch.as_tensor(counts[c0:c0 + m], device=dev)[:, None]
+        bad = torch.rand(m, nmax, device=dev, generator=torch.Generator(device=dev).manual_seed(c0)) < 0.15
+        rnd = torch.randn(m, nmax, 3, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(c0 + 1))
+        b2 = torch.where(bad[..., None], rnd / rnd.norm(dim=-1, keepdim=True), g.bvs2)
+        parts.append((g.bvs1[keep], b2[keep], g.covs2[keep], g.init_q, g.init_t))
+    f1, f2, cv, q0, t0 = (torch.cat([p[i] for p in parts]) for i in range(5))
+    with Batch(capi.MODE_TARGET, off) as b:
+        b.fill(f1, f2, cv)
+        q, t, mask, cnt = b.solve_pipeline(q0, t0, want_inliers=True)
+    torch.cuda.synchronize()
+    for a in range(0, P, 2048):
+        z = min(P, a + 2048)
+        sl = slice(int(off[a]), int(off[z]))
+        with Batch(capi.MODE_TARGET, off[a:z + 1] - off[a]) as b:
+            b.fill(f1[sl], f2[sl], cv[sl])
+            qs, ts, ms, cs = b.solve_pipeline(q0[a:z].contiguous(), t0[a:z].contiguous(), want_inliers=True,
+                                              options=capi.default_pipeline_options(first_pair_id=a))
+        assert torch.equal(ms, mask[sl]) and torch.equal(cs, cnt[a:z]), (a, z)
+        assert torch.equal(qs, q[a:z]) and torch.equal(ts, t[a:z]), (a, z)
+    assert int(cnt[:3].max()) <= 10 and bool((cnt[8:] > 30).all())          # tiny pairs: no sampling / all inliers
