@@ -73,6 +73,18 @@ def test_argument_validation_without_device():
     offs = np.array([0, 4], dtype=np.int64)
     assert L.pnec_hip_problem_create(0, 9, 1, offs.ctypes.data, C.byref(h)) == -1
     assert L.pnec_hip_solve(None, None, None, 1, None, 1e-13, None, None, None, None, None, None, 0, None) == -1
+    # capacity-shaped batches and the per-frame handle: arguments are checked before any device is touched
+    assert L.pnec_hip_problem_create_capacity(0, capi.MODE_TARGET, 0, 100, C.byref(h)) == -1
+    assert L.pnec_hip_problem_create_capacity(0, 9, 4, 100, C.byref(h)) == -1
+    assert L.pnec_hip_problem_reshape(None, 1, offs.ctypes.data, None) == -1
+    assert L.pnec_hip_frame_create(0, 0, None, C.byref(h)) == -1 and b"max_corr" in L.pnec_hip_last_error()
+    assert L.pnec_hip_frame_create(0, 100, None, None) == -1
+    assert L.pnec_hip_frame_solve(None, 1, None, None, None, None, None, None, None, None, None, None) == -1
+    assert L.pnec_hip_frame_load(None, 1, None, None, None, None) == -1
+    assert L.pnec_hip_frame_capacity(None) == 0 and L.pnec_hip_frame_destroy(None) == 0
+    po = capi.default_pipeline_options()
+    assert (po.use_ransac, po.weighted_iterations, po.first_pair_id, po.ransac_seed) == (1, 10, 0, 1)
+    assert C.sizeof(capi.PipelineOptions) == 6 * 4 + 8 + 8 + 8 + 8 + C.sizeof(capi.Options)   # first_pair_id where ABI 2 had reserved[2]
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
