@@ -1560,6 +1560,88 @@ __device__ __forceinline__ double reprojection_score(const double (&f1)[3], cons
          (1.0 - (f2[0] * p2[0] + f2[1] * p2[1] + f2[2] * p2[2]) * in2);
 }
 
+// ---- RANSAC scoring: the pair's bearings in registers, one model after the other -------------------------------------
+// The first kScoreTiles x 64 correspondences of the pair (f1 | f2: six planes) are loaded ONCE per round into registers,
+// lane l holding correspondence 64 i + l of tile i (coalesced; scalar plane base + lane offset + immediate, see
+// load_planes_issue); what a larger pair has beyond them is streamed from memory per model.
+constexpr int kScoreTiles = 8;
+struct ScoreTiles { double f[kScoreTiles][6]; };
+
+__device__ __forceinline__ void score_tiles_issue(ScoreTiles &P, const double *bs, int st, int nn, int lane) {
+  const unsigned long long b64 = reinterpret_cast<unsigned long long>(bs);
+  const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
+  const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
+  const char *sb = reinterpret_cast<const char *>(((unsigned long long)bhi << 32) | blo);
+  const size_t plane_bytes = (size_t)(unsigned)__builtin_amdgcn_readfirstlane(st) * sizeof(double);
+  const unsigned voff = 8u * (unsigned)lane;
+  auto tile = [&](auto tc) {
+    constexpr int i = decltype(tc)::value;
+    // a tile that starts inside the pair lies inside its planes (stride = n rounded up to 64: the padding reads zeros)
+    load_planes_issue<6, 8 * kWave * i>(P.f[i], sb, plane_bytes, voff, kWave * i < nn);
+  };
+  tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{});
+  tile(std::integral_constant<int, 2>{}); tile(std::integral_constant<int, 3>{});
+  tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{});
+  tile(std::integral_constant<int, 6>{}); tile(std::integral_constant<int, 7>{});
+  static_assert(kScoreTiles == 8, "one call per tile above");
+}
+// everything issued before has landed (s_waitcnt vmcnt(0), carrying the first tile as operands); the other tiles are
+// tied to a point after it (volatile statements keep their order)
+__device__ __forceinline__ void score_tiles_arrived(ScoreTiles &P) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(P.f[0][0]), "+v"(P.f[0][1]), "+v"(P.f[0][2]), "+v"(P.f[0][3]), "+v"(P.f[0][4]), "+v"(P.f[0][5]));
+#pragma unroll
+  for (int i = 1; i < kScoreTiles; ++i)
+    asm volatile("" : "+v"(P.f[i][0]), "+v"(P.f[i][1]), "+v"(P.f[i][2]), "+v"(P.f[i][3]), "+v"(P.f[i][4]), "+v"(P.f[i][5]));
+}
+
+// Inliers of ONE model over the whole pair.  `beat` is the count the model has to exceed to matter (the best so far of
+// RANSAC's sequential rule): once even "every remaining correspondence is an inlier" cannot get it there, the scan stops
+// and the count so far is returned -- any value <= beat leads to the same decision, so the rule's outcome is exactly the
+// full scan's.  All wave-uniform.
+// (Until round 3 the sixteen hypotheses of a round were scored side by side, a quad each, from tiles staged in LDS:
+// nothing could be skipped, because a lane that leaves a SIMD instruction early saves nothing.  One after the other, a
+// model fitted to a contaminated sample -- a handful of inliers against ~450 -- is dropped after one or two of the
+// eight tiles.)
+__device__ __forceinline__ int model_inliers_until_beaten(const ScoreTiles &P, const double *__restrict__ bs, int st, int nn,
+                                                           const double (&R)[9], const double (&t)[3], double threshold,
+                                                           int lane, int beat) {
+  int cnt = 0;
+  bool beaten = false;
+  auto tile = [&](auto tc) {
+    constexpr int i = decltype(tc)::value;
+    if (beaten || kWave * i >= nn) return;  // wave-uniform
+    const double f1[3] = {P.f[i][0], P.f[i][1], P.f[i][2]}, f2[3] = {P.f[i][3], P.f[i][4], P.f[i][5]};
+    const bool in = (kWave * i + lane < nn) && reprojection_score(f1, f2, R, t) < threshold;
+    cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
+    const int left = nn - kWave * (i + 1);
+    beaten = cnt + (left > 0 ? left : 0) <= beat;
+  };
+  tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{});
+  tile(std::integral_constant<int, 2>{}); tile(std::integral_constant<int, 3>{});
+  tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{});
+  tile(std::integral_constant<int, 6>{}); tile(std::integral_constant<int, 7>{});
+  if (beaten || nn <= kWave * kScoreTiles) return cnt;
+  // the rest of a pair of more than 512 correspondences: from memory, the next tile in flight while this one is scored
+  double cur[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) cur[c] = bs[(int64_t)c * st + kWave * kScoreTiles + lane];
+  for (int i0 = kWave * kScoreTiles; i0 < nn; i0 += kWave) {
+    double nxt[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (i0 + kWave < nn) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) nxt[c] = bs[(int64_t)c * st + i0 + kWave + lane];
+    }
+    const double f1[3] = {cur[0], cur[1], cur[2]}, f2[3] = {cur[3], cur[4], cur[5]};
+    const bool in = (i0 + lane < nn) && reprojection_score(f1, f2, R, t) < threshold;
+    cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
+    const int left = nn - i0 - kWave;
+    if (cnt + (left > 0 ? left : 0) <= beat) break;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) cur[c] = nxt[c];
+  }
+  return cnt;
+}
+
 constexpr int kHypPerRound = 16;  // hypotheses evaluated per round = quads per wavefront
 enum : int { kRpSample = 0, kRpNewton, kRpModel, kRpScore, kRpConsume, kRpInliers, kRpFinal, kRpTotal };
 
@@ -1597,7 +1679,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
   __shared__ double Gh[kHypPerRound][36];  // the 36 sums of each hypothesis' sample
   __shared__ double G[36];                 // ... of the inliers of the best model
   __shared__ double best_model[12];        // R (9) + t (3)
-  __shared__ double tile[2][6][kWave];     // bearings of 64 correspondences (scoring), double-buffered
+  __shared__ double models[kHypPerRound][12];  // R (9) + t (3) of the round's hypotheses (scored one after the other)
   __shared__ int sel_lds[PNEC_HIP_MAX_RANSAC_SAMPLE][kWave];  // each lane's sample (indexed dynamically: not registers)
   double q0[4] = {a.init_q[4 * pair], a.init_q[4 * pair + 1], a.init_q[4 * pair + 2], a.init_q[4 * pair + 3]};
   {
@@ -1706,44 +1788,30 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
         if (ev < 0.0) { t[0] = -t[0]; t[1] = -t[1]; t[2] = -t[2]; }
       }
       PNEC_PHASE_END(kRpModel);
-      // ---- inlier count of every hypothesis over the whole pair: tiles of 64 correspondences staged in
-      // LDS by the wavefront (coalesced), each quad scores its hypothesis, a quarter of the tile per lane
-      int cnt = 0;
-      {
-        double nxt[6];  // the next tile's share of this lane, in flight while the current tile is scored
+      // ---- the models go to LDS; then ONE HYPOTHESIS AFTER THE OTHER, in the order of the sequential rule, is scored
+      // by the whole wavefront and consumed (model_inliers_until_beaten: a model that cannot beat the best so far is
+      // dropped after a tile or two; the rule's decisions are those of the full counts)
+      if (active && role == 0) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) nxt[c] = n > 0 ? base[(int64_t)c * stride + lane] : 0.0;
-        int buf = 0;
-        for (int i0 = 0; i0 < n; i0 += kWave, buf ^= 1) {
-#pragma unroll
-          for (int c = 0; c < 6; ++c) tile[buf][c][lane] = nxt[c];
-          if (i0 + kWave < n) {  // < stride: the padding of the last tile reads zeros
-#pragma unroll
-            for (int c = 0; c < 6; ++c) nxt[c] = base[(int64_t)c * stride + i0 + kWave + lane];
-          }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          const int left = n - i0 < kWave ? n - i0 : kWave;
-#pragma unroll 4
-          for (int jj = 0; jj < (active ? kWave / 4 : 0); ++jj) {
-            const int j = 4 * jj + role;
-            const double f1[3] = {tile[buf][0][j], tile[buf][1][j], tile[buf][2][j]};
-            const double f2[3] = {tile[buf][3][j], tile[buf][4][j], tile[buf][5][j]};
-            // padding entries are zeros: their score is NaN and never counts
-            cnt += (j < left && reprojection_score(f1, f2, R, t) < a.threshold) ? 1 : 0;
-          }
-          // the other buffer is written next; this one again only after the next tile has been scored
-          __builtin_amdgcn_wave_barrier();
-        }
+        for (int i = 0; i < 9; ++i) models[hyp][i] = R[i];
+        models[hyp][9] = t[0]; models[hyp][10] = t[1]; models[hyp][11] = t[2];
       }
-      cnt = quad_sum_int(cnt);
-      PNEC_PHASE_END(kRpScore);
-      // ---- consume the 16 hypotheses in order with the sequential rule (all of it wave-uniform)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // the pair's bearings for the scoring.  (Issue and wait back to back: a register that a load in flight will
+      // write is not the compiler's to move or spill, and it does not know -- nothing may sit between the two.)
+      ScoreTiles tiles;
+      score_tiles_issue(tiles, base, stride, n, lane);
+      score_tiles_arrived(tiles);
       int winner = -1;
-      for (int j = 0; j < kHypPerRound; ++j) {
-        const int cj = __builtin_amdgcn_readlane(cnt, 4 * j);
+      for (int j = 0; j < needed; ++j) {  // (hypotheses beyond `needed` would meet it >= k: never consumed)
         if (!((double)it < k)) { stop = true; break; }
+        double Rj[9], tj[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rj[i] = models[j][i];
+        tj[0] = models[j][9]; tj[1] = models[j][10]; tj[2] = models[j][11];
+        const int cj = model_inliers_until_beaten(tiles, base, stride, n, Rj, tj, a.threshold, lane, best_count);
         if (cj > best_count) {
           best_count = cj;
           winner = j;
@@ -1756,11 +1824,8 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
         ++it;
         if (it > a.max_iterations) { stop = true; break; }
       }
-      if (winner >= 0 && hyp == winner && role == 0) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) best_model[i] = R[i];
-        best_model[9] = t[0]; best_model[10] = t[1]; best_model[11] = t[2];
-      }
+      PNEC_PHASE_END(kRpScore);
+      if (winner >= 0 && lane < 12) best_model[lane] = models[winner][lane];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1854,7 +1919,7 @@ struct Ransac2Lds {
   int tsel[2 * kHypPerRound][PNEC_HIP_MAX_RANSAC_SAMPLE];  // the sample
   int tits[2 * kHypPerRound];
   int tlist[2 * kHypPerRound];       // the round's queue: slots of the active hypotheses
-  double tile[6][kWave];             // bearings of 64 correspondences (scoring)
+  double models[kHypPerRound][12];   // R (9) + t (3) of the hypotheses of the pair being scored
   double best_model[2][12];          // R (9) + t (3) per pair
   double G[2][36];                   // sums of the inliers of the best model
 };
@@ -2172,38 +2237,25 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
         if (ev < 0.0) { t[0] = -t[0]; t[1] = -t[1]; t[2] = -t[2]; }
       }
       PNEC_PHASE_END(kRpModel);
-      // inlier count of every hypothesis over the whole pair: tiles of 64 correspondences staged in LDS by the
-      // wavefront (coalesced, the next tile's loads in flight while this one is scored), a quarter of the tile per lane
-      int cnt = 0;
-      {
-        double nxt[6];
+      // the models go to LDS; then one hypothesis after the other, in the order of the sequential rule, is scored by
+      // the whole wavefront and consumed (see the one-pair kernel)
+      if (active && role == 0) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) nxt[c] = nn > 0 ? bs[(int64_t)c * st + lane] : 0.0;
-        for (int i0 = 0; i0 < nn; i0 += kWave) {
-#pragma unroll
-          for (int c = 0; c < 6; ++c) lds.tile[c][lane] = nxt[c];
-          if (i0 + kWave < nn) {  // < stride: the padding of the last tile reads zeros
-#pragma unroll
-            for (int c = 0; c < 6; ++c) nxt[c] = bs[(int64_t)c * st + i0 + kWave + lane];
-          }
-          lds_sync();
-          const int left = nn - i0 < kWave ? nn - i0 : kWave;
-#pragma unroll 4
-          for (int jj = 0; jj < (active ? kWave / 4 : 0); ++jj) {
-            const int j = 4 * jj + role;
-            const double f1[3] = {lds.tile[0][j], lds.tile[1][j], lds.tile[2][j]};
-            const double f2[3] = {lds.tile[3][j], lds.tile[4][j], lds.tile[5][j]};
-            cnt += (j < left && reprojection_score(f1, f2, R, t) < a.threshold) ? 1 : 0;
-          }
-          lds_sync();  // one buffer: everybody has read the tile before the next one is written
-        }
+        for (int i = 0; i < 9; ++i) lds.models[hyp][i] = R[i];
+        lds.models[hyp][9] = t[0]; lds.models[hyp][10] = t[1]; lds.models[hyp][11] = t[2];
       }
-      cnt = quad_sum_int(cnt);
-      PNEC_PHASE_END(kRpScore);
+      lds_sync();
+      ScoreTiles tiles;  // the pair's bearings for the scoring (issue and wait back to back, see the one-pair kernel)
+      score_tiles_issue(tiles, bs, st, nn, lane);
+      score_tiles_arrived(tiles);
       int winner = -1;
-      for (int j = 0; j < kHypPerRound; ++j) {
-        const int cj = __builtin_amdgcn_readlane(cnt, 4 * j);
+      for (int j = 0; j < needed[pp]; ++j) {
         if (!((double)it[pp] < k[pp])) { stop[pp] = true; break; }
+        double Rj[9], tj[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rj[i] = lds.models[j][i];
+        tj[0] = lds.models[j][9]; tj[1] = lds.models[j][10]; tj[2] = lds.models[j][11];
+        const int cj = model_inliers_until_beaten(tiles, bs, st, nn, Rj, tj, a.threshold, lane, best_count[pp]);
         if (cj > best_count[pp]) {
           best_count[pp] = cj;
           winner = j;
@@ -2216,11 +2268,8 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
         ++it[pp];
         if (it[pp] > a.max_iterations) { stop[pp] = true; break; }
       }
-      if (winner >= 0 && hyp == winner && role == 0) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) lds.best_model[pp][i] = R[i];
-        lds.best_model[pp][9] = t[0]; lds.best_model[pp][10] = t[1]; lds.best_model[pp][11] = t[2];
-      }
+      PNEC_PHASE_END(kRpScore);
+      if (winner >= 0 && lane < 12) lds.best_model[pp][lane] = lds.models[winner][lane];
       lds_sync();
       PNEC_PHASE_END(kRpConsume);
     }
