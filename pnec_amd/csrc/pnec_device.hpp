@@ -392,6 +392,10 @@ __device__ __forceinline__ void load_planes_saddr(double (&e)[NC], const char *s
 // issue them all (load_planes_issue), then planes_arrived() on the FIRST set -- s_waitcnt vmcnt(0): everything issued
 // before has landed -- and planes_after() on every other set, which ties its values to a point after that wait
 // (volatile statements keep their order; readers of the values depend on these statements' outputs).
+// NOTHING may stand between the issue and the wait: to the compiler the asm statement has written its output when it
+// returns, so it is free to copy, spill or re-use that register at once -- while the load that will really write it is
+// still in flight.  (RANSAC's scoring once had its model phase in between: the late writes landed in registers that
+// held other values by then -- wrong counts at some pair sizes, rounds that never ended at others.)
 template <int NC, int IMM>
 __device__ __forceinline__ void load_planes_issue(double (&e)[NC], const char *sbase, size_t plane_bytes, unsigned lo, bool in) {
 #pragma unroll
