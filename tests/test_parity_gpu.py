@@ -592,6 +592,41 @@ def test_ransac_eigensolver_and_inlier_selection_device_vs_oracle(oracle):
         sel.close()
 
 
+@pytest.mark.parametrize("outliers", [0.15, 0.45])
+def test_ransac_scoring_tile_boundaries_and_early_drop_vs_oracle(oracle, outliers):
+    """RANSAC scores its models one after the other over tiles of 64 correspondences -- eight tiles in registers, the
+    rest of a larger pair streamed -- and drops a model once it cannot beat the best so far (pnec_frontend.hip
+    model_inliers_until_beaten).  Exactness of that drop and every tile boundary, against the oracle's full counts:
+    identical masks, counts and iteration numbers for sizes around 64 k, 512 (registers | stream) and beyond;
+    45 % outliers make the rule run for several rounds of sixteen hypotheses (pnec.cc:239-272)."""
+    sizes = [64, 65, 100, 127, 128, 129, 300, 448, 449, 511, 512, 513, 575, 576, 577, 700, 1100]
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    rng = np.random.default_rng(17)
+    f1s, f2s, cvs, Rs, qs = [], [], [], [], []
+    for p, n in enumerate(sizes):
+        g = sim.generate(1, n, seed=400 + p)
+        f2 = g.bvs2[0].numpy().copy()
+        bad = rng.choice(n, int(outliers * n), replace=False)
+        v = rng.normal(size=(len(bad), 3))
+        f2[bad] = v / np.linalg.norm(v, axis=1, keepdims=True)
+        f1s.append(g.bvs1[0].numpy()); f2s.append(f2); cvs.append(g.covs2[0].numpy())
+        Rs.append(g.init_R[0].numpy()); qs.append(g.init_q[0].numpy())
+    f1, f2, c2 = np.concatenate(f1s), np.concatenate(f2s), np.concatenate(cvs)
+    with Batch(capi.MODE_TARGET, offsets) as b:
+        b.fill(f1, f2, c2)
+        q, t, mask, cnt, its = b.ransac_eigensolver(np.stack(qs), seed=5)
+    rounds = 0
+    for p, n in enumerate(sizes):
+        sl = slice(offsets[p], offsets[p + 1])
+        Ro, to, mo, ito = oracle.ransac_eigensolver(f1[sl], f2[sl], Rs[p], seed=5, pair_id=p)
+        assert its[p] == ito, (n, its[p], ito)
+        np.testing.assert_array_equal(mask[sl].astype(bool), mo, err_msg=str(n))
+        assert cnt[p] == mo.sum(), n
+        rounds += (ito + 15) // 16
+    if outliers > 0.4:
+        assert rounds > 3 * len(sizes)   # the sequential rule ran across rounds, not just inside the first
+
+
 def test_device_buffer_cache_reuses_and_releases():
     """batches created and destroyed in a loop reuse cached device buffers; release_cache returns them"""
     L = capi.lib()
