@@ -34,7 +34,7 @@ hipError_t launch_ransac_eigensolver(const double *, const int64_t *, const int6
                                      uint8_t *, int32_t *, int32_t *, double *, int32_t *, hipStream_t, hipStream_t,
                                      hipEvent_t, hipEvent_t);
 hipError_t launch_select(int, const double *, const int64_t *, const int64_t *, const int32_t *, const uint8_t *,
-                         double *, const int64_t *, const int32_t *, int64_t, hipStream_t);
+                         double *, const int64_t *, const int32_t *, int32_t *, int64_t *, int64_t, hipStream_t);
 hipError_t launch_nec_eigensolver(const double *, const int64_t *, const int32_t *, int64_t, const double *,
                                   double *, double *, int32_t *, double *, int32_t *, hipStream_t);
 hipError_t launch_weighted_eigensolver(int, const double *, const int64_t *, const int32_t *, int64_t, int,
@@ -1775,7 +1775,10 @@ static int alloc_like(pnec_hip_problem *src, hipStream_t stream, pnec_hip_proble
 
 // PNEC::InlierExtraction on the device, nothing read back: counts by ballot, offsets by a scan, the kept
 // correspondences compacted pair by pair into dst (which has src's capacity).  All on `stream`.
-static int select_into(pnec_hip_problem *src, const uint8_t *d_mask, hipStream_t stream, pnec_hip_problem *dst) {
+// known_counts (optional, device): the inliers per pair when the producer of the mask counted them already (RANSAC
+// does): the counting launch is skipped
+static int select_into(pnec_hip_problem *src, const uint8_t *d_mask, hipStream_t stream, pnec_hip_problem *dst,
+                       const int32_t *known_counts = nullptr) {
   const int64_t P = src->n_pairs;
   if (dst->view_src_gen != src->layout_gen) {  // the source has been re-shaped since dst copied its block layout
     if (P > 0)
@@ -1791,13 +1794,26 @@ static int select_into(pnec_hip_problem *src, const uint8_t *d_mask, hipStream_t
     dst->offsets = src->offsets;
   }
   if (P > 0) {
-    hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)P), dim3(kWave), 0, stream, d_mask, src->d_offsets,
-                       src->d_count, dst->d_count, P == 1 ? dst->d_offsets : (int64_t *)nullptr);
-    if (P > 1) hipLaunchKernelGGL(offsets_scan_kernel, dim3(1), dim3(1024), 0, stream, dst->d_count, dst->d_offsets, P);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess)
+    hipError_t e = hipSuccess;
+    if (known_counts) {
+      // (the copy kernel also installs the counts in dst and, for a batch of one pair, its AoS offsets; the scan
+      // of a larger batch's counts follows it: nothing in the copy needs the new offsets)
       e = launch_select(src->nc, src->d_data, src->d_block_offset, src->d_offsets, src->d_count, d_mask, dst->d_data,
-                        dst->d_block_offset, dst->d_count, P, stream);
+                        dst->d_block_offset, known_counts, dst->d_count, P == 1 ? dst->d_offsets : (int64_t *)nullptr, P,
+                        stream);
+      if (e == hipSuccess && P > 1) {
+        hipLaunchKernelGGL(offsets_scan_kernel, dim3(1), dim3(1024), 0, stream, dst->d_count, dst->d_offsets, P);
+        e = hipGetLastError();
+      }
+    } else {
+      hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)P), dim3(kWave), 0, stream, d_mask, src->d_offsets,
+                         src->d_count, dst->d_count, P == 1 ? dst->d_offsets : (int64_t *)nullptr);
+      if (P > 1) hipLaunchKernelGGL(offsets_scan_kernel, dim3(1), dim3(1024), 0, stream, dst->d_count, dst->d_offsets, P);
+      e = hipGetLastError();
+      if (e == hipSuccess)
+        e = launch_select(src->nc, src->d_data, src->d_block_offset, src->d_offsets, src->d_count, d_mask, dst->d_data,
+                          dst->d_block_offset, dst->d_count, dst->d_count, nullptr, P, stream);
+    }
     if (e != hipSuccess) return fail_hip(e, "select_kernel");
   }
   if (!dst->lazy) {  // it had been given exact sizes: back to the source's bounds, buckets included

@@ -2343,14 +2343,26 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
 }
 
 // ---- InlierExtraction (pnec.cc:210-229): compact the masked correspondences of every pair into a
-// new batch, order preserved.  One wavefront per pair; positions by ballot prefix counts.
+// new batch, order preserved.  One wavefront per pair -- or, with gridDim.y = nc, per pair and component plane (a
+// handful of pairs, the per-frame handle's one: twelve wavefronts copy where one did); positions by ballot prefix
+// counts.  dst_count_in: the inliers per pair (from the mask: mask_count_kernel, or RANSAC's own count of the mask it
+// wrote); when dst_count_out differs it receives a copy, and single_offsets (a batch of ONE pair) the new AoS offsets.
 __global__ __launch_bounds__(kWave) void select_kernel(int nc, const double *src, const int64_t *src_block,
                                                        const int64_t *src_offsets, const int32_t *src_count,
                                                        const uint8_t *mask, double *dst,
-                                                       const int64_t *dst_block, const int32_t *dst_count) {
+                                                       const int64_t *dst_block, const int32_t *dst_count_in,
+                                                       int32_t *dst_count_out, int64_t *single_offsets) {
   const int64_t pair = blockIdx.x;
   const int lane = threadIdx.x;
-  const int n = src_count[pair], m = dst_count[pair];
+  const int n = src_count[pair], m = dst_count_in[pair];
+  const int c_begin = gridDim.y > 1 ? (int)blockIdx.y : 0, c_end = gridDim.y > 1 ? (int)blockIdx.y + 1 : nc;
+  if (blockIdx.y == 0 && lane == 0) {
+    if (dst_count_out != dst_count_in) dst_count_out[pair] = m;
+    if (single_offsets) {
+      single_offsets[0] = 0;
+      single_offsets[1] = m;
+    }
+  }
   const int sstride = (n + kWave - 1) & ~(kWave - 1), dstride = (m + kWave - 1) & ~(kWave - 1);
   const double *sb = src + src_block[pair];
   double *db = dst + dst_block[pair];
@@ -2370,7 +2382,7 @@ __global__ __launch_bounds__(kWave) void select_kernel(int nc, const double *src
       pos[j] = written + __popcll(b & ((1ull << lane) - 1ull));
       written += __popcll(b);
     }
-    for (int c = 0; c < nc; ++c) {
+    for (int c = c_begin; c < c_end; ++c) {
       const double *sc = sb + (int64_t)c * sstride + base + lane;
       double *dc = db + (int64_t)c * dstride;
       double v[kChunks];
@@ -2382,14 +2394,21 @@ __global__ __launch_bounds__(kWave) void select_kernel(int nc, const double *src
     }
   }
   for (int idx = m + lane; idx < dstride; idx += kWave)  // zero padding of the last 64-chunk
-    for (int c = 0; c < nc; ++c) db[(int64_t)c * dstride + idx] = 0.0;
+    for (int c = c_begin; c < c_end; ++c) db[(int64_t)c * dstride + idx] = 0.0;
 }
 
 hipError_t launch_select(int nc, const double *src, const int64_t *src_block, const int64_t *src_offsets,
                          const int32_t *src_count, const uint8_t *mask, double *dst, const int64_t *dst_block,
-                         const int32_t *dst_count, int64_t n_pairs, hipStream_t stream) {
-  hipLaunchKernelGGL(select_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, nc, src, src_block,
-                     src_offsets, src_count, mask, dst, dst_block, dst_count);
+                         const int32_t *dst_count_in, int32_t *dst_count_out, int64_t *single_offsets, int64_t n_pairs,
+                         hipStream_t stream) {
+  // a wavefront per component plane while the pairs alone would not fill the GPU (PNEC_SELECT_SPLIT=0|1 forces: A/B)
+  static const int forced = [] {
+    const char *ev = std::getenv("PNEC_SELECT_SPLIT");
+    return ev && *ev ? std::atoi(ev) : -1;
+  }();
+  const bool split = forced >= 0 ? forced != 0 : n_pairs < 4096;
+  hipLaunchKernelGGL(select_kernel, dim3((unsigned)n_pairs, split ? (unsigned)nc : 1u), dim3(kWave), 0, stream, nc, src,
+                     src_block, src_offsets, src_count, mask, dst, dst_block, dst_count_in, dst_count_out, single_offsets);
   return hipGetLastError();
 }
 

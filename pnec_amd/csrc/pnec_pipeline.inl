@@ -118,11 +118,15 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
     }
     // the eigensolver on the inliers (latency-bound: sixteen pairs per wavefront, one wavefront per SIMD) runs
     // beside InlierExtraction (bandwidth-bound), which only needs the masks; both join before the weighted stage
-    if (int rc = ensure_side_streams(p, 1)) return rc;
+    // (a handful of pairs -- the per-frame handle's one -- stay on one stream: the fork and the join through events
+    // cost ~15 us, more than the two small launches take one after the other)
+    const bool fork = P >= 1024;
+    if (fork)
+      if (int rc = ensure_side_streams(p, 1)) return rc;
     e = launch_ransac_eigensolver(p->d_data, p->d_block_offset, p->d_offsets, p->d_count, P, d_iq, o.ransac_seed,
                                   (unsigned long long)o.first_pair_id, o.max_ransac_iterations, o.ransac_sample_size, o.ransac_threshold, es_q, es_t,
-                                  d_mask, d_cnt, nullptr, p->d_front, p->d_front_i, stream, p->side_streams[0],
-                                  p->fork_event, p->side_done[0]);
+                                  d_mask, d_cnt, nullptr, p->d_front, p->d_front_i, stream, fork ? p->side_streams[0] : nullptr,
+                                  fork ? p->fork_event : nullptr, fork ? p->side_done[0] : nullptr);
     if (e != hipSuccess) return fail_hip(e, "ransac_eigensolver_kernel");
     // (the cached InlierExtraction target has the capacity of the source; a re-shaped source is re-synced into it
     // by select_into, by layout generation)
@@ -131,8 +135,8 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
       p->sel_view = nullptr;
       if (int rc = alloc_like(p, stream, &p->sel_view)) return rc;
     }
-    if (int rc = select_into(p, d_mask, stream, p->sel_view)) return rc;
-    PNEC_HIP_TRY(hipStreamWaitEvent(stream, p->side_done[0], 0));  // es_q / es_t are there from here on
+    if (int rc = select_into(p, d_mask, stream, p->sel_view, d_cnt)) return rc;  // (RANSAC counted the mask it wrote)
+    if (fork) PNEC_HIP_TRY(hipStreamWaitEvent(stream, p->side_done[0], 0));  // es_q / es_t are there from here on
     stage = p->sel_view;
   } else {
     e = launch_nec_eigensolver(p->d_data, p->d_block_offset, p->d_count, P, d_iq, es_q, es_t, nullptr, p->d_front,
