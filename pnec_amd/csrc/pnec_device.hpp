@@ -360,6 +360,23 @@ __device__ __forceinline__ bool rows_all_finite(const double (&c)[6]) {
   return __builtin_amdgcn_ballot_w64(!(z == 0.0)) == 0ull;
 }
 
+// One 8-byte global load in the scalar-base form, destination DST (read-write operand: lanes the caller masks off keep
+// their value), 32-bit lane offset LO, scalar base PL, immediate IMM.  The base goes through an s_mov inside the
+// statement: when the compiler has just fetched PL with a VALU instruction (v_readlane from a spilled-SGPR lane,
+// v_readfirstlane), a vector-memory instruction reading that SGPR needs five wait states (CDNA ISA, "manually inserted
+// wait states") -- the compiler inserts them for its own instructions and cannot see into this text.  Scalar reads of
+// such a register are interlocked, and a scalar-written register has no such rule, so the copy is all it takes.
+// (Found the hard way: a kernel with enough scalar state to spill it addressed these loads with the register's OLD
+// contents -- an exec mask for a pointer's upper half -- and faulted, or silently read elsewhere.)
+#define PNEC_GLOBAL_LOAD_SADDR(DST, LO, PL, IMM)                                                                   \
+  do {                                                                                                           \
+    unsigned long long pnec_sbase_;                                                                              \
+    asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx2 %0, %2, %1 offset:%4"                                  \
+                 : "+v"(DST), "=&s"(pnec_sbase_)                                                                 \
+                 : "v"(LO), "s"(PL), "n"(IMM)                                                                    \
+                 : "memory");                                                                                    \
+  } while (0)
+
 // One correspondence per lane from a pair's SoA planes in memory: plane c of the pair starts at sbase + c * plane_bytes
 // (scalar registers), the lane's correspondence sits `lo` + IMM bytes into it.  (The solver's tail pass, geometry
 // (12, 1, 3), and the weighted stage's table build.)  Spelled as
@@ -377,7 +394,7 @@ __device__ __forceinline__ void load_planes_saddr(double (&e)[NC], const char *s
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const char *pl = sbase + (size_t)c * plane_bytes;
-      asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "+v"(e[c]) : "v"(lo), "s"(pl), "n"(IMM) : "memory");
+      PNEC_GLOBAL_LOAD_SADDR(e[c], lo, pl, IMM);
     }
     if constexpr (NC == 12)
       asm volatile("s_waitcnt vmcnt(0)"
@@ -404,7 +421,7 @@ __device__ __forceinline__ void load_planes_issue(double (&e)[NC], const char *s
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const char *pl = sbase + (size_t)c * plane_bytes;
-      asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "+v"(e[c]) : "v"(lo), "s"(pl), "n"(IMM) : "memory");
+      PNEC_GLOBAL_LOAD_SADDR(e[c], lo, pl, IMM);
     }
   }
 }

@@ -661,7 +661,8 @@ __device__ __forceinline__ void fib_prod_issue(double (&p)[6], const char *plane
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const char *pl = planes + (size_t)k * 512 * sizeof(double);
-    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(p[k]) : "v"(voff), "s"(pl), "n"(J * 64 * 8) : "memory");
+    p[k] = 0.0;
+    PNEC_GLOBAL_LOAD_SADDR(p[k], voff, pl, J * 64 * 8);  // (pnec_device.hpp: the base goes through a scalar move)
   }
 }
 __device__ __forceinline__ void fib_prod_arrived(double (&p)[6], bool first) {
@@ -2113,6 +2114,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
   }
   unsigned long long ph_clk[kPhCount] = {0};
   const unsigned long long ph_start = a.trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long rt_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   PNEC_PHASE_BEGIN();
   auto lds_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2337,6 +2339,10 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
       if (a.trace) {
         ph_clk[kRpTotal] = (__builtin_amdgcn_s_memtime() - ph_start) / 2;  // two pairs shared this wavefront
         for (int kk = 0; kk < kPhCount; ++kk) a.trace[kPhCount * pair[pp] + kk] = kk == kRpTotal ? ph_clk[kk] : ph_clk[kk] / 2;
+        // the wavefront's place on the launch's timeline, in the constant-rate counter all CUs share (10 ns ticks;
+        // in the slots of the one-pair form's counters)
+        a.trace[kPhCount * pair[pp] + kRpFinal] = rt_start;
+        a.trace[kPhCount * pair[pp] + 11] = __builtin_amdgcn_s_memrealtime();
       }
     }
   }
@@ -2511,6 +2517,26 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
       std::fprintf(stderr, "ransac_eigensolver phases (mean s_memtime clocks per pair, %lld pairs):", (long long)n_pairs);
       for (int k = 0; k < kPhCount; ++k) std::fprintf(stderr, " %s=%.0f", names[k], m[k] / (double)n_pairs);
       std::fprintf(stderr, "\n");
+      if (two && n_pairs > 1) {
+        // the launch's timeline from the wavefronts' start / end stamps (two-pair form): how much of it is the tail
+        std::vector<unsigned long long> st, en;
+        for (int64_t p = 0; p < n_pairs; p += 2) {
+          st.push_back(h[(size_t)(kPhCount * p + kRpFinal)]);
+          en.push_back(h[(size_t)(kPhCount * p + 11)]);
+        }
+        const unsigned long long t0 = *std::min_element(st.begin(), st.end());
+        const unsigned long long t1 = *std::max_element(en.begin(), en.end());
+        std::vector<double> dur(st.size()), end(st.size());
+        double busy = 0.0;
+        for (size_t i = 0; i < st.size(); ++i) { dur[i] = (double)(en[i] - st[i]); end[i] = (double)(en[i] - t0); busy += dur[i]; }
+        std::sort(dur.begin(), dur.end());
+        std::sort(end.begin(), end.end());
+        std::sort(st.begin(), st.end());
+        auto q = [](const std::vector<double> &v, double f) { return v[(size_t)(f * (double)(v.size() - 1))]; };
+        std::fprintf(stderr, "  timeline (10 ns ticks, %zu wavefronts): launch %.0f | wavefront p50 %.0f p90 %.0f p99 %.0f max %.0f | done at 50 %% %.0f 90 %% %.0f 99 %% %.0f | last start %.0f | wavefront time / launch = %.0f slots busy on average\n",
+                     st.size(), (double)(t1 - t0), q(dur, 0.5), q(dur, 0.9), q(dur, 0.99), dur.back(), q(end, 0.5), q(end, 0.9), q(end, 0.99),
+                     (double)(st.back() - t0), busy / (double)(t1 - t0));
+      }
     }
     (void)hipFree(a.trace);
   }
