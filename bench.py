@@ -91,6 +91,9 @@ def parse_args(argv=None):
                     help="kitti_all: the whole PNEC::Solve chain per pair (pnec_hip_solve_pipeline: RANSAC eigensolver, "
                          "inlier extraction, weighted eigensolver + SCF, refinement) instead of the refinement alone")
     ap.add_argument("--outliers", type=float, default=0.10, help="--chain: share of gross mismatches in the synthetic set")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="--chain: steps kept in flight, each on its own stream and its own copy of the batch (the chain's "
+                         "kernels end in tails of a few long pairs; the next step's work fills them).  1 = one at a time")
     return ap.parse_args(argv)
 
 
@@ -209,6 +212,12 @@ def build_kitti_all(args, rank, world, device):
     if tr.n_pairs:
         batch.fill(as_dev(tr.bvs1), as_dev(tr.bvs2), as_dev(tr.covs))
     sh.batch, sh.q0, sh.t0 = batch, as_dev(tr.init_q).contiguous(), as_dev(tr.init_t).contiguous()
+    sh.batches = [batch]
+    for _ in range(max(1, args.in_flight) - 1 if args.chain else 0):   # one copy of the shard per step in flight
+        extra = Batch(capi.MODE_TARGET, tr.offsets, device=device.index)
+        if tr.n_pairs:
+            extra.fill(as_dev(tr.bvs1), as_dev(tr.bvs2), as_dev(tr.covs))
+        sh.batches.append(extra)
     k = min(tr.n_pairs, 2048)
     m = int(tr.offsets[k])
     sh.sample = (tr.offsets[:k + 1], as_dev(tr.bvs1)[:m], as_dev(tr.bvs2)[:m], as_dev(tr.covs)[:m], sh.q0[:k], sh.t0[:k])
@@ -355,10 +364,12 @@ def run(args):
     first_global = sum(sh.sizes[:rank])
     if args.chain and args.workload != "kitti_all":
         raise SystemExit("--chain goes with --workload kitti_all")
+    in_flight = max(1, args.in_flight) if (args.chain and not cpu) else 1
     gather = RecordGather(world, rank, sizes=sh.sizes, device=None if (cpu or args.sync_gather) else device,
-                          host_staged=args.share_gpu)
+                          host_staged=args.share_gpu, slots=in_flight + 1)
     host_collective = world > 1 and not cpu and (args.share_gpu and args.sync_gather)
-    outs = [None, None]
+    outs = [None] * gather.SLOTS
+    which = [0]   # the copy of the batch (and the stream) the next step runs on
 
     if cpu:
         from pnec_amd.batch import SolveResult
@@ -391,7 +402,7 @@ def run(args):
 
             def solve(slot):
                 # one pnec_hip_solve_pipeline call; the record's "iterations" column carries the inlier count
-                q, t, _, cnt = sh.batch.solve_pipeline(sh.q0, sh.t0, options=popts, want_inliers=True)
+                q, t, _, cnt = sh.batches[which[0]].solve_pipeline(sh.q0, sh.t0, options=popts, want_inliers=True)
                 outs[slot] = SolveResult(q, t, torch.zeros(my_pairs, dtype=torch.float64, device=device), cnt,
                                          torch.zeros(my_pairs, dtype=torch.int32, device=device))
                 return outs[slot]
@@ -405,18 +416,26 @@ def run(args):
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
         ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    def step(i=None):
-        slot = gather.acquire()
-        if i is not None and ev0:
-            ev0[i].record()
-        res = solve(slot)
-        if i is not None and ev1:
-            ev1[i].record()
-        if host_collective:   # --share-gpu --sync-gather: gloo moves host tensors only
-            from pnec_amd.batch import SolveResult as _SR
-            gather.submit(slot, _SR(*(x.cpu() for x in (res.q, res.t, res.cost, res.iterations, res.status))))
-        else:
-            gather.submit(slot, res)
+    streams = [torch.cuda.Stream(device=device) for _ in range(in_flight)] if in_flight > 1 else None
+
+    def step(i=None, overlap=True):
+        import contextlib
+        ctx = contextlib.nullcontext()
+        if streams is not None and overlap:   # this step's launches (and its events, and its gather) on its own stream
+            which[0] = (which[0] + 1) % in_flight
+            ctx = torch.cuda.stream(streams[which[0]])
+        with ctx:
+            slot = gather.acquire()
+            if i is not None and ev0:
+                ev0[i].record()
+            res = solve(slot)
+            if i is not None and ev1:
+                ev1[i].record()
+            if host_collective:   # --share-gpu --sync-gather: gloo moves host tensors only
+                from pnec_amd.batch import SolveResult as _SR
+                gather.submit(slot, _SR(*(x.cpu() for x in (res.q, res.t, res.cost, res.iterations, res.status))))
+            else:
+                gather.submit(slot, res)
         return res
 
     def fence():
@@ -450,6 +469,15 @@ def run(args):
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    one_at_a_time = None
+    if in_flight > 1 and world == 1:   # the same steps one after the other on one stream, for the record
+        which[0] = 0
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(None, overlap=False)
+        gather.drain()
+        fence()
+        one_at_a_time = sh.total_pairs * args.steps / (time.perf_counter() - t1)
 
     if rank == 0:
         value = sh.total_pairs * args.steps / elapsed
@@ -501,7 +529,12 @@ def run(args):
                                                          int(sh.pair_sizes.max())],
                                    "options": "reference defaults: RANSAC eigensolver (5000 its max, 10-point samples), "
                                               "weighted_iterations 10 + SCF, Ceres-default refinement"})
+            line["config"]["steps_in_flight"] = in_flight
             line["chain"] = {"device_ms_per_step_rank0": dev_ms,
+                             "steps_in_flight": in_flight,
+                             "pairs_per_s_one_step_at_a_time": one_at_a_time,
+                             "in_flight_note": "each step in flight runs on its own stream and its own copy of the batch; "
+                                               "device_ms_per_step is one step's span while the others run beside it",
                              "inlier_share_mean": float((inl / torch.as_tensor(sh.pair_sizes, dtype=torch.float64)).mean()),
                              "note": "one pnec_hip_solve_pipeline call per step and rank; stage kernels and their bounds: "
                                      "profiles/r03_full_pipeline_kernels.md"}

@@ -103,8 +103,9 @@ class RecordGather:
     SLOTS = 2
 
     def __init__(self, world: int, rank: int, sizes=None, dst: int = 0, device=None, host_staged: bool = False,
-                 force_collective: bool = False):
+                 force_collective: bool = False, slots: int = 2):
         self.world, self.rank, self.sizes, self.dst = world, rank, sizes, dst
+        self.SLOTS = max(2, int(slots))   # result buffers in rotation (more than two: several steps in flight)
         self.cuda = device is not None and torch.device(device).type == "cuda"
         self.host_staged = bool(host_staged) and self.cuda
         self.force = bool(force_collective)

@@ -19,6 +19,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 dev = torch.device("cuda:0")
 batch = Batch.uniform(capi.MODE_TARGET, B, N)
+extra = [Batch.uniform(capi.MODE_TARGET, B, N) for _ in range(2)]   # copies: three calls in flight (below)
 qs, ts, first = [], [], None
 for c in range(0, B, 5000):
     m = min(5000, B - c)
@@ -29,6 +30,8 @@ for c in range(0, B, 5000):
     rnd = rnd / rnd.norm(dim=-1, keepdim=True)
     g.bvs2 = torch.where(bad[..., None], rnd, g.bvs2)
     batch.fill(g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3), first_pair=c, n_pairs=m)
+    for e in extra:
+        e.fill(g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3), first_pair=c, n_pairs=m)
     qs.append(g.init_q); ts.append(g.init_t)
     if first is None:
         first = g
@@ -51,6 +54,27 @@ t_ls, res = timed(lambda: sel.solve(qw, tw))
 # the product path: the whole chain as ONE call (pnec_hip_solve_pipeline; no host synchronisation between stages)
 t_one, (q_one, t_one_t) = timed(lambda: batch.solve_pipeline(q0, t0), reps=5)
 one_call_equals_stages = bool(torch.equal(q_one, res.q) and torch.equal(t_one_t, res.t))
+# ... and with three calls in flight, each on its own stream and its own copy of the batch: the stages end in tails of a
+# few long pairs (a quarter of the RANSAC launch at this size); the next call's work fills them
+streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+copies = [batch] + extra
+
+
+def in_flight(rounds=4):
+    outs = []
+    for _ in range(rounds):
+        for b_, s_ in zip(copies, streams):
+            with torch.cuda.stream(s_):
+                outs.append(b_.solve_pipeline(q0, t0))
+    return outs
+
+
+torch.cuda.synchronize(); in_flight(1); torch.cuda.synchronize()
+tt = []
+for _ in range(3):
+    t = time.perf_counter(); o3 = in_flight(); torch.cuda.synchronize(); tt.append(time.perf_counter() - t)
+t_three = float(np.median(tt)) / 12.0
+three_equal = bool(all(torch.equal(o[0], q_one) for o in o3))
 Rg = torch.cat([sim.generate(min(5000, B - c), N, seed=1 + c, device=dev).R_gt for c in range(0, min(B, 5000), 5000)])
 dq = res.rotation_matrices()[: Rg.shape[0]]
 err = torch.acos(((dq.transpose(-1, -2) @ Rg).diagonal(dim1=-2, dim2=-1).sum(-1).clamp(-1, 3) - 1).clamp(-2, 2) / 2).mul(180 / np.pi)
@@ -74,6 +98,8 @@ print(json.dumps({
                "weighted_es+scf": t_wes * 1e3, "ls_refinement": t_ls * 1e3},
     "gpu_pairs_per_s_full_pipeline": B / (t_ran + t_sel + t_wes + t_ls),
     "gpu_ms_one_call_pipeline": t_one * 1e3, "gpu_pairs_per_s_one_call_pipeline": B / t_one,
+    "gpu_ms_per_call_three_in_flight": t_three * 1e3, "gpu_pairs_per_s_three_calls_in_flight": B / t_three,
+    "three_in_flight_bitwise_equals_one_call": three_equal,
     "one_call_bitwise_equals_stage_by_stage": one_call_equals_stages,
     "mean_inliers": float(cnt.double().mean()), "mean_ransac_iterations": float(its.double().mean()),
     "median_rot_err_deg_vs_ground_truth": float(err.median()),
