@@ -159,6 +159,10 @@ def test_bench_chain_workload_two_ranks_share_the_gpu():
     assert two["unit"] == one["unit"] == "pairs/s" and "chain" in two and "roofline" not in two
     assert 0.8 < two["chain"]["inlier_share_mean"] < 0.95                    # 10 % gross mismatches rejected
     assert two["records_sha256"] == one["records_sha256"]
+    # ... and steps in flight (each on its own stream and copy of the batch; the default is three) against one at a time
+    assert one["chain"]["steps_in_flight"] == 3 and one["chain"]["pairs_per_s_one_step_at_a_time"] > 0
+    seq = _run_bench(["--gpus", "1", "--workload", "kitti_all", "--chain", "--steps", "2", "--warmup", "1", "--in-flight", "1"])
+    assert seq["chain"]["steps_in_flight"] == 1 and seq["records_sha256"] == one["records_sha256"]
 
 
 RCCL_ONE_RANK = r'''
