@@ -1923,6 +1923,7 @@ struct Ransac2Lds {
   double models[kHypPerRound][12];   // R (9) + t (3) of the hypotheses of the pair being scored
   double best_model[2][12];          // R (9) + t (3) per pair
   double G[2][36];                   // sums of the inliers of the best model
+  double parked[32];                 // a finished pair waiting for the kernel's end while its slot is lent (see below)
 };
 
 // es_minimise_quad<1> for a QUEUE of problems: problem slot s has its sums at Gtab[s], its start at tv[s]; on return
@@ -2095,13 +2096,14 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
   int n[2], stride[2], it[2] = {0, 0}, best_count[2] = {-1, -1};
   const double *base[2];
   double k[2] = {1.0, 1.0}, v0[2][3], R0[2][9];
-  bool stop[2], can_sample[2];
+  bool stop[2], can_sample[2], exists[2];
+  bool lent = false;  // slot 1 works for slot 0's pair (its second sixteen hypotheses of a round)
 #pragma unroll
   for (int pp = 0; pp < 2; ++pp) {
     pair[pp] = 2 * (int64_t)blockIdx.x + pp;
-    const bool exists = pair[pp] < a.n_pairs;
-    const int64_t pq = exists ? pair[pp] : 0;
-    n[pp] = exists ? a.count[pq] : 0;
+    exists[pp] = pair[pp] < a.n_pairs;
+    const int64_t pq = exists[pp] ? pair[pp] : 0;
+    n[pp] = exists[pp] ? a.count[pq] : 0;
     stride[pp] = (n[pp] + kWave - 1) & ~(kWave - 1);
     base[pp] = a.data + a.block_offset[pq];
     double q0[4] = {a.init_q[4 * pq], a.init_q[4 * pq + 1], a.init_q[4 * pq + 2], a.init_q[4 * pq + 3]};
@@ -2109,7 +2111,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
     for (int c = 0; c < 4; ++c) q0[c] *= qn;
     rot_from_quat(q0, R0[pp]);
     rot_to_cayley(R0[pp], v0[pp]);
-    can_sample[pp] = exists && n[pp] >= ss && ss >= 1;
+    can_sample[pp] = exists[pp] && n[pp] >= ss && ss >= 1;
     stop[pp] = !can_sample[pp];
   }
   unsigned long long ph_clk[kPhCount] = {0};
@@ -2128,6 +2130,57 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
     for (int pp = 0; pp < 2; ++pp) {
       go[pp] = !stop[pp] && (double)it[pp] < k[pp];
       if (!go[pp]) stop[pp] = true;
+    }
+    // ---- A pair whose partner is done takes the partner's slot as well: from its next round on, slot 1 works on the
+    // pair's SECOND sixteen hypotheses of the round (it + 16 ...), consumed after slot 0's by the same sequential rule.
+    // The long pairs are the ones a launch ends with (a quarter of it is their tail): half as many rounds for them.
+    // The finished pair waits in LDS for the kernel's end.  All of this is state shuffling at a round's boundary --
+    // the round's code does not know; and since neither slot nor round enters a hypothesis' arithmetic: same bits.
+    if (!lent && go[0] != go[1]) {
+      auto park = [&](auto dc) {  // the done (or absent) pair of slot D
+        constexpr int D = decltype(dc)::value;
+        if (lane == 0) {
+          lds.parked[0] = (double)it[D];
+          lds.parked[1] = (double)n[D];
+          lds.parked[2] = exists[D] ? 1.0 : 0.0;
+          lds.parked[3] = can_sample[D] ? 1.0 : 0.0;
+          lds.parked[4] = (double)pair[D];   // (exact: pair indices are far below 2^53)
+#pragma unroll
+          for (int i = 0; i < 9; ++i) lds.parked[5 + i] = R0[D][i];
+        }
+        if (lane < 12) lds.parked[16 + lane] = lds.best_model[D][lane];
+      };
+      if (go[0]) {
+        park(std::integral_constant<int, 1>{});
+      } else {
+        park(std::integral_constant<int, 0>{});
+        lds_sync();
+        // the pair that goes on moves to slot 0 (slot 1's hypotheses are consumed second)
+        pair[0] = pair[1]; n[0] = n[1]; stride[0] = stride[1]; base[0] = base[1];
+        it[0] = it[1]; best_count[0] = best_count[1]; k[0] = k[1];
+        can_sample[0] = can_sample[1]; exists[0] = exists[1]; stop[0] = false; go[0] = true;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v0[0][i] = v0[1][i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R0[0][i] = R0[1][i];
+        if (lane < 12) lds.best_model[0][lane] = lds.best_model[1][lane];
+      }
+      pair[1] = pair[0]; n[1] = n[0]; stride[1] = stride[0]; base[1] = base[0];
+      can_sample[1] = can_sample[0];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) v0[1][i] = v0[0][i];
+      lent = true;
+      lds_sync();
+    }
+    if (lent) {  // slot 1 continues where slot 0's sixteen end
+      it[1] = it[0] + kHypPerRound;
+      k[1] = k[0];
+      best_count[1] = best_count[0];
+      stop[1] = false;
+      go[1] = go[0] && it[0] > 0 && (double)it[1] < k[1];  // (the first round evaluates 16 hypotheses, as ever)
+    }
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
       // the first round evaluates all 16 hypotheses; a later round only those that can still be consumed (see the
       // one-pair kernel)
       needed[pp] = !go[pp] ? 0 : (it[pp] == 0 ? kHypPerRound : (int)fmin(ceil(k[pp] - (double)it[pp]), (double)kHypPerRound));
@@ -2273,14 +2326,43 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
       PNEC_PHASE_END(kRpScore);
       if (winner >= 0 && lane < 12) lds.best_model[pp][lane] = lds.models[winner][lane];
       lds_sync();
+      if (lent) {
+        if (pp == 0) {  // slot 1 consumes next, from where this slot's rule stands now
+          k[1] = k[0];
+          best_count[1] = best_count[0];
+          if (stop[0]) go[1] = false;
+        } else {        // what slot 1 consumed is the pair's: hand it back
+          // (slot 1 only runs when slot 0 consumed its full sixteen: it[0] is where slot 1 started)
+          it[0] = it[1];
+          k[0] = k[1];
+          best_count[0] = best_count[1];
+          stop[0] = stop[0] || stop[1];
+          if (winner >= 0 && lane < 12) lds.best_model[0][lane] = lds.best_model[1][lane];
+          lds_sync();
+        }
+      }
       PNEC_PHASE_END(kRpConsume);
     }
+  }
+  if (lent) {  // the pair that waited goes back into slot 1 for the common ending
+    lds_sync();
+    it[1] = (int)lds.parked[0];
+    n[1] = (int)lds.parked[1];
+    exists[1] = lds.parked[2] != 0.0;
+    can_sample[1] = lds.parked[3] != 0.0;
+    pair[1] = (int64_t)lds.parked[4];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R0[1][i] = lds.parked[5 + i];
+    stride[1] = (n[1] + kWave - 1) & ~(kWave - 1);
+    base[1] = a.data + a.block_offset[exists[1] ? pair[1] : 0];
+    if (lane < 12) lds.best_model[1][lane] = lds.parked[16 + lane];
+    lds_sync();
   }
   // ---- per pair: inliers of the best model (all correspondences when sampling is impossible), their 36 sums, the
   // first inlier; handed to es_batch_kernel<kEpiTranslation> as in the one-pair kernel
 #pragma unroll
   for (int pp = 0; pp < 2; ++pp) {
-    if (pair[pp] >= a.n_pairs) continue;
+    if (!exists[pp]) continue;
     const double *bs = base[pp];
     const int st = stride[pp], nn = n[pp];
     double bR[9], bt[3] = {0.0, 0.0, 1.0};
