@@ -627,6 +627,54 @@ def test_ransac_scoring_tile_boundaries_and_early_drop_vs_oracle(oracle, outlier
         assert rounds > 3 * len(sizes)   # the sequential rule ran across rounds, not just inside the first
 
 
+TWO_PAIR_HARD = r'''
+import os, sys
+sys.path.insert(0, os.environ["PNEC_ROOT"])
+import numpy as np
+from oracle import pnec_oracle as oracle
+from pnec_amd import Batch, capi
+from pnec_amd import simulation as sim
+sizes = [64, 100, 129, 300, 448, 511, 512, 513, 576, 700, 1100, 37, 5, 256, 384] * 3   # 45 pairs (odd: a wavefront with one)
+offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+rng = np.random.default_rng(23)
+f1s, f2s, cvs, Rs, qs = [], [], [], [], []
+for p, n in enumerate(sizes):
+    g = sim.generate(1, n, seed=700 + p)
+    f2 = g.bvs2[0].numpy().copy()
+    bad = rng.choice(n, int((0.25 + 0.25 * (p % 3 == 0)) * n), replace=False)     # 25 % / 50 % gross outliers
+    v = rng.normal(size=(len(bad), 3))
+    f2[bad] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    f1s.append(g.bvs1[0].numpy()); f2s.append(f2); cvs.append(g.covs2[0].numpy())
+    Rs.append(g.init_R[0].numpy()); qs.append(g.init_q[0].numpy())
+f1, f2, c2 = np.concatenate(f1s), np.concatenate(f2s), np.concatenate(cvs)
+with Batch(capi.MODE_TARGET, offsets) as b:
+    b.fill(f1, f2, c2)
+    q, t, mask, cnt, its = b.ransac_eigensolver(np.stack(qs), seed=9)
+long_pairs = 0
+for p, n in enumerate(sizes):
+    sl = slice(offsets[p], offsets[p + 1])
+    Ro, to, mo, ito = oracle.ransac_eigensolver(f1[sl], f2[sl], Rs[p], seed=9, pair_id=p)
+    assert its[p] == ito, (p, n, its[p], ito)
+    assert (mask[sl].astype(bool) == mo).all(), (p, n)
+    assert cnt[p] == mo.sum(), (p, n)
+    long_pairs += ito > 48
+assert long_pairs >= 10, long_pairs     # pairs that ran for rounds with the wavefront to themselves
+print("TWO_PAIR_HARD_OK", long_pairs)
+'''
+
+
+def test_two_pair_ransac_with_a_lent_slot_on_hard_pairs_vs_oracle():
+    """The two-pair RANSAC kernel (normally from 4 096 pairs up; forced here) on 45 ragged pairs with 25 % and 50 % gross
+    outliers: the pairs that need many rounds outlive their partners and run their rounds over BOTH slot groups (the
+    finished partner parked in LDS, pnec_frontend.hip).  Masks, counts and iteration numbers equal the oracle's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PNEC_ROOT=root, PNEC_RANSAC_FORM="2")
+    r = subprocess.run([sys.executable, "-c", TWO_PAIR_HARD], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "TWO_PAIR_HARD_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_device_buffer_cache_reuses_and_releases():
     """batches created and destroyed in a loop reuse cached device buffers; release_cache returns them"""
     L = capi.lib()
