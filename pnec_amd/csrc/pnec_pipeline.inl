@@ -128,16 +128,22 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
                                   d_mask, d_cnt, nullptr, p->d_front, p->d_front_i, stream, fork ? p->side_streams[0] : nullptr,
                                   fork ? p->fork_event : nullptr, fork ? p->side_done[0] : nullptr);
     if (e != hipSuccess) return fail_hip(e, "ransac_eigensolver_kernel");
-    // (the cached InlierExtraction target has the capacity of the source; a re-shaped source is re-synced into it
-    // by select_into, by layout generation)
-    if (!p->sel_view || p->sel_view->cap_doubles < p->data_doubles || p->sel_view->cap_pairs < P) {
-      if (p->sel_view) pnec_hip_problem_destroy(p->sel_view);
-      p->sel_view = nullptr;
-      if (int rc = alloc_like(p, stream, &p->sel_view)) return rc;
+    // InlierExtraction -- when a later stage works on the inliers.  With use_nec and no refinement (what the
+    // reference's odometry forces, frame2frame.cc:127-128) or with neither weighted iterations nor refinement the chain
+    // ends at the eigensolver's pose: the inlier mask and count are the outputs, and the copy would feed nothing.
+    const bool inliers_used = o.use_ceres || (!o.use_nec && o.weighted_iterations > 1);
+    if (inliers_used) {
+      // (the cached InlierExtraction target has the capacity of the source; a re-shaped source is re-synced into it
+      // by select_into, by layout generation)
+      if (!p->sel_view || p->sel_view->cap_doubles < p->data_doubles || p->sel_view->cap_pairs < P) {
+        if (p->sel_view) pnec_hip_problem_destroy(p->sel_view);
+        p->sel_view = nullptr;
+        if (int rc = alloc_like(p, stream, &p->sel_view)) return rc;
+      }
+      if (int rc = select_into(p, d_mask, stream, p->sel_view, d_cnt)) return rc;  // (RANSAC counted the mask it wrote)
+      stage = p->sel_view;
     }
-    if (int rc = select_into(p, d_mask, stream, p->sel_view, d_cnt)) return rc;  // (RANSAC counted the mask it wrote)
     if (fork) PNEC_HIP_TRY(hipStreamWaitEvent(stream, p->side_done[0], 0));  // es_q / es_t are there from here on
-    stage = p->sel_view;
   } else {
     e = launch_nec_eigensolver(p->d_data, p->d_block_offset, p->d_count, P, d_iq, es_q, es_t, nullptr, p->d_front,
                                p->d_front_i, stream);

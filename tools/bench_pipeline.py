@@ -54,6 +54,10 @@ t_ls, res = timed(lambda: sel.solve(qw, tw))
 # the product path: the whole chain as ONE call (pnec_hip_solve_pipeline; no host synchronisation between stages)
 t_one, (q_one, t_one_t) = timed(lambda: batch.solve_pipeline(q0, t0), reps=5)
 one_call_equals_stages = bool(torch.equal(q_one, res.q) and torch.equal(t_one_t, res.t))
+# what the reference's odometry actually runs per frame pair: Frame2Frame forces use_nec, no refinement
+# (frame2frame.cc:127-128, quirk C2): the chain ends at the RANSAC eigensolver's pose (no InlierExtraction needed)
+o_vo = capi.default_pipeline_options(use_nec=1, use_ceres=0)
+t_vo, _ = timed(lambda: batch.solve_pipeline(q0, t0, o_vo), reps=5)
 # ... and with three calls in flight, each on its own stream and its own copy of the batch: the stages end in tails of a
 # few long pairs (a quarter of the RANSAC launch at this size); the next call's work fills them
 streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
@@ -100,6 +104,8 @@ print(json.dumps({
                "weighted_es+scf": t_wes * 1e3, "ls_refinement": t_ls * 1e3},
     "gpu_pairs_per_s_full_pipeline": B / (t_ran + t_sel + t_wes + t_ls),
     "gpu_ms_one_call_pipeline": t_one * 1e3, "gpu_pairs_per_s_one_call_pipeline": B / t_one,
+    "gpu_ms_one_call_odometry_options": t_vo * 1e3, "gpu_pairs_per_s_one_call_odometry_options": B / t_vo,
+    "odometry_options": "use_nec, no refinement -- what Frame2Frame forces (frame2frame.cc:127-128)",
     "gpu_ms_per_call_three_in_flight": t_three * 1e3, "gpu_pairs_per_s_three_calls_in_flight": B / t_three,
     "three_in_flight_bitwise_equals_one_call": three_equal,
     "one_call_bitwise_equals_stage_by_stage": one_call_equals_stages,
