@@ -94,7 +94,14 @@ int main(int argc, char **argv) {
     // one frame pair per call through the whole default chain, as the odometry front end calls it
     // (frame2frame.cc:129-132): PNEC::Solve(bvs1, bvs2, covs, init, inliers), host arrays in, pose out
     const int reps = argc > 3 ? std::atoi(argv[3]) : 300;
+    // optional 4th argument "vo": the options Frame2Frame forces whatever the configuration says -- use_nec, no
+    // refinement (frame2frame.cc:127-128)
+    const bool vo = argc > 4 && std::strcmp(argv[4], "vo") == 0;
     pnec::rel_pose_estimation::Options options;
+    if (vo) {
+      options.use_nec_ = true;
+      options.use_ceres_ = false;
+    }
     pnec::rel_pose_estimation::PNEC pnec_solver(options);
     const pnec::SE3d init(pnec::Quaterniond(0.975, 0.1, -0.14, 0.115).normalized().toRotationMatrix(),
                           pnec::Vector3d(0.28, -0.22, 0.92).normalized());
@@ -111,9 +118,11 @@ int main(int argc, char **argv) {
       n_inl = inliers.size();
     }
     std::sort(us.begin(), us.end());
-    std::printf("{\"call\": \"PNEC::Solve, reference-default Options (RANSAC eigensolver, weighted eigensolver + SCF, refinement), "
+    std::printf("{\"call\": \"PNEC::Solve, %s, "
                 "host arrays in, pose + inliers out\", \"correspondences\": %d, \"inliers\": %zu, \"reps\": %d, "
                 "\"median_us\": %.1f, \"p10_us\": %.1f, \"p90_us\": %.1f, \"checksum\": %.6f}\n",
+                vo ? "the odometry's forced Options (use_nec, no refinement: RANSAC eigensolver only)"
+                   : "reference-default Options (RANSAC eigensolver, weighted eigensolver + SCF, refinement)",
                 n, n_inl, reps, us[us.size() / 2], us[us.size() / 10], us[us.size() * 9 / 10], sink / reps);
     return 0;
   }
