@@ -305,6 +305,9 @@ int pnec_hip_stream_wait(pnec_hip_stream *s, int64_t ticket, double *out_q, doub
  *   load    only the ingest (arrays -> SoA planes of the handle's batch, asynchronous on the handle's stream);
  *           *problem is the handle's batch, valid until the next load / solve / destroy, for callers that run the
  *           stages one by one (the timed PNEC::Solve overloads, pnec.cc:135-208) on pnec_hip_frame_stream().
+ *           The caller's arrays are copied into the handle's pinned staging block before load returns (they may be
+ *           reused at once); load first waits for everything queued earlier on the handle's stream, because the
+ *           previous ingest reads that staging block when it executes -- two loads in a row are safe, not overlapped.
  * n <= max_corr (pnec_hip_frame_capacity).  Not thread-safe: one handle per thread. */
 typedef struct pnec_hip_frame pnec_hip_frame;
 int pnec_hip_frame_create(int device, int64_t max_corr, void *stream, pnec_hip_frame **out);

@@ -15,6 +15,8 @@ LIB_PATH = os.environ.get("PNEC_HIP_LIB") or os.path.join(_HERE, "libpnec_hip.so
 ABI_VERSION = 3  # PNEC_HIP_ABI_VERSION of include/pnec_hip.h this binding was written against
 MODE_NEC, MODE_TARGET, MODE_HOST, MODE_SYM = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
+# pnec_hip_status
+OK, ERR_INVALID_ARGUMENT, ERR_HIP_RUNTIME, ERR_UNSUPPORTED, ERR_BUSY = 0, -1, -2, -3, -4
 TERM_NAMES = {
     0: "function_tolerance",
     1: "parameter_tolerance",

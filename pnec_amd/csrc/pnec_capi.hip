@@ -1125,7 +1125,9 @@ int pnec_hip_problem_reshape(pnec_hip_problem *p, int64_t n_pairs, const int64_t
 static int problem_reshape_impl(pnec_hip_problem *p, int64_t n_pairs, const int64_t *offsets, hipStream_t stream,
                                 bool upload) {
   if (!p) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "problem is NULL");
-  if (p->cap_pairs <= 0 || !p->owns_data)
+  // (d_meta: the index arrays in ONE block, which only pnec_hip_problem_create[_capacity] makes -- an InlierExtraction
+  // target has capacity too, but its index arrays are separate allocations that upload_meta would leak and replace)
+  if (p->cap_pairs <= 0 || !p->owns_data || !p->d_meta)
     return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "not a capacity-shaped batch (pnec_hip_problem_create_capacity)");
   std::vector<int64_t> block_offset;
   std::vector<int32_t> count;
@@ -1826,6 +1828,8 @@ static int select_into(pnec_hip_problem *src, const uint8_t *d_mask, hipStream_t
   dst->lazy_stream = stream;
   dst->n_corr = src->n_corr;
   dst->n_max = src->n_max;
+  dst->n_pairs = P;
+  dst->data_doubles = src->data_doubles;  // (also when the block layout is unchanged but the pair's size is not)
   if (dst->host_counts != src->host_counts) {  // a re-shaped source: the launch geometries follow its new bounds
     dst->host_counts = src->host_counts;
     dst->offsets = src->offsets;

@@ -214,26 +214,6 @@ __device__ __forceinline__ double wave_allreduce_sum(double x) {
   return x;
 }
 
-// smallest value over the 64 lanes (fmin: a NaN loses against a number); every lane ends with it
-__device__ __forceinline__ double wave_allreduce_min(double x) {
-  x = fmin(x, dpp_perm<0xB1>(x));
-  x = fmin(x, dpp_perm<0x4E>(x));
-  x = fmin(x, dpp_perm<0x141>(x));
-  x = fmin(x, dpp_perm<0x140>(x));
-  {
-    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
-    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    x = fmin(make_double((int)b[0], (int)a[0]), make_double((int)b[1], (int)a[1]));
-  }
-  {
-    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
-    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    x = fmin(make_double((int)b[0], (int)a[0]), make_double((int)b[1], (int)a[1]));
-  }
-  return x;
-}
 
 // Sum each of the 21 accumulators over the 64 lanes and return the sums in scalar registers.
 // v_permlane32_swap / v_permlane16_swap exchange half of one register with the other half of

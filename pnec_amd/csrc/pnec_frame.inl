@@ -130,8 +130,13 @@ int pnec_hip_frame_load(pnec_hip_frame *f, int64_t n, const double *bvs1, const 
   if (n < 0 || n > f->max_corr) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "more correspondences than the handle was created for");
   if (n > 0 && (!bvs1 || !bvs2)) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bvs1/bvs2 is NULL");
   DeviceGuard guard(f->device);
-  // the previous frame's kernels read the staging block and the batch: they are done (every call synchronises
-  // the stream before it returns), so both may be overwritten
+  // The ingest kernel reads the staging block over PCIe when it EXECUTES, and this call only enqueues it: a second
+  // load -- or a load after DEVICE-space stage calls the caller queued on the handle's stream -- must not overwrite
+  // bearings the GPU is still reading.  pnec_hip_frame_solve leaves the stream drained, so this costs a query there.
+  {
+    const hipError_t es = hipStreamSynchronize(f->stream);
+    if (es != hipSuccess) return fail_hip(es, "pnec_hip_frame_load: work queued earlier on the handle's stream failed");
+  }
   f->loaded = -1;
   char *h = f->h_base, *d = f->d_base;
   if (n > 0) {

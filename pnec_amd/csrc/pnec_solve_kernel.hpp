@@ -140,8 +140,12 @@ enum : int { kIIter = 0, kIFirst, kIReuseDiag, kINumInvalid, kIStepOk,
 __host__ __device__ constexpr bool geometry_ok(int mode, int cpl, int wpp, int ldsk) {
   const int nc = num_components(mode);
   if (cpl == 12) return wpp == 1 && ldsk == 3 && nc <= 12;  // (8, 1, 3) + tail: the 6- and 12-plane payloads
-  const long lds = (long)wpp * (ldsk * nc * kWave * 8 + (kSlab + kUnif) * 8 + kINumI * 4) + (wpp > 1 ? 2L * wpp * kSumSlots * 8 : 0) +
-                   16 * 8 * 4 /* gather offsets of lm_advance_rows (A/B build) */;
+#ifdef PNEC_ADVANCE_ROWS
+  constexpr long ab_lds = 16 * 8 * 4;  // gather offsets of lm_advance_rows (A/B build only)
+#else
+  constexpr long ab_lds = 0;
+#endif
+  const long lds = (long)wpp * (ldsk * nc * kWave * 8 + (kSlab + kUnif) * 8 + kINumI * 4) + (wpp > 1 ? 2L * wpp * kSumSlots * 8 : 0) + ab_lds;
   if (lds > 160 * 1024) return false;
   if (cpl == 8 && ldsk == 0) return nc <= 18;
   return nc * (cpl - ldsk) <= 72;

@@ -85,9 +85,10 @@ class Stream:
 
     def wait(self, ticket: int) -> SolveResult:
         P = self._pairs.get(int(ticket))
-        if P is None:   # let the library name the problem (INVALID_ARGUMENT: unknown or already collected ticket)
-            capi.check(self._lib.pnec_hip_stream_wait(self._h, int(ticket), None, None, None, None, None))
-            raise capi.PnecHipError(-1, "unknown or already collected ticket")
+        if P is None:
+            # not a ticket this object handed out (or one already collected).  The library is NOT asked: a wait with
+            # NULL outputs on a ticket it does know would consume it and drop its results.
+            raise capi.PnecHipError(capi.ERR_INVALID_ARGUMENT, "unknown or already collected ticket")
         del self._pairs[int(ticket)]
         out = SolveResult(np.empty((P, 4)), np.empty((P, 3)), np.empty(P), np.empty(P, dtype=np.int32),
                           np.empty(P, dtype=np.int32))

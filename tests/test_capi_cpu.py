@@ -94,3 +94,35 @@ def test_fails_loudly_without_gpu():
     with pytest.raises(capi.PnecHipError) as ei:
         Batch.uniform(capi.MODE_TARGET, 2, 10)
     assert ei.value.code == -2
+
+
+def test_hand_written_loads_are_not_touched_between_issue_and_wait():
+    """The scalar-base global loads of pnec_device.hpp are issued by one asm statement and waited for by a later one;
+    the compiler may legally move a copy or a spill of the destination in between (it believes the register written
+    when the issue statement returns).  tools/check_asm_loads.py reads the gfx950 code of the BUILT library and fails
+    when any instruction names such a destination before the s_waitcnt that retires the load; the Makefile runs it
+    after every link.  Here: the checker itself on hand-made listings (it must see a violation when there is one),
+    then on the library the other tests load."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_asm_loads", os.path.join(ROOT, "tools", "check_asm_loads.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    good = """0000 <k>:
+	s_mov_b64 s[4:5], s[2:3]
+	global_load_dwordx2 v[28:29], v186, s[4:5]
+	v_mov_b64_e32 v[30:31], 0
+	s_mov_b64 s[4:5], s[2:3]
+	global_load_dwordx2 v[30:31], v186, s[4:5] offset:512
+	s_waitcnt vmcnt(0)
+	v_add_f64 v[2:3], v[28:29], v[30:31]
+	s_endpgm""".split("\n")
+    assert chk.check_disassembly(good) == (2, [])
+    moved = list(good)
+    moved.insert(6, "\tv_mov_b32_e32 v40, v29")                     # a copy of a register whose load is in flight
+    assert len(chk.check_disassembly(moved)[1]) == 1
+    short = [l.replace("vmcnt(0)", "vmcnt(1)") for l in good]       # the wait leaves the second load outstanding
+    assert len(chk.check_disassembly(short)[1]) == 1
+    if not os.path.exists(chk.OBJDUMP):
+        pytest.skip("no llvm-objdump in this image")
+    seen, bad = chk.check_disassembly(chk.disassemble(capi.LIB_PATH))
+    assert seen > 500 and bad == [], bad[:5]
