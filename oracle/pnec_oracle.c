@@ -206,6 +206,25 @@ double pnec_oracle_cost_function(int64_t n, const double *bvs1, const double *bv
 }
 
 /* ------------------------------------------------------------------ covariance propagation */
+/* pnec::common::RotationBetweenPoints(point1, point2) (common.cc:118-124): I + [v]x + [v]x^2 / (1 + c), v = p1 x p2,
+ * c = p1.p2, for unit vectors (the C++ does not normalise; scripts/pnec/math.py:42-64 does, which is the same thing for
+ * unit input).  Column-major output, like every 3x3 this file hands out. */
+void pnec_oracle_rotation_between_points(const double p1[3], const double p2[3], double Rm[9]) {
+  double c[3], K[9], K2[9];
+  cross3(p1, p2, c);
+  skew(c, K); /* row-major */
+  const double d = dot3(p1, p2);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0.0;
+      for (int k = 0; k < 3; ++k) a += K[3 * i + k] * K[3 * k + j];
+      K2[3 * i + j] = a;
+    }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      Rm[3 * j + i] = (i == j ? 1.0 : 0.0) + K[3 * i + j] + K2[3 * i + j] / (1.0 + d);
+}
+
 /* common.cc:118-124 with point1 = (0,0,1); column-major output */
 static void rotation_from_z(const double v[3], double Rm[9]) {
   const double z[3] = {0.0, 0.0, 1.0};

@@ -105,6 +105,8 @@ def lib() -> C.CDLL:
                                                  C.POINTER(Options), C.c_int, _dp, _dp, _dp, _ip,
                                                  _ip]
         _lib.pnec_oracle_max_threads.restype = C.c_int
+        _lib.pnec_oracle_rotation_between_points.argtypes = [_dp, _dp, _dp]
+        _lib.pnec_oracle_rotation_between_points.restype = None
         _lib.pnec_oracle_unscented_transform.argtypes = [_dp, _dp, _dp, C.c_double, C.c_int, _dp]
         _lib.pnec_oracle_unproject.argtypes = [_dp, _dp, _dp]
         _lib.pnec_oracle_sym_eig3.argtypes = [_dp, _dp, _dp]
@@ -165,6 +167,15 @@ def covs_to_colmajor9(covs: np.ndarray) -> np.ndarray:
 
 
 CAMERA_OMNIDIRECTIONAL, CAMERA_PINHOLE = 0, 1
+
+
+def rotation_between_points(p1, p2):
+    """common.cc:118-124 (unit vectors in, 3x3 numpy matrix out: p2 = R p1)."""
+    a, ap = _d(p1)
+    b, bp = _d(p2)
+    out = np.zeros(9)
+    lib().pnec_oracle_rotation_between_points(ap, bp, out.ctypes.data_as(_dp))
+    return out.reshape(3, 3).T
 
 
 def unscented_transform(mu, cov, K_inv=None, kappa=1.0, camera_model=CAMERA_PINHOLE):

@@ -12,6 +12,10 @@ Reference functions exercised (scripts/pnec/...):
   common.pnec_energy_translations common.py:62-86
   math.skew, math.unscented_transform (diagonal covariances only: for non-diagonal ones the
       Python uses ROWS of the Cholesky factor where the C++ uses COLUMNS -- SURVEY.md 8c)
+  math.rotation_between_points   math.py:42-64     <-> RotationBetweenPoints (common.cc:118-124)
+  math.unscented_transform(..., omnidirectional=True)  math.py:73-123: covariances that are DIAGONAL in the tangent
+      frame of the point (cov = Rb diag(a, b, 0) Rb', Rb = rotation_between_points(z, point)) -- the same restriction
+      as the pinhole case, for the same reason (rows vs columns of the 2x2 Cholesky factor)
   scf.fibonacci_sphere, scf.obj_fun   scf.py
 """
 import os
@@ -105,6 +109,23 @@ def main():
     covs[:, 0, 0] = diag[:, 0]
     covs[:, 1, 1] = diag[:, 1]
     ut = np.stack([rm.unscented_transform(pts[i], covs[i], False, 1.0) for i in range(16)])
+    # rotation_between_points + the omnidirectional branch of the unscented transform (round 4; a generator of their
+    # own, so that the earlier fixtures keep their values)
+    rng4 = np.random.default_rng(404)
+    rb_p1 = random_bearings(rng4, 12)
+    rb_p2 = random_bearings(rng4, 12)
+    rb_p1[0], rb_p2[0] = np.array([0.0, 0.0, 1.0]), np.array([0.0, 0.0, 1.0])            # identity
+    rb_p1[1], rb_p2[1] = np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0])            # a quarter turn
+    rb_out = np.stack([rm.rotation_between_points(rb_p1[i], rb_p2[i]) for i in range(12)])
+    omni_pts = random_bearings(rng4, 24) * rng4.uniform(4.0, 8.0, size=(24, 1))             # sphere of radius U(4, 8) (experiments.cc:109-126)
+    omni_pts[:, 2] = np.abs(omni_pts[:, 2]) + 0.2                                        # away from the antipode of +z
+    omni_pts[0] = np.array([0.0, 0.0, 5.0])                                              # on the axis: Rb = I
+    omni_diag = rng4.uniform(0.2, 2.0, size=(24, 2)) * 1e-4
+    omni_covs = np.zeros((24, 3, 3))
+    for i in range(24):
+        Rb = rm.rotation_between_points(np.array([0.0, 0.0, 1.0]), omni_pts[i] / np.linalg.norm(omni_pts[i]))
+        omni_covs[i] = Rb @ np.diag([omni_diag[i, 0], omni_diag[i, 1], 0.0]) @ Rb.T
+    omni_out = np.stack([rm.unscented_transform(omni_pts[i], omni_covs[i], True, 1.0) for i in range(24)])
     fib = np.asarray(rs.fibonacci_sphere(500))
     # scf.obj_fun (hard-wired to k = 10 matrices): sum_i x'A_i x / x'B_i x
     nvec = rng.normal(size=(10, 3))
@@ -116,6 +137,8 @@ def main():
     obj = rs.obj_fun(X, Ai, Bi)
     np.savez_compressed(os.path.join(HERE, "math_golden.npz"), skew_in=vs, skew_out=skews,
                         ut_points=pts, ut_covs=covs, ut_out=ut, fibonacci_500=fib,
+                        rb_p1=rb_p1, rb_p2=rb_p2, rb_out=rb_out,
+                        omni_points=omni_pts, omni_covs=omni_covs, omni_diag=omni_diag, omni_out=omni_out,
                         obj_Ai=Ai, obj_Bi=Bi, obj_X=X, obj_out=obj)
     print(f"wrote {idx} energy cases, math goldens")
 

@@ -279,3 +279,23 @@ def test_unscented_transform_oracle_vs_reference_goldens(oracle, golden_dir):
         b = oracle.unproject(mu[:2], np.linalg.inv(K))
         p = np.linalg.inv(K) @ np.array([mu[0], mu[1], 1.0])
         np.testing.assert_allclose(b, p / np.linalg.norm(p), atol=1e-15)
+
+
+def test_rotation_between_points_and_omnidirectional_unscented_transform_goldens(oracle, golden_dir):
+    """Round-4 pins: scripts/pnec/math.py:42-64 (rotation_between_points <-> RotationBetweenPoints, common.cc:118-124)
+    and the omnidirectional branch of math.py:73-123 (<-> common.cc:476-483) for covariances that are diagonal in the
+    point's tangent frame -- the case in which the reference's Python (rows of the Cholesky factor) and its C++
+    (columns) agree.  Checked: the C restatement, and the harness's torch versions the simulator uses."""
+    z = np.load(f"{golden_dir}/math_golden.npz")
+    for p1, p2, want in zip(z["rb_p1"], z["rb_p2"], z["rb_out"]):
+        got = oracle.rotation_between_points(p1, p2)
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-14)       # (1 / (1 + c) amplifies the last bits)
+        np.testing.assert_allclose(got @ p1, p2, atol=2e-14)
+    zs = z["rb_p1"][:2]                                               # the two cases that start at +z: the harness's form
+    got = sim.rotation_between_z_and(torch.from_numpy(z["rb_p2"][:2])).numpy()
+    assert np.array_equal(zs, np.array([[0.0, 0.0, 1.0]] * 2))
+    np.testing.assert_allclose(got, z["rb_out"][:2], atol=1e-15)
+    for i in range(len(z["omni_points"])):
+        got = oracle.unscented_transform(z["omni_points"][i], z["omni_covs"][i], None, 1.0, oracle.CAMERA_OMNIDIRECTIONAL)
+        np.testing.assert_allclose(got, z["omni_out"][i], rtol=1e-9, atol=1e-20)
+    assert np.linalg.norm(z["omni_out"], axis=(1, 2)).min() > 1e-8     # (the tolerances above mean something)

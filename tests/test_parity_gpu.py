@@ -429,6 +429,10 @@ def test_unscented_transform_device_vs_oracle_and_goldens(oracle, golden_dir):
     bvs, covs = frontend.unscented_transform(z["ut_points"], z["ut_covs"])
     np.testing.assert_allclose(covs, z["ut_out"], rtol=1e-10, atol=1e-22)
     np.testing.assert_allclose(bvs, z["ut_points"] / np.linalg.norm(z["ut_points"], axis=1, keepdims=True), atol=1e-15)
+    # the omnidirectional branch against the reference's Python (round-4 goldens: tangent-diagonal covariances)
+    bo, co = frontend.unscented_transform(z["omni_points"], z["omni_covs"], np.eye(3), 1.0, frontend.CAMERA_OMNIDIRECTIONAL)
+    np.testing.assert_allclose(co, z["omni_out"], rtol=1e-9, atol=1e-20)
+    np.testing.assert_allclose(bo, z["omni_points"] / np.linalg.norm(z["omni_points"], axis=1, keepdims=True), atol=1e-15)
     rng = np.random.default_rng(8)
     n = 5000
     K = np.array([[718.856, 0, 607.19], [0, 718.856, 185.22], [0, 0, 1.0]])
