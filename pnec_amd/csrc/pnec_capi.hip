@@ -32,7 +32,9 @@ hipError_t launch_solve_aos_mode_3(int, int, int, const SolveArgs &, hipStream_t
 hipError_t launch_ransac_eigensolver(const double *, const int64_t *, const int64_t *, const int32_t *, int64_t,
                                      const double *, unsigned long long, unsigned long long, int, int, double, double *, double *,
                                      uint8_t *, int32_t *, int32_t *, double *, int32_t *, hipStream_t, hipStream_t,
-                                     hipEvent_t, hipEvent_t);
+                                     hipEvent_t, hipEvent_t, int, double *, const int64_t *, int32_t *, int64_t *, void *);
+size_t ransac_workspace_bytes(int64_t);
+int64_t ransac_split_threshold();
 hipError_t launch_select(int, const double *, const int64_t *, const int64_t *, const int32_t *, const uint8_t *,
                          double *, const int64_t *, const int32_t *, int32_t *, int64_t *, int64_t, hipStream_t);
 hipError_t launch_nec_eigensolver(const double *, const int64_t *, const int32_t *, int64_t, const double *,
@@ -84,6 +86,9 @@ struct pnec_hip_problem {
   double *d_front = nullptr;
   int32_t *d_front_i = nullptr;
   int64_t front_pairs = 0;
+  // workspace of the RANSAC stage's split form (large batches; pnec_ransac_split.inl)
+  void *d_ransac_ws = nullptr;
+  size_t ransac_ws_bytes = 0;
   // ragged batches: pairs grouped by the smallest launch geometry that holds them (built lazily)
   struct Bucket {
     int cpl, wpp, ldsk;
@@ -927,6 +932,22 @@ int ensure_side_streams(pnec_hip_problem *p, size_t n) {
   return 0;
 }
 
+// the RANSAC stage's workspace, for batches large enough to run its split form (null otherwise)
+int ensure_ransac_ws(pnec_hip_problem *p) {
+  if (p->n_pairs < ransac_split_threshold()) return 0;
+  const size_t want = ransac_workspace_bytes(p->n_pairs);
+  if (want > p->ransac_ws_bytes) {
+    if (p->d_ransac_ws) (void)dev_free(p->d_ransac_ws);
+    p->d_ransac_ws = nullptr;
+    p->ransac_ws_bytes = 0;
+    char *w = nullptr;
+    PNEC_HIP_TRY(dev_alloc(&w, want));
+    p->d_ransac_ws = w;
+    p->ransac_ws_bytes = want;
+  }
+  return 0;
+}
+
 int ensure_front(pnec_hip_problem *p) {
   const int64_t P = std::max<int64_t>(p->n_pairs, 1);
   if (P > p->front_pairs) {
@@ -1182,6 +1203,7 @@ int pnec_hip_problem_destroy(pnec_hip_problem *p) {
   release(p->d_stage_i);
   release(p->d_front);
   release(p->d_front_i);
+  release(p->d_ransac_ws);
   // (the device has drained: nothing is pending on these, so the next owner starts clean)
   for (hipStream_t st : p->side_streams) {
     if (drained) pool_stream_put(st, p->device); else (void)hipStreamDestroy(st);
@@ -1718,13 +1740,16 @@ int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint6
       d_mask = tmp_mask;
     }
   }
-  if (int rc = ensure_front(p)) {
+  int rc_ws = ensure_front(p);
+  if (!rc_ws) rc_ws = ensure_ransac_ws(p);
+  if (rc_ws) {
     if (tmp_mask) (void)dev_free(tmp_mask);
-    return rc;
+    return rc_ws;
   }
   hipError_t e = launch_ransac_eigensolver(p->d_data, p->d_block_offset, p->d_offsets, p->d_count, P, d_q, seed,
                                            /*first_pair_id*/ 0ull, max_iterations, sample_size, threshold, d_oq, d_ot, d_mask, d_cnt, d_it,
-                                           p->d_front, p->d_front_i, stream, nullptr, nullptr, nullptr);
+                                           p->d_front, p->d_front_i, stream, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                                           nullptr, nullptr, p->n_pairs >= ransac_split_threshold() ? p->d_ransac_ws : nullptr);
   if (e == hipSuccess && space == PNEC_HIP_MEM_HOST) {
     e = hipMemcpyAsync(out_q, d_oq, sizeof(double) * 4 * P, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_t, d_ot, sizeof(double) * 3 * P, hipMemcpyDeviceToHost, stream);
@@ -1779,8 +1804,10 @@ static int alloc_like(pnec_hip_problem *src, hipStream_t stream, pnec_hip_proble
 // correspondences compacted pair by pair into dst (which has src's capacity).  All on `stream`.
 // known_counts (optional, device): the inliers per pair when the producer of the mask counted them already (RANSAC
 // does): the counting launch is skipped
-static int select_into(pnec_hip_problem *src, const uint8_t *d_mask, hipStream_t stream, pnec_hip_problem *dst,
-                       const int32_t *known_counts = nullptr) {
+// select_prepare: dst follows the source's current shape (block layout by generation); select_finish: the offsets of the
+// kept correspondences + the host-side bookkeeping.  Between the two something fills dst's planes and counts: the copy
+// kernel below (select_into), or the RANSAC stage itself (the chain: InlierExtraction fused into a pair's last pass).
+static int select_prepare(pnec_hip_problem *src, hipStream_t stream, pnec_hip_problem *dst) {
   const int64_t P = src->n_pairs;
   if (dst->view_src_gen != src->layout_gen) {  // the source has been re-shaped since dst copied its block layout
     if (P > 0)
@@ -1792,9 +1819,44 @@ static int select_into(pnec_hip_problem *src, const uint8_t *d_mask, hipStream_t
     dst->buckets.clear();
     if (dst->d_bucket_pairs) (void)dev_free(dst->d_bucket_pairs);
     dst->d_bucket_pairs = nullptr;
-    dst->lazy = false;  // (so that the block below re-installs the source's bounds)
+    dst->lazy = false;  // (so that select_finish re-installs the source's bounds)
     dst->offsets = src->offsets;
   }
+  return 0;
+}
+static int select_finish(pnec_hip_problem *src, hipStream_t stream, pnec_hip_problem *dst, bool scan = true) {
+  const int64_t P = src->n_pairs;
+  if (scan && P > 1) {
+    hipLaunchKernelGGL(offsets_scan_kernel, dim3(1), dim3(1024), 0, stream, dst->d_count, dst->d_offsets, P);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "offsets_scan_kernel");
+  }
+  if (!dst->lazy) {  // it had been given exact sizes: back to the source's bounds, buckets included
+    dst->buckets.clear();
+    if (dst->d_bucket_pairs) (void)dev_free(dst->d_bucket_pairs);
+    dst->d_bucket_pairs = nullptr;
+    dst->offsets = src->offsets;
+  }
+  dst->lazy = true;
+  dst->lazy_stream = stream;
+  dst->n_corr = src->n_corr;
+  dst->n_max = src->n_max;
+  dst->n_pairs = P;
+  dst->data_doubles = src->data_doubles;  // (also when the block layout is unchanged but the pair's size is not)
+  if (dst->host_counts != src->host_counts) {  // a re-shaped source: the launch geometries follow its new bounds
+    dst->host_counts = src->host_counts;
+    dst->offsets = src->offsets;
+    dst->buckets.clear();
+    if (dst->d_bucket_pairs) (void)dev_free(dst->d_bucket_pairs);
+    dst->d_bucket_pairs = nullptr;
+  }
+  return 0;
+}
+
+static int select_into(pnec_hip_problem *src, const uint8_t *d_mask, hipStream_t stream, pnec_hip_problem *dst,
+                       const int32_t *known_counts = nullptr) {
+  const int64_t P = src->n_pairs;
+  if (int rc = select_prepare(src, stream, dst)) return rc;
   if (P > 0) {
     hipError_t e = hipSuccess;
     if (known_counts) {
@@ -1818,26 +1880,7 @@ static int select_into(pnec_hip_problem *src, const uint8_t *d_mask, hipStream_t
     }
     if (e != hipSuccess) return fail_hip(e, "select_kernel");
   }
-  if (!dst->lazy) {  // it had been given exact sizes: back to the source's bounds, buckets included
-    dst->buckets.clear();
-    if (dst->d_bucket_pairs) (void)dev_free(dst->d_bucket_pairs);
-    dst->d_bucket_pairs = nullptr;
-    dst->offsets = src->offsets;
-  }
-  dst->lazy = true;
-  dst->lazy_stream = stream;
-  dst->n_corr = src->n_corr;
-  dst->n_max = src->n_max;
-  dst->n_pairs = P;
-  dst->data_doubles = src->data_doubles;  // (also when the block layout is unchanged but the pair's size is not)
-  if (dst->host_counts != src->host_counts) {  // a re-shaped source: the launch geometries follow its new bounds
-    dst->host_counts = src->host_counts;
-    dst->offsets = src->offsets;
-    dst->buckets.clear();
-    if (dst->d_bucket_pairs) (void)dev_free(dst->d_bucket_pairs);
-    dst->d_bucket_pairs = nullptr;
-  }
-  return 0;
+  return select_finish(src, stream, dst, /*scan*/ false);  // (the scans are among the launches above)
 }
 
 int pnec_hip_problem_select(pnec_hip_problem *src, const uint8_t *mask, int space, void *stream_,

@@ -1506,6 +1506,10 @@ __global__ __launch_bounds__(WMAX *kWave, PNEC_WES_WAVES_PER_SIMD) void weighted
 // k = log(1 - 0.99) / log(1 - w^s), eigensolver re-run on the inliers; rand() replaced by a
 // counter-based hash of (seed, pair, hypothesis, draw)) ------------------------------------------
 // (kernel shape: see ransac_eigensolver_kernel below)
+struct RansacState {  // per pair: where RANSAC's sequential rule stands between two launches (pnec_ransac_split.inl)
+  int32_t *it, *best, *needed, *task0;
+  double *k, *model;  // model [P][12]: R (9) + t (3) of the best hypothesis so far
+};
 struct RansacArgs {
   const double *data;
   const int64_t *block_offset;
@@ -1522,6 +1526,15 @@ struct RansacArgs {
   int max_iterations, sample_size;
   double threshold;
   FrontScratch scratch;  // what es_batch_kernel needs to finish the pair (sums of the inliers, start, first inlier)
+  // InlierExtraction fused into the pair's last pass (null: none): the target batch has the source's block layout
+  int nc;                      // component planes of the source (6 NEC, 12 TARGET / HOST, 18 SYM)
+  double *sel_data;
+  const int64_t *sel_block;
+  int32_t *sel_count;
+  int64_t *sel_single_offsets; // a batch of ONE pair: its AoS offsets [0, m]
+  // ransac_eigensolver_kernel<true>: the pairs resumed from the round kernels' state
+  const int32_t *resume_list, *resume_count;
+  RansacState resume;
 };
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
@@ -1568,7 +1581,34 @@ __device__ __forceinline__ double reprojection_score(const double (&f1)[3], cons
 constexpr int kScoreTiles = 8;
 struct ScoreTiles { double f[kScoreTiles][6]; };
 
-__device__ __forceinline__ void score_tiles_issue(ScoreTiles &P, const double *bs, int st, int nn, int lane) {
+// ONE asm statement issues all 48 loads AND waits for them (round 4; until then an issue statement and a separate wait
+// statement: to the compiler an asm statement has written its outputs when it returns, so it was free to copy or spill a
+// destination register between the two -- while the load that would really write it was still in flight.  It did, the
+// first time this code was compiled under a tighter register budget: tools/check_asm_loads.py caught two scratch stores
+// of tile registers in front of the wait).  Tiles beyond the pair are branched over, wave-uniformly (a tile that starts
+// inside the pair lies inside its planes: stride = n rounded up to 64, the padding reads zeros; one that starts beyond
+// it may lie beyond the allocation), their registers keep the zeros they came with.  Scalar-base form of global_load
+// (base + 32-bit lane offset + immediate; why: pnec_device.hpp load_planes_saddr); the s_nop covers a plane base the
+// compiler has just fetched with a VALU instruction (VALU-written SGPR -> VMEM address: 5 wait states).
+#define PNEC_ST_TILE(i, off)                                                          \
+  "s_cmp_le_u32 %[nt], " #i "\n\ts_cbranch_scc1 1f\n\t"                               \
+  "global_load_dwordx2 %[d" #i "0], %[lo], %[b0] offset:" #off "\n\t"                  \
+  "global_load_dwordx2 %[d" #i "1], %[lo], %[b1] offset:" #off "\n\t"                  \
+  "global_load_dwordx2 %[d" #i "2], %[lo], %[b2] offset:" #off "\n\t"                  \
+  "global_load_dwordx2 %[d" #i "3], %[lo], %[b3] offset:" #off "\n\t"                  \
+  "global_load_dwordx2 %[d" #i "4], %[lo], %[b4] offset:" #off "\n\t"                  \
+  "global_load_dwordx2 %[d" #i "5], %[lo], %[b5] offset:" #off "\n\t"
+#define PNEC_ST_OUT(i)                                                                                              \
+  [d##i##0] "+v"(P.f[i][0]), [d##i##1] "+v"(P.f[i][1]), [d##i##2] "+v"(P.f[i][2]), [d##i##3] "+v"(P.f[i][3]), \
+  [d##i##4] "+v"(P.f[i][4]), [d##i##5] "+v"(P.f[i][5])
+// The two-statement form (issue, then a separate wait): what the one- and two-pair kernels have run since round 3.
+// Nothing in the source keeps the compiler from touching a destination between the two statements; what it actually
+// did is checked after every link (tools/check_asm_loads.py).  Kept for those two kernels because the one-statement
+// form below, correct in the round kernel, makes the ONE-PAIR kernel return wrong poses and run on for minutes
+// (measured on the GPU, both with EXEC masking and with branches inside the statement; that kernel is the only one
+// here with a real call -- es_minimise_quad is not inlined -- and spills 114 scalar registers; not understood, so not
+// used there).
+__device__ __forceinline__ void score_tiles_load_2s(ScoreTiles &P, const double *bs, int st, int nn, int lane) {
   const unsigned long long b64 = reinterpret_cast<unsigned long long>(bs);
   const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
   const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
@@ -1577,23 +1617,42 @@ __device__ __forceinline__ void score_tiles_issue(ScoreTiles &P, const double *b
   const unsigned voff = 8u * (unsigned)lane;
   auto tile = [&](auto tc) {
     constexpr int i = decltype(tc)::value;
-    // a tile that starts inside the pair lies inside its planes (stride = n rounded up to 64: the padding reads zeros)
     load_planes_issue<6, 8 * kWave * i>(P.f[i], sb, plane_bytes, voff, kWave * i < nn);
   };
   tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{});
   tile(std::integral_constant<int, 2>{}); tile(std::integral_constant<int, 3>{});
   tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{});
   tile(std::integral_constant<int, 6>{}); tile(std::integral_constant<int, 7>{});
-  static_assert(kScoreTiles == 8, "one call per tile above");
-}
-// everything issued before has landed (s_waitcnt vmcnt(0), carrying the first tile as operands); the other tiles are
-// tied to a point after it (volatile statements keep their order)
-__device__ __forceinline__ void score_tiles_arrived(ScoreTiles &P) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(P.f[0][0]), "+v"(P.f[0][1]), "+v"(P.f[0][2]), "+v"(P.f[0][3]), "+v"(P.f[0][4]), "+v"(P.f[0][5]));
 #pragma unroll
   for (int i = 1; i < kScoreTiles; ++i)
     asm volatile("" : "+v"(P.f[i][0]), "+v"(P.f[i][1]), "+v"(P.f[i][2]), "+v"(P.f[i][3]), "+v"(P.f[i][4]), "+v"(P.f[i][5]));
 }
+__device__ __forceinline__ void score_tiles_load(ScoreTiles &P, const double *bs, int st, int nn, int lane) {
+  static_assert(kScoreTiles == 8 && kWave == 64, "eight tiles of 64 correspondences, 512 bytes per tile and plane");
+  const unsigned long long b64 = reinterpret_cast<unsigned long long>(bs);
+  const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
+  const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
+  const char *sb = reinterpret_cast<const char *>(((unsigned long long)bhi << 32) | blo);
+  const size_t plane_bytes = (size_t)(unsigned)__builtin_amdgcn_readfirstlane(st) * sizeof(double);
+  const unsigned voff = 8u * (unsigned)lane;
+  const unsigned nt = (unsigned)__builtin_amdgcn_readfirstlane((nn + kWave - 1) / kWave);  // tiles that start inside the pair
+#pragma unroll
+  for (int i = 0; i < kScoreTiles; ++i)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) P.f[i][c] = 0.0;
+  asm volatile("s_nop 4\n\t"
+               PNEC_ST_TILE(0, 0) PNEC_ST_TILE(1, 512) PNEC_ST_TILE(2, 1024) PNEC_ST_TILE(3, 1536)
+               PNEC_ST_TILE(4, 2048) PNEC_ST_TILE(5, 2560) PNEC_ST_TILE(6, 3072) PNEC_ST_TILE(7, 3584)
+               "1:\n\ts_waitcnt vmcnt(0)"
+               : PNEC_ST_OUT(0), PNEC_ST_OUT(1), PNEC_ST_OUT(2), PNEC_ST_OUT(3), PNEC_ST_OUT(4), PNEC_ST_OUT(5), PNEC_ST_OUT(6),
+                 PNEC_ST_OUT(7)
+               : [lo] "v"(voff), [nt] "s"(nt), [b0] "s"(sb), [b1] "s"(sb + plane_bytes), [b2] "s"(sb + 2 * plane_bytes),
+                 [b3] "s"(sb + 3 * plane_bytes), [b4] "s"(sb + 4 * plane_bytes), [b5] "s"(sb + 5 * plane_bytes)
+               : "memory", "scc");
+}
+#undef PNEC_ST_TILE
+#undef PNEC_ST_OUT
 
 // Inliers of ONE model over the whole pair.  `beat` is the count the model has to exceed to matter (the best so far of
 // RANSAC's sequential rule): once even "every remaining correspondence is an inlier" cannot get it there, the scan stops
@@ -1658,6 +1717,85 @@ __device__ __forceinline__ int quad_sum_int(int x) {
   return x;
 }
 
+// ---- a hypothesis' sample and its sums, in registers (round 4) ------------------------------------------------------------
+// The draw-until-distinct loop of the kernels' first version kept the sample in LDS (a dynamically indexed array is not
+// registers) and read it back entry by entry in the duplicate test -- a chain of dependent LDS round trips per draw, and a
+// wavefront fence per accepted entry in the two-pair form.  Here the sample is sixteen registers with static indices only:
+// the duplicate test compares against all of them under a mask, the insertion is a select per register.  Same draws, same
+// order, same sample.  (All four lanes of a quad draw the same sample.)
+__device__ __forceinline__ void ransac_sample_regs(unsigned long long seed, unsigned long long pid, unsigned long long hh,
+                                                   int n, int ss, int (&s)[PNEC_HIP_MAX_RANSAC_SAMPLE]) {
+#pragma unroll
+  for (int j = 0; j < PNEC_HIP_MAX_RANSAC_SAMPLE; ++j) s[j] = -1;
+  int m = 0;
+  unsigned long long draw = 0;
+  while (m < ss) {
+    long long idx = (long long)(rng_uniform(seed, pid, hh, draw++) * (double)n);
+    if (idx >= n) idx = n - 1;
+    bool dup = false;
+#pragma unroll
+    for (int j = 0; j < PNEC_HIP_MAX_RANSAC_SAMPLE; ++j) dup = dup || (j < m && s[j] == (int)idx);
+    if (!dup) {
+#pragma unroll
+      for (int j = 0; j < PNEC_HIP_MAX_RANSAC_SAMPLE; ++j) s[j] = (j == m) ? (int)idx : s[j];
+      ++m;
+    }
+  }
+}
+// entry 4 t + role of the sample (what lane `role` of the quad works on in its t-th turn)
+__device__ __forceinline__ int ransac_sample_pick(const int (&s)[PNEC_HIP_MAX_RANSAC_SAMPLE], int t, int role) {
+  static_assert(PNEC_HIP_MAX_RANSAC_SAMPLE == 16, "four turns of four lanes");
+  const int a0 = t == 0 ? s[0] : (t == 1 ? s[4] : (t == 2 ? s[8] : s[12]));
+  const int a1 = t == 0 ? s[1] : (t == 1 ? s[5] : (t == 2 ? s[9] : s[13]));
+  const int a2 = t == 0 ? s[2] : (t == 1 ? s[6] : (t == 2 ? s[10] : s[14]));
+  const int a3 = t == 0 ? s[3] : (t == 1 ? s[7] : (t == 2 ? s[11] : s[15]));
+  return role == 0 ? a0 : (role == 1 ? a1 : (role == 2 ? a2 : a3));
+}
+// The 36 sums G_kl[a][c] and the sum of f1 over the sample: the quad's lanes split it (lane `role` takes entries role,
+// role + 4, ...), ALL of a lane's gathers in flight together (the first version waited out a round trip to memory per entry),
+// accumulated entry by entry in the first version's order, then added up over the quad.
+__device__ __forceinline__ void ransac_sample_sums(const double *bs, int st, int ss, bool active,
+                                                   const int (&s)[PNEC_HIP_MAX_RANSAC_SAMPLE], int role, double (&Gl)[36],
+                                                   double (&ev1)[3]) {
+  constexpr int kTurns = PNEC_HIP_MAX_RANSAC_SAMPLE / 4;
+  double e[kTurns][6];
+  bool on[kTurns];
+#pragma unroll
+  for (int t = 0; t < kTurns; ++t) {
+    on[t] = active && 4 * t + role < ss;
+    const int idx = on[t] ? ransac_sample_pick(s, t, role) : 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) e[t][c] = on[t] ? bs[(int64_t)c * st + idx] : 0.0;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ev1[c] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 36; ++i) Gl[i] = 0.0;
+#pragma unroll
+  for (int t = 0; t < kTurns; ++t) {
+    if (on[t]) {
+      const double f1[3] = {e[t][0], e[t][1], e[t][2]}, f2[3] = {e[t][3], e[t][4], e[t][5]};
+      const double p[6] = {f2[0] * f2[0], f2[0] * f2[1], f2[0] * f2[2], f2[1] * f2[1], f2[1] * f2[2], f2[2] * f2[2]};
+      const double qq[6] = {f1[0] * f1[0], f1[0] * f1[1], f1[0] * f1[2], f1[1] * f1[1], f1[1] * f1[2], f1[2] * f1[2]};
+#pragma unroll
+      for (int kl = 0; kl < 6; ++kl)
+#pragma unroll
+        for (int ac = 0; ac < 6; ++ac) Gl[6 * kl + ac] += p[kl] * qq[ac];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ev1[c] += f1[c];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 36; ++i) Gl[i] = quad_sum(Gl[i]);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ev1[c] = quad_sum(ev1[c]);
+}
+
+#ifndef PNEC_RANSAC_WAVES_PER_SIMD
+#define PNEC_RANSAC_WAVES_PER_SIMD 2
+#endif
+#include "pnec_ransac_split.inl"
+
 // ONE WAVEFRONT PER FRAME PAIR, ONE QUAD PER HYPOTHESIS: a round evaluates 16 hypotheses.  The four lanes
 // of a quad share the hypothesis' Newton iteration (es_minimise_quad: the finite-difference probes and the
 // Armijo step lengths of one evaluation) and split the correspondences when it is scored.  Everything
@@ -1667,13 +1805,15 @@ __device__ __forceinline__ int quad_sum_int(int x) {
 // second round because ONE of its four pairs needs it (~1.9 -> ~1.4 rounds per pair), the slowest of 16
 // instead of 64 Newton iterations sets the pace, and the register need is es_minimise_quad's, which fits
 // two wavefronts per SIMD -- the other wavefront now fills the latency gaps of this one's chains.
-#ifndef PNEC_RANSAC_WAVES_PER_SIMD
-#define PNEC_RANSAC_WAVES_PER_SIMD 2
-#endif
+// RESUME: the pairs of a.resume_list, each from the state the round kernels left it in (pnec_ransac_split.inl), by a
+// grid-stride loop; otherwise pair = block, from the start.
+template <bool RESUME>
 __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eigensolver_kernel(const RansacArgs a) {
   const int lane = threadIdx.x;
   const int hyp = lane >> 2, role = lane & 3;
-  const int64_t pair = blockIdx.x;
+  const int64_t n_work = RESUME ? (int64_t)*a.resume_count : 1;
+  for (int64_t work = RESUME ? (int64_t)blockIdx.x : 0; work < n_work; work += RESUME ? (int64_t)gridDim.x : 1) {
+  const int64_t pair = RESUME ? (int64_t)a.resume_list[work] : (int64_t)blockIdx.x;
   const int n = a.count[pair];
   const int stride = (n + kWave - 1) & ~(kWave - 1);
   const double *base = a.data + a.block_offset[pair];
@@ -1700,6 +1840,13 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
     int best_count = -1;
     double k = 1.0;
     bool stop = !can_sample;
+    if constexpr (RESUME) {
+      it = a.resume.it[pair];
+      best_count = a.resume.best[pair];
+      k = a.resume.k[pair];
+      if (lane < 12) best_model[lane] = a.resume.model[12 * pair + lane];
+      wave_lds_sync();
+    }
     while (!stop && (double)it < k) {  // wave-uniform
       const unsigned long long h = (unsigned long long)(it + hyp);
       // The first round evaluates all 16 hypotheses before any bound is known.  A later round knows k: hypothesis
@@ -1803,8 +1950,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
       // the pair's bearings for the scoring.  (Issue and wait back to back: a register that a load in flight will
       // write is not the compiler's to move or spill, and it does not know -- nothing may sit between the two.)
       ScoreTiles tiles;
-      score_tiles_issue(tiles, base, stride, n, lane);
-      score_tiles_arrived(tiles);
+      score_tiles_load_2s(tiles, base, stride, n, lane);
       int winner = -1;
       for (int j = 0; j < needed; ++j) {  // (hypotheses beyond `needed` would meet it >= k: never consumed)
         if (!((double)it < k)) { stop = true; break; }
@@ -1842,64 +1988,16 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
     bt[0] = best_model[9]; bt[1] = best_model[10]; bt[2] = best_model[11];
   }
 
-  // ---- inliers of the best model (all correspondences when sampling is impossible), their 36 sums,
-  // the first inlier (ComposeM on the inlier list starts at its second entry, C7)
-  double acc[36];
-#pragma unroll
-  for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-  int my_count = 0, my_first = 0x7fffffff;
-  const int64_t aos0 = a.offsets[pair];
-  for (int idx = lane; idx < n; idx += kWave) {
-    const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
-    const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
-                          base[(int64_t)5 * stride + idx]};
-    bool in = true;
-    if (can_sample) in = reprojection_score(f1, f2, bR, bt) < a.threshold;
-    if (a.out_mask) a.out_mask[aos0 + idx] = in ? 1 : 0;
-    if (in) {
-      ++my_count;
-      if (idx < my_first) my_first = idx;
-      const double p[6] = {f2[0] * f2[0], f2[0] * f2[1], f2[0] * f2[2], f2[1] * f2[1], f2[1] * f2[2], f2[2] * f2[2]};
-      const double qq[6] = {f1[0] * f1[0], f1[0] * f1[1], f1[0] * f1[2], f1[1] * f1[1], f1[1] * f1[2], f1[2] * f1[2]};
-#pragma unroll
-      for (int kl = 0; kl < 6; ++kl)
-#pragma unroll
-        for (int ac = 0; ac < 6; ++ac) acc[6 * kl + ac] = __builtin_fma(p[kl], qq[ac], acc[6 * kl + ac]);
-    }
+  // ---- inliers of the best model (all correspondences when sampling is impossible), the mask, their 36 sums, the
+  // first inlier -- optimizeModelCoefficients (the eigensolver on the inliers from the best model's rotation, ComposeM
+  // without the first inlier, TranslationFromM) runs in es_batch_kernel<kEpiTranslation>, sixteen pairs per wavefront --
+  // and InlierExtraction when a target is given
+  ransac_finish_pair(a, pair, n, stride, base, bR, bt, can_sample, it, lane, G);
+  if (a.trace && lane == 0) {
+    ph_clk[kRpTotal] = __builtin_amdgcn_s_memtime() - ph_start;
+    for (int k = 0; k < kPhCount; ++k) a.trace[kPhCount * pair + k] = ph_clk[k];
   }
-#pragma unroll
-  for (int i = 0; i < 36; ++i) {
-    const double sres = wave_allreduce_sum(acc[i]);
-    if (lane == 0) G[i] = sres;
-  }
-  const int total = (int)wave_allreduce_sum((double)my_count);
-  int first = my_first;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const int o = __shfl_xor(first, off);
-    first = o < first ? o : first;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  PNEC_PHASE_END(kRpInliers);
-  // optimizeModelCoefficients -- the eigensolver on the inliers from the best model's rotation, ComposeM
-  // without the first inlier, TranslationFromM -- runs in es_batch_kernel<kEpiTranslation>, sixteen pairs per
-  // wavefront: hand it the inliers' sums, the start, the count and the first inlier
-  if (lane < 36) a.scratch.G[36 * pair + lane] = G[lane];
-  if (lane == 0) {
-    double v[3];
-    rot_to_cayley(bR, v);
-    a.scratch.v0[3 * pair] = v[0]; a.scratch.v0[3 * pair + 1] = v[1]; a.scratch.v0[3 * pair + 2] = v[2];
-    a.scratch.n_scale[pair] = (double)(total > 0 ? total : 1);
-    a.scratch.first[pair] = total > 0 ? first : -1;
-    if (a.out_count) a.out_count[pair] = total;
-    if (a.out_iterations) a.out_iterations[pair] = it;
-    if (a.trace) {
-      ph_clk[kRpTotal] = __builtin_amdgcn_s_memtime() - ph_start;
-      for (int k = 0; k < kPhCount; ++k) a.trace[kPhCount * pair + k] = ph_clk[k];
-    }
+  if constexpr (RESUME) wave_lds_sync();  // (the next pair reuses the LDS)
   }
 }
 
@@ -2193,46 +2291,15 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
       const bool active = hyp < needed[pp];
       const unsigned long long hh = (unsigned long long)(it[pp] + hyp);
       const unsigned long long pid = a.pair_id_base + (unsigned long long)pair[pp];
-      if (active) {
-        // (all four lanes of the quad draw the same sample; lane `role == 0` records it)
-        int m = 0;
-        unsigned long long draw = 0;
-        while (m < ss) {
-          long long idx = (long long)(rng_uniform(a.seed, pid, hh, draw++) * (double)n[pp]);
-          if (idx >= n[pp]) idx = n[pp] - 1;
-          bool dup = false;
-          for (int j = 0; j < m; ++j) dup = dup || (lds.tsel[slot][j] == (int)idx);
-          if (!dup) {
-            if (role == 0) lds.tsel[slot][m] = (int)idx;
-            // the quad's other lanes read the entry back in the duplicate test: make it visible
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            ++m;
-          }
-        }
-      }
-      lds_sync();
-      double ev1[3] = {0, 0, 0};
-      double Gl[36];
-      for (int i = 0; i < 36; ++i) Gl[i] = 0.0;
-      const double *bs = base[pp];
-      const int st = stride[pp];
-      for (int j = role; j < (active ? ss : 0); j += 4) {
-        const int idx = lds.tsel[slot][j];
-        const double f1[3] = {bs[idx], bs[(int64_t)st + idx], bs[(int64_t)2 * st + idx]};
-        const double f2[3] = {bs[(int64_t)3 * st + idx], bs[(int64_t)4 * st + idx], bs[(int64_t)5 * st + idx]};
-        const double p[6] = {f2[0] * f2[0], f2[0] * f2[1], f2[0] * f2[2], f2[1] * f2[1], f2[1] * f2[2], f2[2] * f2[2]};
-        const double qq[6] = {f1[0] * f1[0], f1[0] * f1[1], f1[0] * f1[2], f1[1] * f1[1], f1[1] * f1[2], f1[2] * f1[2]};
-        for (int kl = 0; kl < 6; ++kl)
-          for (int ac = 0; ac < 6; ++ac) Gl[6 * kl + ac] += p[kl] * qq[ac];
-        for (int c = 0; c < 3; ++c) ev1[c] += f1[c];
-      }
-#pragma unroll
-      for (int i = 0; i < 36; ++i) Gl[i] = quad_sum(Gl[i]);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) ev1[c] = quad_sum(ev1[c]);
+      // the sample in registers, its gathers all in flight together (ransac_sample_regs / ransac_sample_sums above); the
+      // model phase reads the sample from LDS
+      int smp[PNEC_HIP_MAX_RANSAC_SAMPLE];
+      if (active) ransac_sample_regs(a.seed, pid, hh, n[pp], ss, smp);
+      double ev1[3], Gl[36];
+      ransac_sample_sums(base[pp], stride[pp], ss, active, smp, role, Gl, ev1);
       if (role == 0 && active) {
+#pragma unroll
+        for (int j = 0; j < PNEC_HIP_MAX_RANSAC_SAMPLE; ++j) lds.tsel[slot][j] = smp[j];
 #pragma unroll
         for (int i = 0; i < 36; ++i) lds.Gh[slot][i] = Gl[i];
 #pragma unroll
@@ -2301,8 +2368,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
       }
       lds_sync();
       ScoreTiles tiles;  // the pair's bearings for the scoring (issue and wait back to back, see the one-pair kernel)
-      score_tiles_issue(tiles, bs, st, nn, lane);
-      score_tiles_arrived(tiles);
+      score_tiles_load_2s(tiles, bs, st, nn, lane);
       int winner = -1;
       for (int j = 0; j < needed[pp]; ++j) {
         if (!((double)it[pp] < k[pp])) { stop[pp] = true; break; }
@@ -2418,6 +2484,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
       a.scratch.first[pair[pp]] = total > 0 ? first : -1;
       if (a.out_count) a.out_count[pair[pp]] = total;
       if (a.out_iterations) a.out_iterations[pair[pp]] = it[pp];
+      if (a.sel_data) a.sel_count[pair[pp]] = total;
       if (a.trace) {
         ph_clk[kRpTotal] = (__builtin_amdgcn_s_memtime() - ph_start) / 2;  // two pairs shared this wavefront
         for (int kk = 0; kk < kPhCount; ++kk) a.trace[kPhCount * pair[pp] + kk] = kk == kRpTotal ? ph_clk[kk] : ph_clk[kk] / 2;
@@ -2427,6 +2494,8 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
         a.trace[kPhCount * pair[pp] + 11] = __builtin_amdgcn_s_memrealtime();
       }
     }
+    if (a.sel_data)  // InlierExtraction (this wavefront's own mask bytes back: each lane reads what it wrote)
+      compact_pair(a.nc, bs, nn, a.out_mask + aos0, a.sel_data + a.sel_block[pair[pp]], total, lane);
   }
 }
 
@@ -2500,13 +2569,125 @@ hipError_t launch_select(int nc, const double *src, const int64_t *src_block, co
   return hipGetLastError();
 }
 
+// ---- the split form's workspace (pnec_ransac_split.inl): per-pair state, the pair lists, two task pools, counters.
+// Pool A holds a round of sixteen hypotheses for every pair; pool B what the later rounds' pairs ask for (most pairs are
+// done after one round; a pair that does not fit is handed to the resumed one-pair kernel -- slower, never wrong).
+constexpr int kSplitCounters = 64;
+constexpr int kSplitMaxRounds = 6;
+static int64_t split_pool_a(int64_t P) { return (int64_t)kHypPerRound * P; }
+static int64_t split_pool_b(int64_t P) { return 4 * P + 4096; }
+size_t ransac_workspace_bytes(int64_t n_pairs) {
+  const int64_t P = n_pairs, ta = split_pool_a(P), tb = split_pool_b(P);
+  size_t b = 0;
+  b += sizeof(double) * (size_t)(13 * P);                      // k, model
+  b += sizeof(double) * (size_t)((ta + tb) * kTaskD);          // task records
+  b += sizeof(int32_t) * (size_t)(4 * P + 3 * P);              // it, best, needed, task0 | two lists + the hand-over list
+  b += sizeof(int32_t) * (size_t)((ta + tb) * kTaskSel);       // samples
+  b += sizeof(int32_t) * kSplitCounters;
+  return b + 256;
+}
+// The split form is an A/B build of the stage, not its default: bit-identical to the other forms and, as measured in
+// round 4, slower (3.67 against 2.55 ms per 20 000 pairs: DESIGN.md 12).  PNEC_RANSAC_FORM=3 switches it on for batches
+// of PNEC_RANSAC_SPLIT_MIN (4096) pairs and more; nothing is allocated for it otherwise.
+int64_t ransac_split_threshold() {
+  static const int64_t thr = [] {
+    const char *form = std::getenv("PNEC_RANSAC_FORM");
+    if (!form || std::atoi(form) != 3) return (int64_t)1 << 62;
+    const char *ev = std::getenv("PNEC_RANSAC_SPLIT_MIN");
+    return ev && *ev ? (int64_t)std::atoll(ev) : (int64_t)4096;
+  }();
+  return thr;
+}
+
+static hipError_t launch_ransac_split(RansacArgs a, void *ws, hipStream_t stream) {
+  const int64_t P = a.n_pairs, ta = split_pool_a(P), tb = split_pool_b(P);
+  // carve the workspace (doubles first: alignment)
+  double *d = reinterpret_cast<double *>(ws);
+  RansacSplitArgs s;
+  std::memset(&s, 0, sizeof(s));
+  s.st.k = d; d += P;
+  s.st.model = d; d += 12 * P;
+  RansacPool pool[2];
+  pool[0].rec = d; d += ta * kTaskD; pool[0].cap = (int32_t)std::min<int64_t>(ta, 0x7fffffff);
+  pool[1].rec = d; d += tb * kTaskD; pool[1].cap = (int32_t)std::min<int64_t>(tb, 0x7fffffff);
+  int32_t *ip = reinterpret_cast<int32_t *>(d);
+  s.st.it = ip; ip += P;
+  s.st.best = ip; ip += P;
+  s.st.needed = ip; ip += P;
+  s.st.task0 = ip; ip += P;
+  int32_t *list[2];
+  list[0] = ip; ip += P;
+  list[1] = ip; ip += P;
+  int32_t *left = ip; ip += P;
+  pool[0].sel = ip; ip += ta * kTaskSel;
+  pool[1].sel = ip; ip += tb * kTaskSel;
+  int32_t *cnt = ip;  // [round][4]: tasks claimed, queue position, pairs listed | [kSplitCounters - 1]: pairs handed over
+  hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int32_t) * kSplitCounters, stream);
+  if (e != hipSuccess) return e;
+  static const int rounds = [] {
+    const char *ev = std::getenv("PNEC_RANSAC_ROUNDS");
+    const int r = ev && *ev ? std::atoi(ev) : 3;
+    return r < 1 ? 1 : (r > kSplitMaxRounds ? kSplitMaxRounds : r);
+  }();
+  static const int cap2 = [] {
+    const char *ev = std::getenv("PNEC_RANSAC_ROUND_CAP");
+    const int r = ev && *ev ? std::atoi(ev) : 64;
+    return r < 16 ? 16 : (r / 16) * 16;
+  }();
+  int32_t *n_left = cnt + kSplitCounters - 1;
+  s.r = a;
+  s.list_left = left;
+  s.n_list_left = n_left;
+  const unsigned queue_waves = 2048;  // 256 CUs x 4 SIMDs x 2: every slot of the device, each pulling until the queue is dry
+  for (int r = 1; r <= rounds + 1; ++r) {
+    // launch r: consume round r-1's hypotheses (r > 1), prepare round r's (r <= rounds)
+    RansacPool &nx = pool[(r - 1) & 1], &pv = pool[r & 1];
+    s.prev = pv;
+    s.prev.n_tasks = cnt + 4 * (r - 1);
+    s.prev.queue = cnt + 4 * (r - 1) + 1;
+    s.next = nx;
+    s.next.n_tasks = cnt + 4 * r;
+    s.next.queue = cnt + 4 * r + 1;
+    s.list_prev = r > 1 ? list[(r - 1) & 1] : nullptr;
+    s.n_list_prev = r > 1 ? cnt + 4 * (r - 1) + 2 : nullptr;
+    s.list_next = list[r & 1];
+    s.n_list_next = cnt + 4 * r + 2;
+    s.cap_round = r == 1 ? kHypPerRound : (r == 2 ? cap2 : 4 * cap2);
+    s.last = r > rounds ? 1 : 0;
+    if (r == 1) {
+      hipLaunchKernelGGL(ransac_round_kernel<true>, dim3((unsigned)P), dim3(kWave), 0, stream, s);
+    } else {
+      const unsigned blocks = (unsigned)(r == 2 ? P : std::max<int64_t>(256, P / 4));
+      hipLaunchKernelGGL(ransac_round_kernel<false>, dim3(blocks), dim3(kWave), 0, stream, s);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (r <= rounds) {
+      EsQueueArgs q;
+      q.pool = s.next;
+      const unsigned waves = (unsigned)std::min<int64_t>(queue_waves, r == 1 ? P : std::max<int64_t>(64, P / 4));
+      hipLaunchKernelGGL(es_queue_kernel, dim3(waves), dim3(kWave), 0, stream, q);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+  }
+  // whoever is still going: the one-pair kernel from where the rule stands
+  a.resume_list = left;
+  a.resume_count = n_left;
+  a.resume = s.st;
+  hipLaunchKernelGGL(ransac_eigensolver_kernel<true>, dim3((unsigned)std::min<int64_t>(P, 1024)), dim3(kWave), 0, stream, a);
+  return hipGetLastError();
+}
+
+// sel (optional): InlierExtraction fused into each pair's last pass -- nc component planes, target planes / block layout /
+// counts (+ the AoS offsets of a ONE-pair batch).  ws (optional): ransac_workspace_bytes(n_pairs) bytes of device memory;
+// with it, batches of ransac_split_threshold() pairs and more run the split form.
 hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_offset, const int64_t *offsets,
                                      const int32_t *count, int64_t n_pairs, const double *init_q,
                                      unsigned long long seed, unsigned long long pair_id_base, int max_iterations,
                                      int sample_size, double threshold, double *out_q, double *out_t, uint8_t *out_mask,
                                      int32_t *out_count, int32_t *out_iterations, double *scratch_d,
                                      int32_t *scratch_i, hipStream_t stream, hipStream_t tail_stream,
-                                     hipEvent_t tail_fork, hipEvent_t tail_done) {
+                                     hipEvent_t tail_fork, hipEvent_t tail_done, int sel_nc, double *sel_data,
+                                     const int64_t *sel_block, int32_t *sel_count, int64_t *sel_single_offsets, void *ws) {
   // tail_stream (optional): the eigensolver on the inliers (es_batch_kernel, which writes out_q / out_t) runs
   // there, forked from `stream` after the RANSAC kernel -- the caller goes on with work that only needs the
   // masks (InlierExtraction) and makes `stream` wait for tail_done before anything reads out_q / out_t
@@ -2530,6 +2711,11 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   a.max_iterations = max_iterations;
   a.sample_size = sample_size;
   a.threshold = threshold;
+  a.nc = sel_nc;
+  a.sel_data = sel_data;
+  a.sel_block = sel_block;
+  a.sel_count = sel_count;
+  a.sel_single_offsets = sel_single_offsets;
   const char *tr = std::getenv("PNEC_HIP_TRACE_FRONT");
   if (tr && *tr) {
     const hipError_t e0 = hipMalloc(&a.trace, sizeof(unsigned long long) * kPhCount * (size_t)n_pairs);
@@ -2548,12 +2734,19 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
     const char *ev = std::getenv("PNEC_RANSAC_FORM");
     return ev && *ev ? std::atoi(ev) : 0;
   }();
-  const bool two = forced_form ? forced_form == 2 : n_pairs >= 4096;
-  if (two)
-    hipLaunchKernelGGL(ransac2_eigensolver_kernel, dim3((unsigned)((n_pairs + 1) / 2)), dim3(kWave), 0, stream, a);
-  else
-    hipLaunchKernelGGL(ransac_eigensolver_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
-  hipError_t e = hipGetLastError();
+  // PNEC_RANSAC_FORM=1|2|3 forces the one-pair / two-pair / split form (A/B runs; 3 needs the workspace)
+  const bool split = ws && !a.trace && forced_form == 3 && n_pairs >= ransac_split_threshold();
+  const bool two = !split && (forced_form == 1 ? false : (forced_form == 2 ? true : n_pairs >= 4096));
+  hipError_t e = hipSuccess;
+  if (split) {
+    e = launch_ransac_split(a, ws, stream);
+  } else {
+    if (two)
+      hipLaunchKernelGGL(ransac2_eigensolver_kernel, dim3((unsigned)((n_pairs + 1) / 2)), dim3(kWave), 0, stream, a);
+    else
+      hipLaunchKernelGGL(ransac_eigensolver_kernel<false>, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
+    e = hipGetLastError();
+  }
   if (e == hipSuccess) {
     EsBatchArgs b;
     std::memset(&b, 0, sizeof(b));

@@ -123,25 +123,36 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
     const bool fork = P >= 1024;
     if (fork)
       if (int rc = ensure_side_streams(p, 1)) return rc;
-    e = launch_ransac_eigensolver(p->d_data, p->d_block_offset, p->d_offsets, p->d_count, P, d_iq, o.ransac_seed,
-                                  (unsigned long long)o.first_pair_id, o.max_ransac_iterations, o.ransac_sample_size, o.ransac_threshold, es_q, es_t,
-                                  d_mask, d_cnt, nullptr, p->d_front, p->d_front_i, stream, fork ? p->side_streams[0] : nullptr,
-                                  fork ? p->fork_event : nullptr, fork ? p->side_done[0] : nullptr);
-    if (e != hipSuccess) return fail_hip(e, "ransac_eigensolver_kernel");
+    if (int rc = ensure_ransac_ws(p)) return rc;
     // InlierExtraction -- when a later stage works on the inliers.  With use_nec and no refinement (what the
     // reference's odometry forces, frame2frame.cc:127-128) or with neither weighted iterations nor refinement the chain
     // ends at the eigensolver's pose: the inlier mask and count are the outputs, and the copy would feed nothing.
+    // It is FUSED into the RANSAC stage (round 4): the wavefront that has just scored a pair's best model over all its
+    // correspondences compacts the kept ones into the target batch while the planes are still in the caches -- no
+    // select launch, no second trip of the mask and the payload through HBM.
     const bool inliers_used = o.use_ceres || (!o.use_nec && o.weighted_iterations > 1);
+    pnec_hip_problem *sv = nullptr;
     if (inliers_used) {
       // (the cached InlierExtraction target has the capacity of the source; a re-shaped source is re-synced into it
-      // by select_into, by layout generation)
+      // by select_prepare, by layout generation)
       if (!p->sel_view || p->sel_view->cap_doubles < p->data_doubles || p->sel_view->cap_pairs < P) {
         if (p->sel_view) pnec_hip_problem_destroy(p->sel_view);
         p->sel_view = nullptr;
         if (int rc = alloc_like(p, stream, &p->sel_view)) return rc;
       }
-      if (int rc = select_into(p, d_mask, stream, p->sel_view, d_cnt)) return rc;  // (RANSAC counted the mask it wrote)
-      stage = p->sel_view;
+      sv = p->sel_view;
+      if (int rc = select_prepare(p, stream, sv)) return rc;
+    }
+    e = launch_ransac_eigensolver(p->d_data, p->d_block_offset, p->d_offsets, p->d_count, P, d_iq, o.ransac_seed,
+                                  (unsigned long long)o.first_pair_id, o.max_ransac_iterations, o.ransac_sample_size, o.ransac_threshold, es_q, es_t,
+                                  d_mask, d_cnt, nullptr, p->d_front, p->d_front_i, stream, fork ? p->side_streams[0] : nullptr,
+                                  fork ? p->fork_event : nullptr, fork ? p->side_done[0] : nullptr, p->nc,
+                                  sv ? sv->d_data : nullptr, sv ? sv->d_block_offset : nullptr, sv ? sv->d_count : nullptr,
+                                  sv && P == 1 ? sv->d_offsets : nullptr, p->d_ransac_ws);
+    if (e != hipSuccess) return fail_hip(e, "ransac_eigensolver_kernel");
+    if (sv) {
+      if (int rc = select_finish(p, stream, sv)) return rc;  // (the AoS offsets of the kept correspondences: one scan)
+      stage = sv;
     }
     if (fork) PNEC_HIP_TRY(hipStreamWaitEvent(stream, p->side_done[0], 0));  // es_q / es_t are there from here on
   } else {
