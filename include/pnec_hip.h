@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define PNEC_HIP_ABI_VERSION 3
+#define PNEC_HIP_ABI_VERSION 4
 #define PNEC_HIP_MAX_RANSAC_SAMPLE 16 /* largest Options::ransac_sample_size_ the RANSAC kernel is built for */
 
 typedef enum pnec_hip_status {
@@ -222,6 +222,13 @@ int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint6
 int pnec_hip_problem_select(pnec_hip_problem *src, const uint8_t *mask, int space, void *stream,
                             pnec_hip_problem **out);
 
+/* The same InlierExtraction into the batch's CACHED target (the one pnec_hip_solve_pipeline compacts into): nothing is
+ * allocated after the first call on `src`, nothing is to be destroyed.  *out is owned by `src` and valid until the next
+ * select_view / solve_pipeline on `src`, a re-shape that outgrows it, or src's destruction.  For callers that run the
+ * stages of PNEC::Solve one by one per frame (the timed overloads, pnec.cc:135-208) on a persistent batch. */
+int pnec_hip_problem_select_view(pnec_hip_problem *src, const uint8_t *mask, int space, void *stream,
+                                 pnec_hip_problem **out);
+
 /* PNEC::WeightedEigensolver (src/rel_pose_estimation/pnec.cc:283-348) for every pair of a
  * TARGET-mode problem: (weighted_iterations - 1) rounds of { weights from the INITIAL pose x 1e-8,
  * eigensolver on the weighted bearings, 500-direction Fibonacci search of obj_fun
@@ -265,6 +272,22 @@ void pnec_hip_default_pipeline_options(pnec_hip_pipeline_options *opt);
 int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const double *init_t,
                             const pnec_hip_pipeline_options *opt, double *out_q, double *out_t,
                             uint8_t *out_inlier_mask, int32_t *out_inlier_count, int space, void *stream);
+
+/* ---- several GPUs of one node, one process ----------------------------------------------------------------
+ * The reference fans out at process level (scripts/run_simulation.sh:52-67, scripts/parallel_kitti.sh:60-69: one
+ * process per experiment / sequence).  Frame pairs are independent, so a batch shards with no data-path exchange:
+ * pnec_hip_partition gives contiguous ranges of pairs balanced by correspondence count (bounds[n_parts + 1]; part r
+ * owns pairs [bounds[r], bounds[r+1]) -- the rule the multi-process bench uses, pnec_amd/distributed.py::partition);
+ * pnec_hip_solve_pipeline_multi runs PNEC::Solve (as pnec_hip_solve_pipeline) on one batch per entry of `devices`,
+ * one host thread and one stream each, from HOST arrays in the reference layout (as pnec_hip_problem_fill: bvs 3
+ * doubles, covs 9 doubles column-major per correspondence, NULL covs = NEC-only data for use_nec) and writes every
+ * pair's result into the caller's arrays; it returns when all shards are done.  A device may be listed more than
+ * once.  RANSAC draws belong to the GLOBAL pair index, so the results do not depend on the device list. */
+int pnec_hip_partition(int64_t n_pairs, const int64_t *offsets, int32_t n_parts, int64_t *bounds);
+int pnec_hip_solve_pipeline_multi(int32_t n_devices, const int32_t *devices, int64_t n_pairs, const int64_t *offsets,
+                                  const double *bvs1, const double *bvs2, const double *covs, const double *init_q,
+                                  const double *init_t, const pnec_hip_pipeline_options *opt, double *out_q,
+                                  double *out_t, uint8_t *out_inlier_mask, int32_t *out_inlier_count);
 
 /* ---- streaming: one frame pair (or a few) per call, as the reference's odometry calls the solver ----
  * (Frame2Frame::PNECAlign -> PNEC::Solve once per frame, src/rel_pose_estimation/frame2frame.cc:122-141;

@@ -164,6 +164,11 @@ double pnec_oracle_weight(const double f1[3], const double f2[3], const double t
                           const double *cov, double reg, int host_frame);
 void pnec_oracle_cayley_to_rot(const double v[3], double R[9]);
 void pnec_oracle_rot_to_cayley(const double R[9], double v[3]);
+/* Which iteration the eigenvalue minimisations run: 0 (default) damped Newton to ~1e-12 rad -- what the device runs;
+ * 1 [EXT, from memory, unverified] opengv's own normalised steepest descent with an adaptive step, which stops ~1e-5 rad
+ * short (pnec_oracle_frontend.c).  A process-wide switch for test tooling; set it before, not during, a batch call. */
+void pnec_oracle_set_eigensolver_scheme(int scheme);
+int pnec_oracle_get_eigensolver_scheme(void);
 /* opengv::relative_pose::eigensolver restated (Kneip-Lynen eigenvalue minimisation); R row-major */
 int pnec_oracle_eigensolver(int64_t n, const double *bvs1, const double *bvs2, const double R0[9],
                             double R_out[9], int32_t *iterations);

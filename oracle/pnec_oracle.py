@@ -243,6 +243,16 @@ def rot_to_cayley(R):
     return v
 
 
+def set_eigensolver_scheme(scheme: int) -> None:
+    """0 (default): the damped Newton iteration the device runs; 1: [EXT, from memory, unverified] opengv's own
+    normalised steepest descent with an adaptive step, which stops ~1e-5 rad short of the minimiser
+    (pnec_oracle_frontend.c).  Process-wide; affects every eigenvalue minimisation of the oracle's front stages."""
+    L = lib()
+    L.pnec_oracle_set_eigensolver_scheme.argtypes = [C.c_int]
+    L.pnec_oracle_set_eigensolver_scheme.restype = None
+    L.pnec_oracle_set_eigensolver_scheme(int(scheme))
+
+
 def eigensolver(bvs1, bvs2, R0):
     """rotation minimising the smallest eigenvalue of M(R) (Kneip-Lynen), started at R0"""
     b1, b1p = _d(bvs1)

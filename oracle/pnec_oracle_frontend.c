@@ -248,10 +248,60 @@ static int solve3_spd(const double H[9], const double b[3], double x[3]) {
   return 1;
 }
 
+/* ---- [EXT, FROM MEMORY, UNVERIFIED] opengv's own iteration ----------------------------------------------------
+ * opengv is not in the reference tree; oracle and device restate its eigensolver as "minimise
+ * lambda_min(M(R)) over the Cayley parameters" with the damped Newton iteration below, converged to ~1e-12 rad.  What
+ * opengv::relative_pose::modules::eigensolver_main does instead, as far as its published source is remembered (nothing
+ * here can check it): steepest descent along the NORMALISED gradient with an adaptive step length lambda -- start 0.01;
+ * in the first iteration doubled while the value keeps falling, up to 0.08; halved while a step does not improve the
+ * value -- at most 50 iterations, stopped once lambda < 1e-5.  It therefore leaves the rotation ~1e-5 rad short of the
+ * minimiser.  Scheme 1 runs that descent wherever scheme 0 runs the Newton iteration (RANSAC hypotheses, the eigensolver
+ * on the inliers, the plain eigensolver), so that the part of the chain whose OUTPUT is the eigensolver stage's pose --
+ * the odometry's forced options, frame2frame.cc:127-128 -- can be compared with "what opengv might return"
+ * (tools/verify_odometry_options.py).  Test tooling only; the default is 0. */
+static int g_es_scheme = 0;
+void pnec_oracle_set_eigensolver_scheme(int scheme) { g_es_scheme = scheme; }
+int pnec_oracle_get_eigensolver_scheme(void) { return g_es_scheme; }
+
+static double es_value_grad(const es_data *D, const double v[3], double g[3]);
+static int eigensolver_descent_ext(const es_data *D, double v[3]) {
+  double lam = 0.01;
+  const double max_lam = 0.08, mod = 2.0, min_xtol = 1e-5;
+  double g[3];
+  double ev = es_value_grad(D, v, g);
+  int it = 0;
+  for (; it < 50; ++it) {
+    const double nrm = sqrt(dot3(g, g));
+    if (!(nrm > 0.0)) break;
+    const double d[3] = {g[0] / nrm, g[1] / nrm, g[2] / nrm};
+    double sp[3] = {v[0] - lam * d[0], v[1] - lam * d[1], v[2] - lam * d[2]};
+    double sev = es_value_grad(D, sp, NULL);
+    if (it == 0) {
+      while (sev < ev) {
+        ev = sev;
+        if (lam * mod > max_lam) break;
+        lam *= mod;
+        for (int k = 0; k < 3; ++k) sp[k] = v[k] - lam * d[k];
+        sev = es_value_grad(D, sp, NULL);
+      }
+    }
+    while (sev > ev && lam > 1e-12) {
+      lam /= mod;
+      for (int k = 0; k < 3; ++k) sp[k] = v[k] - lam * d[k];
+      sev = es_value_grad(D, sp, NULL);
+    }
+    for (int k = 0; k < 3; ++k) v[k] = sp[k];
+    ev = es_value_grad(D, v, g);
+    if (lam < min_xtol) { ++it; break; }
+  }
+  return it;
+}
+
 /* Damped Newton on v (Cayley): Hessian by forward differences of the analytic gradient
  * (h = 1e-6), Levenberg shift until positive definite and descending, Armijo backtracking.
  * Stops when |step|_inf < 1e-12, |grad|_inf < 1e-14 * (1 + |lambda|) * n, or after 50 iterations. */
 static int eigensolver_cayley(const es_data *Dp, double v[3]) {
+  if (g_es_scheme == 1) return eigensolver_descent_ext(Dp, v);
   const es_data D = *Dp;
   const int64_t n = D.n;
   double g[3];

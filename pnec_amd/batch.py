@@ -72,7 +72,8 @@ class Batch:
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            self._lib.pnec_hip_problem_destroy(self._h)
+            if not getattr(self, "_borrowed", False):     # (a select(view=True) result belongs to its source)
+                self._lib.pnec_hip_problem_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -353,23 +354,26 @@ class Batch:
             q.ctypes.data, t.ctypes.data, mask.ctypes.data, cnt.ctypes.data, its.ctypes.data, capi.MEM_HOST, None))
         return q, t, mask[:M], cnt, its
 
-    def select(self, mask) -> "Batch":
-        """PNEC::InlierExtraction (pnec.cc:210-229): new Batch with the masked correspondences."""
+    def select(self, mask, view: bool = False) -> "Batch":
+        """PNEC::InlierExtraction (pnec.cc:210-229): new Batch with the masked correspondences.
+        view=True: into this batch's cached target (pnec_hip_problem_select_view: nothing allocated after the first
+        call, the result belongs to this batch and is replaced by the next such call)."""
         h = C.c_void_p()
         M = self.num_correspondences
+        fn = self._lib.pnec_hip_problem_select_view if view else self._lib.pnec_hip_problem_select
         if _is_torch(mask):
             import torch
             m = mask if mask.dtype == torch.uint8 else (mask != 0).to(torch.uint8)
             m = self._dev_tensor(m, "mask", (M,), dtype=torch.uint8)
-            capi.check(self._lib.pnec_hip_problem_select(self._h, m.data_ptr(), capi.MEM_DEVICE,
-                                                         torch.cuda.current_stream(self.device).cuda_stream,
-                                                         C.byref(h)))
+            capi.check(fn(self._h, m.data_ptr(), capi.MEM_DEVICE, torch.cuda.current_stream(self.device).cuda_stream,
+                          C.byref(h)))
         else:
             m = np.ascontiguousarray(mask, dtype=np.uint8)
             if m.shape != (M,):
                 raise ValueError(f"mask: expected shape ({M},), got {m.shape}")
-            capi.check(self._lib.pnec_hip_problem_select(self._h, m.ctypes.data, capi.MEM_HOST, None, C.byref(h)))
+            capi.check(fn(self._h, m.ctypes.data, capi.MEM_HOST, None, C.byref(h)))
         out = Batch.__new__(Batch)
+        out._borrowed = bool(view)
         out._lib, out.mode, out.device, out._h = self._lib, self.mode, self.device, h
         out.n_pairs = self.n_pairs
         # InlierExtraction ran on the device and nothing was read back: the new batch's offsets are

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PNEC_HIP_LIB: load an alternative build of the same ABI (kernel A/B experiments only)
 LIB_PATH = os.environ.get("PNEC_HIP_LIB") or os.path.join(_HERE, "libpnec_hip.so")
 
-ABI_VERSION = 3  # PNEC_HIP_ABI_VERSION of include/pnec_hip.h this binding was written against
+ABI_VERSION = 4  # PNEC_HIP_ABI_VERSION of include/pnec_hip.h this binding was written against
 MODE_NEC, MODE_TARGET, MODE_HOST, MODE_SYM = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 # pnec_hip_status
@@ -54,9 +54,12 @@ SYMBOLS = [
     "pnec_hip_nec_eigensolver",
     "pnec_hip_ransac_eigensolver",
     "pnec_hip_problem_select",
+    "pnec_hip_problem_select_view",
     "pnec_hip_weighted_eigensolver",
     "pnec_hip_default_pipeline_options",
     "pnec_hip_solve_pipeline",
+    "pnec_hip_partition",
+    "pnec_hip_solve_pipeline_multi",
     "pnec_hip_stream_create",
     "pnec_hip_stream_destroy",
     "pnec_hip_problem_create_capacity",
@@ -180,6 +183,10 @@ def lib() -> C.CDLL:
     L.pnec_hip_ransac_eigensolver.argtypes = [_vp, _vp, C.c_uint64, C.c_int32, C.c_int32, C.c_double, _vp, _vp,
                                               _vp, _vp, _vp, C.c_int, _vp]
     L.pnec_hip_problem_select.argtypes = [_vp, _vp, C.c_int, _vp, C.POINTER(_vp)]
+    L.pnec_hip_problem_select_view.argtypes = [_vp, _vp, C.c_int, _vp, C.POINTER(_vp)]
+    L.pnec_hip_partition.argtypes = [C.c_int64, _vp, C.c_int32, _vp]
+    L.pnec_hip_solve_pipeline_multi.argtypes = [C.c_int32, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                C.POINTER(PipelineOptions), _vp, _vp, _vp, _vp]
     L.pnec_hip_weighted_eigensolver.argtypes = [_vp, _vp, _vp, C.c_double, C.c_int32, _vp, _vp, C.c_int, _vp]
     L.pnec_hip_default_pipeline_options.argtypes = [C.POINTER(PipelineOptions)]
     L.pnec_hip_default_pipeline_options.restype = None

@@ -97,6 +97,7 @@ int main(int argc, char **argv) {
     // optional 4th argument "vo": the options Frame2Frame forces whatever the configuration says -- use_nec, no
     // refinement (frame2frame.cc:127-128)
     const bool vo = argc > 4 && std::strcmp(argv[4], "vo") == 0;
+    const bool timed = argc > 4 && std::strcmp(argv[4], "timed") == 0;   // the overload that fills a FrameTiming
     pnec::rel_pose_estimation::Options options;
     if (vo) {
       options.use_nec_ = true;
@@ -108,11 +109,15 @@ int main(int argc, char **argv) {
     std::vector<double> us;
     double sink = 0.0;
     size_t n_inl = 0;
+    pnec::common::FrameTiming last_timing(0);
     for (int r = 0; r < reps + 20; ++r) {
       std::vector<int> inliers;
+      pnec::common::FrameTiming frame_timing(r);
       const auto tic = std::chrono::steady_clock::now();
-      const pnec::SE3d sol = pnec_solver.Solve(b1, b2, covs, init, inliers);
+      const pnec::SE3d sol = timed ? pnec_solver.Solve(b1, b2, covs, init, inliers, frame_timing)
+                                   : pnec_solver.Solve(b1, b2, covs, init, inliers);
       const auto toc = std::chrono::steady_clock::now();
+      last_timing = frame_timing;
       if (r >= 20) us.push_back(std::chrono::duration<double, std::micro>(toc - tic).count());
       sink += sol.translation()[2];
       n_inl = inliers.size();
@@ -120,10 +125,12 @@ int main(int argc, char **argv) {
     std::sort(us.begin(), us.end());
     std::printf("{\"call\": \"PNEC::Solve, %s, "
                 "host arrays in, pose + inliers out\", \"correspondences\": %d, \"inliers\": %zu, \"reps\": %d, "
-                "\"median_us\": %.1f, \"p10_us\": %.1f, \"p90_us\": %.1f, \"checksum\": %.6f}\n",
+                "\"median_us\": %.1f, \"p10_us\": %.1f, \"p90_us\": %.1f, \"checksum\": %.6f, \"frame_timing_us\": \"%s\"}\n",
                 vo ? "the odometry's forced Options (use_nec, no refinement: RANSAC eigensolver only)"
-                   : "reference-default Options (RANSAC eigensolver, weighted eigensolver + SCF, refinement)",
-                n, n_inl, reps, us[us.size() / 2], us[us.size() / 10], us[us.size() * 9 / 10], sink / reps);
+                   : (timed ? "reference-default Options, the TIMED overload (stage by stage, FrameTiming filled)"
+                            : "reference-default Options (RANSAC eigensolver, weighted eigensolver + SCF, refinement)"),
+                n, n_inl, reps, us[us.size() / 2], us[us.size() / 10], us[us.size() * 9 / 10], sink / reps,
+                timed ? last_timing.TimingRowUs().c_str() : "");
     return 0;
   }
   if (argc > 2 && std::strcmp(argv[2], "timing") == 0) {

@@ -3,6 +3,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 
@@ -230,6 +231,13 @@ std::ostream &operator<<(std::ostream &os, const FrameTiming &ft) {
   return os;
 }
 
+std::string FrameTiming::TimingRowUs() const {
+  char buf[192];
+  std::snprintf(buf, sizeof(buf), "%d %.1f %.1f %.1f %.1f %.1f", id_, nec_es_us_, it_es_us_, avg_it_es_us_, ceres_us_,
+                OptimizationTimeUs());
+  return buf;
+}
+
 std::ostream &operator<<(std::ostream &os, const Timing &timing) {
   os << FrameTiming::TimingHeader() << std::endl;
   for (const FrameTiming &ft : timing.frame_timings_) os << ft << std::endl;
@@ -451,9 +459,8 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
                      std::vector<int> &inliers, common::FrameTiming *timing) {
   // pnec.cc:77-124 (timed twin :135-208), stage by stage on the device.
   using clock = std::chrono::high_resolution_clock;
-  auto ms_since = [](clock::time_point t0) {
-    return (long)std::chrono::duration_cast<std::chrono::milliseconds>(clock::now() - t0).count();
-  };
+  // (one reading per stage: the millisecond field is the microsecond reading truncated, as duration_cast does)
+  auto us_since = [](clock::time_point t0) { return std::chrono::duration<double, std::micro>(clock::now() - t0).count(); };
   auto tic = clock::now();
   const Quaterniond q0(initial_pose.rotationMatrix());
   double q[4], t[3];
@@ -479,11 +486,7 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
   PairOnDevice dev(optimization::SolverOptions().device, bvs1, bvs2, projected_covs);
   void *const st = pnec_hip_frame_stream(dev.frame);   // the ingest is queued there: the stages follow it
   pnec_hip_problem *stage = dev.prob.p;   // the batch the later stages run on (inliers under RANSAC)
-  pnec_hip_problem *selected = nullptr;
-  struct Guard {
-    pnec_hip_problem *&p;
-    ~Guard() { if (p) pnec_hip_problem_destroy(p); }
-  } guard{selected};
+  pnec_hip_problem *selected = nullptr;   // the handle's cached InlierExtraction target: nothing to destroy
   // ES_solution = Eigensolver(bvs1, bvs2, initial_pose, inliers)
   inliers.clear();
   if (options_.use_ransac_) {
@@ -494,12 +497,12 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
     for (size_t i = 0; i < bvs1.size(); ++i)
       if (mask[i]) inliers.push_back((int)i);
     // InlierExtraction (pnec.cc:210-229)
-    Check(pnec_hip_problem_select(dev.prob.p, mask.data(), PNEC_HIP_MEM_HOST, st, &selected));
+    Check(pnec_hip_problem_select_view(dev.prob.p, mask.data(), PNEC_HIP_MEM_HOST, st, &selected));
     stage = selected;
   } else {
     Check(pnec_hip_nec_eigensolver(dev.prob.p, q0.coeffs(), q, t, PNEC_HIP_MEM_HOST, st));
   }
-  if (timing) timing->nec_es_ = ms_since(tic);
+  if (timing) { timing->nec_es_us_ = us_since(tic); timing->nec_es_ = (long)(timing->nec_es_us_ / 1000.0); }
   const pnec_hip_options o = optimization::SolverOptions().ToHip();
   double oq[4], ot[3];
   if (options_.use_nec_) {
@@ -515,7 +518,7 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
       b1 = bvs1; b2 = bvs2;
     }
     const SE3d nec = NECCeresSolver(b1, b2, PoseFromQT(q, t));
-    if (timing) timing->ceres_ = ms_since(tic);
+    if (timing) { timing->ceres_us_ = us_since(tic); timing->ceres_ = (long)(timing->ceres_us_ / 1000.0); }
     return nec;
   }
   double qi[4], ti[3];
@@ -527,8 +530,10 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
                                         (int32_t)options_.weighted_iterations_, qi, ti, PNEC_HIP_MEM_HOST,
                                         st));
     if (timing) {
-      timing->it_es_ = ms_since(tic);
+      timing->it_es_us_ = us_since(tic);
+      timing->it_es_ = (long)(timing->it_es_us_ / 1000.0);
       timing->avg_it_es_ = timing->it_es_ / (long)options_.weighted_iterations_;
+      timing->avg_it_es_us_ = timing->it_es_us_ / (double)options_.weighted_iterations_;
     }
   } else if (options_.weighted_iterations_ == 1) {
     std::memcpy(qi, q, sizeof(qi));
@@ -543,7 +548,7 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
   tic = clock::now();
   Check(pnec_hip_solve(stage, qi, ti, 1, nullptr, options_.regularization_, &o, oq, ot, nullptr, nullptr,
                        nullptr, PNEC_HIP_MEM_HOST, st));
-  if (timing) timing->ceres_ = ms_since(tic);
+  if (timing) { timing->ceres_us_ = us_since(tic); timing->ceres_ = (long)(timing->ceres_us_ / 1000.0); }
   return PoseFromQT(oq, ot);
 }
 
@@ -655,6 +660,32 @@ std::vector<SE3d> PNEC::SolveBatch(const std::vector<FramePair> &pairs, std::vec
   if (inliers && options_.use_ransac_) mask.assign(total ? total : 1, 0);
   Check(pnec_hip_solve_pipeline(prob.p, h.q0.data(), h.t0.data(), &po, q.data(), t.data(),
                                 mask.empty() ? nullptr : mask.data(), nullptr, PNEC_HIP_MEM_HOST, nullptr));
+  if (!mask.empty())
+    for (int64_t p = 0; p < B; ++p)
+      for (int64_t i = h.offsets[p]; i < h.offsets[p + 1]; ++i)
+        if (mask[i]) (*inliers)[p].push_back((int)(i - h.offsets[p]));
+  for (int64_t p = 0; p < B; ++p) out[p] = PoseFromQT(&q[4 * p], &t[3 * p]);
+  return out;
+}
+
+std::vector<SE3d> PNEC::SolveBatch(const std::vector<FramePair> &pairs, const std::vector<int> &devices,
+                                   std::vector<std::vector<int>> *inliers) {
+  const int64_t B = (int64_t)pairs.size();
+  std::vector<SE3d> out(B);
+  if (inliers) inliers->assign(B, {});
+  if (B == 0) return out;
+  if (devices.empty()) throw std::invalid_argument("SolveBatch: empty device list");
+  const FlatBatch h(pairs);
+  const int64_t total = h.offsets[B];
+  const pnec_hip_pipeline_options po = ToPipeline(options_);
+  std::vector<double> q(4 * B), t(3 * B);
+  std::vector<uint8_t> mask;
+  if (inliers && options_.use_ransac_) mask.assign(total ? total : 1, 0);
+  std::vector<int32_t> devs(devices.begin(), devices.end());
+  Check(pnec_hip_solve_pipeline_multi((int32_t)devs.size(), devs.data(), B, h.offsets.data(),
+                                      total ? h.b1[0].data() : nullptr, total ? h.b2[0].data() : nullptr,
+                                      total ? h.cv[0].data() : nullptr, h.q0.data(), h.t0.data(), &po, q.data(), t.data(),
+                                      mask.empty() ? nullptr : mask.data(), nullptr));
   if (!mask.empty())
     for (int64_t p = 0; p < B; ++p)
       for (int64_t i = h.offsets[p]; i < h.offsets[p + 1]; ++i)

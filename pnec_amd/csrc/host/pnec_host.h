@@ -56,6 +56,15 @@ struct FrameTiming {
   int TotalTime() const { return (int)(frame_loading_ + feature_creation_) + OptimizationTime(); }
   int id_;
   long frame_loading_ = 0, feature_creation_ = 0, nec_es_ = 0, it_es_ = 0, avg_it_es_ = 0, ceres_ = 0;  // ms
+  // The same stage timers in MICROSECONDS (not in the reference: its millisecond counts were made for a solver that
+  // takes tens of milliseconds per frame; here a whole PNEC::Solve is ~0.2 ms and every field above rounds to 0).
+  // Filled by the timed PNEC::Solve overloads next to the millisecond fields; the row operator<< streams -- the
+  // reference's timing.txt format -- does not show them, TimingRowUs() does.
+  double nec_es_us_ = 0.0, it_es_us_ = 0.0, avg_it_es_us_ = 0.0, ceres_us_ = 0.0;
+  double OptimizationTimeUs() const { return nec_es_us_ + it_es_us_ + ceres_us_; }
+  // "id nec-es it-es avg-it-es ceres optimization", microseconds with one decimal
+  std::string TimingRowUs() const;
+  static std::string TimingHeaderUs() { return "ID NEC-ES[us] IT-ES[us] AVG-IT-ES[us] CERES[us] OPTIMIZATION[us]"; }
 };
 // src/common/timing.cc:49-58: one row of timing.txt -- "id loading features nec-es it-es avg-it-es ceres
 // optimization total", blank separated.  Every field is an integral millisecond count there
@@ -242,6 +251,12 @@ class PNEC {
   // and the same per-pair results as calling Solve() pair by pair (RANSAC draws are a function of
   // the pair's index in the batch: pair i of a batch reproduces Solve() only for i = 0).
   std::vector<SE3d> SolveBatch(const std::vector<FramePair> &pairs,
+                               std::vector<std::vector<int>> *inliers = nullptr);
+  // Addition: the same over several GPUs of the node from this one process (the reference fans out by process:
+  // scripts/parallel_kitti.sh:60-69).  `devices` lists the GPUs (a device may appear twice); the pairs are split
+  // into contiguous ranges balanced by correspondence count, one host thread + batch + stream per entry
+  // (pnec_hip_solve_pipeline_multi).  Same results as the single-device call whatever the list.
+  std::vector<SE3d> SolveBatch(const std::vector<FramePair> &pairs, const std::vector<int> &devices,
                                std::vector<std::vector<int>> *inliers = nullptr);
   // Addition: CeresSolver for many pairs in one device launch (ragged sizes allowed).
   std::vector<SE3d> CeresSolverBatch(const std::vector<FramePair> &pairs,

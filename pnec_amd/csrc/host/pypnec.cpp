@@ -119,7 +119,8 @@ py::list ceres_solver_batch(py::list bvs1, py::list bvs2, py::list covs, py::lis
 // PNEC::Solve with the reference's default Options (or the flags given) for a list of pairs: every
 // stage one launch over the batch.  Returns (poses, inliers).
 py::tuple solve_batch(py::list bvs1, py::list bvs2, py::list covs, py::list init_poses, bool use_ransac,
-                      bool use_nec, bool use_ceres, int weighted_iterations, double regularization) {
+                      bool use_nec, bool use_ceres, int weighted_iterations, double regularization,
+                      std::vector<int> devices) {
   const size_t B = bvs1.size();
   if (bvs2.size() != B || covs.size() != B || init_poses.size() != B)
     throw std::invalid_argument("all lists must have one entry per frame pair");
@@ -141,7 +142,7 @@ py::tuple solve_batch(py::list bvs1, py::list bvs2, py::list covs, py::list init
   {
     py::gil_scoped_release release;
     pnec::rel_pose_estimation::PNEC solver(options);
-    poses = solver.SolveBatch(pairs, &inliers);
+    poses = devices.empty() ? solver.SolveBatch(pairs, &inliers) : solver.SolveBatch(pairs, devices, &inliers);
   }
   py::list out, inl;
   for (const auto &T : poses) out.append(FromPose(T));
@@ -245,6 +246,14 @@ py::tuple solve(arr bvs1, arr bvs2, arr covs, arr init_pose, int overload, bool 
     d["optimization"] = timing.OptimizationTime();
     d["total"] = timing.TotalTime();
     d["header"] = pnec::common::FrameTiming::TimingHeader();
+    // the microsecond twins (this library's addition: a whole Solve is a fraction of a millisecond here)
+    d["nec_es_us"] = timing.nec_es_us_;
+    d["it_es_us"] = timing.it_es_us_;
+    d["avg_it_es_us"] = timing.avg_it_es_us_;
+    d["ceres_us"] = timing.ceres_us_;
+    d["optimization_us"] = timing.OptimizationTimeUs();
+    d["row_us"] = timing.TimingRowUs();
+    d["header_us"] = pnec::common::FrameTiming::TimingHeaderUs();
     tim = d;
   }
   return py::make_tuple(FromPose(pose), inl, tim);
@@ -274,8 +283,9 @@ PYBIND11_MODULE(pypnec, m) {
         "PNEC::Solve for one frame pair through one of its four overloads");
   m.def("solve_batch", &solve_batch, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"), py::arg("init_poses"),
         py::arg("use_ransac") = true, py::arg("use_nec") = false, py::arg("use_ceres") = true,
-        py::arg("weighted_iterations") = 10, py::arg("regularization") = 1e-13,
-        "PNEC::Solve for a list of frame pairs, every stage one device launch over the batch (addition)");
+        py::arg("weighted_iterations") = 10, py::arg("regularization") = 1e-13, py::arg("devices") = std::vector<int>{},
+        "PNEC::Solve for a list of frame pairs, every stage one device launch over the batch (addition); devices: the "
+        "GPUs to shard the pairs over from this process (empty: the default device)");
   m.def("ceres_solver_batch", &ceres_solver_batch, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"),
         py::arg("init_poses"), py::arg("regularization") = 1e-13,
         "PNEC::CeresSolver for a list of frame pairs in one device launch (addition)");

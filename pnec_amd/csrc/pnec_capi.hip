@@ -2,6 +2,8 @@
 // (reference AoS -> SoA planes), launch selection, and the small auxiliary kernels.
 #include <hip/hip_runtime.h>
 
+#include <thread>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -1923,6 +1925,42 @@ int pnec_hip_problem_select(pnec_hip_problem *src, const uint8_t *mask, int spac
   return 0;
 }
 
+int pnec_hip_problem_select_view(pnec_hip_problem *src, const uint8_t *mask, int space, void *stream_,
+                                 pnec_hip_problem **out) {
+  if (!src || !mask || !out) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (space != PNEC_HIP_MEM_DEVICE && space != PNEC_HIP_MEM_HOST)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad memory space");
+  *out = nullptr;
+  DeviceGuard guard(src->device);
+  hipStream_t stream = (hipStream_t)stream_;
+  if (space == PNEC_HIP_MEM_HOST)
+    if (int rc = materialize(src)) return rc;  // a host mask is sized by the source's exact total
+  if (!src->sel_view || src->sel_view->cap_doubles < src->data_doubles || src->sel_view->cap_pairs < src->n_pairs) {
+    if (src->sel_view) pnec_hip_problem_destroy(src->sel_view);
+    src->sel_view = nullptr;
+    if (int rc = alloc_like(src, stream, &src->sel_view)) return rc;
+  }
+  const uint8_t *d_mask = mask;
+  if (space == PNEC_HIP_MEM_HOST) {
+    const int64_t M = std::max<int64_t>(src->n_corr, 1);
+    if (src->mask_bytes < M) {
+      if (src->d_mask) (void)dev_free(src->d_mask);
+      src->d_mask = nullptr;
+      src->mask_bytes = 0;
+      const int64_t want = std::max<int64_t>(M, src->cap_doubles / std::max(src->nc, 1));
+      PNEC_HIP_TRY(dev_alloc(&src->d_mask, (size_t)want));
+      src->mask_bytes = want;
+    }
+    if (src->n_corr > 0)
+      PNEC_HIP_TRY(hipMemcpyAsync(src->d_mask, mask, (size_t)src->n_corr, hipMemcpyHostToDevice, stream));
+    d_mask = src->d_mask;
+  }
+  if (int rc = select_into(src, d_mask, stream, src->sel_view)) return rc;
+  if (space == PNEC_HIP_MEM_HOST) PNEC_HIP_TRY(hipStreamSynchronize(stream));  // (the caller may reuse `mask`)
+  *out = src->sel_view;
+  return 0;
+}
+
 int pnec_hip_unscented_transform(int64_t n, const double *mu, const double *covs, const double *K_inv,
                                  double kappa, int camera_model, double *out_bvs, double *out_covs,
                                  int space, int device, void *stream_) {
@@ -2043,6 +2081,7 @@ int pnec_hip_selftest(int device) {
 #include "pnec_pipeline.inl"
 #include "pnec_stream.inl"
 #include "pnec_frame.inl"
+#include "pnec_multi.inl"
 
 int64_t pnec_hip_release_cache(int device) {
   std::lock_guard<std::mutex> lock(g_mem_mutex);

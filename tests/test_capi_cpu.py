@@ -77,6 +77,7 @@ def test_argument_validation_without_device():
     assert L.pnec_hip_problem_create_capacity(0, capi.MODE_TARGET, 0, 100, C.byref(h)) == -1
     assert L.pnec_hip_problem_create_capacity(0, 9, 4, 100, C.byref(h)) == -1
     assert L.pnec_hip_problem_reshape(None, 1, offs.ctypes.data, None) == -1
+    assert L.pnec_hip_problem_select_view(None, None, 0, None, C.byref(h)) == -1
     assert L.pnec_hip_frame_create(0, 0, None, C.byref(h)) == -1 and b"max_corr" in L.pnec_hip_last_error()
     assert L.pnec_hip_frame_create(0, 100, None, None) == -1
     assert L.pnec_hip_frame_solve(None, 1, None, None, None, None, None, None, None, None, None, None) == -1

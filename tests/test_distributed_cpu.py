@@ -79,3 +79,27 @@ def test_pack_unpack_round_trip():
     back = pd.unpack_records(pd.pack_records(res))
     assert torch.equal(back.q, res.q) and torch.equal(back.t, res.t)
     assert torch.equal(back.iterations, res.iterations) and torch.equal(back.status, res.status)
+
+
+def test_c_abi_partition_is_the_python_partition():
+    """pnec_hip_partition (the shard boundaries of pnec_hip_solve_pipeline_multi, one process, several GPUs) follows
+    the rule of pnec_amd.distributed.partition (the multi-process bench): contiguous ranges of pairs balanced by
+    correspondence count, a pure function of the sizes."""
+    import ctypes as C
+    from pnec_amd import capi
+    L = capi.lib()
+    rng = np.random.default_rng(3)
+    for counts in (rng.integers(1, 700, size=1000), np.full(64, 512), np.array([5, 0, 0, 900, 3]), np.array([7]),
+                   rng.integers(0, 3, size=50)):
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        for parts in (1, 2, 3, 8, 16):
+            got = np.zeros(parts + 1, dtype=np.int64)
+            assert L.pnec_hip_partition(len(counts), off.ctypes.data, parts, got.ctypes.data) == 0
+            np.testing.assert_array_equal(got, pd.partition(counts, parts))
+    got = np.zeros(3, dtype=np.int64)
+    assert L.pnec_hip_partition(0, None, 2, got.ctypes.data) == 0 and not got.any()
+    assert L.pnec_hip_partition(4, None, 2, got.ctypes.data) == -1
+    assert L.pnec_hip_partition(4, off.ctypes.data, 0, got.ctypes.data) == -1
+    # the multi-device entry checks its arguments before touching a device
+    assert L.pnec_hip_solve_pipeline_multi(0, None, 1, off.ctypes.data, None, None, None, None, None, None, None, None,
+                                           None, None) == -1

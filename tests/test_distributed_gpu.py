@@ -208,3 +208,54 @@ def test_rccl_gather_of_device_records_on_the_side_stream_one_rank_communicator(
     r = subprocess.run([sys.executable, "-c", RCCL_ONE_RANK], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     assert "RCCL_GATHER_ON_SIDE_STREAM_OK" in r.stdout
+
+
+def test_one_process_multi_device_entry_equals_the_single_device_call():
+    """pnec_hip_solve_pipeline_multi / PNEC::SolveBatch(pairs, devices) (round 4): the batch sharded over a device LIST
+    from one process -- contiguous ranges by pnec_hip_partition, one host thread + batch + stream per entry, RANSAC draws
+    by global pair index.  With the one GPU a box has: devices = [0, 0] and [0, 0, 0] (two / three handles and threads
+    on the same device) must give the single-device call's poses, masks and counts bit for bit, ragged sizes included."""
+    import numpy as np
+    from pnec_amd import Batch, capi
+    from pnec_amd import simulation as sim
+    rng = np.random.default_rng(12)
+    P = 700
+    counts = rng.integers(40, 600, size=P).astype(np.int64)
+    counts[:3] = [5, 513, 64]
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    g = sim.generate(1, int(off[-1]), seed=5)
+    poses = sim.generate(P, 4, seed=6)
+    f1, f2, cv = g.bvs1[0].numpy(), g.bvs2[0].numpy().copy(), g.covs2[0].numpy()
+    bad = rng.random(len(f2)) < 0.1
+    v = rng.normal(size=(int(bad.sum()), 3))
+    f2[bad] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    c9 = np.ascontiguousarray(np.transpose(cv, (0, 2, 1)).reshape(-1, 9))
+    q0, t0 = poses.init_q.numpy().copy(), poses.init_t.numpy().copy()
+    L = capi.lib()
+    with Batch(capi.MODE_TARGET, off) as b:
+        b.fill(f1, f2, cv)
+        q, t, mask, cnt = b.solve_pipeline(q0, t0, want_inliers=True)
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        d = np.asarray(devs, dtype=np.int32)
+        oq, ot = np.zeros((P, 4)), np.zeros((P, 3))
+        om, oc = np.zeros(int(off[-1]), dtype=np.uint8), np.zeros(P, dtype=np.int32)
+        capi.check(L.pnec_hip_solve_pipeline_multi(len(d), d.ctypes.data, P, off.ctypes.data, f1.ctypes.data, f2.ctypes.data,
+                                                   c9.ctypes.data, q0.ctypes.data, t0.ctypes.data, None, oq.ctypes.data,
+                                                   ot.ctypes.data, om.ctypes.data, oc.ctypes.data))
+        np.testing.assert_array_equal(oq, np.asarray(q)), devs
+        np.testing.assert_array_equal(ot, np.asarray(t))
+        np.testing.assert_array_equal(om, np.asarray(mask).astype(np.uint8))
+        np.testing.assert_array_equal(oc, np.asarray(cnt))
+    # a device that does not exist is an error, not a hang
+    d = np.asarray([0, 99], dtype=np.int32)
+    assert L.pnec_hip_solve_pipeline_multi(2, d.ctypes.data, P, off.ctypes.data, f1.ctypes.data, f2.ctypes.data, c9.ctypes.data,
+                                           q0.ctypes.data, t0.ctypes.data, None, oq.ctypes.data, ot.ctypes.data, None, None) == -1
+    # the facade's overload (C++ through pybind): the same poses and inlier lists as its single-device SolveBatch
+    import pypnec
+    lists = lambda a: [a[off[p]:off[p + 1]] for p in range(40)]
+    T0 = [np.vstack([np.hstack([poses.init_R[p].numpy(), poses.init_t[p].numpy()[:, None]]), [0, 0, 0, 1]]) for p in range(40)]
+    one, inl_one = pypnec.solve_batch(lists(f1), lists(f2), lists(cv), T0)
+    two, inl_two = pypnec.solve_batch(lists(f1), lists(f2), lists(cv), T0, devices=[0, 0])
+    for a, bb in zip(one, two):
+        np.testing.assert_array_equal(a, bb)
+    assert list(inl_one) == list(inl_two)

@@ -293,6 +293,13 @@ def test_all_four_solve_overloads_agree_and_fill_the_timing_like_the_reference(o
         assert min(tim["nec_es"], tim["it_es"], tim["avg_it_es"], tim["ceres"]) >= 0     # all written (ms)
         assert tim["avg_it_es"] == tim["it_es"] // 10
         assert tim["optimization"] == tim["nec_es"] + tim["it_es"] + tim["ceres"] and tim["total"] == tim["optimization"]
+        # the microsecond twins (round 4): every stage took SOME time, the millisecond fields are their truncations,
+        # and the row prints them with the id in front
+        for k in ("nec_es", "it_es", "ceres"):
+            assert 1.0 < tim[k + "_us"] < 5e5 and tim[k] == int(tim[k + "_us"] / 1000.0), (k, tim)
+        assert tim["avg_it_es_us"] == pytest.approx(tim["it_es_us"] / 10) and tim["optimization_us"] == pytest.approx(
+            tim["nec_es_us"] + tim["it_es_us"] + tim["ceres_us"])
+        assert tim["row_us"].split()[0] == "7" and len(tim["row_us"].split()) == len(tim["header_us"].split()) == 6
     # which fields each Options branch writes (-1 = left as the caller had it)
     _, _, tim = pypnec.solve(b1, b2, cv, init, overload=3, use_nec=True)
     assert tim["nec_es"] >= 0 and tim["ceres"] >= 0 and tim["it_es"] == -1 and tim["avg_it_es"] == -1

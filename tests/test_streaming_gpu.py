@@ -353,3 +353,38 @@ def test_pipeline_survives_degenerate_pairs():
         assert np.isfinite(q[p]).all() and np.isfinite(t[p]).all() and np.isfinite(qn[p]).all(), p
     np.testing.assert_array_equal(q[7:], np.asarray(q_ref)[7:])      # pairs are independent
     np.testing.assert_array_equal(np.asarray(cnt)[7:], np.asarray(cnt_ref)[7:])
+
+
+def test_select_view_is_bitwise_select_and_reuses_one_target():
+    """pnec_hip_problem_select_view (round 4): InlierExtraction into the batch's CACHED target -- what the timed
+    PNEC::Solve overloads use per frame instead of creating and destroying a batch.  Same planes, counts and offsets
+    as pnec_hip_problem_select, for host and device masks, twice in a row with different masks (the second call
+    replaces the first result in place), and the later stages give the same bits on either."""
+    import torch
+    counts = np.array([100, 64, 513, 9, 300], dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(counts)])
+    g = sim.generate(1, int(off[-1]), seed=77, device="cuda:0")
+    poses = sim.generate(len(counts), 4, seed=78, device="cuda:0")
+    f1, f2, cv = g.bvs1[0], g.bvs2[0], g.covs2[0]
+    rng = np.random.default_rng(5)
+    with Batch(capi.MODE_TARGET, off) as b:
+        b.fill(f1, f2, cv)
+        for rep in range(2):
+            mask = (rng.random(int(off[-1])) < (0.8 if rep == 0 else 0.5)).astype(np.uint8)
+            for m in (mask, torch.from_numpy(mask).cuda()):
+                own = b.select(m)
+                view = b.select(m, view=True)
+                np.testing.assert_array_equal(view.offsets, own.offsets)
+                # the planes: a target keeps the SOURCE's block layout; pair p's kept correspondences fill the first
+                # round_up(m_p, 64) doubles of each of its 12 planes (what lies beyond belongs to nobody)
+                pv, po = view.export_payload(), own.export_payload()
+                block = np.concatenate([[0], np.cumsum(12 * ((counts + 63) // 64 * 64))])
+                kept = np.diff(own.offsets)
+                for p in range(len(counts)):
+                    used = 12 * int((kept[p] + 63) // 64 * 64)
+                    np.testing.assert_array_equal(pv[block[p]:block[p] + used], po[block[p]:block[p] + used])
+                r_own = own.solve(poses.init_q, poses.init_t)
+                r_view = view.solve(poses.init_q, poses.init_t)
+                assert torch.equal(r_own.q, r_view.q) and torch.equal(r_own.iterations, r_view.iterations)
+                view.close()          # (a no-op for the library: the target belongs to b)
+                own.close()
