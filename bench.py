@@ -64,6 +64,91 @@ FLOP_PER_CORR_PASS = 153
 # weight, no Jacobian, no normal equations): 24 FMA + 17 MUL + 1 max + 1 rsq = 43 instructions, 67 flop
 VALU_INSTR_PER_CORR_COST_PASS = 43
 FLOP_PER_CORR_COST_PASS = 67
+# ---- the chain's front stages: algorithmic FP64 flop per unit of work (counted from the algebra of pnec_frontend.hip, an
+# FMA = 2 flop; DESIGN.md 5b has the derivations).  The NUMBER of units a launch holds depends on the data (Newton
+# iterations per hypothesis, where a model is dropped); it is counted once by a -DPNEC_WORK_COUNT build of the library
+# (tools/count_chain_work.py -> profiles/chain_work_latest.json) and combined here with the live stage times.
+FLOP_ES_QUAD_EVAL = 4 * 1123 + 160   # lambda_min(M(R)) + eigenvector + gradient at 4 points (M from the 36 sums 411, eigenpair
+                                     # by Rayleigh-quotient iteration ~274, gradient 391, Cayley 47) + the iteration's head
+FLOP_SCORE_CORR = 117                # reprojection score of one correspondence against one model
+FLOP_INLIER_CORR = 117 + 84          # ... + its 36 sums when it is an inlier
+FLOP_SAMPLE_CORR = 84                # a sampled correspondence's share of the 36 sums
+FLOP_SUMS36W_CORR = 145              # weight + 36 weighted sums
+FLOP_WES_TABLE_CORR = 129            # n = f1 x R f2 and B = f1hat R Sigma R' f1hat' + reg I
+FLOP_WES_COST_CORR = 28              # (t.n)^2 / t'Bt
+FLOP_WES_SCF_CORR = 36               # A_i / t'B_i t into the 3x3 sum
+FLOP_WES_BOUND_CORR = 18             # n n' / trace(B)
+
+
+def chain_stage_rooflines(counts, stage_ms, payload_bytes, inlier_payload_bytes, refinement):
+    """Roofline block per stage of the chain: VALU-bound stages by algorithmic flop (committed work counts x the flop
+    model above) against the FP64 vector peak, the bandwidth-bound ones by the bytes they must move against HBM."""
+    out = []
+    if counts:
+        r, w = counts["ransac_stage"], counts["weighted_stage"]
+        ss = 10
+        fl = (r.get("ransac_quad_evaluations", 0) + r.get("es_on_inliers_quad_evaluations", 0)) * FLOP_ES_QUAD_EVAL \
+            + r.get("ransac_scored_tiles", 0) * 64 * FLOP_SCORE_CORR + r.get("ransac_inlier_pass_corr", 0) * FLOP_INLIER_CORR \
+            + r.get("ransac_hypotheses", 0) * ss * FLOP_SAMPLE_CORR
+        t = stage_ms["ransac_es"] * 1e-3
+        out.append({"stage": "RANSAC eigensolver + InlierExtraction (ransac*_eigensolver_kernel, es_batch_kernel<1>)",
+                    "bound": "valu_fp64", "achieved": fl / t / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": fl / t / 1e12 / FP64_VALU_PEAK_TFLOPS, "ms": stage_ms["ransac_es"], "algorithmic_gflop": fl / 1e9,
+                    "work": {k: r[k] for k in r}, "hbm_bytes_min": payload_bytes + inlier_payload_bytes,
+                    "hbm_frac_if_it_were_the_bound": (payload_bytes + inlier_payload_bytes) / t / 1e9 / HBM_PEAK_GBS})
+        fl = (w.get("es_first_quad_evaluations", 0) + w.get("weighted_inkernel_quad_evaluations", 0)) * FLOP_ES_QUAD_EVAL \
+            + w.get("sums36_weighted_corr", 0) * FLOP_SUMS36W_CORR + w.get("weighted_table_corr", 0) * FLOP_WES_TABLE_CORR \
+            + w.get("weighted_cost_corr", 0) * FLOP_WES_COST_CORR + w.get("weighted_scf_corr", 0) * FLOP_WES_SCF_CORR \
+            + w.get("weighted_bound_corr", 0) * FLOP_WES_BOUND_CORR
+        t = stage_ms["weighted_es"] * 1e-3
+        out.append({"stage": "weighted eigensolver + SCF (sums36_kernel<true>, es_batch_kernel<0>, weighted_eigensolver_kernel)",
+                    "bound": "valu_fp64", "achieved": fl / t / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": fl / t / 1e12 / FP64_VALU_PEAK_TFLOPS, "ms": stage_ms["weighted_es"], "algorithmic_gflop": fl / 1e9,
+                    "work": {k: w[k] for k in w}, "hbm_bytes_min": 2 * inlier_payload_bytes,
+                    "hbm_frac_if_it_were_the_bound": 2 * inlier_payload_bytes / t / 1e9 / HBM_PEAK_GBS})
+    else:
+        for k, name in (("ransac_es", "RANSAC eigensolver + InlierExtraction"), ("weighted_es", "weighted eigensolver + SCF")):
+            out.append({"stage": name, "bound": "valu_fp64", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": None, "ms": stage_ms[k],
+                        "note": "no committed work counts for this workload (tools/count_chain_work.py)"})
+    out.append(refinement)
+    return out
+
+
+def load_chain_counts(name, pairs, corr):
+    try:
+        c = json.load(open(os.path.join(ROOT, "profiles", "chain_work_latest.json")))["workloads"][name]
+        return c if (c["pairs"], c["correspondences"]) == (pairs, corr) else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def refinement_roofline(batch, res, kernel_ms, ragged, capi, launch=None):
+    """The roofline block of one launch of lm_solve_kernel<TARGET> over `batch` (result `res`): read-once HBM bytes and
+    algorithmic FP64 flop (153 per correspondence and full pass, 67 for the cost-only pass of a solve that ends at the
+    iteration cap) against the two roofs."""
+    import torch
+    my_pairs = int(res.iterations.numel())
+    payload = batch.payload_bytes
+    iters_done = res.iterations.to(torch.float64)
+    passes = float(iters_done.mean()) + 1.0 if my_pairs else 0.0
+    sizes = torch.as_tensor(np.diff(batch.offsets), dtype=torch.float64, device=iters_done.device)
+    n_hyp = my_pairs // max(1, len(sizes))
+    if n_hyp > 1:
+        sizes = sizes.repeat_interleave(n_hyp)
+    corr_passes = float(((iters_done + 1.0) * sizes).sum()) if my_pairs else 0.0
+    capped = res.status == capi.TERM_MAX_ITERATIONS
+    cost_corr = float((capped.to(torch.float64) * sizes).sum()) if my_pairs else 0.0
+    full_corr = corr_passes - cost_corr
+    t = kernel_ms * 1e-3
+    flops = FLOP_PER_CORR_PASS * full_corr + FLOP_PER_CORR_COST_PASS * cost_corr
+    gbs = payload / t / 1e9
+    return {"stage": "refinement (lm_solve_kernel<TARGET>)", "bound": "hbm", "bound_binding": "valu_fp64",
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "ms": kernel_ms,
+            "algorithmic_bytes_per_launch": payload, "passes": passes,
+            "valu": {"achieved": flops / t / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flops / t / 1e12 / FP64_VALU_PEAK_TFLOPS},
+            "binding_frac": flops / t / 1e12 / FP64_VALU_PEAK_TFLOPS, "launch": launch}
 
 
 def parse_args(argv=None):
@@ -80,6 +165,10 @@ def parse_args(argv=None):
     ap.add_argument("--wpp", type=int, default=0, help="launch tuning: wavefronts per solve")
     ap.add_argument("--ldsk", type=int, default=0, help="launch tuning: correspondences per lane kept in LDS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="sim100k on one GPU: skip the `secondary` array (BASELINE configs 3, 4, 5 and the whole chain, measured "
+                         "in the same process after the headline)")
+    ap.add_argument("--quick-secondary", action="store_true", help="fewer steps / a shorter stream in the secondary runs (tests)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
     ap.add_argument("--sync-gather", action="store_true", help="gather on the solve's stream (A/B of the overlap)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="gloo + stubbed solve: exercises spawn/partition/gather without a GPU")
@@ -328,6 +417,221 @@ def profiled_counters(lib_path, key):
 
 
 # ---------------------------------------------------------------------------------------------------
+# the other BASELINE configs, measured in the same process after the headline (the `secondary` array of the line)
+def _quat_angles(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    d = np.abs(np.sum(a * b, axis=1)).clip(0, 1)
+    v = np.stack([a[:, 3] * b[:, 0] - a[:, 0] * b[:, 3] - a[:, 1] * b[:, 2] + a[:, 2] * b[:, 1],
+                  a[:, 3] * b[:, 1] + a[:, 0] * b[:, 2] - a[:, 1] * b[:, 3] - a[:, 2] * b[:, 0],
+                  a[:, 3] * b[:, 2] - a[:, 0] * b[:, 1] + a[:, 1] * b[:, 0] - a[:, 2] * b[:, 3]], 1)
+    return 2.0 * np.arctan2(np.linalg.norm(v, axis=1), d)
+
+
+def chain_stage_times(batch, q0, t0, reps=3):
+    """The chain stage by stage (the same launches as the one call, bit-identical results) with events between the
+    stages: ms per stage, mean of `reps` after one warm-up."""
+    import torch
+    acc = {"ransac_es": 0.0, "inlier_extraction": 0.0, "weighted_es": 0.0, "refinement": 0.0}
+    res = None
+    for r in range(reps + 1):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        qr, tr, mask, cnt, its = batch.ransac_eigensolver(q0, seed=1)
+        ev[1].record()
+        sel = batch.select(mask, view=True)
+        ev[2].record()
+        qw, tw = sel.weighted_eigensolver(qr, tr, 1e-13, 10)
+        ev[3].record()
+        res = sel.solve(qw, tw)
+        ev[4].record()
+        torch.cuda.synchronize()
+        if r:
+            for k, (a, b) in zip(acc, zip(ev[:-1], ev[1:])):
+                acc[k] += a.elapsed_time(b) / reps
+    sel_payload = int(cnt.sum()) * 96
+    return acc, res, sel, sel_payload
+
+
+def secondary_lines(device, capi, quick=False):
+    """BASELINE configs 3, 4, 5 and the whole PNEC::Solve chain on this GPU, each {workload, value, unit, ms_per_step,
+    roofline, parity}; an entry that fails reports its error instead of taking the headline down with it."""
+    import torch
+
+    from oracle import pnec_oracle as po
+    from pnec_amd import Batch, select_best
+    from pnec_amd import simulation as sim
+    from pnec_amd import tracks as tk
+    out = []
+    cores = po.max_threads()
+
+    def guarded(fn):
+        try:
+            out.append(fn())
+        except Exception as e:   # noqa: BLE001 -- the line must come out
+            out.append({"workload": fn.__name__, "error": f"{type(e).__name__}: {e}"})
+        torch.cuda.synchronize()
+
+    def timed(fn, steps, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        e1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        t0 = time.perf_counter()
+        r = None
+        for i in range(steps):
+            e0[i].record()
+            r = fn()
+            e1[i].record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / steps * 1e3
+        return r, wall, float(np.mean([a.elapsed_time(b) for a, b in zip(e0, e1)]))
+
+    sizes = tk.kitti_all_sizes()
+    P = int(len(sizes))
+
+    def kitti_all_refinement():
+        tr = tk.kitti_all_shard(0, P, device=device)
+        with Batch(capi.MODE_TARGET, tr.offsets, device=device.index) as b:
+            b.fill(tr.bvs1, tr.bvs2, tr.covs)
+            q0, t0 = tr.init_q.contiguous(), tr.init_t.contiguous()
+            opts = capi.default_options()
+            res, wall, kms = timed(lambda: b.solve(q0, t0, reg=1e-13, options=opts), 10 if quick else 30, 5)
+            roof = refinement_roofline(b, res, kms, True, capi, b.describe_launch(opts))
+            k = 256
+            m = int(tr.offsets[k])
+            oq = po.solve_batch(po.MODE_TARGET, np.asarray(tr.offsets[:k + 1]), tr.bvs1[:m].cpu().numpy(), tr.bvs2[:m].cpu().numpy(),
+                                po.covs_to_colmajor9(tr.covs[:m].cpu().numpy()), None, 1e-13, q0[:k].cpu().numpy(),
+                                t0[:k].cpu().numpy(), options=po.default_options(jacobian_mode=po.JAC_NUMERIC_CENTRAL),
+                                num_threads=cores)
+            ang = _quat_angles(res.q[:k].cpu().numpy(), oq[0])
+            its_eq = int((res.iterations[:k].cpu().numpy() == oq[3]).sum())
+        return {"workload": "configs[4] on one GPU: all KITTI 00-10 frame pairs (23 190 ragged pairs, synthetic KITTI-like stand-in), "
+                            "refinement with Ceres-default termination", "value": P / (wall * 1e-3), "unit": "solves/s",
+                "ms_per_step": wall, "kernel_ms": kms, "lm_iterations_mean": float(res.iterations.double().mean()),
+                "roofline": roof, "parity": {"max_rot_err_rad": float(ang.max()), "median_rot_err_rad": float(np.median(ang)),
+                                             "n_pairs": k, "iteration_counts_equal": its_eq, "tolerance_rad": 1e-6,
+                                             "against": "oracle (central differences + Ceres LM policy), same inputs"}}
+
+    def kitti_all_chain():
+        tr = tk.kitti_all_shard(0, P, device=device, outlier_frac=0.10)
+        q0, t0 = tr.init_q.contiguous(), tr.init_t.contiguous()
+        batches = []
+        for _ in range(3):
+            b = Batch(capi.MODE_TARGET, tr.offsets, device=device.index)
+            b.fill(tr.bvs1, tr.bvs2, tr.covs)
+            batches.append(b)
+        try:
+            one = lambda: batches[0].solve_pipeline(q0, t0, want_inliers=True)
+            (q, t, mask, cnt), wall1, dev1 = timed(one, 6 if quick else 12, 3)
+            streams = [torch.cuda.Stream(device=device) for _ in range(3)]
+            steps = 9 if quick else 18
+            for i in range(3):
+                with torch.cuda.stream(streams[i]):
+                    batches[i].solve_pipeline(q0, t0, want_inliers=True)
+            torch.cuda.synchronize()
+            t_0 = time.perf_counter()
+            for i in range(steps):
+                with torch.cuda.stream(streams[i % 3]):
+                    batches[i % 3].solve_pipeline(q0, t0, want_inliers=True)
+            torch.cuda.synchronize()
+            wall3 = (time.perf_counter() - t_0) / steps * 1e3
+            stage_ms, res, sel, sel_payload = chain_stage_times(batches[0], q0, t0)
+            assert torch.equal(res.q, q)                       # the stages one by one == the one call, bit for bit
+            counts = load_chain_counts("kitti_all_chain", P, int(sizes.sum()))
+            roofs = chain_stage_rooflines(counts, {"ransac_es": stage_ms["ransac_es"] + stage_ms["inlier_extraction"],
+                                                   "weighted_es": stage_ms["weighted_es"]},
+                                          batches[0].payload_bytes // 2, sel_payload,
+                                          refinement_roofline(sel, res, stage_ms["refinement"], True, capi))
+            k = 64
+            m = int(tr.offsets[k])
+            o = po.solve_chain_batch(np.asarray(tr.offsets[:k + 1]), tr.bvs1[:m].cpu().numpy(), tr.bvs2[:m].cpu().numpy(),
+                                     tr.covs[:m].cpu().numpy(), q0[:k].cpu().numpy(), seed=1, num_threads=cores)
+            ang = _quat_angles(q[:k].cpu().numpy(), o["q"])
+            masks_eq = bool((mask[:m].cpu().numpy().astype(bool) == o["mask"]).all())
+        finally:
+            for b in batches:
+                b.close()
+        return {"workload": "PNEC::Solve, whole chain with the reference's default Options (RANSAC eigensolver, InlierExtraction, "
+                            "weighted eigensolver + SCF, refinement) over all KITTI 00-10 frame pairs (23 190 ragged pairs, "
+                            "synthetic stand-in, 10 % gross mismatches), one pnec_hip_solve_pipeline call per step",
+                "value": P / (wall3 * 1e-3), "unit": "pairs/s", "ms_per_step": wall3, "steps_in_flight": 3,
+                "pairs_per_s_one_call_at_a_time": P / (wall1 * 1e-3), "ms_per_step_one_call_at_a_time": wall1,
+                "stage_ms_stage_by_stage": stage_ms, "roofline": roofs,
+                "inlier_share_mean": float((cnt.double() / torch.as_tensor(sizes, dtype=torch.float64, device=device)).mean()),
+                "parity": {"max_rot_err_rad": float(ang.max()), "median_rot_err_rad": float(np.median(ang)), "n_pairs": k,
+                           "inlier_masks_identical": masks_eq, "tolerance_rad": 1e-6,
+                           "against": "the oracle's chain (pnec_oracle_solve_chain_batch), same inputs and draws"}}
+
+    def multi_hypothesis():
+        Bp, N, H = 64, 4096, 64
+        g = sim.generate(Bp, N, seed=9, device=device)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(5)
+        hyp = torch.randn(Bp * H, 3, generator=gen, dtype=torch.float64, device=device)
+        hyp = hyp / hyp.norm(dim=1, keepdim=True)
+        hyp[::H] = g.init_t
+        opts = capi.default_options(max_num_iterations=10, check_convergence=0)
+        with Batch.uniform(capi.MODE_TARGET, Bp, N, device=device.index) as b:
+            b.fill(g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3))
+
+            def go():
+                r = b.solve(g.init_q, None, options=opts, hyp_t=hyp, n_hyp=H)
+                select_best(r.cost, H)
+                return r
+            res, wall, kms = timed(go, 5 if quick else 10, 2)
+            roof = refinement_roofline(b, res, kms, False, capi, b.describe_launch(opts))
+            oo = po.default_options(jacobian_mode=po.JAC_NUMERIC_CENTRAL, max_num_iterations=10, check_convergence=0)
+            worst, its_ok = 0.0, True
+            for (pp, h) in ((0, 0), (63, 63), (17, 5), (40, 33)):
+                sres = po.solve(po.MODE_TARGET, g.bvs1[pp].cpu().numpy(), g.bvs2[pp].cpu().numpy(), g.covs2[pp].cpu().numpy(), None,
+                                1e-13, g.init_q[pp].cpu().numpy(), hyp[pp * H + h].cpu().numpy(), oo)
+                worst = max(worst, float(_quat_angles(res.q[pp * H + h][None].cpu().numpy(), sres.q[None])[0]))
+                its_ok = its_ok and int(res.iterations[pp * H + h]) == sres.iterations
+        return {"workload": "configs[3]: multi-hypothesis, 64 pairs x 4096 correspondences x 64 random t-hat starts sharing the pair's "
+                            "payload (4096 solves per launch, 8 wavefronts per solve), 10 LM iterations, + select_best",
+                "value": Bp * H / (wall * 1e-3), "unit": "solves/s", "ms_per_step": wall, "kernel_ms": kms, "roofline": roof,
+                "parity": {"max_rot_err_rad": worst, "n_solves": 4, "iteration_counts_equal": its_ok, "tolerance_rad": 1e-6,
+                           "against": "oracle (central differences + Ceres LM policy), sampled (pair, hypothesis) solves"}}
+
+    def kitti00_streamed():
+        from pnec_amd.streaming import Stream
+        Ps = 1000 if quick else 4541
+        offsets, f1, f2, c2, R_gt, t_gt, q0, t0 = sim.generate_kitti_like(Ps, mean_corr=500, seed=3)
+        f1, f2, c2, q0, t0 = (x.numpy() for x in (f1, f2, c2, q0, t0))
+        with Batch(capi.MODE_TARGET, offsets, device=device.index) as b:
+            b.fill(f1, f2, c2)
+            ref = b.solve(q0, t0)
+        gq = np.zeros((Ps, 4))
+        with Stream(max_corr=int(np.diff(offsets).max()), slots=8, device=device.index) as st:
+            for rep in range(2):                       # the first pass warms the handle
+                tickets, nxt = [], 0
+                t_0 = time.perf_counter()
+                for pp in range(Ps):
+                    a, e = offsets[pp], offsets[pp + 1]
+                    tickets.append(st.submit(capi.MODE_TARGET, f1[a:e], f2[a:e], c2[a:e], None, q0[pp], t0[pp]))
+                    if len(tickets) == 8:
+                        gq[nxt] = st.wait(tickets.pop(0)).q[0]
+                        nxt += 1
+                while tickets:
+                    gq[nxt] = st.wait(tickets.pop(0)).q[0]
+                    nxt += 1
+                wall = time.perf_counter() - t_0
+        return {"workload": f"configs[2]: a KITTI-00-like sequence of {Ps} consecutive frame pairs (synthetic stand-in, ~500 ragged "
+                            "correspondences) STREAMED one pair per call (pnec_hip_stream_*: host arrays in, pose out, 8 in flight), "
+                            "refinement with Ceres-default termination; includes the host-side copies and the Python loop",
+                "value": Ps / wall, "unit": "pairs/s", "ms_per_step": wall / Ps * 1e3,
+                "roofline": {"bound": "latency", "note": "one pair per launch: bounded by the submit path (memcpy into pinned staging + one "
+                                                         "launch + flag poll), not by a device roof; the same pairs as one batch: see the "
+                                                         "kitti_all entry"},
+                "parity": {"bitwise_equal_to_the_batched_call": bool(np.array_equal(gq, np.asarray(ref.q))), "n_pairs": Ps}}
+
+    for fn in (kitti_all_refinement, kitti_all_chain, multi_hypothesis, kitti00_streamed):
+        guarded(fn)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
 def run(args):
     import torch
     import torch.distributed as dist
@@ -520,8 +824,8 @@ def run(args):
             if args.workload == "kitti_all":
                 line["config"]["corr_per_rank"] = sh.shard_corr
         elif args.chain:
-            # the chain is five kernels of different character; no single roofline describes it.
-            # Reported: the device time of this rank's shard per step and the inlier statistics of the last step.
+            # the chain is a handful of kernels of different character: one roofline block per STAGE.
+            # Also reported: the device time of this rank's shard per step and the inlier statistics of the last step.
             dev_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
             inl = gathered[:, 8].detach().cpu()
             line["config"].update({"corr_per_rank": sh.shard_corr,
@@ -530,14 +834,22 @@ def run(args):
                                    "options": "reference defaults: RANSAC eigensolver (5000 its max, 10-point samples), "
                                               "weighted_iterations 10 + SCF, Ceres-default refinement"})
             line["config"]["steps_in_flight"] = in_flight
-            line["chain"] = {"device_ms_per_step_rank0": dev_ms,
+            stage_ms, sres, ssel, sel_payload = chain_stage_times(sh.batches[0], sh.q0, sh.t0)
+            counts = load_chain_counts("kitti_all_chain", sh.total_pairs, int(sh.pair_sizes.sum())) \
+                if (world == 1 and not args.tracks and args.outliers == 0.10) else None
+            line["roofline"] = chain_stage_rooflines(
+                counts, {"ransac_es": stage_ms["ransac_es"] + stage_ms["inlier_extraction"], "weighted_es": stage_ms["weighted_es"]},
+                sh.batches[0].payload_bytes // 2, sel_payload, refinement_roofline(ssel, sres, stage_ms["refinement"], True, capi))
+            line["chain"] = {"device_ms_per_step_rank0": dev_ms, "stage_ms_stage_by_stage_rank0": stage_ms,
                              "steps_in_flight": in_flight,
                              "pairs_per_s_one_step_at_a_time": one_at_a_time,
                              "in_flight_note": "each step in flight runs on its own stream and its own copy of the batch; "
                                                "device_ms_per_step is one step's span while the others run beside it",
                              "inlier_share_mean": float((inl / torch.as_tensor(sh.pair_sizes, dtype=torch.float64)).mean()),
-                             "note": "one pnec_hip_solve_pipeline call per step and rank; stage kernels and their bounds: "
-                                     "profiles/r03_full_pipeline_kernels.md"}
+                             "note": "one pnec_hip_solve_pipeline call per step and rank; `roofline` has one block per stage "
+                                     "(stage times from the same chain run stage by stage on rank 0; algorithmic flop from the "
+                                     "committed work counts, profiles/chain_work_latest.json); stage kernels: "
+                                     "profiles/r04_full_pipeline_kernels.md"}
         else:
             kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
             batch = sh.batch
@@ -614,6 +926,13 @@ def run(args):
                 base, parity = cpu_baseline(sh.sample, n_sample, opts, res.q)
                 line["cpu_baseline"] = base
                 line["parity"] = parity
+            if args.workload == "sim100k" and world == 1 and not args.no_secondary and not args.no_cpu_baseline:
+                # the other configs + the chain, on this GPU, after the headline's timed region (the headline's batch is
+                # released first: nothing of it is timed any more)
+                sh.batch.close()
+                t_sec = time.perf_counter()
+                line["secondary"] = secondary_lines(device, capi, quick=args.quick_secondary)
+                line["secondary_wall_s"] = time.perf_counter() - t_sec
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -367,6 +367,13 @@ int pnec_hip_describe_launch(const pnec_hip_problem *p, const pnec_hip_options *
  * Jacobi sweeps, on generic, nearly degenerate, rank-deficient and badly scaled matrices).  0 = all good. */
 int pnec_hip_selftest(int device);
 
+/* Work counters of the front stages, for roofline accounting: how many evaluations of the eigenvalue function, scored
+ * tiles, table builds, ... the launches since the last reset held (the indices: enum kWk* in pnec_frontend.hip; the
+ * numbers depend on the data, not on the timing).  Only a library built with -DPNEC_WORK_COUNT counts
+ * (tools/count_chain_work.py builds and runs one); the production build compiles the counting out and reports
+ * *compiled_in = 0 and zeros.  Waits for the device. */
+int pnec_hip_work_counters(int device, int reset, uint64_t *out16, int32_t *compiled_in);
+
 /* The library keeps freed device buffers for reuse (batches are created and destroyed per frame or per
  * frame set in a pipeline; hipMalloc/hipFree cost tens of microseconds for small buffers and far more for
  * GB-sized ones).  Cap: environment

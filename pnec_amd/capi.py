@@ -76,6 +76,7 @@ SYMBOLS = [
     "pnec_hip_unscented_transform",
     "pnec_hip_describe_launch",
     "pnec_hip_selftest",
+    "pnec_hip_work_counters",
     "pnec_hip_release_cache",
 ]
 
@@ -185,6 +186,7 @@ def lib() -> C.CDLL:
     L.pnec_hip_problem_select.argtypes = [_vp, _vp, C.c_int, _vp, C.POINTER(_vp)]
     L.pnec_hip_problem_select_view.argtypes = [_vp, _vp, C.c_int, _vp, C.POINTER(_vp)]
     L.pnec_hip_partition.argtypes = [C.c_int64, _vp, C.c_int32, _vp]
+    L.pnec_hip_work_counters.argtypes = [C.c_int, C.c_int, _vp, C.POINTER(C.c_int32)]
     L.pnec_hip_solve_pipeline_multi.argtypes = [C.c_int32, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp,
                                                 C.POINTER(PipelineOptions), _vp, _vp, _vp, _vp]
     L.pnec_hip_weighted_eigensolver.argtypes = [_vp, _vp, _vp, C.c_double, C.c_int32, _vp, _vp, C.c_int, _vp]

@@ -35,6 +35,7 @@ hipError_t launch_ransac_eigensolver(const double *, const int64_t *, const int6
                                      const double *, unsigned long long, unsigned long long, int, int, double, double *, double *,
                                      uint8_t *, int32_t *, int32_t *, double *, int32_t *, hipStream_t, hipStream_t,
                                      hipEvent_t, hipEvent_t, int, double *, const int64_t *, int32_t *, int64_t *, void *);
+hipError_t frontend_work_counters(int, unsigned long long *, int *);
 size_t ransac_workspace_bytes(int64_t);
 int64_t ransac_split_threshold();
 hipError_t launch_select(int, const double *, const int64_t *, const int64_t *, const int32_t *, const uint8_t *,
@@ -1922,6 +1923,18 @@ int pnec_hip_problem_select(pnec_hip_problem *src, const uint8_t *mask, int spac
     }
   }
   *out = dst;
+  return 0;
+}
+
+int pnec_hip_work_counters(int device, int reset, uint64_t *out16, int32_t *compiled_in) {
+  if (!out16) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "out16 is NULL");
+  DeviceGuard guard(device);
+  if (!guard.ok) return fail(PNEC_HIP_ERR_HIP_RUNTIME, "hipSetDevice failed (no such device?)");
+  unsigned long long c[16];
+  int in = 0;
+  PNEC_HIP_TRY(frontend_work_counters(reset, c, &in));
+  for (int i = 0; i < 16; ++i) out16[i] = (uint64_t)c[i];
+  if (compiled_in) *compiled_in = in;
   return 0;
 }
 

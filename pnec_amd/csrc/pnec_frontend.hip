@@ -63,6 +63,35 @@ __device__ unsigned long long g_dbg[16];
 #define PNEC_DBG_WAVE(i)
 #endif
 
+// -DPNEC_WORK_COUNT: WORK counters of the front stages (a measurement build: tools/count_chain_work.py).  What a
+// stage's roofline needs besides its duration is how much algorithmic work a launch held -- evaluations of the eigenvalue
+// function, scored tiles, table builds, passes over the tables -- and that depends on the data (how many Newton
+// iterations a hypothesis takes, where a model is dropped).  The counts are properties of the workload, not of the
+// timing: they are taken once with this build, committed (profiles/chain_work_latest.json) and combined with the live
+// stage times by bench.py.  The production build compiles every PNEC_WORK_ADD to nothing.
+enum : int {
+  kWkRansacEvals = 0,    // quad-evaluations (value + gradient at a point and its three Hessian probes, or four step lengths) of hypothesis minimisations
+  kWkRansacHyps,         // hypotheses prepared (sample, 36 sums, jittered start)
+  kWkRansacTiles,        // tiles of 64 correspondences scored against a model
+  kWkRansacInlierCorr,   // correspondences of the final inlier pass
+  kWkEsTailEvals,        // quad-evaluations of the eigensolver on the inliers (es_batch_kernel<translation>)
+  kWkEsFirstEvals,       // ... of the plain / weighted stage's first minimisation (es_batch_kernel<none>)
+  kWkWesEvals,           // ... of the weighted kernel's own later rounds
+  kWkWesTableCorr,       // correspondences whose (n, B) table was built
+  kWkWesCostCorr,        // correspondence terms of cost evaluations (current translation, candidate directions)
+  kWkWesScfCorr,         // correspondence terms of SCF steps
+  kWkWesBoundCorr,       // correspondence terms of the direction bound's matrix
+  kWkSumsCorr,           // correspondences of the 36-sums passes (plain)
+  kWkSumsWeightedCorr,   // ... weighted
+  kWkCount = 16
+};
+#ifdef PNEC_WORK_COUNT
+__device__ unsigned long long g_work[kWkCount];
+#define PNEC_WORK_ADD(i, n) atomicAdd(&g_work[i], (unsigned long long)(n))
+#else
+#define PNEC_WORK_ADD(i, n) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // symmetric 3x3 eigen-decomposition, cyclic Jacobi; eigenvalues ascending, eigenvectors in the
 // columns of V (row-major), largest-magnitude component of each made positive.
@@ -639,6 +668,12 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
   }
   if (e_out) { e_out[0] = eb[0]; e_out[1] = eb[1]; e_out[2] = eb[2]; }
   if (evals_out) *evals_out = evals;
+#ifdef PNEC_WORK_COUNT
+  // TAG 1: a RANSAC hypothesis (one problem per quad); TAG 2: es_batch_kernel (one pair per quad; which epilogue: the
+  // caller moves the count); TAG 0: the weighted kernel's in-kernel rounds (every quad repeats the pair's problem: once)
+  if (TAG == 1 && role == 0 && active) PNEC_WORK_ADD(kWkRansacEvals, evals);
+  if (TAG == 0 && threadIdx.x == 0 && active) PNEC_WORK_ADD(kWkWesEvals, evals);
+#endif
   return it;
 }
 
@@ -819,6 +854,7 @@ __global__ __launch_bounds__(kWave) void sums36_kernel(const FrontArgs a, const 
     t0[0] = a.init_t[3 * pair]; t0[1] = a.init_t[3 * pair + 1]; t0[2] = a.init_t[3 * pair + 2];
   }
   pass_sums36<WEIGHTED>(base, n, stride, R0, t0, WEIGHTED ? a.reg : 0.0, lane, G);
+  if (lane == 0) PNEC_WORK_ADD(WEIGHTED ? kWkSumsWeightedCorr : kWkSumsCorr, n);
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (lane < 36) out.G[36 * pair + lane] = G[lane];
@@ -864,7 +900,13 @@ __global__ __launch_bounds__(kWave, 2) void es_batch_kernel(const EsBatchArgs a)
   const bool mine = first_pair + quad < a.n_pairs;
   const int64_t pair = mine ? first_pair + quad : a.n_pairs - 1;
   double v[3] = {a.s.v0[3 * pair], a.s.v0[3 * pair + 1], a.s.v0[3 * pair + 2]};
+#ifdef PNEC_WORK_COUNT
+  int evals_here = 0;
+  const int it = es_minimise_quad<1, 3>(Gs[quad], v, a.s.n_scale[pair], nullptr, true, &evals_here);   // (TAG 3: counted here)
+  if (mine && (lane & 3) == 0) PNEC_WORK_ADD(EPI == kEpiNone ? kWkEsFirstEvals : kWkEsTailEvals, evals_here);
+#else
   const int it = es_minimise_quad<1, 2>(Gs[quad], v, a.s.n_scale[pair]);
+#endif
 #ifdef PNEC_FRONT_DEBUG
   if (mine && (lane & 3) == 0) {
     atomicMax(&g_dbg[12], (unsigned long long)it);
@@ -1143,6 +1185,7 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
       planes_arrived(pe[0]);
 #pragma unroll
       for (int k = 1; k < KR; ++k) planes_after(pe[k]);
+      if (threadIdx.x == 0) PNEC_WORK_ADD(kWkWesTableCorr, n);
 #pragma unroll
       for (int k = 0; k < KR; ++k) {
         const int idx = (WPP > 1 ? wave * KR * kWave : 0) + lane + kWave * k;
@@ -1170,6 +1213,7 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
       pair_sum(cs);
       cur_cost = cs[0];
     }
+    if (threadIdx.x == 0) PNEC_WORK_ADD(kWkWesCostCorr, n);
     PNEC_PHASE_END(kPhCost);
     [[maybe_unused]] auto energy_term = [](double tx, double ty, double tz, const double(&nn)[3], const double(&B)[6]) {
       const double aa = tx * nn[0] + ty * nn[1] + tz * nn[2];
@@ -1201,6 +1245,7 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
           m[4] = __builtin_fma(wy, rn[k][2], m[4]); m[5] = __builtin_fma(wz, rn[k][2], m[5]);
         }
         pair_sum(m);
+        if (threadIdx.x == 0) PNEC_WORK_ADD(kWkWesBoundCorr, n);
         // t' M t for this lane's directions from the planes of products (all 48 loads in flight together), a hair
         // below the bound: the costs it is compared with carry their own rounding.  The bounds belong to the
         // tables: later rounds on the same rotation compare them with their own current cost without a load.
@@ -1267,6 +1312,7 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
           }
           double cs[1] = {sacc};
           pair_sum(cs);
+          if (threadIdx.x == 0) PNEC_WORK_ADD(kWkWesCostCorr, n);
           if (fib_min_idx < 0 || cs[0] < fib_min_cost) {
             fib_min_cost = cs[0];
             fib_min_idx = c;
@@ -1412,6 +1458,7 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
         e[3] += w * nn[1] * nn[1]; e[4] += w * nn[1] * nn[2]; e[5] += w * nn[2] * nn[2];
       });
       pair_sum(e);
+      if (threadIdx.x == 0) PNEC_WORK_ADD(kWkWesScfCorr, n);
       const double E[9] = {e[0], e[1], e[2], e[1], e[3], e[4], e[2], e[4], e[5]};
       // smallest eigenvector of E: Rayleigh-quotient iteration from the current t (the iteration is
       // near its fixed point after the first step or two), Jacobi sweeps when that cannot be vouched for
@@ -1667,9 +1714,13 @@ __device__ __forceinline__ int model_inliers_until_beaten(const ScoreTiles &P, c
                                                            int lane, int beat) {
   int cnt = 0;
   bool beaten = false;
+  [[maybe_unused]] int tiles_scored = 0;
   auto tile = [&](auto tc) {
     constexpr int i = decltype(tc)::value;
     if (beaten || kWave * i >= nn) return;  // wave-uniform
+#ifdef PNEC_WORK_COUNT
+    ++tiles_scored;
+#endif
     const double f1[3] = {P.f[i][0], P.f[i][1], P.f[i][2]}, f2[3] = {P.f[i][3], P.f[i][4], P.f[i][5]};
     const bool in = (kWave * i + lane < nn) && reprojection_score(f1, f2, R, t) < threshold;
     cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
@@ -1680,6 +1731,9 @@ __device__ __forceinline__ int model_inliers_until_beaten(const ScoreTiles &P, c
   tile(std::integral_constant<int, 2>{}); tile(std::integral_constant<int, 3>{});
   tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{});
   tile(std::integral_constant<int, 6>{}); tile(std::integral_constant<int, 7>{});
+#ifdef PNEC_WORK_COUNT
+  if (lane == 0) PNEC_WORK_ADD(kWkRansacTiles, tiles_scored + ((beaten || nn <= kWave * kScoreTiles) ? 0 : (nn - kWave * kScoreTiles + kWave - 1) / kWave));  // (the streamed rest: counted as scored in full)
+#endif
   if (beaten || nn <= kWave * kScoreTiles) return cnt;
   // the rest of a pair of more than 512 correspondences: from memory, the next tile in flight while this one is scored
   double cur[6];
@@ -1869,6 +1923,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
           for (int j = 0; j < m; ++j) dup = dup || (sel(j) == (int)idx);
           if (!dup) sel(m++) = (int)idx;
         }
+        if (role == 0) PNEC_WORK_ADD(kWkRansacHyps, 1);
       }
       double ev1[3] = {0, 0, 0};  // sum f1 (for the directional evidence)
       {
@@ -2053,8 +2108,12 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
   if (quad < n_tasks) arm(tlist[quad]);
   int next = kHypPerRound;  // wave-uniform: the next entry of tlist to hand out
   int trips = 0;            // evaluations as the wavefront executes them (diagnostics)
+  [[maybe_unused]] int my_evals = 0;
   for (;;) {
     ++trips;
+#ifdef PNEC_WORK_COUNT
+    if (state != kDone) ++my_evals;
+#endif
     if (state != kDone) {
       const double *G = Gtab[slot];
       // ---- the point this lane evaluates in this trip
@@ -2181,6 +2240,9 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
     next += __builtin_popcountll(fb);
     if (__builtin_amdgcn_ballot_w64(state != kDone) == 0ull) break;
   }
+#ifdef PNEC_WORK_COUNT
+  if (role == 0) PNEC_WORK_ADD(kWkRansacEvals, my_evals);
+#endif
   return trips;
 }
 
@@ -2295,6 +2357,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
       // model phase reads the sample from LDS
       int smp[PNEC_HIP_MAX_RANSAC_SAMPLE];
       if (active) ransac_sample_regs(a.seed, pid, hh, n[pp], ss, smp);
+      if (active && role == 0) PNEC_WORK_ADD(kWkRansacHyps, 1);
       double ev1[3], Gl[36];
       ransac_sample_sums(base[pp], stride[pp], ss, active, smp, role, Gl, ev1);
       if (role == 0 && active) {
@@ -2467,6 +2530,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
       if (lane == 0) lds.G[pp][i] = sres;
     }
     const int total = (int)wave_allreduce_sum((double)my_count);
+    if (lane == 0) PNEC_WORK_ADD(kWkRansacInlierCorr, nn);
     int first = my_first;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -2919,6 +2983,25 @@ hipError_t fibonacci_table(int device) {
     g_fib_ready[device] = true;
   }
   return hipSuccess;
+}
+
+// the work counters of the current device (PNEC_WORK_COUNT builds; otherwise *compiled_in = 0 and zeros)
+hipError_t frontend_work_counters(int reset, unsigned long long *out16, int *compiled_in) {
+  for (int i = 0; i < kWkCount; ++i) out16[i] = 0;
+#ifdef PNEC_WORK_COUNT
+  *compiled_in = 1;
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_work), sizeof(unsigned long long) * kWkCount);
+  if (e == hipSuccess && reset) {
+    const unsigned long long zeros[kWkCount] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_work), zeros, sizeof(zeros));
+  }
+  return e;
+#else
+  (void)reset;
+  *compiled_in = 0;
+  return hipSuccess;
+#endif
 }
 
 // scratch_d: kFrontScratchDoubles * n_pairs doubles, scratch_i: kFrontScratchInts * n_pairs ints (device)

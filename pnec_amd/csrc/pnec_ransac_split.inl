@@ -128,6 +128,7 @@ __device__ __forceinline__ int ransac_finish_pair(const RansacArgs &a, int64_t p
     if (lane == 0) G[i] = sres;
   }
   const int total = (int)wave_allreduce_sum((double)my_count);
+  if (lane == 0) PNEC_WORK_ADD(kWkRansacInlierCorr, n);
   int first = my_first;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -170,6 +171,7 @@ __device__ __forceinline__ void ransac_prepare_group(const RansacArgs &a, unsign
   const unsigned long long hh = (unsigned long long)(it0 + hyp);
   int smp[PNEC_HIP_MAX_RANSAC_SAMPLE];
   if (active) ransac_sample_regs(a.seed, pid, hh, n, ss, smp);
+  if (active && role == 0) PNEC_WORK_ADD(kWkRansacHyps, 1);
   ransac_sample_sums(bs, st, ss, active, smp, role, Gl, ev1);
   if (active && role == 0) {
 #pragma unroll
@@ -438,7 +440,11 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void es_queue_ke
   wave_lds_sync();
   arm_read();
   prefetch(hand_out(cur_task >= 0));
+  [[maybe_unused]] int my_evals = 0;
   for (;;) {
+#ifdef PNEC_WORK_COUNT
+    if (state != kDone) ++my_evals;
+#endif
     if (state != kDone) {
       const double *G = Gq[quad];
       // ---- the point this lane evaluates in this trip (es_minimise_queue's trip, line for line)
@@ -567,4 +573,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void es_queue_ke
     }
     if (__builtin_amdgcn_ballot_w64(state != kDone || cur_task >= 0) == 0ull) break;
   }
+#ifdef PNEC_WORK_COUNT
+  if (role == 0) PNEC_WORK_ADD(kWkRansacEvals, my_evals);
+#endif
 }

@@ -146,3 +146,27 @@ def test_profiled_counters_are_dropped_when_the_device_code_changed(tmp_path, mo
     committed = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
     assert committed["kernel_sources_sha256"] == bench.kernel_sources_sha256(), \
         "profiles/traffic_latest.json is stale: re-run tools/profile_bench.sh + tools/make_traffic_json.py"
+
+
+def test_chain_stage_rooflines_from_committed_work_counts():
+    """bench.py --chain prints one roofline block per stage: algorithmic flop = committed work counts
+    (profiles/chain_work_latest.json, taken by a -DPNEC_WORK_COUNT build) x the flop model, over the live stage time.
+    The counts are keyed by workload (pairs, correspondences): another workload gets blocks without a fraction, never a
+    stale one; and the committed file has the two bench workloads with plausible contents."""
+    import bench
+    c = bench.load_chain_counts("kitti_all_chain", 23190, 11595556)
+    assert c is not None and c["ransac_stage"]["ransac_hypotheses"] >= 16 * 23190
+    assert 5 < c["ransac_stage"]["ransac_quad_evaluations"] / c["ransac_stage"]["ransac_hypotheses"] < 20
+    assert bench.load_chain_counts("kitti_all_chain", 23190, 1) is None and bench.load_chain_counts("nope", 1, 1) is None
+    ref = {"stage": "refinement", "bound": "hbm", "frac": 0.3}
+    blocks = bench.chain_stage_rooflines(c, {"ransac_es": 2.0, "weighted_es": 1.0}, 10**9, 9 * 10**8, ref)
+    assert [b["bound"] for b in blocks] == ["valu_fp64", "valu_fp64", "hbm"] and blocks[2] is ref
+    r = blocks[0]
+    want = ((c["ransac_stage"]["ransac_quad_evaluations"] + c["ransac_stage"]["es_on_inliers_quad_evaluations"]) * bench.FLOP_ES_QUAD_EVAL
+            + c["ransac_stage"]["ransac_scored_tiles"] * 64 * bench.FLOP_SCORE_CORR
+            + c["ransac_stage"]["ransac_inlier_pass_corr"] * bench.FLOP_INLIER_CORR
+            + c["ransac_stage"]["ransac_hypotheses"] * 10 * bench.FLOP_SAMPLE_CORR)
+    assert r["algorithmic_gflop"] == pytest.approx(want / 1e9) and r["achieved"] == pytest.approx(want / 2e-3 / 1e12)
+    assert 0.0 < r["frac"] < 1.0 and 0.0 < blocks[1]["frac"] < 1.0          # below the roof at these (realistic) times
+    none = bench.chain_stage_rooflines(None, {"ransac_es": 2.0, "weighted_es": 1.0}, 1, 1, ref)
+    assert none[0]["frac"] is None and "no committed work counts" in none[0]["note"]

@@ -259,3 +259,26 @@ def test_one_process_multi_device_entry_equals_the_single_device_call():
     for a, bb in zip(one, two):
         np.testing.assert_array_equal(a, bb)
     assert list(inl_one) == list(inl_two)
+
+
+def test_default_bench_line_carries_the_other_configs_and_the_chain():
+    """`python bench.py` on one GPU (what the driver runs): besides the headline the ONE JSON line has a `secondary` array
+    -- BASELINE configs 3, 4, 5 and the whole PNEC::Solve chain, measured in the same process -- each with value, unit,
+    ms_per_step, roofline and parity, none of them failed, parity within the north star's tolerance, the chain entry with
+    one roofline block per stage (run here with fewer steps and a shorter headline batch)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--pairs", "20000",
+                        "--quick-secondary", "--cpu-sample", "64"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["metric"].startswith("PNEC pose solves/sec") and line["value"] > 1e6 and "roofline" in line and "cpu_baseline" in line
+    sec = line["secondary"]
+    assert len(sec) == 4 and not any("error" in e for e in sec), [e.get("error") for e in sec]
+    for e in sec:
+        assert e["value"] > 0 and e["unit"] in ("solves/s", "pairs/s") and e["ms_per_step"] > 0 and "roofline" in e
+        p = e["parity"]
+        assert p.get("max_rot_err_rad", 0.0) <= 1e-6 and p.get("bitwise_equal_to_the_batched_call", True)
+    chain = sec[1]
+    assert chain["parity"]["inlier_masks_identical"] and [b["bound"] for b in chain["roofline"]] == ["valu_fp64", "valu_fp64", "hbm"]
+    assert all(b["frac"] is not None and 0 < b["frac"] < 1 for b in chain["roofline"])
+    assert chain["value"] >= chain["pairs_per_s_one_call_at_a_time"] * 0.9
