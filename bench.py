@@ -417,6 +417,68 @@ def profiled_counters(lib_path, key):
 
 
 # ---------------------------------------------------------------------------------------------------
+# N > 1: pre-flight + the first collective under a watchdog.  The multi-GPU path has never met more than one device on
+# the builder's boxes; whatever goes wrong the first time it does (a communicator that cannot form, IPC handles the
+# driver refuses, a rank that never arrives) must come out as ONE JSON line with an "error", not as a hang.
+def _fail_line(args, what, detail):
+    print(json.dumps({"metric": "PNEC pose solves/sec (512 corr, 10 GN iters)" if args.workload == "sim100k" else "PNEC (kitti_all)",
+                      "value": None, "unit": "solves/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                      "error": what, "detail": detail}), flush=True)
+
+
+def join_job(args, world, rank, device, cpu):
+    import datetime
+    import threading
+
+    import torch
+    import torch.distributed as dist
+    backend = "gloo" if (cpu or args.share_gpu) else "nccl"
+    info = {"backend": backend, "world_size": world, "rank": rank, "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+            "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+            "NCCL_DEBUG": os.environ.get("NCCL_DEBUG"), "torch": torch.__version__}
+    if not cpu:
+        info["visible_devices"] = torch.cuda.device_count()
+        info["device"] = str(device)
+        try:
+            info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:   # noqa: BLE001
+            info["rccl_version"] = f"unavailable ({e})"
+    if rank == 0:
+        print(json.dumps({"preflight": info}), file=sys.stderr, flush=True)
+    limit = float(os.environ.get("PNEC_BENCH_JOIN_TIMEOUT_S", "180"))
+    stage = ["init_process_group"]
+
+    def watchdog():
+        if rank == 0:
+            _fail_line(args, f"multi-GPU start-up did not finish within {limit:.0f} s (stuck in {stage[0]})", info)
+        else:
+            print(json.dumps({"rank": rank, "error": f"stuck in {stage[0]}", "preflight": info}), file=sys.stderr, flush=True)
+        os._exit(3)
+
+    timer = threading.Timer(limit, watchdog)
+    timer.daemon = True
+    timer.start()
+    try:
+        if backend == "gloo":
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=limit))
+        else:
+            dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=limit))
+        stage[0] = "the first collective (all_reduce of one number per rank)"
+        probe = torch.ones(1, dtype=torch.float64, device="cpu" if backend == "gloo" else device)
+        dist.all_reduce(probe)
+        if not cpu:
+            torch.cuda.synchronize()
+        if int(probe.item()) != world:
+            raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
+    except Exception as e:   # noqa: BLE001
+        timer.cancel()
+        if rank == 0:
+            _fail_line(args, f"{stage[0]} failed: {type(e).__name__}: {e}", info)
+        raise SystemExit(3)
+    timer.cancel()
+
+
+# ---------------------------------------------------------------------------------------------------
 # the other BASELINE configs, measured in the same process after the headline (the `secondary` array of the line)
 def _quat_angles(a, b):
     a, b = np.asarray(a), np.asarray(b)
@@ -655,10 +717,7 @@ def run(args):
         device = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if cpu or args.share_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=device)
+        join_job(args, world, rank, device, cpu)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     n_ranks = dist.get_world_size() if world > 1 else 1
 

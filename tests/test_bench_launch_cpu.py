@@ -170,3 +170,21 @@ def test_chain_stage_rooflines_from_committed_work_counts():
     assert 0.0 < r["frac"] < 1.0 and 0.0 < blocks[1]["frac"] < 1.0          # below the roof at these (realistic) times
     none = bench.chain_stage_rooflines(None, {"ransac_es": 2.0, "weighted_es": 1.0}, 1, 1, ref)
     assert none[0]["frac"] is None and "no committed work counts" in none[0]["note"]
+
+
+def test_a_rank_that_never_arrives_gives_a_json_error_line_not_a_hang():
+    """bench.py --gpus N (N > 1) pre-flight: rank 0 reports the backend, the visible devices, the RCCL version and
+    HSA_ENABLE_IPC_MODE_LEGACY on stderr before the first collective, and start-up is bounded: here rank 1 of a 2-rank
+    job is never started -- rank 0 must end within its limit with ONE JSON line carrying "error" (value null)."""
+    import json
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               PNEC_BENCH_JOIN_TIMEOUT_S="6")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-500:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] is None and line["n_gpus"] == 2 and ("init_process_group" in line["error"] or "did not finish" in line["error"])
+    pre = json.loads(next(l for l in r.stderr.splitlines() if l.startswith('{"preflight"')))["preflight"]
+    assert pre["backend"] == "gloo" and pre["world_size"] == 2 and "HSA_ENABLE_IPC_MODE_LEGACY" in pre
