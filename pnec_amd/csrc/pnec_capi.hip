@@ -116,6 +116,12 @@ struct pnec_hip_problem {
   bool owns_data = true;               // false: a re-typed view of another batch's buffers (NEC view of a TARGET batch)
   pnec_hip_problem *sel_view = nullptr;  // pipeline: cached InlierExtraction target (same capacity, reused)
   pnec_hip_problem *nec_view = nullptr;  // pipeline: this batch's bearings as a NEC-family batch (no copy)
+  // pipeline, large batches: contiguous ranges of the pairs as batches of their own (views: no data of their own,
+  // index arrays = slices of this batch's), each with its scratch and its stream, and the same for the InlierExtraction
+  // target -- the chain runs on them side by side (pnec_pipeline.inl)
+  std::vector<pnec_hip_problem *> chunk_views, chunk_sel_views;
+  std::vector<hipStream_t> chunk_streams;
+  std::vector<hipEvent_t> chunk_done;
   uint8_t *d_mask = nullptr;             // pipeline: inlier mask [n_corr]
   int64_t mask_bytes = 0;
 };
@@ -1189,6 +1195,8 @@ int pnec_hip_problem_destroy(pnec_hip_problem *p) {
   // when they go back to the cache
   const bool drained = hipDeviceSynchronize() == hipSuccess;
   auto release = [&](void *ptr) { (void)dev_free_impl(ptr, drained); };
+  for (pnec_hip_problem *v : p->chunk_views) pnec_hip_problem_destroy(v);
+  for (pnec_hip_problem *v : p->chunk_sel_views) pnec_hip_problem_destroy(v);
   if (p->sel_view) pnec_hip_problem_destroy(p->sel_view);
   if (p->nec_view) pnec_hip_problem_destroy(p->nec_view);
   release(p->d_mask);
@@ -1212,6 +1220,12 @@ int pnec_hip_problem_destroy(pnec_hip_problem *p) {
     if (drained) pool_stream_put(st, p->device); else (void)hipStreamDestroy(st);
   }
   for (hipEvent_t ev : p->side_done) {
+    if (drained) pool_event_put(ev, p->device); else (void)hipEventDestroy(ev);
+  }
+  for (hipStream_t st : p->chunk_streams) {
+    if (drained) pool_stream_put(st, p->device); else (void)hipStreamDestroy(st);
+  }
+  for (hipEvent_t ev : p->chunk_done) {
     if (drained) pool_event_put(ev, p->device); else (void)hipEventDestroy(ev);
   }
   if (p->fork_event) {

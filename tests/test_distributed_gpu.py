@@ -156,7 +156,10 @@ def test_bench_chain_workload_two_ranks_share_the_gpu():
     against one rank: same gathered records"""
     two = _run_bench(["--gpus", "2", "--share-gpu", "--workload", "kitti_all", "--chain", "--steps", "2", "--warmup", "1"])
     one = _run_bench(["--gpus", "1", "--workload", "kitti_all", "--chain", "--steps", "2", "--warmup", "1"])
-    assert two["unit"] == one["unit"] == "pairs/s" and "chain" in two and "roofline" not in two
+    assert two["unit"] == one["unit"] == "pairs/s" and "chain" in two
+    # one roofline block per stage (round 4); the work counts behind the flop figures belong to the one-rank synthetic set
+    assert [b["bound"] for b in one["roofline"]] == ["valu_fp64", "valu_fp64", "hbm"] and one["roofline"][0]["frac"] is not None
+    assert two["roofline"][0]["frac"] is None and two["roofline"][2]["frac"] > 0
     assert 0.8 < two["chain"]["inlier_share_mean"] < 0.95                    # 10 % gross mismatches rejected
     assert two["records_sha256"] == one["records_sha256"]
     # ... and steps in flight (each on its own stream and copy of the batch; the default is three) against one at a time
