@@ -90,7 +90,8 @@ typedef struct pnec_hip_options {
   int32_t corr_per_lane;                     /* 0 = auto; launch tuning: correspondences held per lane */
   int32_t waves_per_pair;                    /* 0 = auto; launch tuning: wavefronts cooperating on one solve */
   int32_t lds_corr_per_lane;                 /* launch tuning: how many of corr_per_lane live in LDS */
-  int32_t reserved;                          /* must be 0 */
+  int32_t reserved;                          /* 0; bit 0 (diagnostics): add the correspondence-passes this call executes --
+                                                in full / cost-only -- to pnec_hip_work_counters()[13] / [14] */
   double function_tolerance;                 /* 1e-6 */
   double gradient_tolerance;                 /* 1e-10 */
   double parameter_tolerance;                /* 1e-8 */
@@ -371,7 +372,9 @@ int pnec_hip_selftest(int device);
  * tiles, table builds, ... the launches since the last reset held (the indices: enum kWk* in pnec_frontend.hip; the
  * numbers depend on the data, not on the timing).  Only a library built with -DPNEC_WORK_COUNT counts
  * (tools/count_chain_work.py builds and runs one); the production build compiles the counting out and reports
- * *compiled_in = 0 and zeros.  Waits for the device. */
+ * *compiled_in = 0 and zeros.  Entries [13] and [14] work in every build: the correspondence-passes the refinement
+ * executed in full (residual, weight, Jacobian, normal equations) and cost-only (after a rejected step and at the iteration
+ * cap) in the pnec_hip_solve calls made with pnec_hip_options.reserved bit 0 set.  Waits for the device. */
 int pnec_hip_work_counters(int device, int reset, uint64_t *out16, int32_t *compiled_in);
 
 /* The library keeps freed device buffers for reuse (batches are created and destroyed per frame or per

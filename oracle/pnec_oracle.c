@@ -659,6 +659,22 @@ static int chol_solve5(const double A[25], const double b[5], double y[5]) {
 }
 
 /* Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy [EXT], default options. */
+/* diagnostics (test tooling): how many LM steps reached the accept / reject decision, and how many were rejected */
+static long long g_lm_steps_evaluated = 0, g_lm_steps_rejected = 0;
+static long long g_lm_promise[2][24][2]; /* [after accepted-or-first | after rejected][decade of model_change / cost, -24 .. -1][accepted | rejected] */
+void pnec_oracle_lm_promise_histogram(long long out[96]) { memcpy(out, g_lm_promise, sizeof(g_lm_promise)); memset(g_lm_promise, 0, sizeof(g_lm_promise)); }
+static long long g_lm_transitions[3][2]; /* [first step | after an accepted step | after a rejected step][accepted | rejected] */
+void pnec_oracle_lm_step_counts(int reset, long long out[8]) {
+  out[0] = g_lm_steps_evaluated;
+  out[1] = g_lm_steps_rejected;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 2; ++b) out[2 + 2 * a + b] = g_lm_transitions[a][b];
+  if (reset) {
+    g_lm_steps_evaluated = g_lm_steps_rejected = 0;
+    memset(g_lm_transitions, 0, sizeof(g_lm_transitions));
+  }
+}
+
 static int minimise(const problem_t *P, const pnec_oracle_options *o, state_t *x,
                     double *cost_out, int32_t *iters_out) {
   double cost, H[25], g[5], scale[5], Hs[25], gs[5], diag[5];
@@ -687,6 +703,7 @@ static int minimise(const problem_t *P, const pnec_oracle_options *o, state_t *x
   double radius = o->initial_trust_region_radius, decrease_factor = 2.0;
   int reuse_diagonal = 0, num_invalid = 0, step_is_successful = 1;
   int term;
+  int prev_outcome = 0; /* diagnostics: 0 first step, 1 after an accepted, 2 after a rejected one */
 
   for (;;) {
     /* FinalizeIterationAndCheckIfMinimizerCanContinue */
@@ -746,6 +763,23 @@ static int minimise(const problem_t *P, const pnec_oracle_options *o, state_t *x
       }
     }
     const double rho = (cost - cost_c) / model_cost_change;
+#pragma omp atomic
+    g_lm_steps_evaluated += 1;
+    if (!(rho > o->min_relative_decrease)) {
+#pragma omp atomic
+      g_lm_steps_rejected += 1;
+    }
+    {
+      const int now = rho > o->min_relative_decrease ? 0 : 1;
+#pragma omp atomic
+      g_lm_transitions[prev_outcome][now] += 1;
+      /* the model's promise relative to the cost, by decade, against what the step turned out to be */
+      int dec = (int)floor(log10(fmax(model_cost_change / fmax(cost, 1e-300), 1e-30))) + 24;
+      dec = dec < 0 ? 0 : (dec > 23 ? 23 : dec);
+#pragma omp atomic
+      g_lm_promise[prev_outcome == 2 ? 1 : 0][dec][now] += 1;
+      prev_outcome = 1 + now;
+    }
     if (rho > o->min_relative_decrease) {
       *x = xc;
       x_norm = state_norm(x);

@@ -101,6 +101,9 @@ double pnec_oracle_cost_function(int64_t n, const double *bvs1, const double *bv
 /* pnec::common::UnscentedTransform, src/common/common.cc:467-525 (camera_model: 0 = Omnidirectional,
  * 1 = Pinhole, the order of enum CameraModel at include/common/common.h:62).  mu 3, cov 9 and
  * K_inv 9 column-major, out 9 column-major. */
+/* diagnostics: LM steps that reached Ceres' accept / reject decision since the last reset, how many were rejected, and
+ * the outcome by predecessor: out[2 + 2 a + b], a = first step | after an accepted | after a rejected, b = accepted | rejected */
+void pnec_oracle_lm_step_counts(int reset, long long out[8]);
 /* pnec::common::RotationBetweenPoints (common.cc:118-124) for unit vectors; out column-major */
 void pnec_oracle_rotation_between_points(const double p1[3], const double p2[3], double out[9]);
 void pnec_oracle_unscented_transform(const double mu[3], const double cov[9], const double K_inv[9],

@@ -978,6 +978,7 @@ int ensure_front(pnec_hip_problem *p) {
 extern "C" {
 
 static int materialize(const pnec_hip_problem *cp);
+static int solve_work_buffer(int device, unsigned long long **out);
 
 int pnec_hip_abi_version(void) { return PNEC_HIP_ABI_VERSION; }
 
@@ -1481,6 +1482,9 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
   a.reg = reg;
   a.opt = opt;
   finish_args(a);
+  if (opt.reserved & 1) {   // diagnostics: count the passes this call executes (pnec_hip_work_counters)
+    if (int rc = solve_work_buffer(p->device, &a.work)) return rc;
+  }
 
   if (space == PNEC_HIP_MEM_DEVICE) {
     a.init_q = init_q;
@@ -1940,6 +1944,21 @@ int pnec_hip_problem_select(pnec_hip_problem *src, const uint8_t *mask, int spac
   return 0;
 }
 
+// the refinement's pass counters (pnec_hip_options.reserved bit 0): two 64-bit sums per device, allocated on first use
+static unsigned long long *g_solve_work[64] = {nullptr};
+static int solve_work_buffer(int device, unsigned long long **out) {
+  if (device < 0 || device >= 64) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "device index out of range");
+  std::lock_guard<std::mutex> lock(g_mem_mutex);
+  if (!g_solve_work[device]) {
+    unsigned long long *w = nullptr;
+    PNEC_HIP_TRY(hipMalloc(&w, 2 * sizeof(unsigned long long)));
+    PNEC_HIP_TRY(hipMemset(w, 0, 2 * sizeof(unsigned long long)));
+    g_solve_work[device] = w;
+  }
+  *out = g_solve_work[device];
+  return 0;
+}
+
 int pnec_hip_work_counters(int device, int reset, uint64_t *out16, int32_t *compiled_in) {
   if (!out16) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "out16 is NULL");
   DeviceGuard guard(device);
@@ -1949,6 +1968,16 @@ int pnec_hip_work_counters(int device, int reset, uint64_t *out16, int32_t *comp
   PNEC_HIP_TRY(frontend_work_counters(reset, c, &in));
   for (int i = 0; i < 16; ++i) out16[i] = (uint64_t)c[i];
   if (compiled_in) *compiled_in = in;
+  // [13], [14]: correspondence-passes the refinement executed in full / cost-only, for calls made with
+  // pnec_hip_options.reserved bit 0 set (any build)
+  if (device >= 0 && device < 64 && g_solve_work[device]) {
+    unsigned long long w[2] = {0, 0};
+    PNEC_HIP_TRY(hipDeviceSynchronize());
+    PNEC_HIP_TRY(hipMemcpy(w, g_solve_work[device], sizeof(w), hipMemcpyDeviceToHost));
+    out16[13] = w[0];
+    out16[14] = w[1];
+    if (reset) PNEC_HIP_TRY(hipMemset(g_solve_work[device], 0, sizeof(w)));
+  }
   return 0;
 }
 

@@ -70,6 +70,7 @@ struct SolveArgs {
   int32_t *out_iterations;      // [n_solves] or null
   int32_t *out_status;          // [n_solves] or null
   unsigned long long *trace;    // null, or [n_blocks,4]: s_memtime at start / payload on chip / end, hw id
+  unsigned long long *work;     // null, or [2]: correspondence-passes executed in full / cost-only (pnec_hip_options.reserved bit 0)
   int64_t n_solves;
   int32_t n_hyp;
   int32_t pad_;
@@ -127,6 +128,12 @@ enum : int {
   kSlab = 88
 };
 constexpr int kUnif = 18;   // pass uniforms of the candidate: R[9] | t[3] | dt/dtheta[3] | dt/dphi[2] | pad
+// cost-only pass after a rejected step (lm_advance<COST_FIRST>); -DPNEC_NO_COST_FIRST: the always-speculating kernel (A/B)
+#ifdef PNEC_NO_COST_FIRST
+constexpr bool kCostFirst = false;
+#else
+constexpr bool kCostFirst = true;
+#endif
 // per-solve integer state (LDS)
 enum : int { kIIter = 0, kIFirst, kIReuseDiag, kINumInvalid, kIStepOk,
               kILast,  // the published candidate is evaluated at the iteration cap: its Jacobian can never be used
@@ -420,12 +427,25 @@ __device__ __forceinline__ void write_result(const SolveArgs &a, int64_t s, cons
 // wavefront of the SIMD runs its pass, so it is written to keep LDS round trips off the chain:
 // everything is loaded in one batch up front, values are forwarded in registers (an accepted
 // point's J'J / J'r are the pass's sums themselves), and the stores trail.
+// COST_FIRST (round 4): after a REJECTED step the next candidate's pass is cost-only (ist[kILast] = 2), the way Ceres
+// itself evaluates a candidate -- residuals first, the Jacobian only once the step is accepted.  The fused pass
+// speculates on acceptance (cost, J'J and J'r in one go: 91 instructions per correspondence); for a solve that sits at
+// its noise floor the speculation mostly loses: on the benchmark's batch (ten iterations whatever happens; the solves
+// converge after three or four) 42 % of all steps are rejected, and 83 % of the steps that follow a rejected one
+// (oracle counters, pnec_oracle_lm_step_counts).  The cost-only pass is 43 instructions per correspondence and one sum
+// through the reduction tree instead of 21; when such a step IS accepted the same candidate is evaluated once more in
+// full and this function runs again on the complete sums -- same cost bits (the cost-only pass reduces through the same
+// tree), same decision, same everything downstream: the results are bit for bit those of the always-speculating kernel.
+// With Ceres-default termination there is next to nothing to gain or lose (18 rejected steps in 10 046).
+template <bool COST_FIRST>
 __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, const pnec_hip_options &o,
                                           double inv_max_radius, double inv_min_radius) {
   int iteration = ist[kIIter], reuse_diagonal = ist[kIReuseDiag];
   int num_invalid = ist[kINumInvalid], step_ok = ist[kIStepOk];
   const int first = ist[kIFirst];
-  const bool last = ist[kILast] != 0;  // the pass was the cost-only one: sums 1..20 do not exist
+  const int pass_kind = ist[kILast];     // 0: full pass; 1: cost-only at the iteration cap; 2: cost-only after a rejected step
+  const bool last = pass_kind == 1;      // the pass was the cost-only one: sums 1..20 do not exist
+  const bool cost_first = COST_FIRST && pass_kind == 2;
   int park = ist[kIPark];
   int term = -1;
 
@@ -496,6 +516,12 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
     }
   }
 
+  if (term < 0 && cost_first && accept) {
+    // accepted on its cost alone: its normal equations are needed now -- the same candidate once more, in full.
+    // Nothing has been changed up to here (no counter, no radius, no table): the next call starts from the same state.
+    ist[kILast] = 0;
+    return -1;
+  }
   if (term < 0 && last) {
     // at the iteration cap the solve ends here whatever the verdict on the step (Ceres checks
     // max_num_iterations before anything that would read the new Jacobian)
@@ -648,7 +674,12 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
       slab[kThetaC] = thc;
       slab[kPhiC] = phc;
       slab[kModel] = model_change;
-      ist[kILast] = iteration >= o.max_num_iterations ? 1 : 0;
+      // the next pass: cost-only at the cap; cost-only too when the step just decided was rejected, or when the model
+      // promises less than the cost can resolve (a decrease below ~4e-15 of the cost is inside the rounding of a sum of
+      // 512 squares: on the benchmark's batch 65 % of such steps end rejected even right after an accepted one, and
+      // every step that promises more than 1e-14 is accepted -- oracle histogram, pnec_oracle_lm_promise_histogram)
+      const double cost_now = accept ? cost_c : cost;
+      ist[kILast] = iteration >= o.max_num_iterations ? 1 : ((COST_FIRST && (!accept || model_change <= 4.0e-15 * cost_now)) ? 2 : 0);
       break;
     }
     slab[kInvRadius] = inv_radius;
@@ -1083,6 +1114,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   if constexpr (WPP > 1) __syncthreads();  // the first wavefront's start state is what all of them read
 
   int term;
+  int n_full_passes = 0, n_cost_passes = 0;  // wave-uniform (diagnostics: SolveArgs::work)
   for (;;) {
     // ---- one fused pass at the candidate: sum r^2, J'r, J'J ------------------------------
     PNEC_MARK("uniforms");
@@ -1103,6 +1135,8 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
       double c[6];
       bool cost_only = false;
       if constexpr (RESIDENT) cost_only = to_sgpr(ist[kILast]) != 0;  // wave-uniform
+      n_cost_passes += cost_only ? 1 : 0;
+      n_full_passes += cost_only ? 0 : 1;
       if (cost_only) {
         PNEC_MARK("pass_cost");
         if constexpr (RESIDENT) {
@@ -1255,7 +1289,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
     if constexpr (WPP == 1) {
       __builtin_amdgcn_s_setprio(3);
 #ifndef PNEC_ADVANCE_ROWS
-      if (lane < 4) t = lm_advance(slab, ist, unif, o, inv_max_radius, inv_min_radius);  // one quad, identical work (see the sincos exchange)
+      if (lane < 4) t = lm_advance<RESIDENT && kCostFirst>(slab, ist, unif, o, inv_max_radius, inv_min_radius);  // one quad, identical work (see the sincos exchange)
 #else
       t = lm_advance_rows(slab, ist, unif, gidx_all[0], o, inv_max_radius, inv_min_radius, lane);  // every lane: one component per lane
 #endif
@@ -1266,7 +1300,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
       if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);
 #ifndef PNEC_ADVANCE_ROWS
-        if (lane < 4) t = lm_advance(slab, ist, unif, o, inv_max_radius, inv_min_radius);
+        if (lane < 4) t = lm_advance<RESIDENT && kCostFirst>(slab, ist, unif, o, inv_max_radius, inv_min_radius);
 #else
         t = lm_advance_rows(slab, ist, unif, gidx_all[0], o, inv_max_radius, inv_min_radius, lane);
 #endif
@@ -1282,6 +1316,10 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   PNEC_MARK("result");
   if (threadIdx.x == 0) {
     write_result(a, s, slab, ist[kIIter], term);
+    if (a.work) {
+      atomicAdd(a.work + 0, (unsigned long long)n_full_passes * (unsigned long long)n);
+      atomicAdd(a.work + 1, (unsigned long long)n_cost_passes * (unsigned long long)n);
+    }
     if constexpr (SRC == SRC_AOS) {
       // results live in pinned host memory: make them visible system-wide, then count this block in;
       // the block that completes the submit raises the host's flag (the host polls it, no stream sync)

@@ -796,3 +796,47 @@ def test_tail_geometry_is_bitwise_the_two_wavefront_geometry(oracle, mode):
         worst = max(_rot_err(oracle, _quat_to_R(res.q[p]), _quat_to_R(q[p])) for p in range(B))
         assert worst <= ROT_TOL_REFERENCE, worst
         np.testing.assert_array_equal(res.iterations, it)
+
+
+def test_cost_only_pass_after_a_rejected_step_counts_and_changes_no_bit(oracle):
+    """Round 4: a candidate that follows a rejected step (or whose model promises less than the cost can resolve) is
+    evaluated cost-only first -- Ceres' own order: residuals, then the Jacobian once the step is accepted -- and in full
+    only if its step turns out accepted.  Results must be those of the reference-faithful oracle (iteration counts and
+    codes equal: every decision is the same), and the pass counters (pnec_hip_options.reserved bit 0 ->
+    pnec_hip_work_counters[13], [14]) must show that fewer than iterations + 1 full passes per solve ran in the
+    fixed-iteration mode, where the solves sit at their noise floor for most of their ten iterations."""
+    import ctypes as C
+    P, N = 2000, 512
+    g = sim.generate(P, N, seed=1, device="cuda:0")
+    L = capi.lib()
+    cnt = np.zeros(16, dtype=np.uint64)
+    flag = C.c_int32(0)
+    with Batch.uniform(capi.MODE_TARGET, P, N) as b:
+        b.fill(g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3))
+        for conv, mi in ((0, 10), (1, 50)):
+            opts = capi.default_options(max_num_iterations=mi, check_convergence=conv)
+            plain = b.solve(g.init_q, g.init_t, options=opts)
+            capi.check(L.pnec_hip_work_counters(0, 1, cnt.ctypes.data, C.byref(flag)))
+            counted_opts = capi.default_options(max_num_iterations=mi, check_convergence=conv, reserved=1)
+            counted = b.solve(g.init_q, g.init_t, options=counted_opts)
+            torch.cuda.synchronize()
+            capi.check(L.pnec_hip_work_counters(0, 1, cnt.ctypes.data, C.byref(flag)))
+            assert torch.equal(plain.q, counted.q) and torch.equal(plain.iterations, counted.iterations)
+            full, cost = int(cnt[13]), int(cnt[14])
+            its = plain.iterations.cpu().numpy().astype(np.int64)
+            assert full % N == 0 and cost % N == 0
+            # every solve: iteration zero + one pass per iteration at least; a cost-first candidate that is accepted runs twice
+            assert full + cost >= N * int((its + 1).sum()) and full + cost <= N * int((2 * its + 1).sum())
+            if conv == 0:
+                assert full < 0.8 * N * int((its + 1).sum()), (full, cost)        # the speculation is switched off where it loses
+                assert cost > 0.25 * N * int(its.sum())
+            else:
+                assert cost <= 0.05 * (full + cost)                                # Ceres-default termination: next to nothing rejected
+            # parity with the oracle, decisions included
+            oo = _oracle_opts(oracle, opts, oracle.JAC_ANALYTIC if hasattr(oracle, "JAC_ANALYTIC") else oracle.JAC_NUMERIC_CENTRAL)
+            rq, rit, rst = plain.q.cpu().numpy(), its, plain.status.cpu().numpy()
+            for p in range(0, P, 97):
+                s = oracle.solve(oracle.MODE_TARGET, g.bvs1[p].cpu().numpy(), g.bvs2[p].cpu().numpy(), g.covs2[p].cpu().numpy(), None,
+                                 1e-13, g.init_q[p].cpu().numpy(), g.init_t[p].cpu().numpy(), oo)
+                assert rit[p] == s.iterations and rst[p] == s.status, p
+                assert _rot_err(oracle, _quat_to_R(rq[p]), s.R) <= 1e-8, p

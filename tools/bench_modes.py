@@ -22,6 +22,13 @@ ONLY = sys.argv[2].lower() if len(sys.argv) > 2 else "all"
 GEOM = [int(x) for x in sys.argv[3:6]] if len(sys.argv) > 5 else [0, 0, 0]
 N = 512
 dev = torch.device("cuda:0")
+HBM_PEAK_GBS, FP64_VALU_PEAK_TFLOPS = 8000.0, 78.6          # as in bench.py
+# algorithmic FP64 flop per correspondence: one full pass (eval_corr<MODE> + the 21 accumulating FMAs) | the cost-only
+# pass that ends a solve at the iteration cap (eval_cost<MODE> + 1 FMA).  TARGET: counted from the ISA (62 FMA + 28 MUL +
+# 1 rsq; bench.py); the others from the algebra of pnec_device.hpp with an FMA as 2 flop -- NEC drops the covariance
+# products and the normalisation, HOST adds p = R f1, h = t x p, S h and the two extra Jacobian cross products, SYM both
+# covariance terms.
+FLOP = {"NEC": (112, 30), "PNEC target": (153, 67), "PNEC host": (206, 80), "PNEC symmetric": (227, 101)}
 opts = capi.default_options(max_num_iterations=10, check_convergence=0, corr_per_lane=GEOM[0], waves_per_pair=GEOM[1],
                             lds_corr_per_lane=GEOM[2])
 oo = po.default_options(jacobian_mode=po.JAC_NUMERIC_CENTRAL, max_num_iterations=10, check_convergence=0)
@@ -74,9 +81,29 @@ for name, mode, omode in (("NEC", capi.MODE_NEC, po.MODE_NEC), ("PNEC target", c
                         c9 if mode == capi.MODE_SYM else None, reg, first.init_q[:ns].cpu().numpy(),
                         first.init_t[:ns].cpu().numpy(), options=oo)[0]
     ang = quat_angle(res.q[:ns].cpu().numpy(), oq)
+    full, cost_only = FLOP[name]
+    # the passes the kernel executed (cost-only after rejected steps and at the cap): one counted launch
+    import ctypes as C
+    cnt = np.zeros(16, dtype=np.uint64)
+    flag = C.c_int32(0)
+    capi.check(capi.lib().pnec_hip_work_counters(0, 1, cnt.ctypes.data, C.byref(flag)))
+    o2 = capi.Options.from_buffer_copy(bytes(opts))
+    o2.reserved = 1
+    batch.solve(q0, t0, reg=reg, options=o2)
+    torch.cuda.synchronize()
+    capi.check(capi.lib().pnec_hip_work_counters(0, 1, cnt.ctypes.data, C.byref(flag)))
+    flops = float(cnt[13]) * full + float(cnt[14]) * cost_only
+    gbs = batch.payload_bytes / el / 1e9
     print(json.dumps({"family": name, "pairs": B, "corr": N, "lm_iterations": 10, "ms": el * 1e3,
                       "solves_per_s": B / el, "launch": batch.describe_launch(opts),
                       "payload_bytes_per_pair": batch.payload_bytes // B,
+                      "roofline": {"bound": "hbm", "bound_binding": "valu_fp64", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": batch.payload_bytes,
+                                   "note": "read-once bytes over the wall time of one solve call (launch + kernel)",
+                                   "valu": {"achieved": flops / el / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": flops / el / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                                            "flop_per_corr_full_pass": full, "flop_per_corr_cost_only_pass": cost_only,
+                                            "passes_per_solve_full": float(cnt[13]) / (B * N), "passes_per_solve_cost_only": float(cnt[14]) / (B * N)}},
                       "max_rot_diff_vs_oracle_rad_32_pairs": float(ang.max())}), flush=True)
     batch.close()
     del batch, q0, t0, res
