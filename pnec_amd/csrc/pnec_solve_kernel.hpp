@@ -432,7 +432,7 @@ __device__ __forceinline__ void write_result(const SolveArgs &a, int64_t s, cons
 // speculates on acceptance (cost, J'J and J'r in one go: 91 instructions per correspondence); for a solve that sits at
 // its noise floor the speculation mostly loses: on the benchmark's batch (ten iterations whatever happens; the solves
 // converge after three or four) 42 % of all steps are rejected, and 83 % of the steps that follow a rejected one
-// (oracle counters, pnec_oracle_lm_step_counts).  The cost-only pass is 43 instructions per correspondence and one sum
+// (counted on the CPU checker: DESIGN.md 6).  The cost-only pass is 43 instructions per correspondence and one sum
 // through the reduction tree instead of 21; when such a step IS accepted the same candidate is evaluated once more in
 // full and this function runs again on the complete sums -- same cost bits (the cost-only pass reduces through the same
 // tree), same decision, same everything downstream: the results are bit for bit those of the always-speculating kernel.
@@ -677,7 +677,7 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
       // the next pass: cost-only at the cap; cost-only too when the step just decided was rejected, or when the model
       // promises less than the cost can resolve (a decrease below ~4e-15 of the cost is inside the rounding of a sum of
       // 512 squares: on the benchmark's batch 65 % of such steps end rejected even right after an accepted one, and
-      // every step that promises more than 1e-14 is accepted -- oracle histogram, pnec_oracle_lm_promise_histogram)
+      // every step that promises more than 1e-14 is accepted -- histogram from the CPU checker)
       const double cost_now = accept ? cost_c : cost;
       ist[kILast] = iteration >= o.max_num_iterations ? 1 : ((COST_FIRST && (!accept || model_change <= 4.0e-15 * cost_now)) ? 2 : 0);
       break;
