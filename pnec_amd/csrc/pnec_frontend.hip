@@ -335,11 +335,18 @@ __device__ __forceinline__ void cross3(const double (&a)[3], const double (&b)[3
 // ew (optional): on entry the eigenvector of the smallest eigenvalue at a nearby point (`warm`), on
 // exit the one at this point -- Rayleigh-quotient iteration from it instead of Jacobi sweeps from
 // scratch (sym_eig3_min_rqi; falls back to the sweeps when it cannot vouch for the result).
+#ifdef PNEC_ISA_MARKS
+#define PNEC_FMARK(name) asm volatile("; PNEC_MARK " name)
+#else
+#define PNEC_FMARK(name)
+#endif
 template <int GS>
 __device__ double es_value_grad(const double *G, const double (&v)[3], double *g, double *M_out,
                                 double *ew = nullptr, bool warm = false) {
+  PNEC_FMARK("vg_rot");
   double R[9];
   cayley_to_rot(v, R);
+  PNEC_FMARK("vg_M");
   double r[3][3];  // columns of R
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -388,6 +395,7 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
 #pragma unroll
     for (int i = 0; i < 9; ++i) M_out[i] = M[i];
   }
+  PNEC_FMARK("vg_eig");
   double lam = 0.0, e[3] = {0.0, 0.0, 1.0};
   bool have = false;
   if (ew) {
@@ -422,6 +430,7 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
     e[0] = V[0]; e[1] = V[3]; e[2] = V[6];
   }
   if (ew) { ew[0] = e[0]; ew[1] = e[1]; ew[2] = e[2]; }
+  PNEC_FMARK("vg_grad");
   if (!g) return lam;
   // d lambda = e' dM e = 2 sum_k dr_k . q_k,  q_k = [e]x' (sum_l G_kl [e]x r_l) = (sum_l G_kl y_l) x e
   double y[3][3];
@@ -2110,6 +2119,7 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
   int trips = 0;            // evaluations as the wavefront executes them (diagnostics)
   [[maybe_unused]] int my_evals = 0;
   for (;;) {
+    PNEC_FMARK("q_point");
     ++trips;
 #ifdef PNEC_WORK_COUNT
     if (state != kDone) ++my_evals;
@@ -2134,6 +2144,7 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
       }
       double gp[3], Mp[9], ep[3] = {eb[0], eb[1], eb[2]};
       const double fp = es_value_grad<1>(G, p, gp, Mp, ep, state != kInit);
+      PNEC_FMARK("q_post");
       const double trace_p = Mp[0] + Mp[4] + Mp[8];
       bool at_new_point = false;
       if (state == kShort) {
@@ -2198,6 +2209,7 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
           at_new_point = state != kDone;
         }
       }
+      PNEC_FMARK("q_head");
       if (at_new_point) {
         const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
         if (gmax <= fmax(1e-14 * (1.0 + fabs(f)) * n_scale, 1.1e-13 * trace_cur)) {
@@ -2223,6 +2235,7 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
         }
       }
     }
+    PNEC_FMARK("q_fin");
     // ---- quads that have finished: park the result, take the next problem of the queue (in quad order)
     const bool fin = state == kDone && slot >= 0;
     if (fin && role == 0) {
@@ -2239,7 +2252,9 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
     }
     next += __builtin_popcountll(fb);
     if (__builtin_amdgcn_ballot_w64(state != kDone) == 0ull) break;
+    PNEC_FMARK("q_loop_end");
   }
+  PNEC_FMARK("q_after");
 #ifdef PNEC_WORK_COUNT
   if (role == 0) PNEC_WORK_ADD(kWkRansacEvals, my_evals);
 #endif
