@@ -54,7 +54,7 @@ namespace pnec_hip {
 
 // -DPNEC_FRONT_DEBUG: event counters of the minimiser (diagnostics builds only; tools/build_front_variant.sh)
 #ifdef PNEC_FRONT_DEBUG
-__device__ unsigned long long g_dbg[16];
+__device__ unsigned long long g_dbg[24];
 // wavefront-level event: counted once (x4, to match the per-quad print) by the first active lane
 #define PNEC_DBG_WAVE(i) do { if ((int)threadIdx.x == __builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&g_dbg[i], 4ull); } while (0)
 #define PNEC_DBG_COUNT(i) atomicAdd(&g_dbg[i], 1ull)
@@ -343,6 +343,12 @@ __device__ __forceinline__ void cross3(const double (&a)[3], const double (&b)[3
 template <int GS>
 __device__ double es_value_grad(const double *G, const double (&v)[3], double *g, double *M_out,
                                 double *ew = nullptr, bool warm = false) {
+  // the 36 sums, read ONCE per evaluation, all loads in flight before the first use (read where they are used, the
+  // composition of M waited for the table twelve times per evaluation -- two loads, s_waitcnt, seven instructions,
+  // ... -- and the gradient read all of it a second time)
+  double Gr[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) Gr[i] = G[i * GS];
   PNEC_FMARK("vg_rot");
   double R[9];
   cayley_to_rot(v, R);
@@ -359,12 +365,12 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
   for (int k = 0; k < 3; ++k) {
 #pragma unroll
     for (int l = k; l < 3; ++l) {
-      const double *Gp = G + 6 * s3(k, l) * GS;
+      const double *Gp = Gr + 6 * s3(k, l);
       // T = [r_k]x G: column j of T = r_k x (column j of G); stored by columns
       double Tc[3][3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        const double gj[3] = {Gp[s3(0, j) * GS], Gp[s3(1, j) * GS], Gp[s3(2, j) * GS]};
+        const double gj[3] = {Gp[s3(0, j)], Gp[s3(1, j)], Gp[s3(2, j)]};
         cross3(r[k], gj, Tc[j]);
       }
       // X = T [r_l]x': row i of X = r_l x (row i of T)
@@ -442,10 +448,10 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
     double z[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
-      const double *Gp = G + 6 * s3(k, l) * GS;
+      const double *Gp = Gr + 6 * s3(k, l);
 #pragma unroll
       for (int a = 0; a < 3; ++a)
-        z[a] += Gp[s3(a, 0) * GS] * y[l][0] + Gp[s3(a, 1) * GS] * y[l][1] + Gp[s3(a, 2) * GS] * y[l][2];
+        z[a] += Gp[s3(a, 0)] * y[l][0] + Gp[s3(a, 1)] * y[l][1] + Gp[s3(a, 2)] * y[l][2];
     }
     cross3(z, e, q[k]);
   }
@@ -497,6 +503,78 @@ __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&
   return true;
 }
 
+// The Levenberg shifts of the Newton head are tried in the fixed order 0, 1e-6 tr, 1e-5 tr, ... until the Cholesky
+// factorisation of H + mu I goes through.  A shift that leaves a diagonal entry of H + mu I at or below zero cannot: the
+// factorisation stops at that pivot or an earlier one (pivot i is H_ii + mu minus squares).  Those tries are walked over
+// here at three instructions each instead of a solve -- the sequence of shifts, and the one that is taken, are the
+// sequential rule's (measured on the benchmark's RANSAC stage: 5.3 solves per iteration head as the wavefront executed
+// them, the slowest of its sixteen quads setting the count; an indefinite Hessian far from the minimum needs a shift of
+// its own size, six or seven decades above the first one).
+__device__ __forceinline__ void levenberg_skip_hopeless(const double (&H)[9], double tr, double &mu, int &tries) {
+  const double dmin = fmin(H[0], fmin(H[4], H[8]));
+  while (tries < 40 && dmin + mu <= 0.0) {
+    mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * 10.0;
+    ++tries;
+  }
+}
+
+// The damped Newton direction of an iteration head: d = -(H + mu I)^-1 g for the first shift mu of the sequence
+// 0, 1e-6 tr, 1e-5 tr, ... (at most 40) whose factorisation goes through and gives a descent direction.  H and g are
+// the same in the four lanes of the quad; after the hopeless shifts are walked over, lane `role` tries shift number
+// tries + role, and the first that passes IN THE SEQUENCE'S ORDER wins -- the sequential rule, four tries per solve
+// (the winner's direction reaches the other lanes through the LDS crossbar: no VALU slots).  Every lane computes all
+// four shifts by the same chain of multiplications, so the shift a try uses has the sequential form's bits.
+// Returns false when no shift passes (the caller ends the minimisation: the iterate stays).
+__device__ __forceinline__ bool levenberg_direction(const double (&H)[9], const double (&g)[3], int role, double (&d)[3]) {
+  const double tr = fabs(H[0]) + fabs(H[4]) + fabs(H[8]);
+  double mu = 0.0;
+  int tries = 0;
+  levenberg_skip_hopeless(H, tr, mu, tries);
+  const double mg[3] = {-g[0], -g[1], -g[2]};
+#ifdef PNEC_LEVENBERG_SEQUENTIAL   // A/B: every lane walks the sequence on its own (the form before round 4)
+  for (; tries < 40; ++tries) {
+    PNEC_DBG_WAVE(17);
+    double Hm[9];
+    for (int i = 0; i < 9; ++i) Hm[i] = H[i];
+    Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
+    if (solve3_spd(Hm, mg, d) && (d[0] * g[0] + d[1] * g[1] + d[2] * g[2]) < 0.0) return true;
+    mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * 10.0;
+  }
+  return false;
+#endif
+  const int quad_base = ((int)threadIdx.x & ~3) << 2;  // byte address of the quad's lane 0 for ds_bpermute
+  while (tries < 40) {
+    PNEC_DBG_WAVE(17);               // Levenberg solves as the wavefront executes them
+    const double m0 = mu;
+    const double m1 = (m0 == 0.0) ? 1e-6 * (tr + 1e-300) : m0 * 10.0;
+    const double m2 = m1 * 10.0, m3 = m2 * 10.0;
+    const double mine = role == 0 ? m0 : (role == 1 ? m1 : (role == 2 ? m2 : m3));
+    double Hm[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Hm[i] = H[i];
+    Hm[0] += mine; Hm[4] += mine; Hm[8] += mine;
+    double dd[3];
+    const int pass = (tries + role < 40 && solve3_spd(Hm, mg, dd) && (dd[0] * g[0] + dd[1] * g[1] + dd[2] * g[2]) < 0.0) ? 1 : 0;
+    const int p0 = quad_broadcast<0>(pass), p1 = quad_broadcast<1>(pass), p2 = quad_broadcast<2>(pass),
+              p3 = quad_broadcast<3>(pass);
+    if (p0 | p1 | p2 | p3) {
+      const int winner = p0 ? 0 : (p1 ? 1 : (p2 ? 2 : 3));
+      const int addr = quad_base + (winner << 2);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const long long bits = __builtin_bit_cast(long long, dd[k]);
+        const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)(bits & 0xffffffffll));
+        const int hi = __builtin_amdgcn_ds_bpermute(addr, (int)(bits >> 32));
+        d[k] = __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+      }
+      return true;
+    }
+    mu = m3 * 10.0;
+    tries += 4;
+  }
+  return false;
+}
+
 // Damped Newton on the Cayley vector (opengv's eigensolver minimises lambda_min(M(R)) [EXT]; restated; the
 // CPU checker under oracle/ holds the sequential form): gradient analytic (es_value_grad), Hessian by forward
 // differences of the gradient (h = 1e-6), Levenberg shifts until it is positive definite, Armijo search over
@@ -529,7 +607,7 @@ template <int GS, int TAG = 0>
 __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], double n_scale, double *e_out = nullptr,
                                              bool active = true, int *evals_out = nullptr) {
   enum : int { kInit = 0, kTrial, kShort, kReeval, kDone };
-  const int role = (int)(threadIdx.x & 3);
+  const int role_of_lane = (int)(threadIdx.x & 3);
   const double h = 1e-6, inv_h = 1.0 / h;
   double eb[3] = {0.0, 0.0, 1.0};  // eigenvector of the smallest eigenvalue at the current point
   double f = 0.0, g[3] = {0.0, 0.0, 0.0}, H[9], d[3] = {0.0, 0.0, 0.0};
@@ -538,7 +616,9 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
   bool last_eval = false;
   while (state != kDone) {
     ++evals;  // diagnostics: evaluations of this quad's problem
-    // ---- the point this lane evaluates in this trip
+    // ---- the point this lane evaluates in this trip (role: see es_minimise_queue)
+    int role = role_of_lane;
+    asm volatile("" : "+v"(role));
     double p[3] = {v[0], v[1], v[2]};
     double a_mine = 0.0;
     if (state == kShort) {
@@ -652,20 +732,8 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
         state = kDone;
       } else {
         PNEC_DBG_COUNT(2);             // Newton iterations (x4 lanes)
-        double mu = 0.0;
-        const double tr = fabs(H[0]) + fabs(H[4]) + fabs(H[8]);
-        bool ok = false;
         PNEC_DBG_WAVE(10);             // iteration heads as the wavefront executes them
-        for (int tries = 0; tries < 40; ++tries) {
-          PNEC_DBG_WAVE(9);            // Levenberg tries as the wavefront executes them
-          double Hm[9];
-          for (int i = 0; i < 9; ++i) Hm[i] = H[i];
-          Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
-          const double mg[3] = {-g[0], -g[1], -g[2]};
-          if (solve3_spd(Hm, mg, d) && (d[0] * g[0] + d[1] * g[1] + d[2] * g[2]) < 0.0) { ok = true; break; }
-          mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * 10.0;
-          PNEC_DBG_COUNT(3);           // Levenberg shifts
-        }
+        const bool ok = levenberg_direction(H, g, role, d);
         if (ok) {
           slope = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];
           state = kTrial;
@@ -680,7 +748,7 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
 #ifdef PNEC_WORK_COUNT
   // TAG 1: a RANSAC hypothesis (one problem per quad); TAG 2: es_batch_kernel (one pair per quad; which epilogue: the
   // caller moves the count); TAG 0: the weighted kernel's in-kernel rounds (every quad repeats the pair's problem: once)
-  if (TAG == 1 && role == 0 && active) PNEC_WORK_ADD(kWkRansacEvals, evals);
+  if (TAG == 1 && role_of_lane == 0 && active) PNEC_WORK_ADD(kWkRansacEvals, evals);
   if (TAG == 0 && threadIdx.x == 0 && active) PNEC_WORK_ADD(kWkWesEvals, evals);
 #endif
   return it;
@@ -2096,7 +2164,7 @@ struct Ransac2Lds {
 __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, const double (*Gtab)[36], double (*tv)[3],
                                               double (*te)[3], int *tits, double n_scale) {
   enum : int { kInit = 0, kTrial, kShort, kReeval, kDone };
-  const int lane = (int)threadIdx.x, quad = lane >> 2, role = lane & 3;
+  const int lane = (int)threadIdx.x, quad = lane >> 2, role_of_lane = lane & 3;
   const double h = 1e-6, inv_h = 1.0 / h;
   double v[3] = {0.0, 0.0, 0.0}, eb[3] = {0.0, 0.0, 1.0};
   double f = 0.0, g[3] = {0.0, 0.0, 0.0}, H[9], d[3] = {0.0, 0.0, 0.0};
@@ -2127,6 +2195,11 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
     if (state != kDone) {
       const double *G = Gtab[slot];
       // ---- the point this lane evaluates in this trip
+      // (the lane's role goes through an empty asm statement in every trip: left to itself the compiler hoists the
+      //  probe offsets and step fractions that depend on it out of the loop, runs out of registers and reloads them
+      //  from scratch one by one, each behind its own s_waitcnt -- three trips to memory per evaluation)
+      int role = role_of_lane;
+      asm volatile("" : "+v"(role));
       double p[3] = {v[0], v[1], v[2]};
       double a_mine = 0.0;
       if (state == kShort) {
@@ -2215,17 +2288,8 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
         if (gmax <= fmax(1e-14 * (1.0 + fabs(f)) * n_scale, 1.1e-13 * trace_cur)) {
           state = kDone;
         } else {
-          double mu = 0.0;
-          const double tr = fabs(H[0]) + fabs(H[4]) + fabs(H[8]);
-          bool ok = false;
-          for (int tries = 0; tries < 40; ++tries) {
-            double Hm[9];
-            for (int i = 0; i < 9; ++i) Hm[i] = H[i];
-            Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
-            const double mg[3] = {-g[0], -g[1], -g[2]};
-            if (solve3_spd(Hm, mg, d) && (d[0] * g[0] + d[1] * g[1] + d[2] * g[2]) < 0.0) { ok = true; break; }
-            mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * 10.0;
-          }
+          PNEC_DBG_WAVE(16);           // queue: iteration heads as the wavefront executes them
+          const bool ok = levenberg_direction(H, g, role, d);
           if (ok) {
             slope = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];
             state = kTrial;
@@ -2238,6 +2302,7 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
     PNEC_FMARK("q_fin");
     // ---- quads that have finished: park the result, take the next problem of the queue (in quad order)
     const bool fin = state == kDone && slot >= 0;
+    const int role = role_of_lane;
     if (fin && role == 0) {
       tv[slot][0] = v[0]; tv[slot][1] = v[1]; tv[slot][2] = v[2];
       te[slot][0] = eb[0]; te[slot][1] = eb[1]; te[slot][2] = eb[2];
@@ -2256,7 +2321,7 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
   }
   PNEC_FMARK("q_after");
 #ifdef PNEC_WORK_COUNT
-  if (role == 0) PNEC_WORK_ADD(kWkRansacEvals, my_evals);
+  if (role_of_lane == 0) PNEC_WORK_ADD(kWkRansacEvals, my_evals);
 #endif
   return trips;
 }
@@ -2802,7 +2867,7 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   }
 #ifdef PNEC_FRONT_DEBUG
   {
-    const unsigned long long zeros[16] = {0};
+    const unsigned long long zeros[24] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), zeros, sizeof(zeros));
   }
 #endif
@@ -2849,7 +2914,7 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   }
 #ifdef PNEC_FRONT_DEBUG
   {
-    unsigned long long c[16] = {0};
+    unsigned long long c[24] = {0};
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_dbg), sizeof(c));
     const double per = 1.0 / (4.0 * (double)(n_pairs > 0 ? n_pairs : 1));  // lane counts / 4 = quads, per pair
@@ -2857,6 +2922,8 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
                  "levenberg_shifts=%.2f full_step_rejected=%.2f short_step_batches=%.2f wave_evals=%.2f wave_evals_with_fallback=%.2f | as executed by the wavefront: eigen_steps=%.2f levenberg_tries=%.2f heads=%.2f poly_starts=%.2f\n",
                  c[0] * per, c[1] * per, c[2] * per, c[3] * per, c[4] * per, c[5] * per, c[6] * per, c[7] * per,
                  c[8] * per, c[9] * per, c[10] * per, c[11] * per);
+    std::fprintf(stderr, "  queue form, per pair: heads as executed=%.2f levenberg tries as executed=%.2f | per quad: heads=%.1f shifts=%.2f\n",
+                 c[16] * per, c[17] * per, c[19] * per, c[18] * per);
   }
 #endif
   if (a.trace) {
