@@ -274,6 +274,18 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
                             const pnec_hip_pipeline_options *opt, double *out_q, double *out_t,
                             uint8_t *out_inlier_mask, int32_t *out_inlier_count, int space, void *stream);
 
+/* Launch-order hint of the RANSAC stage (opt-in, scheduling only: results never depend on it).  A launch ends with
+ * its slowest wavefronts: the pairs that need a second and third round of hypotheses (about a tenth at 10 % outliers)
+ * run two to three times as long as the rest and end the launch late when they are dispatched late.  With the hint
+ * enabled the batch remembers every pair's RANSAC hypothesis count of the last call that ran RANSAC on it
+ * (pnec_hip_ransac_eigensolver, pnec_hip_solve_pipeline) and the next call on the same number of pairs dispatches
+ * the pairs that went beyond one round first, each sharing its wavefront with one that did not.  Meaningful when
+ * pair i of the next call is pair i of this one again (other start poses, other seeds, a benchmark loop) or its
+ * successor in a stream of frames (sequence i's next frame pair: outlier ratios persist from frame to frame); a
+ * stale hint costs nothing but the gain.  The reference has no counterpart (opengv's RANSAC runs one pair at a
+ * time, pnec.cc:231-281). */
+int pnec_hip_problem_launch_order_hint(pnec_hip_problem *p, int32_t enable);
+
 /* ---- several GPUs of one node, one process ----------------------------------------------------------------
  * The reference fans out at process level (scripts/run_simulation.sh:52-67, scripts/parallel_kitti.sh:60-69: one
  * process per experiment / sequence).  Frame pairs are independent, so a batch shards with no data-path exchange:

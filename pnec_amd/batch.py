@@ -354,6 +354,11 @@ class Batch:
             q.ctypes.data, t.ctypes.data, mask.ctypes.data, cnt.ctypes.data, its.ctypes.data, capi.MEM_HOST, None))
         return q, t, mask[:M], cnt, its
 
+    def launch_order_hint(self, enable: bool = True) -> None:
+        """Opt in to pnec_hip_problem_launch_order_hint: the next RANSAC launch on this batch dispatches the pairs that
+        needed more than one round of hypotheses in the last one first (scheduling only; results do not change)."""
+        capi.check(self._lib.pnec_hip_problem_launch_order_hint(self._h, 1 if enable else 0))
+
     def select(self, mask, view: bool = False) -> "Batch":
         """PNEC::InlierExtraction (pnec.cc:210-229): new Batch with the masked correspondences.
         view=True: into this batch's cached target (pnec_hip_problem_select_view: nothing allocated after the first

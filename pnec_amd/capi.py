@@ -55,6 +55,7 @@ SYMBOLS = [
     "pnec_hip_ransac_eigensolver",
     "pnec_hip_problem_select",
     "pnec_hip_problem_select_view",
+    "pnec_hip_problem_launch_order_hint",
     "pnec_hip_weighted_eigensolver",
     "pnec_hip_default_pipeline_options",
     "pnec_hip_solve_pipeline",
@@ -185,6 +186,7 @@ def lib() -> C.CDLL:
                                               _vp, _vp, _vp, C.c_int, _vp]
     L.pnec_hip_problem_select.argtypes = [_vp, _vp, C.c_int, _vp, C.POINTER(_vp)]
     L.pnec_hip_problem_select_view.argtypes = [_vp, _vp, C.c_int, _vp, C.POINTER(_vp)]
+    L.pnec_hip_problem_launch_order_hint.argtypes = [_vp, C.c_int32]
     L.pnec_hip_partition.argtypes = [C.c_int64, _vp, C.c_int32, _vp]
     L.pnec_hip_work_counters.argtypes = [C.c_int, C.c_int, _vp, C.POINTER(C.c_int32)]
     L.pnec_hip_solve_pipeline_multi.argtypes = [C.c_int32, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -34,7 +34,8 @@ hipError_t launch_solve_aos_mode_3(int, int, int, const SolveArgs &, hipStream_t
 hipError_t launch_ransac_eigensolver(const double *, const int64_t *, const int64_t *, const int32_t *, int64_t,
                                      const double *, unsigned long long, unsigned long long, int, int, double, double *, double *,
                                      uint8_t *, int32_t *, int32_t *, double *, int32_t *, hipStream_t, hipStream_t,
-                                     hipEvent_t, hipEvent_t, int, double *, const int64_t *, int32_t *, int64_t *, void *);
+                                     hipEvent_t, hipEvent_t, int, double *, const int64_t *, int32_t *, int64_t *, void *, const int32_t *);
+hipError_t launch_ransac_order(const int32_t *, int64_t, int32_t *, hipStream_t);
 hipError_t frontend_work_counters(int, unsigned long long *, int *);
 size_t ransac_workspace_bytes(int64_t);
 int64_t ransac_split_threshold();
@@ -92,6 +93,11 @@ struct pnec_hip_problem {
   // workspace of the RANSAC stage's split form (large batches; pnec_ransac_split.inl)
   void *d_ransac_ws = nullptr;
   size_t ransac_ws_bytes = 0;
+  // launch-order hint of the RANSAC stage (pnec_hip_problem_launch_order_hint): the last run's hypothesis counts and
+  // the order made from them; order_pairs = the number of pairs d_order is a permutation of (0: none yet)
+  bool order_hint = false;
+  int32_t *d_hint_its = nullptr, *d_order = nullptr;
+  int64_t hint_cap = 0, order_pairs = 0;
   // ragged batches: pairs grouped by the smallest launch geometry that holds them (built lazily)
   struct Bucket {
     int cpl, wpp, ldsk;
@@ -957,6 +963,20 @@ int ensure_ransac_ws(pnec_hip_problem *p) {
   return 0;
 }
 
+// The launch-order hint's arrays (two int32 per pair), grown on demand.
+int ensure_order_hint(pnec_hip_problem *p) {
+  if (!p->order_hint || p->hint_cap >= p->n_pairs) return 0;
+  if (p->d_hint_its) (void)dev_free(p->d_hint_its);
+  if (p->d_order) (void)dev_free(p->d_order);
+  p->d_hint_its = p->d_order = nullptr;
+  p->hint_cap = p->order_pairs = 0;
+  const int64_t want = std::max<int64_t>(p->n_pairs, p->cap_pairs);
+  PNEC_HIP_TRY(dev_alloc(&p->d_hint_its, sizeof(int32_t) * (size_t)want));
+  PNEC_HIP_TRY(dev_alloc(&p->d_order, sizeof(int32_t) * (size_t)want));
+  p->hint_cap = want;
+  return 0;
+}
+
 int ensure_front(pnec_hip_problem *p) {
   const int64_t P = std::max<int64_t>(p->n_pairs, 1);
   if (P > p->front_pairs) {
@@ -981,6 +1001,13 @@ static int materialize(const pnec_hip_problem *cp);
 static int solve_work_buffer(int device, unsigned long long **out);
 
 int pnec_hip_abi_version(void) { return PNEC_HIP_ABI_VERSION; }
+
+int pnec_hip_problem_launch_order_hint(pnec_hip_problem *p, int32_t enable) {
+  if (!p) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "NULL problem");
+  p->order_hint = enable != 0;
+  if (!p->order_hint) p->order_pairs = 0;
+  return 0;
+}
 
 const char *pnec_hip_last_error(void) { return g_last_error.c_str(); }
 
@@ -1216,6 +1243,8 @@ int pnec_hip_problem_destroy(pnec_hip_problem *p) {
   release(p->d_front);
   release(p->d_front_i);
   release(p->d_ransac_ws);
+  release(p->d_hint_its);
+  release(p->d_order);
   // (the device has drained: nothing is pending on these, so the next owner starts clean)
   for (hipStream_t st : p->side_streams) {
     if (drained) pool_stream_put(st, p->device); else (void)hipStreamDestroy(st);
@@ -1763,14 +1792,21 @@ int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint6
   }
   int rc_ws = ensure_front(p);
   if (!rc_ws) rc_ws = ensure_ransac_ws(p);
+  if (!rc_ws) rc_ws = ensure_order_hint(p);
   if (rc_ws) {
     if (tmp_mask) (void)dev_free(tmp_mask);
     return rc_ws;
   }
+  if (p->order_hint && !d_it) d_it = p->d_hint_its;
   hipError_t e = launch_ransac_eigensolver(p->d_data, p->d_block_offset, p->d_offsets, p->d_count, P, d_q, seed,
                                            /*first_pair_id*/ 0ull, max_iterations, sample_size, threshold, d_oq, d_ot, d_mask, d_cnt, d_it,
                                            p->d_front, p->d_front_i, stream, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
-                                           nullptr, nullptr, p->n_pairs >= ransac_split_threshold() ? p->d_ransac_ws : nullptr);
+                                           nullptr, nullptr, p->n_pairs >= ransac_split_threshold() ? p->d_ransac_ws : nullptr,
+                                           p->order_hint && p->order_pairs == P ? p->d_order : nullptr);
+  if (e == hipSuccess && p->order_hint) {   // the next call's launch order from this call's counts
+    e = launch_ransac_order(d_it, P, p->d_order, stream);
+    p->order_pairs = P;
+  }
   if (e == hipSuccess && space == PNEC_HIP_MEM_HOST) {
     e = hipMemcpyAsync(out_q, d_oq, sizeof(double) * 4 * P, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_t, d_ot, sizeof(double) * 3 * P, hipMemcpyDeviceToHost, stream);

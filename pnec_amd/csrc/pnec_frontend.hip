@@ -1692,6 +1692,8 @@ struct RansacArgs {
   // ransac_eigensolver_kernel<true>: the pairs resumed from the round kernels' state
   const int32_t *resume_list, *resume_count;
   RansacState resume;
+  // two-pair form: the pairs in launch order (null: as they lie in the batch); see ransac_order_kernel
+  const int32_t *order;
 };
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
@@ -2375,6 +2377,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
   for (int pp = 0; pp < 2; ++pp) {
     pair[pp] = 2 * (int64_t)blockIdx.x + pp;
     exists[pp] = pair[pp] < a.n_pairs;
+    if (a.order && exists[pp]) pair[pp] = a.order[pair[pp]];
     const int64_t pq = exists[pp] ? pair[pp] : 0;
     n[pp] = exists[pp] ? a.count[pq] : 0;
     stride[pp] = (n[pp] + kWave - 1) & ~(kWave - 1);
@@ -2857,6 +2860,46 @@ static hipError_t launch_ransac_split(RansacArgs a, void *ws, hipStream_t stream
 // sel (optional): InlierExtraction fused into each pair's last pass -- nc component planes, target planes / block layout /
 // counts (+ the AoS offsets of a ONE-pair batch).  ws (optional): ransac_workspace_bytes(n_pairs) bytes of device memory;
 // with it, batches of ransac_split_threshold() pairs and more run the split form.
+// Launch order of the two-pair form from the iteration counts of an EARLIER solve of the same pairs (or of their
+// predecessors in a stream of frames): a launch ends with its slowest wavefronts, and the pairs that need a second and
+// third round of hypotheses (a tenth of them; their wavefronts run two to three times the median) end it late when they
+// are dispatched late.  Pairs whose earlier count exceeded one round go first, each sharing its wavefront with a pair
+// that did not (the finished partner's slot group is lent to the long pair); the rest follow in batch order.  Any
+// content of `prev` gives a permutation; results do not depend on the order (draws belong to the pair's global index).
+__global__ __launch_bounds__(1024) void ransac_order_kernel(const int32_t *prev, int64_t n, int32_t *order) {
+  __shared__ int c_long[1024], c_rest[1024];
+  __shared__ int total_long;
+  const int tid = (int)threadIdx.x;
+  const int64_t chunk = (n + 1023) / 1024, lo = tid * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  int nl = 0, nr = 0;
+  for (int64_t i = lo; i < hi; ++i) { if (prev[i] > kHypPerRound) ++nl; else ++nr; }
+  c_long[tid] = nl; c_rest[tid] = nr;
+  __syncthreads();
+  if (tid == 0) {
+    int al = 0, ar = 0;
+    for (int t = 0; t < 1024; ++t) { const int l = c_long[t], r = c_rest[t]; c_long[t] = al; c_rest[t] = ar; al += l; ar += r; }
+    total_long = al;
+  }
+  __syncthreads();
+  const int64_t L = total_long, R = n - L, paired = L < R ? L : R;
+  int64_t il = c_long[tid], ir = c_rest[tid];
+  for (int64_t i = lo; i < hi; ++i) {
+    if (prev[i] > kHypPerRound) {
+      const int64_t pos = il < paired ? 2 * il : paired + il;   // (more long pairs than others: the surplus after the mixed wavefronts)
+      order[pos] = (int32_t)i; ++il;
+    } else {
+      const int64_t pos = ir < paired ? 2 * ir + 1 : paired + ir;
+      order[pos] = (int32_t)i; ++ir;
+    }
+  }
+}
+
+hipError_t launch_ransac_order(const int32_t *iterations, int64_t n_pairs, int32_t *order, hipStream_t stream) {
+  if (n_pairs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ransac_order_kernel, dim3(1), dim3(1024), 0, stream, iterations, n_pairs, order);
+  return hipGetLastError();
+}
+
 hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_offset, const int64_t *offsets,
                                      const int32_t *count, int64_t n_pairs, const double *init_q,
                                      unsigned long long seed, unsigned long long pair_id_base, int max_iterations,
@@ -2864,7 +2907,9 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
                                      int32_t *out_count, int32_t *out_iterations, double *scratch_d,
                                      int32_t *scratch_i, hipStream_t stream, hipStream_t tail_stream,
                                      hipEvent_t tail_fork, hipEvent_t tail_done, int sel_nc, double *sel_data,
-                                     const int64_t *sel_block, int32_t *sel_count, int64_t *sel_single_offsets, void *ws) {
+                                     const int64_t *sel_block, int32_t *sel_count, int64_t *sel_single_offsets, void *ws,
+                                     const int32_t *order) {
+  // order (optional): the pairs in launch order (ransac_order_kernel; honoured by the two-pair form)
   // tail_stream (optional): the eigensolver on the inliers (es_batch_kernel, which writes out_q / out_t) runs
   // there, forked from `stream` after the RANSAC kernel -- the caller goes on with work that only needs the
   // masks (InlierExtraction) and makes `stream` wait for tail_done before anything reads out_q / out_t
@@ -2918,6 +2963,7 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   if (split) {
     e = launch_ransac_split(a, ws, stream);
   } else {
+    if (two) a.order = order;
     if (two)
       hipLaunchKernelGGL(ransac2_eigensolver_kernel, dim3((unsigned)((n_pairs + 1) / 2)), dim3(kWave), 0, stream, a);
     else

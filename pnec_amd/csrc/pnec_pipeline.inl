@@ -133,12 +133,18 @@ static int pipeline_on(pnec_hip_problem *p, const double *d_iq, const double *d_
         if (int rc = select_prepare(p, stream, sv)) return rc;
       }
     }
+    if (int rc = ensure_order_hint(p)) return rc;
     e = launch_ransac_eigensolver(p->d_data, p->d_block_offset, p->d_offsets, p->d_count, P, d_iq, o.ransac_seed,
                                   (unsigned long long)o.first_pair_id, o.max_ransac_iterations, o.ransac_sample_size, o.ransac_threshold, es_q, es_t,
-                                  d_mask, d_cnt, nullptr, p->d_front, p->d_front_i, stream, fork ? p->side_streams[0] : nullptr,
+                                  d_mask, d_cnt, p->order_hint ? p->d_hint_its : nullptr, p->d_front, p->d_front_i, stream, fork ? p->side_streams[0] : nullptr,
                                   fork ? p->fork_event : nullptr, fork ? p->side_done[0] : nullptr, p->nc,
                                   sv ? sv->d_data : nullptr, sv ? sv->d_block_offset : nullptr, sv ? sv->d_count : nullptr,
-                                  sv && !sv_given && P == 1 ? sv->d_offsets : nullptr, p->d_ransac_ws);
+                                  sv && !sv_given && P == 1 ? sv->d_offsets : nullptr, p->d_ransac_ws,
+                                  p->order_hint && p->order_pairs == P ? p->d_order : nullptr);
+    if (e == hipSuccess && p->order_hint) {   // the next call's launch order from this call's counts (pnec_hip_problem_launch_order_hint)
+      e = launch_ransac_order(p->d_hint_its, P, p->d_order, stream);
+      p->order_pairs = P;
+    }
     if (e != hipSuccess) return fail_hip(e, "ransac_eigensolver_kernel");
     if (sv) {
       if (!sv_given)

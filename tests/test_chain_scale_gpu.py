@@ -149,3 +149,44 @@ def test_two_pairs_per_wavefront_ransac_is_bitwise_the_one_pair_form():
         assert torch.equal(ms, mask[sl]) and torch.equal(cs, cnt[a:z]), (a, z)
         assert torch.equal(qs, q[a:z]) and torch.equal(ts, t[a:z]), (a, z)
     assert int(cnt[:3].max()) <= 10 and bool((cnt[8:] > 30).all())          # tiny pairs: no sampling / all inliers
+
+
+@pytest.mark.gpu
+def test_launch_order_hint_changes_the_dispatch_order_and_no_bit(oracle):
+    """pnec_hip_problem_launch_order_hint: the RANSAC stage of the next call dispatches the pairs that took more than one
+    round of hypotheses in the last one first.  Scheduling only: poses, masks and counts of the hinted call are those of
+    the unhinted one, bit for bit -- on a batch large enough for the two-pair form that honours the order, with 30 % gross
+    outliers so that a good part of the pairs goes beyond one round (the order is far from the identity), through both
+    entries that run RANSAC, and again after the batch's contents (not its shape) were replaced (a stale hint)."""
+    import torch
+    from pnec_amd import Batch, capi
+    from pnec_amd import simulation as sim
+    dev = torch.device("cuda:0")
+    P, N = 4600, 160
+    def make(seed):
+        g = sim.generate(P, N, seed=seed, device=dev)
+        bad = torch.rand(P, N, device=dev, generator=torch.Generator(device=dev).manual_seed(seed)) < 0.3
+        rnd = torch.randn(P, N, 3, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(seed + 1))
+        b2 = torch.where(bad[..., None], rnd / rnd.norm(dim=-1, keepdim=True), g.bvs2)
+        return g, b2
+    g, b2 = make(31)
+    batch = Batch.uniform(capi.MODE_TARGET, P, N)
+    batch.fill(g.bvs1.reshape(-1, 3), b2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3))
+    q_ref, t_ref, m_ref, c_ref = batch.solve_pipeline(g.init_q, g.init_t, want_inliers=True)
+    qr_ref, tr_ref, mr_ref, cr_ref, it_ref = batch.ransac_eigensolver(g.init_q, seed=1)
+    assert int((it_ref > 16).sum()) > P // 20                      # the order will not be the identity
+    batch.launch_order_hint(True)
+    for _ in range(2):                                             # first call: no hint yet; second: hinted
+        q, t, m, c = batch.solve_pipeline(g.init_q, g.init_t, want_inliers=True)
+        assert torch.equal(q, q_ref) and torch.equal(t, t_ref) and torch.equal(m, m_ref) and torch.equal(c, c_ref)
+    for _ in range(2):
+        qr, tr, mr, cr, it = batch.ransac_eigensolver(g.init_q, seed=1)
+        assert torch.equal(qr, qr_ref) and torch.equal(mr, mr_ref) and torch.equal(it, it_ref)
+    # new contents, same shape: the hint is stale, the results are the new data's
+    g2, b22 = make(77)
+    batch.fill(g2.bvs1.reshape(-1, 3), b22.reshape(-1, 3), g2.covs2.reshape(-1, 3, 3))
+    q_h, t_h, m_h, c_h = batch.solve_pipeline(g2.init_q, g2.init_t, want_inliers=True)
+    batch.launch_order_hint(False)
+    q_n, t_n, m_n, c_n = batch.solve_pipeline(g2.init_q, g2.init_t, want_inliers=True)
+    assert torch.equal(q_h, q_n) and torch.equal(t_h, t_n) and torch.equal(m_h, m_n) and torch.equal(c_h, c_n)
+    batch.close()

@@ -81,6 +81,15 @@ if not os.environ.get("PNEC_NO_INFLIGHT"):   # (the kernel-trace profile wants e
         t = time.perf_counter(); o3 = in_flight(); torch.cuda.synchronize(); tt.append(time.perf_counter() - t)
     t_three = float(np.median(tt)) / 12.0
     three_equal = bool(all(torch.equal(o[0], q_one) for o in o3))
+# the launch-order hint (pnec_hip_problem_launch_order_hint): the pairs that needed more than one round of hypotheses in
+# the previous call are dispatched first.  Here the previous call solved THE SAME batch, i.e. the hint is perfect: the
+# upper bound of what a stream of temporally coherent frame pairs gets from it
+batch.launch_order_hint(True)
+batch.solve_pipeline(q0, t0); torch.cuda.synchronize()
+t_hint, (q_hint, t_hint_t) = timed(lambda: batch.solve_pipeline(q0, t0), reps=5)
+t_vo_hint, _ = timed(lambda: batch.solve_pipeline(q0, t0, o_vo), reps=5)
+hint_equal = bool(torch.equal(q_hint, q_one) and torch.equal(t_hint_t, t_one_t))
+batch.launch_order_hint(False)
 Rg = torch.cat([sim.generate(min(5000, B - c), N, seed=1 + c, device=dev).R_gt for c in range(0, min(B, 5000), 5000)])
 dq = res.rotation_matrices()[: Rg.shape[0]]
 err = torch.acos(((dq.transpose(-1, -2) @ Rg).diagonal(dim1=-2, dim2=-1).sum(-1).clamp(-1, 3) - 1).clamp(-2, 2) / 2).mul(180 / np.pi)
@@ -108,6 +117,9 @@ print(json.dumps({
     "odometry_options": "use_nec, no refinement -- what Frame2Frame forces (frame2frame.cc:127-128)",
     "gpu_ms_per_call_three_in_flight": t_three * 1e3, "gpu_pairs_per_s_three_calls_in_flight": B / t_three,
     "three_in_flight_bitwise_equals_one_call": three_equal,
+    "gpu_ms_one_call_with_launch_order_hint": t_hint * 1e3, "gpu_pairs_per_s_one_call_with_launch_order_hint": B / t_hint,
+    "gpu_ms_one_call_odometry_options_with_launch_order_hint": t_vo_hint * 1e3,
+    "launch_order_hint": "opt-in; the hint comes from the previous call on the same batch (a perfect hint: upper bound for a coherent stream); results bitwise equal: " + str(hint_equal),
     "one_call_bitwise_equals_stage_by_stage": one_call_equals_stages,
     "mean_inliers": float(cnt.double().mean()), "mean_ransac_iterations": float(its.double().mean()),
     "median_rot_err_deg_vs_ground_truth": float(err.median()),
