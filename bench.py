@@ -632,6 +632,12 @@ def secondary_lines(device, capi, quick=False):
                     batches[i % 3].solve_pipeline(q0, t0, want_inliers=True)
             torch.cuda.synchronize()
             wall3 = (time.perf_counter() - t_0) / steps * 1e3
+            # opt-in launch-order hint: the previous call solved the same batch, so the hint is perfect (an upper bound)
+            batches[0].launch_order_hint(True)
+            one()
+            (qh, th, _mh, _ch), wall1h, _ = timed(one, 6 if quick else 12, 2)
+            batches[0].launch_order_hint(False)
+            hint_equal = bool(torch.equal(qh, q) and torch.equal(th, t))
             stage_ms, res, sel, sel_payload = chain_stage_times(batches[0], q0, t0)
             assert torch.equal(res.q, q)                       # the stages one by one == the one call, bit for bit
             counts = load_chain_counts("kitti_all_chain", P, int(sizes.sum()))
@@ -653,6 +659,10 @@ def secondary_lines(device, capi, quick=False):
                             "synthetic stand-in, 10 % gross mismatches), one pnec_hip_solve_pipeline call per step",
                 "value": P / (wall3 * 1e-3), "unit": "pairs/s", "ms_per_step": wall3, "steps_in_flight": 3,
                 "pairs_per_s_one_call_at_a_time": P / (wall1 * 1e-3), "ms_per_step_one_call_at_a_time": wall1,
+                "pairs_per_s_one_call_with_launch_order_hint": P / (wall1h * 1e-3),
+                "launch_order_hint_note": "opt-in (pnec_hip_problem_launch_order_hint): pairs that needed more than one round of "
+                                          "hypotheses in the previous call go first; here the previous call solved the same batch "
+                                          "(a perfect hint); results bitwise equal: " + str(hint_equal),
                 "stage_ms_stage_by_stage": stage_ms, "roofline": roofs,
                 "inlier_share_mean": float((cnt.double() / torch.as_tensor(sizes, dtype=torch.float64, device=device)).mean()),
                 "parity": {"max_rot_err_rad": float(ang.max()), "median_rot_err_rad": float(np.median(ang)), "n_pairs": k,
