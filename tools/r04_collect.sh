@@ -14,4 +14,6 @@ grep -v '^\[Gloo\]' $G/bench_kitti_chain_2ranks.json > profiles/r04_bench_kitti_
 cp $G/residual_families.jsonl $G/ransac_forms.jsonl $G/full_batch_parity.jsonl profiles/ 2>/dev/null && \
   for f in residual_families ransac_forms full_batch_parity; do mv profiles/$f.jsonl profiles/r04_$f.jsonl; done
 cp $G/pipeline_pmc.txt profiles/r04_pipeline_pmc.txt
+[ -s $G/odometry_options_parity.json ] && cp $G/odometry_options_parity.json profiles/r04_odometry_options_parity.json
+[ -s $G/solve_latency.jsonl ] && cp $G/solve_latency.jsonl profiles/r04_solve_latency.jsonl
 git status --short profiles | head -40

@@ -26,4 +26,7 @@ for f in 2 3; do PNEC_RANSAC_FORM=$f python tools/ab_ransac_forms.py uniform 200
 python tools/verify_full_batch.py 100000 target > $OUT/full_batch_parity.jsonl 2> /dev/null
 python tools/verify_pipeline.py 100000 > $OUT/pipeline_parity_100k.json 2> $OUT/pipeline_parity_100k.err
 python tools/bench_streaming.py > $OUT/streaming.json 2> /dev/null
+# 7. one PNEC::Solve per frame through the facade (default options / the odometry's / the timed overload)
+for n in 100 512 700 2000; do for m in "" vo timed; do ./pnec_amd/pnec_host_demo $n solve_latency 300 $m 2>/dev/null | tail -1 >> $OUT/solve_latency.jsonl; done; done
+python tools/verify_odometry_options.py 2000 > $OUT/odometry_options_parity.json 2> /dev/null
 ls -la $OUT
