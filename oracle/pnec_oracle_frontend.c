@@ -297,6 +297,10 @@ static int eigensolver_descent_ext(const es_data *D, double v[3]) {
   return it;
 }
 
+/* Growth of the Levenberg shift per try (0, 1e-6 tr, then decades; the device's kLevenbergGrowth -- a factor 2 was tried in
+ * round 4 and taken back: fewer iterations here, more evaluations and worse parity on the device, see there). */
+#define ES_LEVENBERG_GROWTH 10.0
+
 /* Damped Newton on v (Cayley): Hessian by forward differences of the analytic gradient
  * (h = 1e-6), Levenberg shift until positive definite and descending, Armijo backtracking.
  * Stops when |step|_inf < 1e-12, |grad|_inf < 1e-14 * (1 + |lambda|) * n, or after 50 iterations. */
@@ -329,7 +333,7 @@ static int eigensolver_cayley(const es_data *Dp, double v[3]) {
       Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
       const double mg[3] = {-g[0], -g[1], -g[2]};
       if (solve3_spd(Hm, mg, d) && dot3(d, g) < 0.0) { ok = 1; break; }
-      mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * 10.0;
+      mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * ES_LEVENBERG_GROWTH;
     }
     if (!ok) break;
     double alpha = 1.0, fn = f, vn[3];

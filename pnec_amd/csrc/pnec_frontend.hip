@@ -536,6 +536,17 @@ __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&
   return true;
 }
 
+// Growth of the Levenberg shift from one try to the next: mu = 0, 1e-6 tr, then x kLevenbergGrowth per try.  Decades.
+// The shift taken lies within one growth factor above the smallest that makes H + mu I positive definite, i.e. up to
+// ten times over-damped, and a minimisation that starts on the flank of a saddle crawls for twenty or thirty iterations
+// (steps of g / mu) -- the rare long minimisations that set the length of a round of 32 (2.75 % of the benchmark's
+// RANSAC hypotheses take 16 and more iterations).  A growth of 2 was tried in round 4 (same constant in the CPU checker):
+// the checker's ITERATION counts fell as predicted (16 and more: 0.5 %), but a shift that close to the threshold leaves
+// H + mu I nearly singular -- steps the Armijo search has to cut back, so the device ran MORE evaluations (182 -> 187
+// per pair), 70 % more Cholesky solves, and the nearly singular solves amplify the rounding differences between device
+// and checker (5 of 20 000 inlier masks differed; none with decades).  Back to 10.
+constexpr double kLevenbergGrowth = 10.0;
+
 // The Levenberg shifts of the Newton head are tried in the fixed order 0, 1e-6 tr, 1e-5 tr, ... until the Cholesky
 // factorisation of H + mu I goes through.  A shift that leaves a diagonal entry of H + mu I at or below zero cannot: the
 // factorisation stops at that pivot or an earlier one (pivot i is H_ii + mu minus squares).  Those tries are walked over
@@ -546,7 +557,7 @@ __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&
 __device__ __forceinline__ void levenberg_skip_hopeless(const double (&H)[9], double tr, double &mu, int &tries) {
   const double dmin = fmin(H[0], fmin(H[4], H[8]));
   while (tries < 40 && dmin + mu <= 0.0) {
-    mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * 10.0;
+    mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * kLevenbergGrowth;
     ++tries;
   }
 }
@@ -571,7 +582,7 @@ __device__ __forceinline__ bool levenberg_direction(const double (&H)[9], const 
     for (int i = 0; i < 9; ++i) Hm[i] = H[i];
     Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
     if (solve3_spd(Hm, mg, d) && (d[0] * g[0] + d[1] * g[1] + d[2] * g[2]) < 0.0) return true;
-    mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * 10.0;
+    mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * kLevenbergGrowth;
   }
   return false;
 #endif
@@ -579,8 +590,8 @@ __device__ __forceinline__ bool levenberg_direction(const double (&H)[9], const 
   while (tries < 40) {
     PNEC_DBG_WAVE(17);               // Levenberg solves as the wavefront executes them
     const double m0 = mu;
-    const double m1 = (m0 == 0.0) ? 1e-6 * (tr + 1e-300) : m0 * 10.0;
-    const double m2 = m1 * 10.0, m3 = m2 * 10.0;
+    const double m1 = (m0 == 0.0) ? 1e-6 * (tr + 1e-300) : m0 * kLevenbergGrowth;
+    const double m2 = m1 * kLevenbergGrowth, m3 = m2 * kLevenbergGrowth;
     const double mine = role == 0 ? m0 : (role == 1 ? m1 : (role == 2 ? m2 : m3));
     double Hm[9];
 #pragma unroll
@@ -602,7 +613,7 @@ __device__ __forceinline__ bool levenberg_direction(const double (&H)[9], const 
       }
       return true;
     }
-    mu = m3 * 10.0;
+    mu = m3 * kLevenbergGrowth;
     tries += 4;
   }
   return false;

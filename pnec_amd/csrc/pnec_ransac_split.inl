@@ -534,17 +534,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void es_queue_ke
         if (gmax <= fmax(1e-14 * (1.0 + fabs(f)) * n_scale, 1.1e-13 * trace_cur)) {
           state = kDone;
         } else {
-          double mu = 0.0;
-          const double tr = fabs(H[0]) + fabs(H[4]) + fabs(H[8]);
-          bool ok = false;
-          for (int tries = 0; tries < 40; ++tries) {
-            double Hm[9];
-            for (int i = 0; i < 9; ++i) Hm[i] = H[i];
-            Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
-            const double mg[3] = {-g[0], -g[1], -g[2]};
-            if (solve3_spd(Hm, mg, d) && (d[0] * g[0] + d[1] * g[1] + d[2] * g[2]) < 0.0) { ok = true; break; }
-            mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * 10.0;
-          }
+          const bool ok = levenberg_direction(H, g, role, d);
           if (ok) {
             slope = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];
             state = kTrial;
