@@ -536,85 +536,55 @@ __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&
   return true;
 }
 
-// Growth of the Levenberg shift from one try to the next: mu = 0, 1e-6 tr, then x kLevenbergGrowth per try.  Decades.
-// The shift taken lies within one growth factor above the smallest that makes H + mu I positive definite, i.e. up to
-// ten times over-damped, and a minimisation that starts on the flank of a saddle crawls for twenty or thirty iterations
-// (steps of g / mu) -- the rare long minimisations that set the length of a round of 32 (2.75 % of the benchmark's
-// RANSAC hypotheses take 16 and more iterations).  A growth of 2 was tried in round 4 (same constant in the CPU checker):
-// the checker's ITERATION counts fell as predicted (16 and more: 0.5 %), but a shift that close to the threshold leaves
-// H + mu I nearly singular -- steps the Armijo search has to cut back, so the device ran MORE evaluations (182 -> 187
-// per pair), 70 % more Cholesky solves, and the nearly singular solves amplify the rounding differences between device
-// and checker (5 of 20 000 inlier masks differed; none with decades).  Back to 10.
+// The damped Newton direction of an iteration head: d = -(H + mu I)^-1 g.  mu = 0 when H is positive definite and the
+// direction descends.  Otherwise mu = 2 |x|, x = a lower bound of H's smallest eigenvalue that is within a few percent
+// of it unless eigenvalues nearly coincide: three Newton steps on the characteristic polynomial from the Gershgorin
+// bound (from the left of the smallest root the iteration rises monotonically and never passes it).  H + mu I then has
+// its smallest eigenvalue at about |lambda_min| -- neither nearly singular nor over-damped.  Should the factorisation
+// still fail (rounding, a NaN), mu grows in decades, at most 40 tries in all; false = no direction (the caller ends the
+// minimisation: the iterate stays).  The CPU checker's sequential form has the same rule.
+//
+// History (round 4).  The shift used to be SEARCHED: 0, 1e-6 tr, 1e-5 tr, ... until the factorisation went through.
+// (i) Event counters showed 5.3 Cholesky solves per head as the wavefront executes them (an indefinite Hessian far from
+// the minimum needs a shift of its own size, six or seven decades above the first, and the slowest of sixteen quads
+// sets the count); walking over the shifts that leave a non-positive diagonal and trying four shifts at once on the
+// quad's lanes brought that to 1.5, bit-identical.  (ii) The lengths of the minimisations have a heavy tail (7.4 Newton
+// iterations on average, p99 21, 50 for the longest) and a round of 32 minimisations on sixteen quads is as long as its
+// rare long one.  Traced on the checker, most long ones start on the flank of a saddle, where the searched shift -- the
+// first decade above the threshold, i.e. anywhere between one and ten times |lambda_min| -- damps the step up to ten
+// times too much and the iteration crawls with steps of g / mu for twenty or thirty iterations.  A finer search (x 2
+// per try) lands close to the threshold too often: nearly singular solves, steps the Armijo search has to cut back,
+// MORE evaluations on the device and worse parity.  The eigenvalue-based shift needs no search: counted on the checker
+// over 2 400 RANSAC hypotheses, in evaluations as the device spends them, 9.96 -> 9.18 per minimisation, minimisations of
+// 22 and more 2.6 % -> 0.7 %, a simulated round of 32 on sixteen quads 31 -> 27 evaluations long.
 constexpr double kLevenbergGrowth = 10.0;
-
-// The Levenberg shifts of the Newton head are tried in the fixed order 0, 1e-6 tr, 1e-5 tr, ... until the Cholesky
-// factorisation of H + mu I goes through.  A shift that leaves a diagonal entry of H + mu I at or below zero cannot: the
-// factorisation stops at that pivot or an earlier one (pivot i is H_ii + mu minus squares).  Those tries are walked over
-// here at three instructions each instead of a solve -- the sequence of shifts, and the one that is taken, are the
-// sequential rule's (measured on the benchmark's RANSAC stage: 5.3 solves per iteration head as the wavefront executed
-// them, the slowest of its sixteen quads setting the count; an indefinite Hessian far from the minimum needs a shift of
-// its own size, six or seven decades above the first one).
-__device__ __forceinline__ void levenberg_skip_hopeless(const double (&H)[9], double tr, double &mu, int &tries) {
-  const double dmin = fmin(H[0], fmin(H[4], H[8]));
-  while (tries < 40 && dmin + mu <= 0.0) {
-    mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * kLevenbergGrowth;
-    ++tries;
+__device__ __forceinline__ double hessian_floor(const double (&H)[9]) {
+  const double m00 = H[0], m01 = H[1], m02 = H[2], m11 = H[4], m12 = H[5], m22 = H[8];
+  const double trh = m00 + m11 + m22;
+  const double c2 = (m00 * m11 - m01 * m01) + (m00 * m22 - m02 * m02) + (m11 * m22 - m12 * m12);
+  const double det = m00 * (m11 * m22 - m12 * m12) - m01 * (m01 * m22 - m12 * m02) + m02 * (m01 * m12 - m11 * m02);
+  double x = fmin(m00 - fabs(m01) - fabs(m02), fmin(m11 - fabs(m01) - fabs(m12), m22 - fabs(m02) - fabs(m12)));
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const double pq = ((x - trh) * x + c2) * x - det, dq = (3.0 * x - 2.0 * trh) * x + c2;
+    if (dq > 0.0) x -= pq * fast_rcp(dq);   // (dq <= 0 cannot happen left of the smallest root; NaN ends up in mu and no try passes)
+    else break;
   }
+  return x;
 }
-
-// The damped Newton direction of an iteration head: d = -(H + mu I)^-1 g for the first shift mu of the sequence
-// 0, 1e-6 tr, 1e-5 tr, ... (at most 40) whose factorisation goes through and gives a descent direction.  H and g are
-// the same in the four lanes of the quad; after the hopeless shifts are walked over, lane `role` tries shift number
-// tries + role, and the first that passes IN THE SEQUENCE'S ORDER wins -- the sequential rule, four tries per solve
-// (the winner's direction reaches the other lanes through the LDS crossbar: no VALU slots).  Every lane computes all
-// four shifts by the same chain of multiplications, so the shift a try uses has the sequential form's bits.
-// Returns false when no shift passes (the caller ends the minimisation: the iterate stays).
 __device__ __forceinline__ bool levenberg_direction(const double (&H)[9], const double (&g)[3], int role, double (&d)[3]) {
+  (void)role;
   const double tr = fabs(H[0]) + fabs(H[4]) + fabs(H[8]);
-  double mu = 0.0;
-  int tries = 0;
-  levenberg_skip_hopeless(H, tr, mu, tries);
   const double mg[3] = {-g[0], -g[1], -g[2]};
-#ifdef PNEC_LEVENBERG_SEQUENTIAL   // A/B: every lane walks the sequence on its own (the form before round 4)
-  for (; tries < 40; ++tries) {
-    PNEC_DBG_WAVE(17);
+  double mu = 0.0;
+  for (int tries = 0; tries < 40; ++tries) {
+    PNEC_DBG_WAVE(17);               // Cholesky solves as the wavefront executes them
     double Hm[9];
+#pragma unroll
     for (int i = 0; i < 9; ++i) Hm[i] = H[i];
     Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
     if (solve3_spd(Hm, mg, d) && (d[0] * g[0] + d[1] * g[1] + d[2] * g[2]) < 0.0) return true;
-    mu = (mu == 0.0) ? 1e-6 * (tr + 1e-300) : mu * kLevenbergGrowth;
-  }
-  return false;
-#endif
-  const int quad_base = ((int)threadIdx.x & ~3) << 2;  // byte address of the quad's lane 0 for ds_bpermute
-  while (tries < 40) {
-    PNEC_DBG_WAVE(17);               // Levenberg solves as the wavefront executes them
-    const double m0 = mu;
-    const double m1 = (m0 == 0.0) ? 1e-6 * (tr + 1e-300) : m0 * kLevenbergGrowth;
-    const double m2 = m1 * kLevenbergGrowth, m3 = m2 * kLevenbergGrowth;
-    const double mine = role == 0 ? m0 : (role == 1 ? m1 : (role == 2 ? m2 : m3));
-    double Hm[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) Hm[i] = H[i];
-    Hm[0] += mine; Hm[4] += mine; Hm[8] += mine;
-    double dd[3];
-    const int pass = (tries + role < 40 && solve3_spd(Hm, mg, dd) && (dd[0] * g[0] + dd[1] * g[1] + dd[2] * g[2]) < 0.0) ? 1 : 0;
-    const int p0 = quad_broadcast<0>(pass), p1 = quad_broadcast<1>(pass), p2 = quad_broadcast<2>(pass),
-              p3 = quad_broadcast<3>(pass);
-    if (p0 | p1 | p2 | p3) {
-      const int winner = p0 ? 0 : (p1 ? 1 : (p2 ? 2 : 3));
-      const int addr = quad_base + (winner << 2);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const long long bits = __builtin_bit_cast(long long, dd[k]);
-        const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)(bits & 0xffffffffll));
-        const int hi = __builtin_amdgcn_ds_bpermute(addr, (int)(bits >> 32));
-        d[k] = __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
-      }
-      return true;
-    }
-    mu = m3 * kLevenbergGrowth;
-    tries += 4;
+    mu = (tries == 0) ? fmax(2.0 * fmax(-hessian_floor(H), 0.0), 1e-6 * (tr + 1e-300)) : mu * kLevenbergGrowth;
   }
   return false;
 }
