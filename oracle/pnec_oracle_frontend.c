@@ -325,7 +325,8 @@ static double es_hessian_floor(const double H[9]) {
 
 /* Damped Newton on v (Cayley): Hessian by forward differences of the analytic gradient
  * (h = 1e-6), Levenberg shift (above) when it is not positive definite and descending, Armijo backtracking.
- * Stops when |step|_inf < 1e-12, |grad|_inf < 1e-14 * (1 + |lambda|) * n, or after 50 iterations. */
+ * Stops when |step|_inf < 1e-12 (1e-6 for a full undamped Newton step), |grad|_inf < 1e-14 * (1 + |lambda|) * n, or after
+ * 50 iterations. */
 static int eigensolver_cayley(const es_data *Dp, double v[3]) {
   if (g_es_scheme == 1) return eigensolver_descent_ext(Dp, v);
   const es_data D = *Dp;
@@ -373,6 +374,9 @@ static int eigensolver_cayley(const es_data *Dp, double v[3]) {
     memcpy(v, vn, sizeof(vn));
     f = es_value_grad(&D, v, g);
     if (smax < 1e-12) { ++it; break; }
+    /* a full undamped Newton step this short: quadratic convergence has put the new point within ~1e-12 of the minimiser
+     * (the device stops here without the confirming evaluation; kNewtonStepDone) */
+    if (mu == 0.0 && alpha == 1.0 && smax < 1e-6) { ++it; break; }
   }
   return it;
 }

@@ -558,6 +558,12 @@ __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&
 // over 2 400 RANSAC hypotheses, in evaluations as the device spends them, 9.96 -> 9.18 per minimisation, minimisations of
 // 22 and more 2.6 % -> 0.7 %, a simulated round of 32 on sixteen quads 31 -> 27 evaluations long.
 constexpr double kLevenbergGrowth = 10.0;
+// A full, undamped Newton step shorter than this ends the minimisation: convergence is quadratic there, the point the
+// step leads to is within ~C * 1e-12 of the minimiser (C = the ratio of third to second derivatives, 1..1e3 here), and
+// the evaluation that would confirm it -- a whole trip of the quad, one in nine -- finds a step of 1e-12.  (Damped steps
+// and cut-back steps say nothing of the kind and keep the old rule: 1e-12.)  Same constant in the CPU checker; counted
+// there: 9.18 -> 8.61 evaluations per RANSAC minimisation, rotations within 1e-9 rad of the fully converged ones.
+constexpr double kNewtonStepDone = 1e-6;
 __device__ __forceinline__ double hessian_floor(const double (&H)[9]) {
   const double m00 = H[0], m01 = H[1], m02 = H[2], m11 = H[4], m12 = H[5], m22 = H[8];
   const double trh = m00 + m11 + m22;
@@ -572,8 +578,10 @@ __device__ __forceinline__ double hessian_floor(const double (&H)[9]) {
   }
   return x;
 }
-__device__ __forceinline__ bool levenberg_direction(const double (&H)[9], const double (&g)[3], int role, double (&d)[3]) {
+__device__ __forceinline__ bool levenberg_direction(const double (&H)[9], const double (&g)[3], int role, double (&d)[3],
+                                                    bool &damped) {
   (void)role;
+  damped = false;
   const double tr = fabs(H[0]) + fabs(H[4]) + fabs(H[8]);
   const double mg[3] = {-g[0], -g[1], -g[2]};
   double mu = 0.0;
@@ -584,6 +592,7 @@ __device__ __forceinline__ bool levenberg_direction(const double (&H)[9], const 
     for (int i = 0; i < 9; ++i) Hm[i] = H[i];
     Hm[0] += mu; Hm[4] += mu; Hm[8] += mu;
     if (solve3_spd(Hm, mg, d) && (d[0] * g[0] + d[1] * g[1] + d[2] * g[2]) < 0.0) return true;
+    damped = true;
     mu = (tries == 0) ? fmax(2.0 * fmax(-hessian_floor(H), 0.0), 1e-6 * (tr + 1e-300)) : mu * kLevenbergGrowth;
   }
   return false;
@@ -626,6 +635,7 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
   double eb[3] = {0.0, 0.0, 1.0};  // eigenvector of the smallest eigenvalue at the current point
   double f = 0.0, g[3] = {0.0, 0.0, 0.0}, H[9], d[3] = {0.0, 0.0, 0.0};
   double slope = 0.0, alpha = 1.0, trace_cur = 0.0;  // trace_cur: trace of M at the current point
+  bool damped = false;                               // the direction d was made with a Levenberg shift
   int state = active ? kInit : kDone, it = 0, ls = 0, evals = 0;
   bool last_eval = false;
   while (state != kDone) {
@@ -707,7 +717,7 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
 #pragma unroll
           for (int k = 0; k < 3; ++k) v[k] = v[k] + d[k];
           ++it;
-          if (smax < 1e-12 || it >= 50) state = kDone;
+          if (smax < (damped ? 1e-12 : kNewtonStepDone) || it >= 50) state = kDone;
         } else {
           PNEC_DBG_COUNT(4);           // full step rejected
           state = kShort;
@@ -747,7 +757,7 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
       } else {
         PNEC_DBG_COUNT(2);             // Newton iterations (x4 lanes)
         PNEC_DBG_WAVE(10);             // iteration heads as the wavefront executes them
-        const bool ok = levenberg_direction(H, g, role, d);
+        const bool ok = levenberg_direction(H, g, role, d, damped);
         if (ok) {
           slope = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];
           state = kTrial;
@@ -2185,6 +2195,7 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
   double v[3] = {0.0, 0.0, 0.0}, eb[3] = {0.0, 0.0, 1.0};
   double f = 0.0, g[3] = {0.0, 0.0, 0.0}, H[9], d[3] = {0.0, 0.0, 0.0};
   double slope = 0.0, alpha = 1.0, trace_cur = 0.0;
+  bool damped = false;
   int state = kDone, it = 0, ls = 0, slot = -1;
   bool last_eval = false;
 #pragma unroll
@@ -2194,7 +2205,7 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
     v[0] = tv[s][0]; v[1] = tv[s][1]; v[2] = tv[s][2];
     eb[0] = 0.0; eb[1] = 0.0; eb[2] = 1.0;
     f = 0.0; g[0] = g[1] = g[2] = 0.0; d[0] = d[1] = d[2] = 0.0;
-    slope = 0.0; alpha = 1.0; trace_cur = 0.0;
+    slope = 0.0; alpha = 1.0; trace_cur = 0.0; damped = false;
     it = 0; ls = 0; last_eval = false;
     state = kInit;
   };
@@ -2280,7 +2291,7 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
 #pragma unroll
             for (int k = 0; k < 3; ++k) v[k] = v[k] + d[k];
             ++it;
-            if (smax < 1e-12 || it >= 50) state = kDone;
+            if (smax < (damped ? 1e-12 : kNewtonStepDone) || it >= 50) state = kDone;
           } else {
             state = kShort;
             alpha = 0.5;
@@ -2305,7 +2316,7 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
           state = kDone;
         } else {
           PNEC_DBG_WAVE(16);           // queue: iteration heads as the wavefront executes them
-          const bool ok = levenberg_direction(H, g, role, d);
+          const bool ok = levenberg_direction(H, g, role, d, damped);
           if (ok) {
             slope = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];
             state = kTrial;

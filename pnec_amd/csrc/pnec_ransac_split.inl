@@ -373,6 +373,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void es_queue_ke
   double v[3] = {0.0, 0.0, 0.0}, eb[3] = {0.0, 0.0, 1.0};
   double f = 0.0, g[3] = {0.0, 0.0, 0.0}, H[9], d[3] = {0.0, 0.0, 0.0};
   double slope = 0.0, alpha = 1.0, trace_cur = 0.0, n_scale = 1.0;
+  bool damped = false;
   int state = kDone, it = 0, ls = 0;
   int cur_task = -1;  // the task this quad is minimising
   bool last_eval = false;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void es_queue_ke
       n_scale = Gq[quad][39];
       eb[0] = 0.0; eb[1] = 0.0; eb[2] = 1.0;
       f = 0.0; g[0] = g[1] = g[2] = 0.0; d[0] = d[1] = d[2] = 0.0;
-      slope = 0.0; alpha = 1.0; trace_cur = 0.0;
+      slope = 0.0; alpha = 1.0; trace_cur = 0.0; damped = false;
       it = 0; ls = 0; last_eval = false;
       state = n_scale > 0.0 ? kInit : kDone;  // (an unused slot of the pool: nothing to minimise)
     }
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void es_queue_ke
 #pragma unroll
             for (int c = 0; c < 3; ++c) v[c] = v[c] + d[c];
             ++it;
-            if (smax < 1e-12 || it >= 50) state = kDone;
+            if (smax < (damped ? 1e-12 : kNewtonStepDone) || it >= 50) state = kDone;
           } else {
             state = kShort;
             alpha = 0.5;
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void es_queue_ke
         if (gmax <= fmax(1e-14 * (1.0 + fabs(f)) * n_scale, 1.1e-13 * trace_cur)) {
           state = kDone;
         } else {
-          const bool ok = levenberg_direction(H, g, role, d);
+          const bool ok = levenberg_direction(H, g, role, d, damped);
           if (ok) {
             slope = d[0] * g[0] + d[1] * g[1] + d[2] * g[2];
             state = kTrial;
