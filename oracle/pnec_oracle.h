@@ -175,6 +175,9 @@ int pnec_oracle_get_eigensolver_scheme(void);
 /* opengv::relative_pose::eigensolver restated (Kneip-Lynen eigenvalue minimisation); R row-major */
 int pnec_oracle_eigensolver(int64_t n, const double *bvs1, const double *bvs2, const double R0[9],
                             double R_out[9], int32_t *iterations);
+/* evaluations of the calling thread's last minimisation, counted as the device's quad spends them (one trip = a point
+ * with its Hessian probes, or four step lengths): diagnostics for tools/sim_ransac_queue.py */
+int pnec_oracle_es_last_trips(void);
 /* scf.cc:53-72 (float division quirk), :43-51, :128-148 (with the alt_construct_E slip) */
 void pnec_oracle_fibonacci_sphere(int samples, double *pts);
 double pnec_oracle_obj_fun(const double t[3], int64_t n, const double *Ai, const double *Bi);

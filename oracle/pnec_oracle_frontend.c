@@ -309,6 +309,11 @@ static int eigensolver_descent_ext(const es_data *D, double v[3]) {
  * the factorisation still fail (rounding, a Hessian with a NaN), the shift grows in decades as before.  Same rule on the
  * device (levenberg_direction). */
 #define ES_LEVENBERG_GROWTH 10.0
+/* Most Newton iterations of one minimisation (the device's kNewtonMaxIterations).  The ones that get this far are
+ * contaminated RANSAC samples crawling along the flank of a saddle or running off to the minimum at infinity of the
+ * Cayley chart; they never yield a round's best model (masks, inlier and hypothesis counts over 1 500 pairs of the
+ * benchmark's data are the same with 25 as with 50), but on the device one of them sets the length of its round. */
+#define ES_MAX_ITERATIONS 25
 static double es_hessian_floor(const double H[9]) {
   const double m00 = H[0], m01 = H[1], m02 = H[2], m11 = H[4], m12 = H[5], m22 = H[8];
   const double trh = m00 + m11 + m22;
@@ -326,15 +331,23 @@ static double es_hessian_floor(const double H[9]) {
 /* Damped Newton on v (Cayley): Hessian by forward differences of the analytic gradient
  * (h = 1e-6), Levenberg shift (above) when it is not positive definite and descending, Armijo backtracking.
  * Stops when |step|_inf < 1e-12 (1e-6 for a full undamped Newton step), |grad|_inf < 1e-14 * (1 + |lambda|) * n, or after
- * 50 iterations. */
+ * ES_MAX_ITERATIONS iterations. */
+static int g_es_trips; /* evaluations of the last minimisation as the device's quad spends them (diagnostics, below) */
+#pragma omp threadprivate(g_es_trips)
+/* One trip of the device's quad = the point with its three Hessian probes, or four step lengths of the Armijo search:
+ * 1 for the start, 1 per iteration whose full step is taken, and ceil(j / 4) + 1 more for one that is cut back j times.
+ * Test tooling for tools/sim_ransac_queue.py (how a round's minimisations pack onto sixteen quads). */
+int pnec_oracle_es_last_trips(void) { return g_es_trips; }
 static int eigensolver_cayley(const es_data *Dp, double v[3]) {
+  g_es_trips = 0;
   if (g_es_scheme == 1) return eigensolver_descent_ext(Dp, v);
   const es_data D = *Dp;
   const int64_t n = D.n;
   double g[3];
   double f = es_value_grad(&D, v, g);
   int it = 0;
-  for (; it < 50; ++it) {
+  g_es_trips = 1;
+  for (; it < ES_MAX_ITERATIONS; ++it) {
     const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
     if (gmax <= 1e-14 * (1.0 + fabs(f)) * (double)(n > 0 ? n : 1)) break;
     double H[9];
@@ -361,14 +374,15 @@ static int eigensolver_cayley(const es_data *Dp, double v[3]) {
     if (!ok) break;
     double alpha = 1.0, fn = f, vn[3];
     const double slope = dot3(d, g);
-    int moved = 0;
-    for (int ls = 0; ls < 40; ++ls) {
+    int moved = 0, ls = 0;
+    for (; ls < 40; ++ls) {
       for (int k = 0; k < 3; ++k) vn[k] = v[k] + alpha * d[k];
       fn = es_value_grad(&D, vn, NULL);
       /* Armijo with a rounding-noise floor: lambda_min carries ~eps * trace(M) of error */
       if (fn <= f + 1e-4 * alpha * slope + 4e-16 * g_es_trace) { moved = 1; break; }
       alpha *= 0.5;
     }
+    g_es_trips += 1 + (ls > 0 ? (ls + 3) / 4 + (moved ? 1 : 0) : 0);
     if (!moved) break;
     const double smax = alpha * fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
     memcpy(v, vn, sizeof(vn));

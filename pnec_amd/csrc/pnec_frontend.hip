@@ -564,6 +564,15 @@ constexpr double kLevenbergGrowth = 10.0;
 // and cut-back steps say nothing of the kind and keep the old rule: 1e-12.)  Same constant in the CPU checker; counted
 // there: 9.18 -> 8.61 evaluations per RANSAC minimisation, rotations within 1e-9 rad of the fully converged ones.
 constexpr double kNewtonStepDone = 1e-6;
+// Most Newton iterations of one minimisation (same constant in the CPU checker: ES_MAX_ITERATIONS).  A minimisation
+// converges in 4..15 iterations; the ones that reach twenty and more are contaminated RANSAC samples whose iterates crawl
+// along the flank of a saddle (strongly negative curvature, a gradient with next to no component along it: steps of
+// g / |lambda|, 1e-4 per iteration, for as long as they are allowed) or run off to the minimum at infinity of the Cayley
+// chart (a rotation by 180 degrees).  Neither ever yields a round's best model -- on 1 500 pairs of the benchmark's data
+// the checker's masks, inlier counts and hypothesis counts are the same with 25 as with 50 (with 20, one pair differs) --
+// but one such minimisation sets the length of its round (53 trips where the round's others take ~27) and the 1 % of
+// wavefronts that hold one are what a launch ends with.  (Until round 4: 50.)
+constexpr int kNewtonMaxIterations = 25;
 __device__ __forceinline__ double hessian_floor(const double (&H)[9]) {
   const double m00 = H[0], m01 = H[1], m02 = H[2], m11 = H[4], m12 = H[5], m22 = H[8];
   const double trh = m00 + m11 + m22;
@@ -675,7 +684,7 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
         for (int k = 0; k < 3; ++k) v[k] = v[k] + alpha * d[k];
         ++it;
         // the loop ends here; with e_out the caller wants the eigenvector AT the new point: one more evaluation
-        last_eval = smax < 1e-12 || it >= 50;
+        last_eval = smax < 1e-12 || it >= kNewtonMaxIterations;
         state = (last_eval && !e_out) ? kDone : kReeval;
       } else {
         alpha *= 0.0625;
@@ -717,7 +726,7 @@ __device__ __noinline__ int es_minimise_quad(const double *G, double (&v)[3], do
 #pragma unroll
           for (int k = 0; k < 3; ++k) v[k] = v[k] + d[k];
           ++it;
-          if (smax < (damped ? 1e-12 : kNewtonStepDone) || it >= 50) state = kDone;
+          if (smax < (damped ? 1e-12 : kNewtonStepDone) || it >= kNewtonMaxIterations) state = kDone;
         } else {
           PNEC_DBG_COUNT(4);           // full step rejected
           state = kShort;
@@ -1011,7 +1020,7 @@ __global__ __launch_bounds__(kWave, 2) void es_batch_kernel(const EsBatchArgs a)
 #ifdef PNEC_FRONT_DEBUG
   if (mine && (lane & 3) == 0) {
     atomicMax(&g_dbg[12], (unsigned long long)it);
-    if (it >= 50) { atomicAdd(&g_dbg[13], 1ull); atomicExch(&g_dbg[11], (unsigned long long)pair); }
+    if (it >= kNewtonMaxIterations) { atomicAdd(&g_dbg[13], 1ull); atomicExch(&g_dbg[11], (unsigned long long)pair); }
     if (it >= 20) atomicAdd(&g_dbg[14], 1ull);
     atomicAdd(&g_dbg[15], (unsigned long long)it);
   }
@@ -1685,6 +1694,9 @@ struct RansacArgs {
   RansacState resume;
   // two-pair form: the pairs in launch order (null: as they lie in the batch); see ransac_order_kernel
   const int32_t *order;
+  // two-pair form: blocks [0, n_double) take the pairs 2 b, 2 b + 1 (of the launch order), blocks from n_double on ONE
+  // pair each, 2 n_double + (b - n_double): the launch's last wavefronts are short ones (see ransac_tail_singles)
+  int64_t n_double;
 };
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
@@ -1891,7 +1903,7 @@ __device__ __forceinline__ void ransac_sample_regs(unsigned long long seed, unsi
     if (idx >= n) idx = n - 1;
     bool dup = false;
 #pragma unroll
-    for (int j = 0; j < PNEC_HIP_MAX_RANSAC_SAMPLE; ++j) dup = dup || (j < m && s[j] == (int)idx);
+    for (int j = 0; j < PNEC_HIP_MAX_RANSAC_SAMPLE; ++j) dup = dup || s[j] == (int)idx;  // (entries from m on are -1, idx >= 0)
     if (!dup) {
 #pragma unroll
       for (int j = 0; j < PNEC_HIP_MAX_RANSAC_SAMPLE; ++j) s[j] = (j == m) ? (int)idx : s[j];
@@ -2257,7 +2269,7 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
 #pragma unroll
           for (int k = 0; k < 3; ++k) v[k] = v[k] + alpha * d[k];
           ++it;
-          last_eval = smax < 1e-12 || it >= 50;
+          last_eval = smax < 1e-12 || it >= kNewtonMaxIterations;
           state = kReeval;  // the eigenvector AT the new point is wanted: one more evaluation even at the end
         } else {
           alpha *= 0.0625;
@@ -2291,7 +2303,7 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
 #pragma unroll
             for (int k = 0; k < 3; ++k) v[k] = v[k] + d[k];
             ++it;
-            if (smax < (damped ? 1e-12 : kNewtonStepDone) || it >= 50) state = kDone;
+            if (smax < (damped ? 1e-12 : kNewtonStepDone) || it >= kNewtonMaxIterations) state = kDone;
           } else {
             state = kShort;
             alpha = 0.5;
@@ -2367,8 +2379,9 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
   bool lent = false;  // slot 1 works for slot 0's pair (its second sixteen hypotheses of a round)
 #pragma unroll
   for (int pp = 0; pp < 2; ++pp) {
-    pair[pp] = 2 * (int64_t)blockIdx.x + pp;
-    exists[pp] = pair[pp] < a.n_pairs;
+    const int64_t blk = (int64_t)blockIdx.x;
+    pair[pp] = blk < a.n_double ? 2 * blk + pp : a.n_double + blk;   // (= 2 n_double + (blk - n_double) for slot 0)
+    exists[pp] = pair[pp] < a.n_pairs && (blk < a.n_double || pp == 0);
     if (a.order && exists[pp]) pair[pp] = a.order[pair[pp]];
     const int64_t pq = exists[pp] ? pair[pp] : 0;
     n[pp] = exists[pp] ? a.count[pq] : 0;
@@ -2454,17 +2467,42 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
       needed[pp] = !go[pp] ? 0 : (it[pp] == 0 ? kHypPerRound : (int)fmin(ceil(k[pp] - (double)it[pp]), (double)kHypPerRound));
     }
     if (!go[0] && !go[1]) break;  // wave-uniform
-    // ---- prepare the round's hypotheses: quad j samples hypothesis j of each pair that goes on
+    // ---- prepare the round's hypotheses: quad j samples hypothesis j of each pair that goes on.
+    // The draws of BOTH slots in one pass: lanes 0, 1 of a quad draw slot 0's sample and jitter, lanes 2, 3 slot 1's,
+    // and the quad gets each by broadcast (until round 4 all four lanes drew slot 0's, then all four slot 1's: the
+    // generator -- a 64-bit hash per draw -- and the draw-until-distinct loop were a seventh of the kernel's time).
+    // Same draws, same samples.
+    int smp_mine[PNEC_HIP_MAX_RANSAC_SAMPLE];
+    {
+      const bool second = role >= 2;
+      const bool act_mine = hyp < (second ? needed[1] : needed[0]);
+      const unsigned long long hh_m = (unsigned long long)((second ? it[1] : it[0]) + hyp);
+      const unsigned long long pid_m = a.pair_id_base + (unsigned long long)(second ? pair[1] : pair[0]);
+#pragma unroll
+      for (int j = 0; j < PNEC_HIP_MAX_RANSAC_SAMPLE; ++j) smp_mine[j] = -1;
+      if (act_mine) ransac_sample_regs(a.seed, pid_m, hh_m, second ? n[1] : n[0], ss, smp_mine);
+    }
+    // the start's jitter: six hashes on four lanes in two turns
+    double jit[2][3];
+    {
+      const unsigned long long pid0 = a.pair_id_base + (unsigned long long)pair[0], pid1 = a.pair_id_base + (unsigned long long)pair[1];
+      const unsigned long long hh0 = (unsigned long long)(it[0] + hyp), hh1 = (unsigned long long)(it[1] + hyp);
+      // turn A: lanes 0..2 -> slot 0's components 0..2, lane 3 -> slot 1's component 0; turn B: lanes 0, 1 -> slot 1's 1, 2
+      const double ja = rng_uniform(a.seed, role < 3 ? pid0 : pid1, role < 3 ? hh0 : hh1, 1000ull + (unsigned long long)(role < 3 ? role : 0));
+      const double jb = rng_uniform(a.seed, pid1, hh1, 1001ull + (unsigned long long)(role & 1));
+      jit[0][0] = quad_broadcast<0>(ja); jit[0][1] = quad_broadcast<1>(ja); jit[0][2] = quad_broadcast<2>(ja);
+      jit[1][0] = quad_broadcast<3>(ja); jit[1][1] = quad_broadcast<0>(jb); jit[1][2] = quad_broadcast<1>(jb);
+    }
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
       const int slot = kHypPerRound * pp + hyp;
       const bool active = hyp < needed[pp];
-      const unsigned long long hh = (unsigned long long)(it[pp] + hyp);
-      const unsigned long long pid = a.pair_id_base + (unsigned long long)pair[pp];
       // the sample in registers, its gathers all in flight together (ransac_sample_regs / ransac_sample_sums above); the
       // model phase reads the sample from LDS
       int smp[PNEC_HIP_MAX_RANSAC_SAMPLE];
-      if (active) ransac_sample_regs(a.seed, pid, hh, n[pp], ss, smp);
+#pragma unroll
+      for (int j = 0; j < PNEC_HIP_MAX_RANSAC_SAMPLE; ++j)
+        smp[j] = pp == 0 ? quad_broadcast<0>(smp_mine[j]) : quad_broadcast<2>(smp_mine[j]);
       if (active && role == 0) PNEC_WORK_ADD(kWkRansacHyps, 1);
       double ev1[3], Gl[36];
       ransac_sample_sums(base[pp], stride[pp], ss, active, smp, role, Gl, ev1);
@@ -2476,7 +2514,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           lds.tev1[slot][c] = ev1[c];
-          lds.tv[slot][c] = v0[pp][c] + (rng_uniform(a.seed, pid, hh, 1000 + c) - 0.5) * 2.0 * 0.01;
+          lds.tv[slot][c] = v0[pp][c] + (jit[pp][c] - 0.5) * 2.0 * 0.01;
         }
       }
     }
@@ -2892,6 +2930,22 @@ hipError_t launch_ransac_order(const int32_t *iterations, int64_t n_pairs, int32
   return hipGetLastError();
 }
 
+// Two-pair form: how many pairs at the END of the launch order get a wavefront of their own.  A launch ends with the
+// wavefronts that started last; two-pair wavefronts run ~300 us, one-pair ones ~190, and while the launch drains the
+// slots the shorter ones leave are idle anyway (their worse packing -- 16 minimisations on 16 quads -- costs nothing
+// there).  PNEC_RANSAC_TAIL_SINGLES overrides (A/B runs; 0 = every wavefront takes two pairs).  Scheduling only: a
+// pair's arithmetic does not depend on the wavefront it shares.
+static int64_t ransac_tail_singles(int64_t n_pairs) {
+  static const int64_t forced = [] {
+    const char *ev = std::getenv("PNEC_RANSAC_TAIL_SINGLES");
+    return ev && *ev ? (int64_t)std::atoll(ev) : (int64_t)-1;
+  }();
+  if (forced >= 0) return forced;
+  // measured at 20 000 pairs x 512 (one box, round 4): 0 -> 2.05, 1 024 -> 2.00, 2 048 -> 2.04, 4 096 -> 2.15 ms: about half
+  // a generation of the 2 048 wavefront slots, and no more than a sixteenth of a smaller batch
+  return std::min<int64_t>(1024, n_pairs / 16);
+}
+
 hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_offset, const int64_t *offsets,
                                      const int32_t *count, int64_t n_pairs, const double *init_q,
                                      unsigned long long seed, unsigned long long pair_id_base, int max_iterations,
@@ -2956,8 +3010,12 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
     e = launch_ransac_split(a, ws, stream);
   } else {
     if (two) a.order = order;
-    if (two)
-      hipLaunchKernelGGL(ransac2_eigensolver_kernel, dim3((unsigned)((n_pairs + 1) / 2)), dim3(kWave), 0, stream, a);
+    if (two) {
+      const int64_t singles = std::min<int64_t>(ransac_tail_singles(n_pairs), n_pairs) & ~(int64_t)1;  // (even: the rest pairs up)
+      a.n_double = (n_pairs - singles + 1) / 2;
+      const int64_t blocks = a.n_double + (n_pairs - std::min<int64_t>(2 * a.n_double, n_pairs));
+      hipLaunchKernelGGL(ransac2_eigensolver_kernel, dim3((unsigned)blocks), dim3(kWave), 0, stream, a);
+    }
     else
       hipLaunchKernelGGL(ransac_eigensolver_kernel<false>, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
     e = hipGetLastError();
@@ -3004,6 +3062,12 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
       double m[kPhCount] = {0};
       for (int64_t p = 0; p < n_pairs; ++p)
         for (int k = 0; k < kPhCount; ++k) m[k] += (double)h[(size_t)(kPhCount * p + k)];
+      if (tr[0] == '/' || tr[0] == '.') {  // a path: the raw [n_pairs, kPhCount] records of this launch (overwritten per launch)
+        if (std::FILE *fp = std::fopen(tr, "wb")) {
+          std::fwrite(h.data(), sizeof(unsigned long long), h.size(), fp);
+          std::fclose(fp);
+        }
+      }
       static const char *names[kPhCount] = {"sample+sums", "newton", "model", "score", "consume", "inliers", "final_es", "total",
                                             "its_sum16", "its_max_sum (two-pair form: evaluations executed)", "rounds", "evaluations_executed (one-pair form)"};
       std::fprintf(stderr, "ransac_eigensolver phases (mean s_memtime clocks per pair, %lld pairs):", (long long)n_pairs);
