@@ -516,6 +516,41 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
   return lam;
 }
 
+// M(R) from the 36 sums alone (es_value_grad's composition, without eigenpair and gradient): for the ordering key of
+// es_queue_order below -- scheduling only, its bits enter no result.
+__device__ __forceinline__ void sums_to_m(const double (&Gr)[36], const double (&R)[9], double (&M)[9]) {
+  double r[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    r[k][0] = R[k]; r[k][1] = R[3 + k]; r[k][2] = R[6 + k];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) M[i] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int l = k; l < 3; ++l) {
+      const double *Gp = Gr + 6 * s3(k, l);
+      double Tc[3][3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double gj[3] = {Gp[s3(0, j)], Gp[s3(1, j)], Gp[s3(2, j)]};
+        cross3(r[k], gj, Tc[j]);
+      }
+      double X[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double Ti[3] = {Tc[0][i], Tc[1][i], Tc[2][i]};
+        cross3(r[l], Ti, X[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) M[3 * i + j] += (k == l) ? X[i][j] : X[i][j] + X[j][i];
+    }
+  }
+}
+
 // 3x3 Cholesky solve with reciprocal square roots (v_rsq_f64 + refinement) in place of the IEEE
 // sqrt / divide sequences (~400 instructions per call otherwise)
 __device__ bool solve3_spd(const double (&H)[9], const double (&b)[3], double (&x)[3]) {
@@ -2188,6 +2223,7 @@ struct Ransac2Lds {
   int tsel[2 * kHypPerRound][PNEC_HIP_MAX_RANSAC_SAMPLE];  // the sample
   int tits[2 * kHypPerRound];
   int tlist[2 * kHypPerRound];       // the round's queue: slots of the active hypotheses
+  double tkey[2 * kHypPerRound];     // ... and the keys it is ordered by (es_queue_order)
   double models[kHypPerRound][12];   // R (9) + t (3) of the hypotheses of the pair being scored
   double best_model[2][12];          // R (9) + t (3) per pair
   double G[2][36];                   // sums of the inliers of the best model
@@ -2526,6 +2562,46 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
       if (lane < n_tasks) lds.tlist[lane] = kHypPerRound * pp + j;
     }
     lds_sync();
+    // ---- the queue's order: likely-long minimisations first (es_queue_order).  The sixteen quads start on the first
+    // sixteen entries together and take the others as they finish; a round is as long as its busiest quad, and a long
+    // minimisation handed out late ends it (replayed from the checker's trip counts, tools/sim_ransac_queue.py: 25.7
+    // trips for a round of 32 in the order of the slots, 20.7 with the lengths known).  What a minimisation will take is
+    // not known, but how far its start is from a rank-two M says much of it: a clean sample starts near its minimum, a
+    // contaminated one does not, and lambda_1 / lambda_2 of M at the start -- from M's invariants alone,
+    // det tr / c2^2, no eigenpair -- ranks the lengths with a correlation of 0.69 (22.1 trips).  One lane per task
+    // composes its M (a third of an evaluation, once per round) and ranks its key among the others'.  Scheduling only:
+    // a hypothesis' arithmetic does not depend on when or where it is minimised.
+    if (n_tasks > kHypPerRound) {  // (wave-uniform; with sixteen or fewer, all start together)
+      double key = 0.0;
+      int slot_l = 0;
+      if (lane < n_tasks) {
+        slot_l = lds.tlist[lane];
+        double Gr[36];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) Gr[i] = lds.Gh[slot_l][i];
+        const double vv[3] = {lds.tv[slot_l][0], lds.tv[slot_l][1], lds.tv[slot_l][2]};
+        double Rk[9], Mk[9];
+        cayley_to_rot(vv, Rk);
+        sums_to_m(Gr, Rk, Mk);
+        const double m01 = 0.5 * (Mk[1] + Mk[3]), m02 = 0.5 * (Mk[2] + Mk[6]), m12 = 0.5 * (Mk[5] + Mk[7]);
+        const double k00 = Mk[4] * Mk[8] - m12 * m12, k11 = Mk[0] * Mk[8] - m02 * m02, k22 = Mk[0] * Mk[4] - m01 * m01;
+        const double c2 = k00 + k11 + k22;
+        const double det = Mk[0] * k00 - m01 * (m01 * Mk[8] - m12 * m02) + m02 * (m01 * m12 - Mk[4] * m02);
+        key = det * (Mk[0] + Mk[4] + Mk[8]) * fast_rcp(c2 * c2);
+        if (!(key > 0.0) || !finite_d(key)) key = 0.0;
+        lds.tkey[lane] = key;
+      }
+      lds_sync();
+      if (lane < n_tasks) {
+        int rank = 0;
+        for (int j = 0; j < n_tasks; ++j) {
+          const double kj = lds.tkey[j];
+          rank += (kj > key || (kj == key && j < lane)) ? 1 : 0;
+        }
+        lds.tlist[rank] = slot_l;
+      }
+      lds_sync();
+    }
     PNEC_PHASE_END(kRpSample);
     const int trips = es_minimise_queue(n_tasks, lds.tlist, lds.Gh, lds.tv, lds.te, lds.tits, (double)ss);
     lds_sync();
