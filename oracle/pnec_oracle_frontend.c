@@ -309,11 +309,18 @@ static int eigensolver_descent_ext(const es_data *D, double v[3]) {
  * the factorisation still fail (rounding, a Hessian with a NaN), the shift grows in decades as before.  Same rule on the
  * device (levenberg_direction). */
 #define ES_LEVENBERG_GROWTH 10.0
-/* Most Newton iterations of one minimisation (the device's kNewtonMaxIterations).  The ones that get this far are
- * contaminated RANSAC samples crawling along the flank of a saddle or running off to the minimum at infinity of the
- * Cayley chart; they never yield a round's best model (masks, inlier and hypothesis counts over 1 500 pairs of the
- * benchmark's data are the same with 25 as with 50), but on the device one of them sets the length of its round. */
-#define ES_MAX_ITERATIONS 25
+/* Most Newton iterations of one minimisation: 50, and 25 for the minimisation of a RANSAC hypothesis (the device's
+ * kNewtonMaxIterations / kHypothesisMaxIterations).  The hypotheses that get that far are contaminated samples crawling
+ * along the flank of a saddle or running off to the minimum at infinity of the Cayley chart; they never yield a round's
+ * best model (masks, inlier and hypothesis counts over 1 500 pairs of the benchmark's data are the same with 25 as with
+ * 50), but on the device one of them sets the length of its round. */
+#define ES_MAX_ITERATIONS 50
+#define ES_HYPOTHESIS_MAX_ITERATIONS 25
+/* A full undamped Newton step shorter than this ends a minimisation (quadratic convergence: the point it leads to is within
+ * ~C * step^2 of the minimiser).  The minimisation of a RANSAC hypothesis has its own constant (the device's
+ * kHypothesisStepDone, where the measurement with 1e-4 is written down); both are 1e-6. */
+#define ES_STEP_DONE 1e-6
+#define ES_HYPOTHESIS_STEP_DONE 1e-6
 static double es_hessian_floor(const double H[9]) {
   const double m00 = H[0], m01 = H[1], m02 = H[2], m11 = H[4], m12 = H[5], m22 = H[8];
   const double trh = m00 + m11 + m22;
@@ -330,15 +337,15 @@ static double es_hessian_floor(const double H[9]) {
 
 /* Damped Newton on v (Cayley): Hessian by forward differences of the analytic gradient
  * (h = 1e-6), Levenberg shift (above) when it is not positive definite and descending, Armijo backtracking.
- * Stops when |step|_inf < 1e-12 (1e-6 for a full undamped Newton step), |grad|_inf < 1e-14 * (1 + |lambda|) * n, or after
- * ES_MAX_ITERATIONS iterations. */
+ * Stops when |step|_inf < 1e-12 (step_done for a full undamped Newton step), |grad|_inf < 1e-14 * (1 + |lambda|) * n, or after
+ * max_it iterations. */
 static int g_es_trips; /* evaluations of the last minimisation as the device's quad spends them (diagnostics, below) */
 #pragma omp threadprivate(g_es_trips)
 /* One trip of the device's quad = the point with its three Hessian probes, or four step lengths of the Armijo search:
  * 1 for the start, 1 per iteration whose full step is taken, and ceil(j / 4) + 1 more for one that is cut back j times.
  * Test tooling for tools/sim_ransac_queue.py (how a round's minimisations pack onto sixteen quads). */
 int pnec_oracle_es_last_trips(void) { return g_es_trips; }
-static int eigensolver_cayley(const es_data *Dp, double v[3]) {
+static int eigensolver_cayley_tol(const es_data *Dp, double v[3], double step_done, int max_it) {
   g_es_trips = 0;
   if (g_es_scheme == 1) return eigensolver_descent_ext(Dp, v);
   const es_data D = *Dp;
@@ -347,7 +354,7 @@ static int eigensolver_cayley(const es_data *Dp, double v[3]) {
   double f = es_value_grad(&D, v, g);
   int it = 0;
   g_es_trips = 1;
-  for (; it < ES_MAX_ITERATIONS; ++it) {
+  for (; it < max_it; ++it) {
     const double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
     if (gmax <= 1e-14 * (1.0 + fabs(f)) * (double)(n > 0 ? n : 1)) break;
     double H[9];
@@ -390,10 +397,11 @@ static int eigensolver_cayley(const es_data *Dp, double v[3]) {
     if (smax < 1e-12) { ++it; break; }
     /* a full undamped Newton step this short: quadratic convergence has put the new point within ~1e-12 of the minimiser
      * (the device stops here without the confirming evaluation; kNewtonStepDone) */
-    if (mu == 0.0 && alpha == 1.0 && smax < 1e-6) { ++it; break; }
+    if (mu == 0.0 && alpha == 1.0 && smax < step_done) { ++it; break; }
   }
   return it;
 }
+static int eigensolver_cayley(const es_data *Dp, double v[3]) { return eigensolver_cayley_tol(Dp, v, ES_STEP_DONE, ES_MAX_ITERATIONS); }
 
 int pnec_oracle_eigensolver(int64_t n, const double *bvs1, const double *bvs2, const double R0[9],
                             double R_out[9], int32_t *iterations) {
@@ -534,7 +542,7 @@ void pnec_oracle_weighted_eigensolver_ex(int64_t n, const double *bvs1, const do
       es_data D = {n, bvs1, w2};
       if (device_early_exits) {
         /* the Cayley vector is carried between rounds, early exit (1) */
-        if (!rotation_final) rotation_final = eigensolver_cayley(&D, v) < 50;
+        if (!rotation_final) rotation_final = eigensolver_cayley(&D, v) < ES_MAX_ITERATIONS;
       } else {
         /* pnec.cc:310-315: a new adapter holding rel_pose's rotation MATRIX, a new eigensolver call */
         pnec_oracle_rot_to_cayley(R, v);
@@ -674,7 +682,7 @@ int pnec_oracle_ransac_eigensolver(int64_t n, const double *bvs1, const double *
     for (int c = 0; c < 3; ++c)
       v[c] = v0[c] + (pnec_oracle_rng_uniform(seed, pair_id, (uint64_t)it, 1000 + c) - 0.5) * 2.0 * 0.01;
     es_data D = {sample_size, s1, s2};
-    eigensolver_cayley(&D, v);
+    eigensolver_cayley_tol(&D, v, ES_HYPOTHESIS_STEP_DONE, ES_HYPOTHESIS_MAX_ITERATIONS);
     pnec_oracle_cayley_to_rot(v, R);
     es_model_translation(sample_size, s1, s2, R, t);
     int count = 0;

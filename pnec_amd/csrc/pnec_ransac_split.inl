@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void es_queue_ke
 #pragma unroll
           for (int c = 0; c < 3; ++c) v[c] = v[c] + alpha * d[c];
           ++it;
-          last_eval = smax < 1e-12 || it >= kNewtonMaxIterations;
+          last_eval = smax < 1e-12 || it >= kHypothesisMaxIterations;
           state = kReeval;  // the eigenvector AT the new point is wanted: one more evaluation even at the end
         } else {
           alpha *= 0.0625;
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void es_queue_ke
 #pragma unroll
             for (int c = 0; c < 3; ++c) v[c] = v[c] + d[c];
             ++it;
-            if (smax < (damped ? 1e-12 : kNewtonStepDone) || it >= kNewtonMaxIterations) state = kDone;
+            if (smax < (damped ? 1e-12 : kHypothesisStepDone) || it >= kHypothesisMaxIterations) state = kDone;
           } else {
             state = kShort;
             alpha = 0.5;

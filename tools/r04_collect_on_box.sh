@@ -1,0 +1,5 @@
+set -x
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+PNEC_HIP_LIB=pnec_amd/csrc/build/var_count/libpnec_hip.so python tools/count_chain_work.py > gpurun_out/chain_work_new.json 2> gpurun_out/chain_work_new.err
+bash tools/r04_profiles.sh > gpurun_out/r04_run.log 2>&1
+tail -5 gpurun_out/r04_run.log
