@@ -47,3 +47,16 @@ res = {"pairs": B, "its_hist": np.bincount(np.minimum(its, 100)).tolist(),
        "trips_per_round_hist": None}
 print(json.dumps(res))
 json.dump(res, open(out, "w"), indent=1)
+
+# ---- the launch's timeline (10 ns ticks -> us): when the last wavefront starts, when the launch has done 50 / 90 / 99 / 100 %
+t0 = w[:, 6].min()
+st_, en_ = (w[:, 6] - t0) * 0.01, (w[:, 11] - t0) * 0.01
+tl = {"launch_us": float(en_.max()), "last_start_us": float(st_.max()), "done_50_90_99_us": [float(np.percentile(en_, q)) for q in (50, 90, 99)],
+      "wavefront_time_over_2048_slots_us": float(dur.sum() / 2048.0), "slots_busy_on_average": float(dur.sum() / en_.max()),
+      "wavefronts_ending_in_the_last_10pct_of_the_launch": int((en_ > 0.9 * en_.max()).sum())}
+late = en_ > 0.9 * en_.max()
+tl["those_wavefronts"] = {"dur_us": float(dur[late].mean()), "rounds": float(w[late, 10].mean()), "trips": float(w[late, 9].mean()),
+                          "start_us": float(st_[late].mean())}
+print(json.dumps(tl))
+res["timeline"] = tl
+json.dump(res, open(out, "w"), indent=1)
