@@ -311,9 +311,8 @@ static int eigensolver_descent_ext(const es_data *D, double v[3]) {
 #define ES_LEVENBERG_GROWTH 10.0
 /* Most Newton iterations of one minimisation: 50, and 25 for the minimisation of a RANSAC hypothesis (the device's
  * kNewtonMaxIterations / kHypothesisMaxIterations).  The hypotheses that get that far are contaminated samples crawling
- * along the flank of a saddle or running off to the minimum at infinity of the Cayley chart; they never yield a round's
- * best model (masks, inlier and hypothesis counts over 1 500 pairs of the benchmark's data are the same with 25 as with
- * 50), but on the device one of them sets the length of its round. */
+ * along the flank of a saddle or running off to the minimum at infinity of the Cayley chart; on the device one of them sets
+ * the length of its round.  A hypothesis cut off there yields no model (pnec_oracle_ransac_eigensolver). */
 #define ES_MAX_ITERATIONS 50
 #define ES_HYPOTHESIS_MAX_ITERATIONS 25
 /* A full undamped Newton step shorter than this ends a minimisation (quadratic convergence: the point it leads to is within
@@ -682,11 +681,14 @@ int pnec_oracle_ransac_eigensolver(int64_t n, const double *bvs1, const double *
     for (int c = 0; c < 3; ++c)
       v[c] = v0[c] + (pnec_oracle_rng_uniform(seed, pair_id, (uint64_t)it, 1000 + c) - 0.5) * 2.0 * 0.01;
     es_data D = {sample_size, s1, s2};
-    eigensolver_cayley_tol(&D, v, ES_HYPOTHESIS_STEP_DONE, ES_HYPOTHESIS_MAX_ITERATIONS);
+    const int newton_its = eigensolver_cayley_tol(&D, v, ES_HYPOTHESIS_STEP_DONE, ES_HYPOTHESIS_MAX_ITERATIONS);
     pnec_oracle_cayley_to_rot(v, R);
     es_model_translation(sample_size, s1, s2, R, t);
+    /* a minimisation that was cut off yields no model: the rule consumes the hypothesis with a count of zero (why: the
+     * device's kHypothesisMaxIterations -- cut off, two floating-point realisations of the iteration stand at different
+     * points of a walk that did not converge, and would score differently) */
     int count = 0;
-    for (int64_t i = 0; i < n; ++i)
+    for (int64_t i = 0; i < n && newton_its < ES_HYPOTHESIS_MAX_ITERATIONS; ++i)
       count += pnec_oracle_reprojection_score(bvs1 + 3 * i, bvs2 + 3 * i, R, t) < threshold;
     if (count > best_count) {
       best_count = count;

@@ -611,14 +611,19 @@ constexpr double kHypothesisStepDone = 1e-6;
 // hypotheses that reach twenty and more are contaminated samples whose iterates crawl along the flank of a saddle
 // (strongly negative curvature, a gradient with next to no component along it: steps of g / |lambda|, 1e-4 per iteration,
 // for as long as they are allowed) or run off to the minimum at infinity of the Cayley chart (a rotation by 180 degrees).
-// Neither ever yields a round's best model -- on 1 500 pairs of the benchmark's data the checker's masks, inlier counts
-// and hypothesis counts are the same with 25 as with 50 (with 20, one pair differs) -- but one such minimisation sets the
+// Next to never does one yield a round's best model, but one such minimisation sets the
 // length of its round (53 trips where the round's others take ~27) and the 1 % of wavefronts that hold one are what a
 // launch ends with.  (Until round 4: 50 everywhere.  The minimisations over a whole pair -- the eigensolver on the
 // inliers, the weighted stage's -- keep 50: there the cap is met by ill-conditioned pairs bouncing at their noise floor,
 // and where it cuts decides how far checker and device end apart.)
 constexpr int kNewtonMaxIterations = 50;
 constexpr int kHypothesisMaxIterations = 25;
+// A hypothesis whose minimisation was cut off there YIELDS NO MODEL: it is consumed by the sequential rule with a count of
+// zero, unscored (kModelCapped below; the checker: the same).  Cut off, checker and device stand at two different points
+// of a long walk -- two floating-point realisations of the iteration drift apart over 25 steps that do not converge --
+// and a model from either would be scored differently by the two; it happened to decide one pair in 20 000.  A count of
+// zero is what such a model is worth (it never was a round's best on the checker), and it is the same on both sides.
+constexpr int kModelCapped = 12;  // models[j][kModelCapped] != 0: hypothesis j's minimisation was cut off
 __device__ __forceinline__ double hessian_floor(const double (&H)[9]) {
   const double m00 = H[0], m01 = H[1], m02 = H[2], m11 = H[4], m12 = H[5], m22 = H[8];
   const double trh = m00 + m11 + m22;
@@ -1775,12 +1780,13 @@ __device__ __forceinline__ double reprojection_score(const double (&f1)[3], cons
     p[k] = 0.5 * (l0 * f1[k] + t[k] + l1 * u[k]);
     d[k] = p[k] - t[k];
   }
-  const double p2[3] = {R[0] * d[0] + R[3] * d[1] + R[6] * d[2], R[1] * d[0] + R[4] * d[1] + R[7] * d[2],
-                        R[2] * d[0] + R[5] * d[1] + R[8] * d[2]};
+  // the point in frame 2 is p2 = R'(p - t) = R'd; the score needs |p2| and f2 . p2 only, and a rotation keeps both:
+  // |R'd| = |d|, f2 . R'd = (R f2) . d = u . d -- nine products less per correspondence and model (the checker forms p2;
+  // the two differ in the last bits of a score that is compared with a threshold ten orders of magnitude above them)
   const double in1 = fast_rsqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
-  const double in2 = fast_rsqrt(p2[0] * p2[0] + p2[1] * p2[1] + p2[2] * p2[2]);
+  const double in2 = fast_rsqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
   return (1.0 - (f1[0] * p[0] + f1[1] * p[1] + f1[2] * p[2]) * in1) +
-         (1.0 - (f2[0] * p2[0] + f2[1] * p2[1] + f2[2] * p2[2]) * in2);
+         (1.0 - (u[0] * d[0] + u[1] * d[1] + u[2] * d[2]) * in2);
 }
 
 // ---- RANSAC scoring: the pair's bearings in registers, one model after the other -------------------------------------
@@ -2036,7 +2042,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
   __shared__ double Gh[kHypPerRound][36];  // the 36 sums of each hypothesis' sample
   __shared__ double G[36];                 // ... of the inliers of the best model
   __shared__ double best_model[12];        // R (9) + t (3)
-  __shared__ double models[kHypPerRound][12];  // R (9) + t (3) of the round's hypotheses (scored one after the other)
+  __shared__ double models[kHypPerRound][13];  // R (9) + t (3) of the round's hypotheses (scored one after the other) + kModelCapped
   __shared__ int sel_lds[PNEC_HIP_MAX_RANSAC_SAMPLE][kWave];  // each lane's sample (indexed dynamically: not registers)
   double q0[4] = {a.init_q[4 * pair], a.init_q[4 * pair + 1], a.init_q[4 * pair + 2], a.init_q[4 * pair + 3]};
   {
@@ -2160,6 +2166,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
 #pragma unroll
         for (int i = 0; i < 9; ++i) models[hyp][i] = R[i];
         models[hyp][9] = t[0]; models[hyp][10] = t[1]; models[hyp][11] = t[2];
+        models[hyp][kModelCapped] = newton_its >= kHypothesisMaxIterations ? 1.0 : 0.0;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -2175,7 +2182,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
 #pragma unroll
         for (int i = 0; i < 9; ++i) Rj[i] = models[j][i];
         tj[0] = models[j][9]; tj[1] = models[j][10]; tj[2] = models[j][11];
-        const int cj = model_inliers_until_beaten(tiles, base, stride, n, Rj, tj, a.threshold, lane, best_count);
+        const int cj = models[j][kModelCapped] != 0.0 ? 0 : model_inliers_until_beaten(tiles, base, stride, n, Rj, tj, a.threshold, lane, best_count);
         if (cj > best_count) {
           best_count = cj;
           winner = j;
@@ -2236,7 +2243,7 @@ struct Ransac2Lds {
   int tits[2 * kHypPerRound];
   int tlist[2 * kHypPerRound];       // the round's queue: slots of the active hypotheses
   double tkey[2 * kHypPerRound];     // ... and the keys it is ordered by (es_queue_order)
-  double models[kHypPerRound][12];   // R (9) + t (3) of the hypotheses of the pair being scored
+  double models[kHypPerRound][13];   // R (9) + t (3) of the hypotheses of the pair being scored + kModelCapped
   double best_model[2][12];          // R (9) + t (3) per pair
   double G[2][36];                   // sums of the inliers of the best model
   double parked[32];                 // a finished pair waiting for the kernel's end while its slot is lent (see below)
@@ -2662,6 +2669,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
 #pragma unroll
         for (int i = 0; i < 9; ++i) lds.models[hyp][i] = R[i];
         lds.models[hyp][9] = t[0]; lds.models[hyp][10] = t[1]; lds.models[hyp][11] = t[2];
+        lds.models[hyp][kModelCapped] = lds.tits[slot] >= kHypothesisMaxIterations ? 1.0 : 0.0;
       }
       lds_sync();
       ScoreTiles tiles;  // the pair's bearings for the scoring (issue and wait back to back, see the one-pair kernel)
@@ -2673,7 +2681,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
 #pragma unroll
         for (int i = 0; i < 9; ++i) Rj[i] = lds.models[j][i];
         tj[0] = lds.models[j][9]; tj[1] = lds.models[j][10]; tj[2] = lds.models[j][11];
-        const int cj = model_inliers_until_beaten(tiles, bs, st, nn, Rj, tj, a.threshold, lane, best_count[pp]);
+        const int cj = lds.models[j][kModelCapped] != 0.0 ? 0 : model_inliers_until_beaten(tiles, bs, st, nn, Rj, tj, a.threshold, lane, best_count[pp]);
         if (cj > best_count[pp]) {
           best_count[pp] = cj;
           winner = j;

@@ -49,7 +49,7 @@ struct RansacSplitArgs {
 
 struct RoundLds {
   int tsel[kHypPerRound][PNEC_HIP_MAX_RANSAC_SAMPLE];
-  double models[kHypPerRound][12];
+  double models[kHypPerRound][13];   // R, t, kModelCapped
   double best_model[12];
   double G[36];
 };
@@ -256,6 +256,7 @@ __global__ __launch_bounds__(kWave, PNEC_ROUND_WAVES_PER_SIMD) void ransac_round
 #pragma unroll
           for (int i = 0; i < 9; ++i) lds.models[hyp][i] = R[i];
           lds.models[hyp][9] = t[0]; lds.models[hyp][10] = t[1]; lds.models[hyp][11] = t[2];
+          lds.models[hyp][kModelCapped] = rec[kTkIts] >= (double)kHypothesisMaxIterations ? 1.0 : 0.0;
         }
         wave_lds_sync();
         int winner = -1;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(kWave, PNEC_ROUND_WAVES_PER_SIMD) void ransac_round
 #pragma unroll
           for (int i = 0; i < 9; ++i) Rj[i] = lds.models[j][i];
           tj[0] = lds.models[j][9]; tj[1] = lds.models[j][10]; tj[2] = lds.models[j][11];
-          const int cj = model_inliers_until_beaten(tiles, base, stride, n, Rj, tj, a.r.threshold, lane, best_count);
+          const int cj = lds.models[j][kModelCapped] != 0.0 ? 0 : model_inliers_until_beaten(tiles, base, stride, n, Rj, tj, a.r.threshold, lane, best_count);
           if (cj > best_count) {
             best_count = cj;
             winner = j;
