@@ -113,8 +113,9 @@ def test_one_call_chain_matches_the_oracle_chain_over_20000_pairs(oracle):
 def test_two_pairs_per_wavefront_ransac_is_bitwise_the_one_pair_form():
     """From 4 096 pairs up the RANSAC stage runs two pairs per wavefront with the hypotheses of both in one queue
     (ransac2_eigensolver_kernel: a quad that has finished a minimisation takes the next hypothesis, whichever pair it
-    belongs to); smaller batches keep one wavefront per pair.  A hypothesis' arithmetic does not depend on which quad
-    minimises it or when, so the whole chain over 6 001 ragged pairs (odd: the last wavefront holds one pair; sizes
+    belongs to; the queue ordered by a key of the minimisations' starts, likely-long ones first; both slots' samples drawn
+    in one pass; the launch's last pairs on wavefronts of their own); smaller batches keep one wavefront per pair.  A
+    hypothesis' arithmetic does not depend on which quad minimises it or when, so the whole chain over 6 001 ragged pairs (odd: the last wavefront holds one pair; sizes
     from below the sample size to beyond one wavefront's 512; gross mismatches) in ONE call must equal, bit for bit,
     the same pairs solved as three batches of <= 2 048 (one-pair form) whose RANSAC draws are offset to the pairs'
     global indices (`first_pair_id`)."""
