@@ -195,3 +195,37 @@ def test_oracle_eigensolver_scheme_switch_opengv_style_descent(oracle):
     R2 = oracle.eigensolver(g.bvs1[0].numpy(), g.bvs2[0].numpy(), g.init_R[0].numpy())
     R2 = R2[0] if isinstance(R2, tuple) else R2
     np.testing.assert_array_equal(R, R2)
+
+
+def test_minimiser_trip_counter_and_the_hypothesis_cap(oracle):
+    """The checker counts a minimisation's evaluations the way the device's quad spends them (one trip = a point with its
+    three Hessian probes, or four step lengths; tools/sim_ransac_queue.py replays the device's queue from these): a clean
+    sample takes a handful, and no RANSAC hypothesis runs past the cap of 25 Newton iterations -- one that reaches it
+    yields no model (pnec_oracle_ransac_eigensolver), which is what keeps checker and device on the same masks."""
+    import ctypes as C
+    L = oracle.lib()
+    L.pnec_oracle_es_last_trips.restype = C.c_int
+    g = sim.generate(1, 200, seed=11)
+    f1, f2, R0 = g.bvs1[0].numpy(), g.bvs2[0].numpy(), g.init_R[0].numpy()
+    R, it = oracle.eigensolver(f1[:10], f2[:10], R0)            # ten clean correspondences: quadratic convergence
+    trips = L.pnec_oracle_es_last_trips()
+    assert 1 <= it <= 12 and it + 1 <= trips <= it + 1 + 3 * it  # a trip for the start, one per full step, <= 3 more per cut-back one
+    # contaminated samples: some minimisations are long; with the whole-pair cap (50) they may run past 25 ...
+    rng = np.random.default_rng(5)
+    longest = 0
+    for _ in range(400):
+        idx = rng.choice(200, 10, replace=False)
+        b2 = f2[idx].copy()
+        bad = rng.random(10) < 0.4
+        junk = rng.normal(size=(10, 3))
+        b2[bad] = (junk / np.linalg.norm(junk, axis=1, keepdims=True))[bad]
+        longest = max(longest, oracle.eigensolver(f1[idx], b2, R0)[1])
+    assert 25 < longest <= 50
+    # ... and RANSAC over a contaminated pair ends with the inliers it should (a cut-off hypothesis counts zero)
+    b2 = f2.copy()
+    bad = rng.random(200) < 0.3
+    junk = rng.normal(size=(200, 3))
+    b2[bad] = (junk / np.linalg.norm(junk, axis=1, keepdims=True))[bad]
+    Rr, tr, mask, its = oracle.ransac_eigensolver(f1, b2, R0, seed=3, pair_id=0)
+    assert mask.sum() >= 0.9 * (~bad).sum() and (mask & bad).sum() <= 0.05 * bad.sum()
+    assert oracle.rotational_difference_deg(Rr, g.R_gt[0].numpy()) < 0.5
