@@ -1,3 +1,4 @@
+# Runs ON THE GPU BOX: rocprofv3 kernel trace of the per-frame PNEC::Solve demo (host_demo solve_latency); prints the last two frames' kernels (start us, duration us, name).
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/s2/frame
