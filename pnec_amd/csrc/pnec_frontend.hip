@@ -1925,6 +1925,19 @@ __device__ __forceinline__ int model_inliers_until_beaten(const ScoreTiles &P, c
 }
 
 constexpr int kHypPerRound = 16;  // hypotheses evaluated per round = quads per wavefront
+// w^s for the rule's bound k = log(1 - 0.99) / log(1 - w^s), s = the sample size (an integer <= 16): by squaring.  (The
+// library's pow() is a double-double logarithm and exponential -- ~250 instructions per new best model -- and the compiler
+// kept its polynomial's coefficients in vector registers outside the rounds' loop, spilled them, and reloaded them one
+// dependent round trip to scratch at a time inside the scoring loop: sixteen of them per call.  The result differs from
+// pow()'s in the last bit at most; k is compared with integers it is never that close to.)
+__device__ __forceinline__ double pow_sample(double w, int s) {
+  double r = 1.0, b = w;
+  for (int e = s; e > 0; e >>= 1) {
+    if (e & 1) r *= b;
+    b *= b;
+  }
+  return r;
+}
 enum : int { kRpSample = 0, kRpNewton, kRpModel, kRpScore, kRpConsume, kRpInliers, kRpFinal, kRpTotal };
 
 // sum over the four lanes of a quad, every lane ends with it (two DPP butterflies; the same bits in all four)
@@ -2187,7 +2200,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
           best_count = cj;
           winner = j;
           const double w = (double)cj / (double)n;
-          double p_no = 1.0 - pow(w, (double)ss);
+          double p_no = 1.0 - pow_sample(w, ss);
           p_no = fmax(2.220446049250313e-16, p_no);
           p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
           k = log(1.0 - 0.99) / log(p_no);
@@ -2686,7 +2699,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
           best_count[pp] = cj;
           winner = j;
           const double w = (double)cj / (double)nn;
-          double p_no = 1.0 - pow(w, (double)ss);
+          double p_no = 1.0 - pow_sample(w, ss);
           p_no = fmax(2.220446049250313e-16, p_no);
           p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
           k[pp] = log(1.0 - 0.99) / log(p_no);

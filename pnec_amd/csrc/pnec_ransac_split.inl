@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kWave, PNEC_ROUND_WAVES_PER_SIMD) void ransac_round
             best_count = cj;
             winner = j;
             const double wr = (double)cj / (double)n;
-            double p_no = 1.0 - pow(wr, (double)ss);
+            double p_no = 1.0 - pow_sample(wr, ss);
             p_no = fmax(2.220446049250313e-16, p_no);
             p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
             k = log(1.0 - 0.99) / log(p_no);
