@@ -1348,11 +1348,18 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
 #pragma unroll
       for (int k = 1; k < KR; ++k) planes_after(pe[k]);
       if (threadIdx.x == 0) PNEC_WORK_ADD(kWkWesTableCorr, n);
+      // the rotation as SCALARS here (it is one per pair; every product below takes one entry of it): this is where the
+      // kernel has the fewest registers -- 96 payload values in flight, the tables forming -- and as eighteen vector
+      // registers the rotation was spilled and reloaded from scratch for each of the eight correspondences (32 reloads
+      // per build, each waited for)
+      double Rs[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rs[i] = to_sgpr(R[i]);
 #pragma unroll
       for (int k = 0; k < KR; ++k) {
         const int idx = (WPP > 1 ? wave * KR * kWave : 0) + lane + kWave * k;
         const bool in = idx < n;
-        corr_nb_of(pe[k], R, a.reg, rn[k], rB[k]);
+        corr_nb_of(pe[k], Rs, a.reg, rn[k], rB[k]);
         if (!in) {  // padding: contributes exactly 0 to every sum (n = 0, B = I)
           rn[k][0] = rn[k][1] = rn[k][2] = 0.0;
           rB[k][0] = rB[k][3] = rB[k][5] = 1.0;
