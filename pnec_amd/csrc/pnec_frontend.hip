@@ -1519,13 +1519,19 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
             // (the single-precision copies of the tables are made here, two correspondences at a time, and die here:
             // kept resident they cost the common path 72 registers it does not have)
             v2f acc4[4] = {{0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}, {0.0f, 0.0f}};
+            // (an opaque zero added before the conversions: they do not depend on the direction, so the compiler moved
+            // all 72 of them out of this loop AND out of the rounds' loop, i.e. in front of this rare branch, into the
+            // path of every pair -- 36 packed values converted and spilled to scratch per pair, for a loop that 1-2 %
+            // of the pairs enter)
+            double zero_here = 0.0;
+            asm volatile("" : "+v"(zero_here));
 #pragma unroll
             for (int j = 0; j < KR / 2; ++j) {
               v2f fn[3], fB[6];
 #pragma unroll
-              for (int cc = 0; cc < 3; ++cc) fn[cc] = v2f{(float)rn[2 * j][cc], (float)rn[2 * j + 1][cc]};
+              for (int cc = 0; cc < 3; ++cc) fn[cc] = v2f{(float)(rn[2 * j][cc] + zero_here), (float)(rn[2 * j + 1][cc] + zero_here)};
 #pragma unroll
-              for (int cc = 0; cc < 6; ++cc) fB[cc] = v2f{(float)rB[2 * j][cc], (float)rB[2 * j + 1][cc]};
+              for (int cc = 0; cc < 6; ++cc) fB[cc] = v2f{(float)(rB[2 * j][cc] + zero_here), (float)(rB[2 * j + 1][cc] + zero_here)};
 #pragma unroll
               for (int jd = 0; jd < 4; ++jd) {
                 const float *fc = c_fib32 + kFibStride * (c + jd);
