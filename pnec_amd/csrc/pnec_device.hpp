@@ -85,6 +85,39 @@ __device__ __forceinline__ void sincos_bounded(double x, double &s, double &c) {
   c = ((q + 1) & 2) ? -b : b;
 }
 
+// The same with every constant pinned to the spot where it is used (a scalar register pair through an empty volatile asm
+// statement: two s_mov per constant and call).  Left to itself the compiler materialises the thirteen coefficients ONCE,
+// in vector registers outside the solve's loop, and in the geometries whose loop has no register to spare -- the tail form
+// (12, 1, 3), the multi-wavefront ones -- it spills them to scratch and reloads them in every call of the LM step: twenty
+// memory round trips on its latency chain (ISA marks, round 4).
+__device__ __forceinline__ double pinned_const(double c) {
+  asm volatile("" : "+s"(c));
+  return c;
+}
+__device__ __forceinline__ void sincos_bounded_pinned(double x, double &s, double &c) {
+  const double k = __builtin_rint(x * pinned_const(0.63661977236758134308));  // 2/pi
+  double r = __builtin_fma(-k, pinned_const(1.57079632679489655800e+00), x);
+  r = __builtin_fma(-k, pinned_const(6.12323399573676603587e-17), r);
+  const double z = r * r;
+  double ps = __builtin_fma(z, pinned_const(1.58969099521155010221e-10), pinned_const(-2.50507602534068634195e-08));
+  ps = __builtin_fma(z, ps, pinned_const(2.75573137070700676789e-06));
+  ps = __builtin_fma(z, ps, pinned_const(-1.98412698298579493134e-04));
+  ps = __builtin_fma(z, ps, pinned_const(8.33333333332248946124e-03));
+  ps = __builtin_fma(z, ps, pinned_const(-1.66666666666666324348e-01));
+  const double sr = __builtin_fma(r * z, ps, r);
+  double pc = __builtin_fma(z, pinned_const(-1.13596475577881948265e-11), pinned_const(2.08757232129817482790e-09));
+  pc = __builtin_fma(z, pc, pinned_const(-2.75573143513906633035e-07));
+  pc = __builtin_fma(z, pc, pinned_const(2.48015872894767294178e-05));
+  pc = __builtin_fma(z, pc, pinned_const(-1.38888888888741095749e-03));
+  pc = __builtin_fma(z, pc, pinned_const(4.16666666666666019037e-02));
+  const double cr = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+  const int q = (int)k & 3;
+  const double a = (q & 1) ? cr : sr;
+  const double b = (q & 1) ? sr : cr;
+  s = (q & 2) ? -a : a;
+  c = ((q + 1) & 2) ? -b : b;
+}
+
 // atan / atan2 / acos for the start angles of a solve (AnglesFromVec, once per solve in one lane):
 // the classic argument reduction at 7/16, 11/16, 19/16, 39/16 with an 11-term odd polynomial
 // (<= 1 ulp of libm, self-tested on the device) -- ~60 instructions instead of the generic libm

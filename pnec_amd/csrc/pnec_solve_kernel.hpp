@@ -657,7 +657,7 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
       const int role = (int)(threadIdx.x & 3);
       const double angle = role == 0 ? nd : (role == 1 ? thc : phc);
       double sa, ca;
-      sincos_bounded(angle, sa, ca);
+      sincos_bounded_pinned(angle, sa, ca);
       const double sn = quad_broadcast<0>(sa), aw = quad_broadcast<0>(ca);
       const double st = quad_broadcast<1>(sa), ct = quad_broadcast<1>(ca);
       const double sp = quad_broadcast<2>(sa), cp = quad_broadcast<2>(ca);
