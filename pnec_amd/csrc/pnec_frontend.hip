@@ -3049,7 +3049,7 @@ hipError_t launch_ransac_order(const int32_t *iterations, int64_t n_pairs, int32
 }
 
 // Two-pair form: how many pairs at the END of the launch order get a wavefront of their own.  A launch ends with the
-// wavefronts that started last; two-pair wavefronts run ~300 us, one-pair ones ~190, and while the launch drains the
+// wavefronts that started last; two-pair wavefronts run ~250 us, one-pair ones about two thirds of that, and while the launch drains the
 // slots the shorter ones leave are idle anyway (their worse packing -- 16 minimisations on 16 quads -- costs nothing
 // there).  PNEC_RANSAC_TAIL_SINGLES overrides (A/B runs; 0 = every wavefront takes two pairs).  Scheduling only: a
 // pair's arithmetic does not depend on the wavefront it shares.
