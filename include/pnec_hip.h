@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define PNEC_HIP_ABI_VERSION 4
+#define PNEC_HIP_ABI_VERSION 5
 #define PNEC_HIP_MAX_RANSAC_SAMPLE 16 /* largest Options::ransac_sample_size_ the RANSAC kernel is built for */
 
 typedef enum pnec_hip_status {
@@ -104,6 +104,24 @@ typedef struct pnec_hip_options {
 } pnec_hip_options;
 
 typedef struct pnec_hip_problem pnec_hip_problem; /* opaque: a batch of pairs resident in HBM */
+
+/* Which iteration stands in for opengv::relative_pose::eigensolver's eigenvalue minimisation -- called at
+ * src/rel_pose_estimation/pnec.cc:274 (plain), :239-258 (RANSAC hypotheses + optimizeModelCoefficients) and :315 (the
+ * weighted stage's rounds).  opengv is NOT in the reference tree: all three are restatements, the last two from memory
+ * of its source (oracle/pnec_oracle_opengv.c says what is remembered and how surely; INTEGRATION.md 6 which to pick).
+ *   NEWTON  damped Newton on lambda_min(M(R(v))) to ~1e-12 rad (rounds 1-4's only form; the fastest).
+ *   DESCENT [EXT] normalised steepest descent, step 0.01 doubled up to 0.08 in the first iteration, halved while the
+ *           value does not improve, stop at step < 1e-5 or 50 iterations: ends ~1e-5 rad short of the minimiser.
+ *   LM      [EXT] Eigen/MINPACK Levenberg-Marquardt (ftol 5e-5, xtol 10 eps, maxfev 100) on the gradient of lambda_min
+ *           of M composed with opengv's REDUCED Cayley rotation (no 1 / (1 + |v|^2)), forward-difference Jacobian: the
+ *           root of that gradient -- 1e-9 (KITTI-like motion) .. 1e-5 rad (|v| ~ 0.3) from NEWTON's minimiser.
+ * Under DESCENT and LM every RANSAC hypothesis is scored (no iteration cap that voids a model), and the weighted
+ * stage runs the eigensolver in every round under DESCENT (each call moves the rotation a little further). */
+typedef enum pnec_hip_eigensolver_scheme {
+  PNEC_HIP_ES_NEWTON = 0,
+  PNEC_HIP_ES_DESCENT = 1,
+  PNEC_HIP_ES_LM = 2
+} pnec_hip_eigensolver_scheme;
 
 int pnec_hip_abi_version(void);
 const char *pnec_hip_last_error(void);
@@ -165,6 +183,11 @@ int64_t pnec_hip_problem_payload_bytes(const pnec_hip_problem *p);
 int pnec_hip_problem_offsets(const pnec_hip_problem *p, int64_t *out);
 int pnec_hip_problem_mode(const pnec_hip_problem *p);
 int pnec_hip_problem_device(const pnec_hip_problem *p);
+/* The scheme the STAGE calls on this batch use (pnec_hip_nec_eigensolver, pnec_hip_ransac_eigensolver,
+ * pnec_hip_weighted_eigensolver; default NEWTON).  pnec_hip_solve_pipeline takes its own from the options.  Under
+ * DESCENT / LM weighted_iterations is limited to 16. */
+int pnec_hip_problem_set_eigensolver_scheme(pnec_hip_problem *p, int32_t scheme);
+int pnec_hip_problem_eigensolver_scheme(const pnec_hip_problem *p);
 
 /* Run InitValues + Optimize + Result for every solve of the batch, entirely on the device.
  *   init_q  [n_pairs,4] xyzw     starting orientation per pair (used as given)
@@ -258,6 +281,9 @@ typedef struct pnec_hip_pipeline_options {
   uint64_t ransac_seed;          /* 1     counter-based draws (see pnec_hip_ransac_eigensolver) */
   pnec_hip_options solver;       /* the refinement's ceres::Solver::Options; PNEC::CeresSolver and
                                     NECCeresSolver default-construct theirs (pnec.cc:355,399) */
+  int32_t eigensolver_scheme;    /* 0     pnec_hip_eigensolver_scheme: which iteration every eigenvalue minimisation of
+                                          the chain runs (ABI 5) */
+  int32_t reserved;              /* 0 */
 } pnec_hip_pipeline_options;
 void pnec_hip_default_pipeline_options(pnec_hip_pipeline_options *opt);
 

@@ -167,11 +167,28 @@ double pnec_oracle_weight(const double f1[3], const double f2[3], const double t
                           const double *cov, double reg, int host_frame);
 void pnec_oracle_cayley_to_rot(const double v[3], double R[9]);
 void pnec_oracle_rot_to_cayley(const double R[9], double v[3]);
-/* Which iteration the eigenvalue minimisations run: 0 (default) damped Newton to ~1e-12 rad -- what the device runs;
- * 1 [EXT, from memory, unverified] opengv's own normalised steepest descent with an adaptive step, which stops ~1e-5 rad
- * short (pnec_oracle_frontend.c).  A process-wide switch for test tooling; set it before, not during, a batch call. */
+/* Which iteration the eigenvalue minimisations run: 0 (default) damped Newton to ~1e-12 rad -- the device's default;
+ * 1, 2 [EXT, from memory, unpinned]: the two recollections of opengv's own iteration (pnec_oracle_opengv.c: 1 = normalised
+ * steepest descent with an adaptive step, stops ~1e-5 rad short; 2 = Eigen's Levenberg-Marquardt on the gradient of
+ * lambda_min composed with the reduced Cayley rotation).  A process-wide switch for test tooling; set it before, not
+ * during, a batch call. */
 void pnec_oracle_set_eigensolver_scheme(int scheme);
 int pnec_oracle_get_eigensolver_scheme(void);
+/* scheme 2: Eigen's LevenbergMarquardtSpace::Status / nfev of the calling thread's last minimisation */
+int pnec_oracle_es_last_info(void);
+int pnec_oracle_es_last_nfev(void);
+/* pnec_oracle_opengv.c: the 36 sums (opengv's xxF..zxF), lambda_min of M(v) composed from them (reduced != 0: with
+ * math::cayley2rot_reduced) with its gradient / eigenvector / second eigenvalue (each optional), and the two minimisers
+ * on the sums (v in/out; return = iterations) */
+void pnec_oracle_sums36(int64_t n, const double *b1, const double *b2, double G[36]);
+double pnec_oracle_es_value_grad_sums(const double G[36], const double v[3], int reduced, double *g, double *e_out,
+                                      double *ev2);
+int pnec_oracle_es_descent(const double G[36], double v[3], int *trips);
+int pnec_oracle_es_lm(const double G[36], double v[3], int *nfev, int *info);
+/* scheme 1 only, OFF by default: ge_main2's disturbed-restart loop around the descent (pnec_oracle_opengv.c: why off) */
+void pnec_oracle_set_eigensolver_restart(int on);
+int pnec_oracle_get_eigensolver_restart(void);
+int pnec_oracle_es_descent_restarts(const double G[36], double v[3], uint64_t seed, uint64_t stream, int *trials);
 /* opengv::relative_pose::eigensolver restated (Kneip-Lynen eigenvalue minimisation); R row-major */
 int pnec_oracle_eigensolver(int64_t n, const double *bvs1, const double *bvs2, const double R0[9],
                             double R_out[9], int32_t *iterations);

@@ -58,7 +58,7 @@ def build(force: bool = False) -> str:
     """Compile oracle/libpnec_oracle.so with the committed Makefile."""
     if force or not os.path.exists(_LIB_PATH) or (
         os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f))
-                                          for f in ("pnec_oracle.c", "pnec_oracle_frontend.c", "pnec_oracle.h"))
+                                          for f in ("pnec_oracle.c", "pnec_oracle_frontend.c", "pnec_oracle_opengv.c", "pnec_oracle.h"))
     ):
         subprocess.run(["make", "-C", _HERE, "-B", "libpnec_oracle.so"], check=True,
                        stdout=subprocess.DEVNULL)
@@ -244,13 +244,65 @@ def rot_to_cayley(R):
 
 
 def set_eigensolver_scheme(scheme: int) -> None:
-    """0 (default): the damped Newton iteration the device runs; 1: [EXT, from memory, unverified] opengv's own
-    normalised steepest descent with an adaptive step, which stops ~1e-5 rad short of the minimiser
-    (pnec_oracle_frontend.c).  Process-wide; affects every eigenvalue minimisation of the oracle's front stages."""
+    """0 (default): the damped Newton iteration the device runs by default; 1, 2: [EXT, from memory, unpinned] the two
+    recollections of opengv's own iteration (pnec_oracle_opengv.c) -- 1 the normalised steepest descent with an adaptive
+    step, which stops ~1e-5 rad short of the minimiser; 2 Eigen's Levenberg-Marquardt on the gradient of lambda_min
+    composed with the reduced Cayley rotation.  Process-wide; affects every eigenvalue minimisation of the front stages."""
     L = lib()
     L.pnec_oracle_set_eigensolver_scheme.argtypes = [C.c_int]
     L.pnec_oracle_set_eigensolver_scheme.restype = None
     L.pnec_oracle_set_eigensolver_scheme(int(scheme))
+
+
+def set_eigensolver_restart(on: bool) -> None:
+    """scheme 1 only: ge_main2's disturbed-restart loop around the descent (off by default; pnec_oracle_opengv.c)"""
+    L = lib()
+    L.pnec_oracle_set_eigensolver_restart.argtypes = [C.c_int]
+    L.pnec_oracle_set_eigensolver_restart(1 if on else 0)
+
+
+def sums36(bvs1, bvs2):
+    b1, b1p = _d(bvs1)
+    b2, b2p = _d(bvs2)
+    G = np.zeros(36)
+    lib().pnec_oracle_sums36.argtypes = [C.c_int64, _dp, _dp, _dp]
+    lib().pnec_oracle_sums36(len(b1), b1p, b2p, G.ctypes.data_as(_dp))
+    return G
+
+
+def es_value_grad_sums(G, v, reduced=False):
+    """-> (lambda_min, gradient [3], eigenvector [3], second eigenvalue) of M(v) composed from the 36 sums"""
+    g_, gp = _d(G)
+    v_, vp = _d(v)
+    g, e, ev2 = np.zeros(3), np.zeros(3), C.c_double()
+    L = lib()
+    L.pnec_oracle_es_value_grad_sums.argtypes = [_dp, _dp, C.c_int, _dp, _dp, C.POINTER(C.c_double)]
+    L.pnec_oracle_es_value_grad_sums.restype = C.c_double
+    lam = L.pnec_oracle_es_value_grad_sums(gp, vp, 1 if reduced else 0, g.ctypes.data_as(_dp), e.ctypes.data_as(_dp),
+                                           C.byref(ev2))
+    return lam, g, e, ev2.value
+
+
+def es_descent(G, v0):
+    """scheme 1 on the 36 sums -> (v, iterations, trips)"""
+    g_, gp = _d(G)
+    v = np.array(v0, dtype=np.float64)
+    trips = C.c_int()
+    L = lib()
+    L.pnec_oracle_es_descent.argtypes = [_dp, _dp, C.POINTER(C.c_int)]
+    it = L.pnec_oracle_es_descent(gp, v.ctypes.data_as(_dp), C.byref(trips))
+    return v, it, trips.value
+
+
+def es_lm(G, v0):
+    """scheme 2 on the 36 sums -> (v, successful iterations, nfev, info)"""
+    g_, gp = _d(G)
+    v = np.array(v0, dtype=np.float64)
+    nfev, info = C.c_int(), C.c_int()
+    L = lib()
+    L.pnec_oracle_es_lm.argtypes = [_dp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    it = L.pnec_oracle_es_lm(gp, v.ctypes.data_as(_dp), C.byref(nfev), C.byref(info))
+    return v, it, nfev.value, info.value
 
 
 def eigensolver(bvs1, bvs2, R0):

@@ -248,54 +248,22 @@ static int solve3_spd(const double H[9], const double b[3], double x[3]) {
   return 1;
 }
 
-/* ---- [EXT, FROM MEMORY, UNVERIFIED] opengv's own iteration ----------------------------------------------------
- * opengv is not in the reference tree; oracle and device restate its eigensolver as "minimise
- * lambda_min(M(R)) over the Cayley parameters" with the damped Newton iteration below, converged to ~1e-12 rad.  What
- * opengv::relative_pose::modules::eigensolver_main does instead, as far as its published source is remembered (nothing
- * here can check it): steepest descent along the NORMALISED gradient with an adaptive step length lambda -- start 0.01;
- * in the first iteration doubled while the value keeps falling, up to 0.08; halved while a step does not improve the
- * value -- at most 50 iterations, stopped once lambda < 1e-5.  It therefore leaves the rotation ~1e-5 rad short of the
- * minimiser.  Scheme 1 runs that descent wherever scheme 0 runs the Newton iteration (RANSAC hypotheses, the eigensolver
- * on the inliers, the plain eigensolver), so that the part of the chain whose OUTPUT is the eigensolver stage's pose --
- * the odometry's forced options, frame2frame.cc:127-128 -- can be compared with "what opengv might return"
- * (tools/verify_odometry_options.py).  Test tooling only; the default is 0. */
+/* ---- which iteration the eigenvalue minimisations run ------------------------------------------------------------------
+ * 0 (default): the damped Newton iteration below on lambda_min(M(R(v))) -- the device's default, converged to ~1e-12 rad.
+ * 1, 2 [EXT, from memory, unpinned]: the two recollections of opengv's own iteration restated in pnec_oracle_opengv.c
+ *   (1: normalised steepest descent with an adaptive step, stops ~1e-5 rad short; 2: Eigen's Levenberg-Marquardt on the
+ *   gradient of lambda_min composed with the REDUCED Cayley rotation -- what eigensolver_main is recalled to run).
+ * The scheme applies wherever scheme 0 runs the Newton iteration (RANSAC hypotheses, the eigensolver on the inliers,
+ * the plain eigensolver, the weighted stage's rounds); schemes 1 and 2 work on the 36 sums, as opengv does.  Test
+ * tooling; a process-wide switch: set it before, not during, a batch call. */
 static int g_es_scheme = 0;
 void pnec_oracle_set_eigensolver_scheme(int scheme) { g_es_scheme = scheme; }
 int pnec_oracle_get_eigensolver_scheme(void) { return g_es_scheme; }
-
-static double es_value_grad(const es_data *D, const double v[3], double g[3]);
-static int eigensolver_descent_ext(const es_data *D, double v[3]) {
-  double lam = 0.01;
-  const double max_lam = 0.08, mod = 2.0, min_xtol = 1e-5;
-  double g[3];
-  double ev = es_value_grad(D, v, g);
-  int it = 0;
-  for (; it < 50; ++it) {
-    const double nrm = sqrt(dot3(g, g));
-    if (!(nrm > 0.0)) break;
-    const double d[3] = {g[0] / nrm, g[1] / nrm, g[2] / nrm};
-    double sp[3] = {v[0] - lam * d[0], v[1] - lam * d[1], v[2] - lam * d[2]};
-    double sev = es_value_grad(D, sp, NULL);
-    if (it == 0) {
-      while (sev < ev) {
-        ev = sev;
-        if (lam * mod > max_lam) break;
-        lam *= mod;
-        for (int k = 0; k < 3; ++k) sp[k] = v[k] - lam * d[k];
-        sev = es_value_grad(D, sp, NULL);
-      }
-    }
-    while (sev > ev && lam > 1e-12) {
-      lam /= mod;
-      for (int k = 0; k < 3; ++k) sp[k] = v[k] - lam * d[k];
-      sev = es_value_grad(D, sp, NULL);
-    }
-    for (int k = 0; k < 3; ++k) v[k] = sp[k];
-    ev = es_value_grad(D, v, g);
-    if (lam < min_xtol) { ++it; break; }
-  }
-  return it;
-}
+static int g_es_info; /* scheme 2: Eigen's status of the calling thread's last minimisation (5 = maxfev reached) */
+static int g_es_nfev;
+#pragma omp threadprivate(g_es_info, g_es_nfev)
+int pnec_oracle_es_last_info(void) { return g_es_info; }
+int pnec_oracle_es_last_nfev(void) { return g_es_nfev; }
 
 /* The Levenberg shift of an iteration whose Hessian is not positive definite: mu = 2 |x|, x = a lower bound of the
  * Hessian's smallest eigenvalue that is within a few percent of it unless eigenvalues nearly coincide -- three Newton
@@ -346,7 +314,16 @@ static int g_es_trips; /* evaluations of the last minimisation as the device's q
 int pnec_oracle_es_last_trips(void) { return g_es_trips; }
 static int eigensolver_cayley_tol(const es_data *Dp, double v[3], double step_done, int max_it) {
   g_es_trips = 0;
-  if (g_es_scheme == 1) return eigensolver_descent_ext(Dp, v);
+  g_es_info = 0;
+  if (g_es_scheme == 1 || g_es_scheme == 2) {
+    double G[36];
+    pnec_oracle_sums36(Dp->n, Dp->b1, Dp->b2, G);
+    if (g_es_scheme == 1) {
+      if (pnec_oracle_get_eigensolver_restart()) return pnec_oracle_es_descent_restarts(G, v, 1, 0, NULL);
+      return pnec_oracle_es_descent(G, v, &g_es_trips);
+    }
+    return pnec_oracle_es_lm(G, v, &g_es_nfev, &g_es_info);
+  }
   const es_data D = *Dp;
   const int64_t n = D.n;
   double g[3];
@@ -539,9 +516,15 @@ void pnec_oracle_weighted_eigensolver_ex(int64_t n, const double *bvs1, const do
     double Rn[9];
     {
       es_data D = {n, bvs1, w2};
-      if (device_early_exits) {
-        /* the Cayley vector is carried between rounds, early exit (1) */
-        if (!rotation_final) rotation_final = eigensolver_cayley(&D, v) < ES_MAX_ITERATIONS;
+      if (device_early_exits && g_es_scheme != 1) {
+        /* the Cayley vector is carried between rounds, early exit (1): a call that ended for any reason other than its
+         * cap (scheme 0: 50 Newton iterations; scheme 2: MINPACK's maxfev) has found the optimum of a function that
+         * never changes (C3).  Scheme 1 has no such exit on the device either: its descent stops ~1e-5 short, and every
+         * further call moves the rotation a little closer, as in the reference's literal loop */
+        if (!rotation_final) {
+          const int its = eigensolver_cayley(&D, v);
+          rotation_final = g_es_scheme == 2 ? g_es_info != 5 : its < ES_MAX_ITERATIONS;
+        }
       } else {
         /* pnec.cc:310-315: a new adapter holding rel_pose's rotation MATRIX, a new eigensolver call */
         pnec_oracle_rot_to_cayley(R, v);
@@ -688,7 +671,9 @@ int pnec_oracle_ransac_eigensolver(int64_t n, const double *bvs1, const double *
      * device's kHypothesisMaxIterations -- cut off, two floating-point realisations of the iteration stand at different
      * points of a walk that did not converge, and would score differently) */
     int count = 0;
-    for (int64_t i = 0; i < n && newton_its < ES_HYPOTHESIS_MAX_ITERATIONS; ++i)
+    const int cut_off = g_es_scheme == 0 && newton_its >= ES_HYPOTHESIS_MAX_ITERATIONS; /* (schemes 1, 2: every hypothesis
+                                                                                              is scored, as opengv does) */
+    for (int64_t i = 0; i < n && !cut_off; ++i)
       count += pnec_oracle_reprojection_score(bvs1 + 3 * i, bvs2 + 3 * i, R, t) < threshold;
     if (count > best_count) {
       best_count = count;

@@ -359,6 +359,11 @@ class Batch:
         needed more than one round of hypotheses in the last one first (scheduling only; results do not change)."""
         capi.check(self._lib.pnec_hip_problem_launch_order_hint(self._h, 1 if enable else 0))
 
+    def set_eigensolver_scheme(self, scheme: int) -> None:
+        """Which iteration the eigenvalue minimisations of the STAGE calls on this batch run (capi.ES_NEWTON / ES_DESCENT /
+        ES_LM; include/pnec_hip.h pnec_hip_eigensolver_scheme).  solve_pipeline takes its own from the options."""
+        capi.check(self._lib.pnec_hip_problem_set_eigensolver_scheme(self._h, int(scheme)))
+
     def select(self, mask, view: bool = False) -> "Batch":
         """PNEC::InlierExtraction (pnec.cc:210-229): new Batch with the masked correspondences.
         view=True: into this batch's cached target (pnec_hip_problem_select_view: nothing allocated after the first
@@ -380,6 +385,16 @@ class Batch:
         out = Batch.__new__(Batch)
         out._borrowed = bool(view)
         out._lib, out.mode, out.device, out._h = self._lib, self.mode, self.device, h
+        if view:
+            # the view lives in this batch's cached target: keep the source alive as long as the view is, and retire
+            # the previous view object (the library has just re-pointed the handle it held)
+            out._source = self
+            old = getattr(self, "_last_view", None)
+            old = old() if old is not None else None
+            if old is not None:
+                old._h = None
+            import weakref
+            self._last_view = weakref.ref(out)
         out.n_pairs = self.n_pairs
         # InlierExtraction ran on the device and nothing was read back: the new batch's offsets are
         # fetched from the library on first use (that call waits for the stream)

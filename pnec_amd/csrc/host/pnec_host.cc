@@ -429,6 +429,7 @@ pnec_hip_pipeline_options ToPipeline(const Options &o) {
   p.ransac_sample_size = o.ransac_sample_size_;
   p.regularization = o.regularization_;
   p.solver = optimization::SolverOptions().ToHip();
+  p.eigensolver_scheme = o.eigensolver_scheme_;
   return p;
 }
 
@@ -487,6 +488,7 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
   void *const st = pnec_hip_frame_stream(dev.frame);   // the ingest is queued there: the stages follow it
   pnec_hip_problem *stage = dev.prob.p;   // the batch the later stages run on (inliers under RANSAC)
   pnec_hip_problem *selected = nullptr;   // the handle's cached InlierExtraction target: nothing to destroy
+  Check(pnec_hip_problem_set_eigensolver_scheme(dev.prob.p, options_.eigensolver_scheme_));
   // ES_solution = Eigensolver(bvs1, bvs2, initial_pose, inliers)
   inliers.clear();
   if (options_.use_ransac_) {
@@ -498,6 +500,7 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
       if (mask[i]) inliers.push_back((int)i);
     // InlierExtraction (pnec.cc:210-229)
     Check(pnec_hip_problem_select_view(dev.prob.p, mask.data(), PNEC_HIP_MEM_HOST, st, &selected));
+    Check(pnec_hip_problem_set_eigensolver_scheme(selected, options_.eigensolver_scheme_));
     stage = selected;
   } else {
     Check(pnec_hip_nec_eigensolver(dev.prob.p, q0.coeffs(), q, t, PNEC_HIP_MEM_HOST, st));
@@ -560,6 +563,7 @@ SE3d PNEC::Eigensolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs
   if (!bvs1.empty())
     Check(pnec_hip_problem_fill(prob.p, 0, 1, bvs1[0].data(), bvs2[0].data(), nullptr, nullptr,
                                 PNEC_HIP_MEM_HOST, nullptr));
+  Check(pnec_hip_problem_set_eigensolver_scheme(prob.p, options_.eigensolver_scheme_));
   const Quaterniond q0(initial_pose.rotationMatrix());
   double q[4], t[3];
   if (options_.use_ransac_) {
@@ -579,6 +583,7 @@ SE3d PNEC::WeightedEigensolver(const bearingVectors_t &bvs1, const bearingVector
                                const std::vector<Matrix3d> &projected_covariances,
                                const SE3d &initial_pose) {
   PairOnDevice dev(optimization::SolverOptions().device, bvs1, bvs2, projected_covariances);
+  Check(pnec_hip_problem_set_eigensolver_scheme(dev.prob.p, options_.eigensolver_scheme_));
   const Quaterniond q0(initial_pose.rotationMatrix());
   double q[4], t[3];
   Check(pnec_hip_weighted_eigensolver(dev.prob.p, q0.coeffs(), initial_pose.translation().data(),

@@ -201,6 +201,11 @@ struct Options {  // pnec_config.h:46-65, same names and defaults
   int min_matches_ = 30;
   int min_inliers_ = 10;
   int min_matches_further_ = 20;
+  // NOT in the reference: which iteration stands in for opengv::relative_pose::eigensolver's eigenvalue minimisation
+  // (pnec.cc:239-258,274,315; opengv is not in the reference tree) -- pnec_hip_eigensolver_scheme in include/pnec_hip.h:
+  // 0 damped Newton (default), 1 normalised descent [EXT], 2 Eigen's Levenberg-Marquardt on the reduced-Cayley gradient
+  // [EXT].  INTEGRATION.md 6.
+  int eigensolver_scheme_ = 0;
 };
 
 // One frame pair of a batch, in the reference's argument shapes.

@@ -120,7 +120,7 @@ py::list ceres_solver_batch(py::list bvs1, py::list bvs2, py::list covs, py::lis
 // stage one launch over the batch.  Returns (poses, inliers).
 py::tuple solve_batch(py::list bvs1, py::list bvs2, py::list covs, py::list init_poses, bool use_ransac,
                       bool use_nec, bool use_ceres, int weighted_iterations, double regularization,
-                      std::vector<int> devices) {
+                      std::vector<int> devices, int eigensolver_scheme) {
   const size_t B = bvs1.size();
   if (bvs2.size() != B || covs.size() != B || init_poses.size() != B)
     throw std::invalid_argument("all lists must have one entry per frame pair");
@@ -137,6 +137,7 @@ py::tuple solve_batch(py::list bvs1, py::list bvs2, py::list covs, py::list init
   options.use_ceres_ = use_ceres;
   options.weighted_iterations_ = (size_t)weighted_iterations;
   options.regularization_ = regularization;
+  options.eigensolver_scheme_ = eigensolver_scheme;
   std::vector<pnec::SE3d> poses;
   std::vector<std::vector<int>> inliers;
   {
@@ -206,7 +207,7 @@ double cost_function(arr bvs1, arr bvs2, arr covs, arr pose) {
 // :135-208): overload 0 = (bvs1, bvs2, covs, init), 1 = (+ inliers), 2 = (+ timing), 3 = (+ inliers,
 // timing).  Returns (pose 4x4, inliers or None, timing dict or None).
 py::tuple solve(arr bvs1, arr bvs2, arr covs, arr init_pose, int overload, bool use_ransac, bool use_nec,
-                bool use_ceres, int weighted_iterations, double regularization) {
+                bool use_ceres, int weighted_iterations, double regularization, int eigensolver_scheme) {
   const auto b1 = ToBearings(bvs1, "bvs1"), b2 = ToBearings(bvs2, "bvs2");
   const auto cv = ToCovariances(covs, "covs");
   const pnec::SE3d init = ToPose(init_pose);
@@ -216,6 +217,7 @@ py::tuple solve(arr bvs1, arr bvs2, arr covs, arr init_pose, int overload, bool 
   options.use_ceres_ = use_ceres;
   options.weighted_iterations_ = (size_t)weighted_iterations;
   options.regularization_ = regularization;
+  options.eigensolver_scheme_ = eigensolver_scheme;
   if (overload < 0 || overload > 3) throw std::invalid_argument("overload must be 0..3");
   pnec::SE3d pose;
   std::vector<int> inliers;
@@ -280,10 +282,13 @@ PYBIND11_MODULE(pypnec, m) {
   m.def("solve", &solve, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"), py::arg("init_pose"),
         py::arg("overload") = 1, py::arg("use_ransac") = true, py::arg("use_nec") = false,
         py::arg("use_ceres") = true, py::arg("weighted_iterations") = 10, py::arg("regularization") = 1e-13,
-        "PNEC::Solve for one frame pair through one of its four overloads");
+        py::arg("eigensolver_scheme") = 0,
+        "PNEC::Solve for one frame pair through one of its four overloads (eigensolver_scheme: which iteration stands in "
+        "for opengv's eigenvalue minimisation, include/pnec_hip.h)");
   m.def("solve_batch", &solve_batch, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"), py::arg("init_poses"),
         py::arg("use_ransac") = true, py::arg("use_nec") = false, py::arg("use_ceres") = true,
         py::arg("weighted_iterations") = 10, py::arg("regularization") = 1e-13, py::arg("devices") = std::vector<int>{},
+        py::arg("eigensolver_scheme") = 0,
         "PNEC::Solve for a list of frame pairs, every stage one device launch over the batch (addition); devices: the "
         "GPUs to shard the pairs over from this process (empty: the default device)");
   m.def("ceres_solver_batch", &ceres_solver_batch, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"),

@@ -34,21 +34,20 @@ hipError_t launch_solve_aos_mode_3(int, int, int, const SolveArgs &, hipStream_t
 hipError_t launch_ransac_eigensolver(const double *, const int64_t *, const int64_t *, const int32_t *, int64_t,
                                      const double *, unsigned long long, unsigned long long, int, int, double, double *, double *,
                                      uint8_t *, int32_t *, int32_t *, double *, int32_t *, hipStream_t, hipStream_t,
-                                     hipEvent_t, hipEvent_t, int, double *, const int64_t *, int32_t *, int64_t *, void *, const int32_t *);
+                                     hipEvent_t, hipEvent_t, int, double *, const int64_t *, int32_t *, int64_t *, const int32_t *, int);
 hipError_t launch_ransac_order(const int32_t *, int64_t, int32_t *, hipStream_t);
 hipError_t frontend_work_counters(int, unsigned long long *, int *);
-size_t ransac_workspace_bytes(int64_t);
-int64_t ransac_split_threshold();
 hipError_t launch_select(int, const double *, const int64_t *, const int64_t *, const int32_t *, const uint8_t *,
                          double *, const int64_t *, const int32_t *, int32_t *, int64_t *, int64_t, hipStream_t);
 hipError_t launch_nec_eigensolver(const double *, const int64_t *, const int32_t *, int64_t, const double *,
-                                  double *, double *, int32_t *, double *, int32_t *, hipStream_t);
+                                  double *, double *, int32_t *, double *, int32_t *, hipStream_t, int);
 hipError_t launch_weighted_eigensolver(int, const double *, const int64_t *, const int32_t *, int64_t, int,
                                        const double *, const double *, double, int, double *, double *,
-                                       int32_t *, double *, int32_t *, hipStream_t);
+                                       int32_t *, double *, int32_t *, hipStream_t, int);
 hipError_t launch_frontend_selftest(double *, hipStream_t);
 // scratch of the front stages, per pair (pnec_frontend.hip FrontScratch)
-constexpr int64_t kFrontDoublesPerPair = 43, kFrontIntsPerPair = 2;
+// (+ 3 kEsMaxRounds doubles and one int per pair: the weighted stage's chained minimisations under eigensolver schemes 1, 2)
+constexpr int64_t kFrontDoublesPerPair = 43 + 3 * kEsMaxRounds, kFrontIntsPerPair = 3;
 }  // namespace pnec_hip
 
 using namespace pnec_hip;
@@ -90,9 +89,8 @@ struct pnec_hip_problem {
   double *d_front = nullptr;
   int32_t *d_front_i = nullptr;
   int64_t front_pairs = 0;
-  // workspace of the RANSAC stage's split form (large batches; pnec_ransac_split.inl)
-  void *d_ransac_ws = nullptr;
-  size_t ransac_ws_bytes = 0;
+  // which iteration the eigenvalue minimisations of the stage calls run (pnec_hip_problem_set_eigensolver_scheme)
+  int es_scheme = 0;
   // launch-order hint of the RANSAC stage (pnec_hip_problem_launch_order_hint): the last run's hypothesis counts and
   // the order made from them; order_pairs = the number of pairs d_order is a permutation of (0: none yet)
   bool order_hint = false;
@@ -947,22 +945,6 @@ int ensure_side_streams(pnec_hip_problem *p, size_t n) {
   return 0;
 }
 
-// the RANSAC stage's workspace, for batches large enough to run its split form (null otherwise)
-int ensure_ransac_ws(pnec_hip_problem *p) {
-  if (p->n_pairs < ransac_split_threshold()) return 0;
-  const size_t want = ransac_workspace_bytes(p->n_pairs);
-  if (want > p->ransac_ws_bytes) {
-    if (p->d_ransac_ws) (void)dev_free(p->d_ransac_ws);
-    p->d_ransac_ws = nullptr;
-    p->ransac_ws_bytes = 0;
-    char *w = nullptr;
-    PNEC_HIP_TRY(dev_alloc(&w, want));
-    p->d_ransac_ws = w;
-    p->ransac_ws_bytes = want;
-  }
-  return 0;
-}
-
 // The launch-order hint's arrays (two int32 per pair), grown on demand.
 int ensure_order_hint(pnec_hip_problem *p) {
   if (!p->order_hint || p->hint_cap >= p->n_pairs) return 0;
@@ -1242,7 +1224,6 @@ int pnec_hip_problem_destroy(pnec_hip_problem *p) {
   release(p->d_stage_i);
   release(p->d_front);
   release(p->d_front_i);
-  release(p->d_ransac_ws);
   release(p->d_hint_its);
   release(p->d_order);
   // (the device has drained: nothing is pending on these, so the next owner starts clean)
@@ -1731,9 +1712,9 @@ static int run_front_stage(pnec_hip_problem *p, bool weighted, const double *ini
   hipError_t e = weighted
                      ? launch_weighted_eigensolver(p->device, p->d_data, p->d_block_offset, p->d_count, P, p->n_max, d_q,
                                                    d_t, reg, weighted_iterations, d_oq, d_ot, nullptr, p->d_front,
-                                                   p->d_front_i, stream)
+                                                   p->d_front_i, stream, p->es_scheme)
                      : launch_nec_eigensolver(p->d_data, p->d_block_offset, p->d_count, P, d_q, d_oq, d_ot,
-                                              nullptr, p->d_front, p->d_front_i, stream);
+                                              nullptr, p->d_front, p->d_front_i, stream, p->es_scheme);
   if (e != hipSuccess) return fail_hip(e, weighted ? "weighted_eigensolver_kernel" : "nec_eigensolver_kernel");
   if (space == PNEC_HIP_MEM_HOST) {
     PNEC_HIP_TRY(hipMemcpyAsync(out_q, d_oq, sizeof(double) * 4 * P, hipMemcpyDeviceToHost, stream));
@@ -1742,6 +1723,15 @@ static int run_front_stage(pnec_hip_problem *p, bool weighted, const double *ini
   }
   return 0;
 }
+
+int pnec_hip_problem_set_eigensolver_scheme(pnec_hip_problem *p, int32_t scheme) {
+  if (!p) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "problem is NULL");
+  if (scheme < PNEC_HIP_ES_NEWTON || scheme > PNEC_HIP_ES_LM)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "eigensolver scheme: 0 (Newton), 1 (descent) or 2 (LM)");
+  p->es_scheme = scheme;
+  return 0;
+}
+int pnec_hip_problem_eigensolver_scheme(const pnec_hip_problem *p) { return p ? p->es_scheme : 0; }
 
 int pnec_hip_nec_eigensolver(pnec_hip_problem *p, const double *init_q, double *out_q, double *out_t,
                              int space, void *stream) {
@@ -1752,6 +1742,8 @@ int pnec_hip_weighted_eigensolver(pnec_hip_problem *p, const double *init_q, con
                                   double reg, int32_t weighted_iterations, double *out_q, double *out_t,
                                   int space, void *stream) {
   if (weighted_iterations < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "weighted_iterations < 0");
+  if (p && p->es_scheme != PNEC_HIP_ES_NEWTON && weighted_iterations - 1 > kEsMaxRounds)
+    return fail(PNEC_HIP_ERR_UNSUPPORTED, "eigensolver schemes 1 and 2 hold at most 16 weighted_iterations");
   return run_front_stage(p, true, init_q, init_t, reg, weighted_iterations, out_q, out_t, space, stream);
 }
 
@@ -1791,7 +1783,6 @@ int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint6
     }
   }
   int rc_ws = ensure_front(p);
-  if (!rc_ws) rc_ws = ensure_ransac_ws(p);
   if (!rc_ws) rc_ws = ensure_order_hint(p);
   if (rc_ws) {
     if (tmp_mask) (void)dev_free(tmp_mask);
@@ -1801,8 +1792,8 @@ int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint6
   hipError_t e = launch_ransac_eigensolver(p->d_data, p->d_block_offset, p->d_offsets, p->d_count, P, d_q, seed,
                                            /*first_pair_id*/ 0ull, max_iterations, sample_size, threshold, d_oq, d_ot, d_mask, d_cnt, d_it,
                                            p->d_front, p->d_front_i, stream, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
-                                           nullptr, nullptr, p->n_pairs >= ransac_split_threshold() ? p->d_ransac_ws : nullptr,
-                                           p->order_hint && p->order_pairs == P ? p->d_order : nullptr);
+                                           nullptr, nullptr,
+                                           p->order_hint && p->order_pairs == P ? p->d_order : nullptr, p->es_scheme);
   if (e == hipSuccess && p->order_hint) {   // the next call's launch order from this call's counts
     e = launch_ransac_order(d_it, P, p->d_order, stream);
     p->order_pairs = P;
@@ -1831,6 +1822,7 @@ static int alloc_like(pnec_hip_problem *src, hipStream_t stream, pnec_hip_proble
   d->device = src->device;
   d->mode = src->mode;
   d->nc = src->nc;
+  d->es_scheme = src->es_scheme;
   d->n_pairs = src->n_pairs;
   d->n_corr = src->n_corr;          // upper bounds until materialize()
   d->n_max = src->n_max;

@@ -311,6 +311,13 @@ __device__ void cayley_to_rot(const double (&v)[3], double (&R)[9]) {
   R[6] = s * 2 * (x * z - y); R[7] = s * 2 * (y * z + x); R[8] = s * (1 - x * x - y * y + z * z);
 }
 
+__device__ __forceinline__ void cayley_to_rot_reduced(const double (&v)[3], double (&R)[9]) {
+  const double x = v[0], y = v[1], z = v[2];
+  R[0] = 1 + x * x - y * y - z * z; R[1] = 2 * (x * y - z); R[2] = 2 * (x * z + y);
+  R[3] = 2 * (x * y + z); R[4] = 1 - x * x + y * y - z * z; R[5] = 2 * (y * z - x);
+  R[6] = 2 * (x * z - y); R[7] = 2 * (y * z + x); R[8] = 1 - x * x - y * y + z * z;
+}
+
 __device__ void rot_to_cayley(const double (&R)[9], double (&v)[3]) {
   double A[9], B[9];
 #pragma unroll
@@ -373,7 +380,10 @@ __device__ __forceinline__ void cross3(const double (&a)[3], const double (&b)[3
 #else
 #define PNEC_FMARK(name)
 #endif
-template <int GS>
+// REDUCED: the rotation without its 1 / (1 + |v|^2) scale (opengv's math::cayley2rot_reduced, which is what its composeM
+// is recalled to use [EXT]): M and lambda_min come out (1 + |v|^2)^2 times larger and the gradient is that function's
+// (eigensolver scheme 2, pnec_es_schemes.inl).
+template <int GS, bool REDUCED = false>
 __device__ double es_value_grad(const double *G, const double (&v)[3], double *g, double *M_out,
                                 double *ew = nullptr, bool warm = false) {
   // the 36 sums, read ONCE per evaluation, all loads in flight before the first use (read where they are used, the
@@ -384,7 +394,8 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
   for (int i = 0; i < 36; ++i) Gr[i] = G[i * GS];
   PNEC_FMARK("vg_rot");
   double R[9];
-  cayley_to_rot(v, R);
+  if constexpr (REDUCED) cayley_to_rot_reduced(v, R);
+  else cayley_to_rot(v, R);
   PNEC_FMARK("vg_M");
   double r[3][3];  // columns of R
 #pragma unroll
@@ -493,12 +504,14 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
   // the three matrices (round 4: ~40 instructions instead of ~120 per evaluation):
   //   sum dN_j . Q = -2 v_j tr Q + 2 (Q[b][a] - Q[a][b]) + 2 sum_i v_i (Q[j][i] + Q[i][j]),   a = j + 1, b = j + 2 (mod 3)
   //   sum  R   . Q = the same number for every j
-  const double inv_s = fast_rcp(1.0 + v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-  double rq = 0.0;  // tr Q + sum R . Q
+  const double inv_s = REDUCED ? 1.0 : fast_rcp(1.0 + v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  double rq = 0.0;  // tr Q + sum R . Q   (REDUCED: d r_k / d v_j = dN_j[:, k], no R term and no scale: tr Q alone)
+  if constexpr (!REDUCED) {
 #pragma unroll
-  for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int rr = 0; rr < 3; ++rr) rq = __builtin_fma(R[3 * rr + k], q[k][rr], rq);
+      for (int rr = 0; rr < 3; ++rr) rq = __builtin_fma(R[3 * rr + k], q[k][rr], rq);
+  }
   rq += q[0][0] + q[1][1] + q[2][2];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -884,6 +897,12 @@ struct FrontArgs {
   // (es_batch_kernel): its minimiser [n_pairs,3] and Newton iteration count [n_pairs]
   const double *pre_G, *pre_v;
   const int32_t *pre_its;
+  // eigensolver schemes 1, 2: ALL the stage's minimisations ran in es_batch_alt_kernel, chained -- round r's minimiser
+  // of pair p at pre_v_rounds[3 (r n_pairs + p)], and how many rounds of the pair have one (after those the rotation is
+  // final) at pre_n_es[p]; null under scheme 0
+  const double *pre_v_rounds;
+  const int32_t *pre_n_es;
+  int64_t n_pairs;
 };
 // phase clocks of the weighted kernel (diagnostics): s_memtime differences accumulated per phase
 enum : int { kPhSums = 0, kPhNewton, kPhTables, kPhSearch, kPhCost, kPhScf, kPhTotal, kPhCount = 12 };
@@ -978,16 +997,21 @@ struct FrontScratch {
   double *v;        // [P,3]  the minimiser
   int32_t *its;     // [P]    Newton iterations taken
   int32_t *first;   // [P]    correspondence ComposeM leaves out (C7), -1: none
+  double *v_rounds; // [kEsMaxRounds,P,3] schemes 1, 2: the weighted stage's minimiser of every round
+  int32_t *n_es;    // [P]    ... and how many rounds have one
 };
-// per pair: 36 + 3 + 1 + 3 doubles and 2 ints (pnec_capi.hip sizes the buffers: kFrontDoublesPerPair / kFrontIntsPerPair)
+// per pair: 36 + 3 + 1 + 3 + 3 kEsMaxRounds doubles and 3 ints (pnec_capi.hip sizes the buffers: kFrontDoublesPerPair /
+// kFrontIntsPerPair)
 FrontScratch front_scratch(double *d, int32_t *i, int64_t P) {
   FrontScratch f;
   f.G = d;
   f.v0 = d + 36 * P;
   f.n_scale = d + 39 * P;
   f.v = d + 40 * P;
+  f.v_rounds = d + 43 * P;
   f.its = i;
   f.first = i + P;
+  f.n_es = i + 2 * P;
   return f;
 }
 
@@ -1038,6 +1062,41 @@ struct EsBatchArgs {
 constexpr int kEpiNone = 0, kEpiTranslation = 1;
 static unsigned es_batch_blocks(int64_t n_pairs) { return (unsigned)((n_pairs + 15) / 16); }
 
+// PNEC::Eigensolver's tail for the pair of a quad (es_batch_kernel<kEpiTranslation>): the rotation as a quaternion and the
+// translation = eigenvector of the smallest eigenvalue of M without the correspondence ComposeM skips (C7)
+__device__ __forceinline__ void es_batch_translation_epilogue(const EsBatchArgs &a, const double *Gq, const double (&v)[3],
+                                                              int64_t pair, bool mine, int it, int lane) {
+  double M[9], R[9];
+  es_value_grad<1>(Gq, v, nullptr, M);
+  cayley_to_rot(v, R);
+  const int f = a.s.first[pair];
+  if (f >= 0) {
+    const int n = a.count[pair];
+    const int stride = (n + kWave - 1) & ~(kWave - 1);
+    const double *base = a.data + a.block_offset[pair];
+    const double f1[3] = {base[f], base[(int64_t)stride + f], base[(int64_t)2 * stride + f]};
+    const double f2[3] = {base[(int64_t)3 * stride + f], base[(int64_t)4 * stride + f], base[(int64_t)5 * stride + f]};
+    const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
+                         R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
+    const double nn[3] = {f1[1] * u[2] - f1[2] * u[1], f1[2] * u[0] - f1[0] * u[2], f1[0] * u[1] - f1[1] * u[0]};
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) M[3 * r + c] -= nn[r] * nn[c];
+  }
+  double w[3], V[9];
+  sym_eig3(M, w, V);
+  if (mine && (lane & 3) == 0) {
+    double qo[4];
+    quat_from_rot_dev(R, qo);
+    const double qn = 1.0 / sqrt(qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3]);
+    for (int k = 0; k < 4; ++k) a.out_q[4 * pair + k] = qo[k] * qn;
+    const double tn = 1.0 / sqrt(V[0] * V[0] + V[3] * V[3] + V[6] * V[6]);
+    a.out_t[3 * pair + 0] = V[0] * tn;
+    a.out_t[3 * pair + 1] = V[3] * tn;
+    a.out_t[3 * pair + 2] = V[6] * tn;
+    if (a.out_iterations) a.out_iterations[pair] = it;
+  }
+}
+
 // sixteen pairs per wavefront, one per quad: minimise lambda_min(M(R)) from v0; kEpiTranslation: then the
 // rotation as a quaternion and the translation = eigenvector of the smallest eigenvalue of M without the
 // correspondence ComposeM skips
@@ -1079,36 +1138,93 @@ __global__ __launch_bounds__(kWave, 2) void es_batch_kernel(const EsBatchArgs a)
       a.s.its[pair] = it;
     }
   } else {
-    double M[9], R[9];
-    es_value_grad<1>(Gs[quad], v, nullptr, M);
-    cayley_to_rot(v, R);
-    const int f = a.s.first[pair];
-    if (f >= 0) {
-      const int n = a.count[pair];
-      const int stride = (n + kWave - 1) & ~(kWave - 1);
-      const double *base = a.data + a.block_offset[pair];
-      const double f1[3] = {base[f], base[(int64_t)stride + f], base[(int64_t)2 * stride + f]};
-      const double f2[3] = {base[(int64_t)3 * stride + f], base[(int64_t)4 * stride + f], base[(int64_t)5 * stride + f]};
-      const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
-                           R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
-      const double nn[3] = {f1[1] * u[2] - f1[2] * u[1], f1[2] * u[0] - f1[0] * u[2], f1[0] * u[1] - f1[1] * u[0]};
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) M[3 * r + c] -= nn[r] * nn[c];
-    }
-    double w[3], V[9];
-    sym_eig3(M, w, V);
-    if (mine && (lane & 3) == 0) {
-      double qo[4];
-      quat_from_rot_dev(R, qo);
-      const double qn = 1.0 / sqrt(qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3]);
-      for (int k = 0; k < 4; ++k) a.out_q[4 * pair + k] = qo[k] * qn;
-      const double tn = 1.0 / sqrt(V[0] * V[0] + V[3] * V[3] + V[6] * V[6]);
-      a.out_t[3 * pair + 0] = V[0] * tn;
-      a.out_t[3 * pair + 1] = V[3] * tn;
-      a.out_t[3 * pair + 2] = V[6] * tn;
-      if (a.out_iterations) a.out_iterations[pair] = it;
-    }
+    es_batch_translation_epilogue(a, Gs[quad], v, pair, mine, it, lane);
   }
+}
+
+constexpr int kHypPerRound = 16;  // hypotheses evaluated per round = quads per wavefront
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#include "pnec_es_schemes.inl"
+
+// es_batch_kernel under eigensolver schemes 1 and 2 (pnec_es_schemes.inl): sixteen pairs per wavefront through the queue
+// form (one task per quad).  kEpiTranslation: one minimisation and the same epilogue.  kEpiNone (the weighted stage):
+// ALL of the stage's minimisations, chained -- the weights never change (C3), so round r + 1 minimises the same function
+// from round r's result and none of it depends on the translation part of the rounds: `rounds` of them under scheme 1
+// (each starts where the last one stopped short, through the rotation MATRIX as pnec.cc:310-311 hands it over), and under
+// scheme 2 until one ends for another reason than maxfev (the rotation is final from there).
+struct EsAltLds {
+  double Gs[16][36];
+  double tv[16][3], te[16][3];
+  int tits[16], tflag[16], tlist[16];
+};
+template <int EPI, int SCHEME>
+__global__ __launch_bounds__(kWave, 2) void es_batch_alt_kernel(const EsBatchArgs a, int rounds) {
+  const int lane = threadIdx.x;
+  const int quad = lane >> 2;
+  __shared__ EsAltLds lds;
+  const int64_t first_pair = 16 * (int64_t)blockIdx.x;
+  for (int i = lane; i < 16 * 36; i += kWave) {
+    int64_t p = first_pair + i / 36;
+    p = p < a.n_pairs ? p : a.n_pairs - 1;
+    lds.Gs[i / 36][i % 36] = a.s.G[36 * p + i % 36];
+  }
+  const int64_t left = a.n_pairs - first_pair;
+  const int n_mine = left < 16 ? (int)left : 16;  // pairs of this wavefront
+  const bool mine = quad < n_mine;
+  const int64_t pair = mine ? first_pair + quad : a.n_pairs - 1;
+  if ((lane & 3) == 0) {
+    lds.tv[quad][0] = a.s.v0[3 * pair]; lds.tv[quad][1] = a.s.v0[3 * pair + 1]; lds.tv[quad][2] = a.s.v0[3 * pair + 2];
+    lds.tlist[quad] = quad;
+  }
+  wave_lds_sync();
+  int it_first = 0;
+  if constexpr (EPI == kEpiTranslation) {
+    es_minimise_queue_alt<SCHEME>(n_mine, lds.tlist, lds.Gs, lds.tv, lds.te, lds.tits, lds.tflag);
+    wave_lds_sync();
+    it_first = lds.tits[quad];
+  } else {
+    bool going = mine;
+    int n_es = 0;
+    for (int r = 0; r < rounds; ++r) {  // wave-uniform exit below
+      // the round's queue: the pairs whose rotation may still move
+      const unsigned long long gb = __builtin_amdgcn_ballot_w64(going && (lane & 3) == 0);
+      const int n_tasks = __builtin_popcountll(gb);
+      if (n_tasks == 0) break;
+      if (going && (lane & 3) == 0) {
+        lds.tlist[__builtin_popcountll(gb & ((1ull << lane) - 1ull))] = quad;
+        if (SCHEME == 1 && r > 0) {  // a new adapter holding rel_pose's rotation MATRIX (pnec.cc:310-311)
+          double vv[3] = {lds.tv[quad][0], lds.tv[quad][1], lds.tv[quad][2]}, Rr[9];
+          cayley_to_rot(vv, Rr);
+          rot_to_cayley(Rr, vv);
+          lds.tv[quad][0] = vv[0]; lds.tv[quad][1] = vv[1]; lds.tv[quad][2] = vv[2];
+        }
+      }
+      wave_lds_sync();
+      es_minimise_queue_alt<SCHEME>(n_tasks, lds.tlist, lds.Gs, lds.tv, lds.te, lds.tits, lds.tflag);
+      wave_lds_sync();
+      if (going) {
+        if ((lane & 3) == 0) {
+          double *dst = a.s.v_rounds + 3 * ((int64_t)r * a.n_pairs + pair);
+          dst[0] = lds.tv[quad][0]; dst[1] = lds.tv[quad][1]; dst[2] = lds.tv[quad][2];
+        }
+        if (r == 0) it_first = lds.tits[quad];
+        n_es = r + 1;
+        if (SCHEME == 2 && lds.tflag[quad] == 0) going = false;
+      }
+      wave_lds_sync();
+    }
+    if (mine && (lane & 3) == 0) {
+      a.s.n_es[pair] = n_es;
+      a.s.its[pair] = it_first;
+    }
+    return;
+  }
+  double v[3] = {lds.tv[quad][0], lds.tv[quad][1], lds.tv[quad][2]};
+  es_batch_translation_epilogue(a, lds.Gs[quad], v, pair, mine, it_first, lane);
 }
 
 // per-correspondence n = f1 x R f2 and B = f1hat R Sigma R' f1hat' + reg I (packed symmetric)
@@ -1300,13 +1416,20 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
     // final and later rounds only redo the translation (newton = 0: "did not move").
     int newton = 0;
     if constexpr (WITH_ES) {
-      if (it == 0) {  // the first round's call ran in es_batch_kernel (sixteen pairs per wavefront)
-        v[0] = a.pre_v[3 * pair]; v[1] = a.pre_v[3 * pair + 1]; v[2] = a.pre_v[3 * pair + 2];
-        newton = a.pre_its[pair];
+      if (a.pre_n_es) {  // schemes 1, 2: every round's call ran in es_batch_alt_kernel, chained
+        const double *pv = a.pre_v_rounds + 3 * ((int64_t)it * a.n_pairs + pair);
+        v[0] = pv[0]; v[1] = pv[1]; v[2] = pv[2];
+        newton = it == 0 ? a.pre_its[pair] : 1;
+        rotation_final = it + 1 >= a.pre_n_es[pair];
       } else {
-        newton = es_minimise_quad<1>(G, v, (double)(n > 0 ? n : 1));
+        if (it == 0) {  // the first round's call ran in es_batch_kernel (sixteen pairs per wavefront)
+          v[0] = a.pre_v[3 * pair]; v[1] = a.pre_v[3 * pair + 1]; v[2] = a.pre_v[3 * pair + 2];
+          newton = a.pre_its[pair];
+        } else {
+          newton = es_minimise_quad<1>(G, v, (double)(n > 0 ? n : 1));
+        }
+        rotation_final = newton < kNewtonMaxIterations;
       }
-      rotation_final = newton < kNewtonMaxIterations;
     }
     if (it == 0) first_iterations = newton;
     PNEC_PHASE_END(kPhNewton);
@@ -1724,10 +1847,6 @@ __global__ __launch_bounds__(WMAX *kWave, PNEC_WES_WAVES_PER_SIMD) void weighted
 // k = log(1 - 0.99) / log(1 - w^s), eigensolver re-run on the inliers; rand() replaced by a
 // counter-based hash of (seed, pair, hypothesis, draw)) ------------------------------------------
 // (kernel shape: see ransac_eigensolver_kernel below)
-struct RansacState {  // per pair: where RANSAC's sequential rule stands between two launches (pnec_ransac_split.inl)
-  int32_t *it, *best, *needed, *task0;
-  double *k, *model;  // model [P][12]: R (9) + t (3) of the best hypothesis so far
-};
 struct RansacArgs {
   const double *data;
   const int64_t *block_offset;
@@ -1750,9 +1869,6 @@ struct RansacArgs {
   const int64_t *sel_block;
   int32_t *sel_count;
   int64_t *sel_single_offsets; // a batch of ONE pair: its AoS offsets [0, m]
-  // ransac_eigensolver_kernel<true>: the pairs resumed from the round kernels' state
-  const int32_t *resume_list, *resume_count;
-  RansacState resume;
   // two-pair form: the pairs in launch order (null: as they lie in the batch); see ransac_order_kernel
   const int32_t *order;
   // two-pair form: blocks [0, n_double) take the pairs 2 b, 2 b + 1 (of the launch order), blocks from n_double on ONE
@@ -1933,7 +2049,6 @@ __device__ __forceinline__ int model_inliers_until_beaten(const ScoreTiles &P, c
   return cnt;
 }
 
-constexpr int kHypPerRound = 16;  // hypotheses evaluated per round = quads per wavefront
 // w^s for the rule's bound k = log(1 - 0.99) / log(1 - w^s), s = the sample size (an integer <= 16): by squaring.  (The
 // library's pow() is a double-double logarithm and exponential -- ~250 instructions per new best model -- and the compiler
 // kept its polynomial's coefficients in vector registers outside the rounds' loop, spilled them, and reloaded them one
@@ -2038,7 +2153,107 @@ __device__ __forceinline__ void ransac_sample_sums(const double *bs, int st, int
 #ifndef PNEC_RANSAC_WAVES_PER_SIMD
 #define PNEC_RANSAC_WAVES_PER_SIMD 2
 #endif
-#include "pnec_ransac_split.inl"
+// ---- helpers of the RANSAC kernels' tails
+
+// InlierExtraction of one pair by one wavefront (the body of select_kernel): eight 64-chunks at a time, first where
+// every kept correspondence goes (mask bytes and ballots only), then the copies component by component
+__device__ __forceinline__ void compact_pair(int nc, const double *sb, int n, const uint8_t *mk, double *db, int m, int lane) {
+  const int sstride = (n + kWave - 1) & ~(kWave - 1), dstride = (m + kWave - 1) & ~(kWave - 1);
+  constexpr int kChunks = 8;
+  int written = 0;
+  for (int base = 0; base < sstride; base += kChunks * kWave) {
+    bool in[kChunks];
+    int pos[kChunks];
+#pragma unroll
+    for (int j = 0; j < kChunks; ++j) {
+      const int idx = base + j * kWave + lane;
+      in[j] = idx < n && mk[idx] != 0;
+      const unsigned long long b = __ballot(in[j]);
+      pos[j] = written + __popcll(b & ((1ull << lane) - 1ull));
+      written += __popcll(b);
+    }
+    for (int c = 0; c < nc; ++c) {
+      const double *sc = sb + (int64_t)c * sstride + base + lane;
+      double *dc = db + (int64_t)c * dstride;
+      double v[kChunks];
+#pragma unroll
+      for (int j = 0; j < kChunks; ++j) v[j] = in[j] ? sc[j * kWave] : 0.0;
+#pragma unroll
+      for (int j = 0; j < kChunks; ++j)
+        if (in[j]) dc[pos[j]] = v[j];
+    }
+  }
+  for (int idx = m + lane; idx < dstride; idx += kWave)  // zero padding of the last 64-chunk
+    for (int c = 0; c < nc; ++c) db[(int64_t)c * dstride + idx] = 0.0;
+}
+
+// The end of a pair's RANSAC: inliers of the best model (all correspondences when sampling is impossible), the mask,
+// their 36 sums and the first inlier (ComposeM on the inlier list starts at its second entry, C7) for
+// es_batch_kernel<kEpiTranslation>, and -- with a target -- InlierExtraction (pnec.cc:210-229) into it.
+// G: 36 doubles of LDS.  The one-pair kernel's tail (the two-pair kernel has the same arithmetic inline).
+__device__ __forceinline__ int ransac_finish_pair(const RansacArgs &a, int64_t pair, int n, int stride, const double *base,
+                                                  const double (&bR)[9], const double (&bt)[3], bool can_sample, int it,
+                                                  int lane, double *G) {
+  double acc[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+  int my_count = 0, my_first = 0x7fffffff;
+  const int64_t aos0 = a.offsets[pair];
+  for (int idx = lane; idx < n; idx += kWave) {
+    const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
+    const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
+                          base[(int64_t)5 * stride + idx]};
+    bool in = true;
+    if (can_sample) in = reprojection_score(f1, f2, bR, bt) < a.threshold;
+    if (a.out_mask) a.out_mask[aos0 + idx] = in ? 1 : 0;
+    if (in) {
+      ++my_count;
+      if (idx < my_first) my_first = idx;
+      const double p[6] = {f2[0] * f2[0], f2[0] * f2[1], f2[0] * f2[2], f2[1] * f2[1], f2[1] * f2[2], f2[2] * f2[2]};
+      const double qq[6] = {f1[0] * f1[0], f1[0] * f1[1], f1[0] * f1[2], f1[1] * f1[1], f1[1] * f1[2], f1[2] * f1[2]};
+#pragma unroll
+      for (int kl = 0; kl < 6; ++kl)
+#pragma unroll
+        for (int ac = 0; ac < 6; ++ac) acc[6 * kl + ac] = __builtin_fma(p[kl], qq[ac], acc[6 * kl + ac]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 36; ++i) {
+    const double sres = wave_allreduce_sum(acc[i]);
+    if (lane == 0) G[i] = sres;
+  }
+  const int total = (int)wave_allreduce_sum((double)my_count);
+  if (lane == 0) PNEC_WORK_ADD(kWkRansacInlierCorr, n);
+  int first = my_first;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(first, off);
+    first = o < first ? o : first;
+  }
+  wave_lds_sync();
+  if (lane < 36) a.scratch.G[36 * pair + lane] = G[lane];
+  if (lane == 0) {
+    double v[3];
+    rot_to_cayley(bR, v);
+    a.scratch.v0[3 * pair] = v[0]; a.scratch.v0[3 * pair + 1] = v[1]; a.scratch.v0[3 * pair + 2] = v[2];
+    a.scratch.n_scale[pair] = (double)(total > 0 ? total : 1);
+    a.scratch.first[pair] = total > 0 ? first : -1;
+    if (a.out_count) a.out_count[pair] = total;
+    if (a.out_iterations) a.out_iterations[pair] = it;
+  }
+  if (a.sel_data) {  // InlierExtraction: this wavefront's own mask bytes back (each lane reads what it wrote)
+    if (lane == 0) {
+      a.sel_count[pair] = total;
+      if (a.sel_single_offsets) {
+        a.sel_single_offsets[0] = 0;
+        a.sel_single_offsets[1] = total;
+      }
+    }
+    compact_pair(a.nc, base, n, a.out_mask + aos0, a.sel_data + a.sel_block[pair], total, lane);
+  }
+  return total;
+}
+
 
 // ONE WAVEFRONT PER FRAME PAIR, ONE QUAD PER HYPOTHESIS: a round evaluates 16 hypotheses.  The four lanes
 // of a quad share the hypothesis' Newton iteration (es_minimise_quad: the finite-difference probes and the
@@ -2049,15 +2264,10 @@ __device__ __forceinline__ void ransac_sample_sums(const double *bs, int st, int
 // second round because ONE of its four pairs needs it (~1.9 -> ~1.4 rounds per pair), the slowest of 16
 // instead of 64 Newton iterations sets the pace, and the register need is es_minimise_quad's, which fits
 // two wavefronts per SIMD -- the other wavefront now fills the latency gaps of this one's chains.
-// RESUME: the pairs of a.resume_list, each from the state the round kernels left it in (pnec_ransac_split.inl), by a
-// grid-stride loop; otherwise pair = block, from the start.
-template <bool RESUME>
 __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eigensolver_kernel(const RansacArgs a) {
   const int lane = threadIdx.x;
   const int hyp = lane >> 2, role = lane & 3;
-  const int64_t n_work = RESUME ? (int64_t)*a.resume_count : 1;
-  for (int64_t work = RESUME ? (int64_t)blockIdx.x : 0; work < n_work; work += RESUME ? (int64_t)gridDim.x : 1) {
-  const int64_t pair = RESUME ? (int64_t)a.resume_list[work] : (int64_t)blockIdx.x;
+  const int64_t pair = (int64_t)blockIdx.x;
   const int n = a.count[pair];
   const int stride = (n + kWave - 1) & ~(kWave - 1);
   const double *base = a.data + a.block_offset[pair];
@@ -2084,13 +2294,6 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
     int best_count = -1;
     double k = 1.0;
     bool stop = !can_sample;
-    if constexpr (RESUME) {
-      it = a.resume.it[pair];
-      best_count = a.resume.best[pair];
-      k = a.resume.k[pair];
-      if (lane < 12) best_model[lane] = a.resume.model[12 * pair + lane];
-      wave_lds_sync();
-    }
     while (!stop && (double)it < k) {  // wave-uniform
       const unsigned long long h = (unsigned long long)(it + hyp);
       // The first round evaluates all 16 hypotheses before any bound is known.  A later round knows k: hypothesis
@@ -2242,8 +2445,6 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eige
   if (a.trace && lane == 0) {
     ph_clk[kRpTotal] = __builtin_amdgcn_s_memtime() - ph_start;
     for (int k = 0; k < kPhCount; ++k) a.trace[kPhCount * pair + k] = ph_clk[k];
-  }
-  if constexpr (RESUME) wave_lds_sync();  // (the next pair reuses the LDS)
   }
 }
 
@@ -2442,6 +2643,9 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
   return trips;
 }
 
+// SCHEME: which iteration minimises a hypothesis' eigenvalue (0: es_minimise_queue; 1, 2: es_minimise_queue_alt, where
+// every hypothesis is scored -- there is no cap that voids a model).
+template <int SCHEME>
 __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eigensolver_kernel(const RansacArgs a) {
   const int lane = threadIdx.x;
   const int hyp = lane >> 2, role = lane & 3;
@@ -2644,7 +2848,9 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
       lds_sync();
     }
     PNEC_PHASE_END(kRpSample);
-    const int trips = es_minimise_queue(n_tasks, lds.tlist, lds.Gh, lds.tv, lds.te, lds.tits, (double)ss);
+    int trips;
+    if constexpr (SCHEME == 0) trips = es_minimise_queue(n_tasks, lds.tlist, lds.Gh, lds.tv, lds.te, lds.tits, (double)ss);
+    else trips = es_minimise_queue_alt<SCHEME>(n_tasks, lds.tlist, lds.Gh, lds.tv, lds.te, lds.tits, nullptr);
     lds_sync();
     PNEC_PHASE_END(kRpNewton);
     if (a.trace) {  // diagnostics (per wavefront = two pairs; halved on the way out): Newton iterations of the round's
@@ -2691,7 +2897,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
 #pragma unroll
         for (int i = 0; i < 9; ++i) lds.models[hyp][i] = R[i];
         lds.models[hyp][9] = t[0]; lds.models[hyp][10] = t[1]; lds.models[hyp][11] = t[2];
-        lds.models[hyp][kModelCapped] = lds.tits[slot] >= kHypothesisMaxIterations ? 1.0 : 0.0;
+        lds.models[hyp][kModelCapped] = (SCHEME == 0 && lds.tits[slot] >= kHypothesisMaxIterations) ? 1.0 : 0.0;
       }
       lds_sync();
       ScoreTiles tiles;  // the pair's bearings for the scoring (issue and wait back to back, see the one-pair kernel)
@@ -2882,6 +3088,14 @@ __global__ __launch_bounds__(kWave) void select_kernel(int nc, const double *src
     for (int c = c_begin; c < c_end; ++c) db[(int64_t)c * dstride + idx] = 0.0;
 }
 
+// the eigensolver on a pair's sums with PNEC::Eigensolver's tail, by scheme
+static void launch_es_batch_translation(const EsBatchArgs &b, int scheme, hipStream_t stream) {
+  const dim3 grid(es_batch_blocks(b.n_pairs)), block(kWave);
+  if (scheme == 1) hipLaunchKernelGGL((es_batch_alt_kernel<kEpiTranslation, 1>), grid, block, 0, stream, b, 1);
+  else if (scheme == 2) hipLaunchKernelGGL((es_batch_alt_kernel<kEpiTranslation, 2>), grid, block, 0, stream, b, 1);
+  else hipLaunchKernelGGL(es_batch_kernel<kEpiTranslation>, grid, block, 0, stream, b);
+}
+
 hipError_t launch_select(int nc, const double *src, const int64_t *src_block, const int64_t *src_offsets,
                          const int32_t *src_count, const uint8_t *mask, double *dst, const int64_t *dst_block,
                          const int32_t *dst_count_in, int32_t *dst_count_out, int64_t *single_offsets, int64_t n_pairs,
@@ -2897,117 +3111,8 @@ hipError_t launch_select(int nc, const double *src, const int64_t *src_block, co
   return hipGetLastError();
 }
 
-// ---- the split form's workspace (pnec_ransac_split.inl): per-pair state, the pair lists, two task pools, counters.
-// Pool A holds a round of sixteen hypotheses for every pair; pool B what the later rounds' pairs ask for (most pairs are
-// done after one round; a pair that does not fit is handed to the resumed one-pair kernel -- slower, never wrong).
-constexpr int kSplitCounters = 64;
-constexpr int kSplitMaxRounds = 6;
-static int64_t split_pool_a(int64_t P) { return (int64_t)kHypPerRound * P; }
-static int64_t split_pool_b(int64_t P) { return 4 * P + 4096; }
-size_t ransac_workspace_bytes(int64_t n_pairs) {
-  const int64_t P = n_pairs, ta = split_pool_a(P), tb = split_pool_b(P);
-  size_t b = 0;
-  b += sizeof(double) * (size_t)(13 * P);                      // k, model
-  b += sizeof(double) * (size_t)((ta + tb) * kTaskD);          // task records
-  b += sizeof(int32_t) * (size_t)(4 * P + 3 * P);              // it, best, needed, task0 | two lists + the hand-over list
-  b += sizeof(int32_t) * (size_t)((ta + tb) * kTaskSel);       // samples
-  b += sizeof(int32_t) * kSplitCounters;
-  return b + 256;
-}
-// The split form is an A/B build of the stage, not its default: bit-identical to the other forms and, as measured in
-// round 4, slower (3.67 against 2.55 ms per 20 000 pairs: DESIGN.md 12).  PNEC_RANSAC_FORM=3 switches it on for batches
-// of PNEC_RANSAC_SPLIT_MIN (4096) pairs and more; nothing is allocated for it otherwise.
-int64_t ransac_split_threshold() {
-  static const int64_t thr = [] {
-    const char *form = std::getenv("PNEC_RANSAC_FORM");
-    if (!form || std::atoi(form) != 3) return (int64_t)1 << 62;
-    const char *ev = std::getenv("PNEC_RANSAC_SPLIT_MIN");
-    return ev && *ev ? (int64_t)std::atoll(ev) : (int64_t)4096;
-  }();
-  return thr;
-}
-
-static hipError_t launch_ransac_split(RansacArgs a, void *ws, hipStream_t stream) {
-  const int64_t P = a.n_pairs, ta = split_pool_a(P), tb = split_pool_b(P);
-  // carve the workspace (doubles first: alignment)
-  double *d = reinterpret_cast<double *>(ws);
-  RansacSplitArgs s;
-  std::memset(&s, 0, sizeof(s));
-  s.st.k = d; d += P;
-  s.st.model = d; d += 12 * P;
-  RansacPool pool[2];
-  pool[0].rec = d; d += ta * kTaskD; pool[0].cap = (int32_t)std::min<int64_t>(ta, 0x7fffffff);
-  pool[1].rec = d; d += tb * kTaskD; pool[1].cap = (int32_t)std::min<int64_t>(tb, 0x7fffffff);
-  int32_t *ip = reinterpret_cast<int32_t *>(d);
-  s.st.it = ip; ip += P;
-  s.st.best = ip; ip += P;
-  s.st.needed = ip; ip += P;
-  s.st.task0 = ip; ip += P;
-  int32_t *list[2];
-  list[0] = ip; ip += P;
-  list[1] = ip; ip += P;
-  int32_t *left = ip; ip += P;
-  pool[0].sel = ip; ip += ta * kTaskSel;
-  pool[1].sel = ip; ip += tb * kTaskSel;
-  int32_t *cnt = ip;  // [round][4]: tasks claimed, queue position, pairs listed | [kSplitCounters - 1]: pairs handed over
-  hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int32_t) * kSplitCounters, stream);
-  if (e != hipSuccess) return e;
-  static const int rounds = [] {
-    const char *ev = std::getenv("PNEC_RANSAC_ROUNDS");
-    const int r = ev && *ev ? std::atoi(ev) : 3;
-    return r < 1 ? 1 : (r > kSplitMaxRounds ? kSplitMaxRounds : r);
-  }();
-  static const int cap2 = [] {
-    const char *ev = std::getenv("PNEC_RANSAC_ROUND_CAP");
-    const int r = ev && *ev ? std::atoi(ev) : 64;
-    return r < 16 ? 16 : (r / 16) * 16;
-  }();
-  int32_t *n_left = cnt + kSplitCounters - 1;
-  s.r = a;
-  s.list_left = left;
-  s.n_list_left = n_left;
-  const unsigned queue_waves = 2048;  // 256 CUs x 4 SIMDs x 2: every slot of the device, each pulling until the queue is dry
-  for (int r = 1; r <= rounds + 1; ++r) {
-    // launch r: consume round r-1's hypotheses (r > 1), prepare round r's (r <= rounds)
-    RansacPool &nx = pool[(r - 1) & 1], &pv = pool[r & 1];
-    s.prev = pv;
-    s.prev.n_tasks = cnt + 4 * (r - 1);
-    s.prev.queue = cnt + 4 * (r - 1) + 1;
-    s.next = nx;
-    s.next.n_tasks = cnt + 4 * r;
-    s.next.queue = cnt + 4 * r + 1;
-    s.list_prev = r > 1 ? list[(r - 1) & 1] : nullptr;
-    s.n_list_prev = r > 1 ? cnt + 4 * (r - 1) + 2 : nullptr;
-    s.list_next = list[r & 1];
-    s.n_list_next = cnt + 4 * r + 2;
-    s.cap_round = r == 1 ? kHypPerRound : (r == 2 ? cap2 : 4 * cap2);
-    s.last = r > rounds ? 1 : 0;
-    if (r == 1) {
-      hipLaunchKernelGGL(ransac_round_kernel<true>, dim3((unsigned)P), dim3(kWave), 0, stream, s);
-    } else {
-      const unsigned blocks = (unsigned)(r == 2 ? P : std::max<int64_t>(256, P / 4));
-      hipLaunchKernelGGL(ransac_round_kernel<false>, dim3(blocks), dim3(kWave), 0, stream, s);
-    }
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (r <= rounds) {
-      EsQueueArgs q;
-      q.pool = s.next;
-      const unsigned waves = (unsigned)std::min<int64_t>(queue_waves, r == 1 ? P : std::max<int64_t>(64, P / 4));
-      hipLaunchKernelGGL(es_queue_kernel, dim3(waves), dim3(kWave), 0, stream, q);
-      if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
-  }
-  // whoever is still going: the one-pair kernel from where the rule stands
-  a.resume_list = left;
-  a.resume_count = n_left;
-  a.resume = s.st;
-  hipLaunchKernelGGL(ransac_eigensolver_kernel<true>, dim3((unsigned)std::min<int64_t>(P, 1024)), dim3(kWave), 0, stream, a);
-  return hipGetLastError();
-}
-
 // sel (optional): InlierExtraction fused into each pair's last pass -- nc component planes, target planes / block layout /
-// counts (+ the AoS offsets of a ONE-pair batch).  ws (optional): ransac_workspace_bytes(n_pairs) bytes of device memory;
-// with it, batches of ransac_split_threshold() pairs and more run the split form.
+// counts (+ the AoS offsets of a ONE-pair batch).
 // Launch order of the two-pair form from the iteration counts of an EARLIER solve of the same pairs (or of their
 // predecessors in a stream of frames): a launch ends with its slowest wavefronts, and the pairs that need a second and
 // third round of hypotheses (a tenth of them; their wavefronts run two to three times the median) end it late when they
@@ -3071,8 +3176,8 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
                                      int32_t *out_count, int32_t *out_iterations, double *scratch_d,
                                      int32_t *scratch_i, hipStream_t stream, hipStream_t tail_stream,
                                      hipEvent_t tail_fork, hipEvent_t tail_done, int sel_nc, double *sel_data,
-                                     const int64_t *sel_block, int32_t *sel_count, int64_t *sel_single_offsets, void *ws,
-                                     const int32_t *order) {
+                                     const int64_t *sel_block, int32_t *sel_count, int64_t *sel_single_offsets,
+                                     const int32_t *order, int scheme) {
   // order (optional): the pairs in launch order (ransac_order_kernel; honoured by the two-pair form)
   // tail_stream (optional): the eigensolver on the inliers (es_batch_kernel, which writes out_q / out_t) runs
   // there, forked from `stream` after the RANSAC kernel -- the caller goes on with work that only needs the
@@ -3120,24 +3225,22 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
     const char *ev = std::getenv("PNEC_RANSAC_FORM");
     return ev && *ev ? std::atoi(ev) : 0;
   }();
-  // PNEC_RANSAC_FORM=1|2|3 forces the one-pair / two-pair / split form (A/B runs; 3 needs the workspace)
-  const bool split = ws && !a.trace && forced_form == 3 && n_pairs >= ransac_split_threshold();
-  const bool two = !split && (forced_form == 1 ? false : (forced_form == 2 ? true : n_pairs >= 4096));
+  // (schemes 1 and 2 exist in the two-pair kernel only: a handful of pairs run it with a wavefront each, n_double = 0)
+  const bool two = scheme != 0 || (forced_form == 1 ? false : (forced_form == 2 ? true : n_pairs >= 4096));
   hipError_t e = hipSuccess;
-  if (split) {
-    e = launch_ransac_split(a, ws, stream);
+  if (two) {
+    a.order = order;
+    const int64_t singles = n_pairs < 4096 && forced_form != 2 ? n_pairs & ~(int64_t)1
+                                                                : std::min<int64_t>(ransac_tail_singles(n_pairs), n_pairs) & ~(int64_t)1;  // (even: the rest pairs up)
+    a.n_double = (n_pairs - singles + 1) / 2;
+    const int64_t blocks = a.n_double + (n_pairs - std::min<int64_t>(2 * a.n_double, n_pairs));
+    if (scheme == 1) hipLaunchKernelGGL(ransac2_eigensolver_kernel<1>, dim3((unsigned)blocks), dim3(kWave), 0, stream, a);
+    else if (scheme == 2) hipLaunchKernelGGL(ransac2_eigensolver_kernel<2>, dim3((unsigned)blocks), dim3(kWave), 0, stream, a);
+    else hipLaunchKernelGGL(ransac2_eigensolver_kernel<0>, dim3((unsigned)blocks), dim3(kWave), 0, stream, a);
   } else {
-    if (two) a.order = order;
-    if (two) {
-      const int64_t singles = std::min<int64_t>(ransac_tail_singles(n_pairs), n_pairs) & ~(int64_t)1;  // (even: the rest pairs up)
-      a.n_double = (n_pairs - singles + 1) / 2;
-      const int64_t blocks = a.n_double + (n_pairs - std::min<int64_t>(2 * a.n_double, n_pairs));
-      hipLaunchKernelGGL(ransac2_eigensolver_kernel, dim3((unsigned)blocks), dim3(kWave), 0, stream, a);
-    }
-    else
-      hipLaunchKernelGGL(ransac_eigensolver_kernel<false>, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
-    e = hipGetLastError();
+    hipLaunchKernelGGL(ransac_eigensolver_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
   }
+  e = hipGetLastError();
   if (e == hipSuccess) {
     EsBatchArgs b;
     std::memset(&b, 0, sizeof(b));
@@ -3155,7 +3258,7 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
       if (e != hipSuccess) return e;
       es_stream = tail_stream;
     }
-    hipLaunchKernelGGL(es_batch_kernel<kEpiTranslation>, dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, es_stream, b);
+    launch_es_batch_translation(b, scheme, es_stream);
     e = hipGetLastError();
     if (e == hipSuccess && tail_stream) e = hipEventRecord(tail_done, tail_stream);
   }
@@ -3343,7 +3446,7 @@ hipError_t frontend_work_counters(int reset, unsigned long long *out16, int *com
 hipError_t launch_nec_eigensolver(const double *data, const int64_t *block_offset, const int32_t *count,
                                   int64_t n_pairs, const double *init_q, double *out_q, double *out_t,
                                   int32_t *out_iterations, double *scratch_d, int32_t *scratch_i,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, int scheme) {
   if (n_pairs <= 0) return hipSuccess;
   FrontArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -3365,7 +3468,7 @@ hipError_t launch_nec_eigensolver(const double *data, const int64_t *block_offse
   b.out_q = out_q;
   b.out_t = out_t;
   b.out_iterations = out_iterations;
-  hipLaunchKernelGGL(es_batch_kernel<kEpiTranslation>, dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, stream, b);
+  launch_es_batch_translation(b, scheme, stream);
   return hipGetLastError();
 }
 
@@ -3373,7 +3476,7 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
                                        const int32_t *count, int64_t n_pairs, int n_max, const double *init_q,
                                        const double *init_t, double reg, int weighted_iterations,
                                        double *out_q, double *out_t, int32_t *out_iterations,
-                                       double *scratch_d, int32_t *scratch_i, hipStream_t stream) {
+                                       double *scratch_d, int32_t *scratch_i, hipStream_t stream, int scheme) {
   if (n_pairs <= 0) return hipSuccess;
   FrontArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -3404,7 +3507,13 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
       (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), zeros, sizeof(zeros), 12 * sizeof(unsigned long long));
     }
 #endif
-    hipLaunchKernelGGL(es_batch_kernel<kEpiNone>, dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, stream, b);
+    const int rounds = std::min(weighted_iterations - 1, kEsMaxRounds);  // (the ABI refuses more under schemes 1, 2)
+    if (scheme == 1)
+      hipLaunchKernelGGL((es_batch_alt_kernel<kEpiNone, 1>), dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, stream, b, rounds);
+    else if (scheme == 2)
+      hipLaunchKernelGGL((es_batch_alt_kernel<kEpiNone, 2>), dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, stream, b, rounds);
+    else
+      hipLaunchKernelGGL(es_batch_kernel<kEpiNone>, dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, stream, b);
     if ((e = hipGetLastError()) != hipSuccess) return e;
 #ifdef PNEC_FRONT_DEBUG
     {
@@ -3421,6 +3530,11 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
   a.pre_G = sc.G;
   a.pre_v = sc.v;
   a.pre_its = sc.its;
+  a.n_pairs = n_pairs;
+  if (scheme != 0) {
+    a.pre_v_rounds = sc.v_rounds;
+    a.pre_n_es = sc.n_es;
+  }
   // PNEC_HIP_TRACE_FRONT=1: per-phase clocks of every pair, averaged and printed to stderr (diagnostics;
   // synchronises, never set it for timed runs)
   const char *tr = std::getenv("PNEC_HIP_TRACE_FRONT");

@@ -21,6 +21,7 @@ void pnec_hip_default_pipeline_options(pnec_hip_pipeline_options *o) {
   o->ransac_threshold = 1.0e-6;    // pnec.cc:248
   o->ransac_seed = 1;
   pnec_hip_default_options(&o->solver);  // PNEC::CeresSolver default-constructs its optimiser (pnec.cc:355)
+  o->eigensolver_scheme = PNEC_HIP_ES_NEWTON;
 }
 
 // this batch's bearings as a NEC-family batch: the first six planes of every block are f1 | f2 whatever
@@ -110,7 +111,6 @@ static int pipeline_on(pnec_hip_problem *p, const double *d_iq, const double *d_
     const bool fork = P >= 1024;
     if (fork)
       if (int rc = ensure_side_streams(p, 1)) return rc;
-    if (int rc = ensure_ransac_ws(p)) return rc;
     // InlierExtraction -- when a later stage works on the inliers.  With use_nec and no refinement (what the
     // reference's odometry forces, frame2frame.cc:127-128) or with neither weighted iterations nor refinement the chain
     // ends at the eigensolver's pose: the inlier mask and count are the outputs, and the copy would feed nothing.
@@ -139,8 +139,8 @@ static int pipeline_on(pnec_hip_problem *p, const double *d_iq, const double *d_
                                   d_mask, d_cnt, p->order_hint ? p->d_hint_its : nullptr, p->d_front, p->d_front_i, stream, fork ? p->side_streams[0] : nullptr,
                                   fork ? p->fork_event : nullptr, fork ? p->side_done[0] : nullptr, p->nc,
                                   sv ? sv->d_data : nullptr, sv ? sv->d_block_offset : nullptr, sv ? sv->d_count : nullptr,
-                                  sv && !sv_given && P == 1 ? sv->d_offsets : nullptr, p->d_ransac_ws,
-                                  p->order_hint && p->order_pairs == P ? p->d_order : nullptr);
+                                  sv && !sv_given && P == 1 ? sv->d_offsets : nullptr,
+                                  p->order_hint && p->order_pairs == P ? p->d_order : nullptr, o.eigensolver_scheme);
     if (e == hipSuccess && p->order_hint) {   // the next call's launch order from this call's counts (pnec_hip_problem_launch_order_hint)
       e = launch_ransac_order(p->d_hint_its, P, p->d_order, stream);
       p->order_pairs = P;
@@ -154,7 +154,7 @@ static int pipeline_on(pnec_hip_problem *p, const double *d_iq, const double *d_
     if (fork) PNEC_HIP_TRY(hipStreamWaitEvent(stream, p->side_done[0], 0));  // es_q / es_t are there from here on
   } else {
     e = launch_nec_eigensolver(p->d_data, p->d_block_offset, p->d_count, P, d_iq, es_q, es_t, nullptr, p->d_front,
-                               p->d_front_i, stream);
+                               p->d_front_i, stream, o.eigensolver_scheme);
     if (e != hipSuccess) return fail_hip(e, "nec_eigensolver_kernel");
     if (want_count_zeros) PNEC_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * P, stream));  // inliers.clear()
   }
@@ -174,7 +174,7 @@ static int pipeline_on(pnec_hip_problem *p, const double *d_iq, const double *d_
       // (the front scratch of p is free again: the RANSAC / eigensolver stage that used it is ahead on the stream)
       e = launch_weighted_eigensolver(p->device, stage->d_data, stage->d_block_offset, stage->d_count, P, stage->n_max,
                                       es_q, es_t, o.regularization, o.weighted_iterations, w_q, w_t, nullptr, p->d_front,
-                                      p->d_front_i, stream);
+                                      p->d_front_i, stream, o.eigensolver_scheme);
       if (e != hipSuccess) return fail_hip(e, "weighted_eigensolver_kernel");
       ci_q = w_q; ci_t = w_t;
     } else if (o.weighted_iterations == 1) {
@@ -224,6 +224,10 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
   if (opt_in) o = *opt_in; else pnec_hip_default_pipeline_options(&o);
   if (o.first_pair_id < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "first_pair_id < 0");
   if (o.weighted_iterations < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "weighted_iterations < 0");
+  if (o.eigensolver_scheme < PNEC_HIP_ES_NEWTON || o.eigensolver_scheme > PNEC_HIP_ES_LM)
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "eigensolver_scheme: 0 (Newton), 1 (descent) or 2 (LM)");
+  if (o.eigensolver_scheme != PNEC_HIP_ES_NEWTON && !o.use_nec && o.weighted_iterations - 1 > kEsMaxRounds)
+    return fail(PNEC_HIP_ERR_UNSUPPORTED, "eigensolver schemes 1 and 2 hold at most 16 weighted_iterations");
   if (!o.use_nec && p->mode != PNEC_HIP_MODE_TARGET)
     return fail(PNEC_HIP_ERR_UNSUPPORTED, "the PNEC chain needs a TARGET-mode problem (bearings + frame-2 covariances)");
   if (o.use_ransac && (o.max_ransac_iterations < 0 || o.ransac_sample_size < 1))

@@ -17,9 +17,15 @@ from pnec_amd import simulation as sim
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+# which iteration the eigenvalue minimisations run (include/pnec_hip.h pnec_hip_eigensolver_scheme): device AND oracle
+SCHEME = int(sys.argv[3]) if len(sys.argv) > 3 else int(os.environ.get("PNEC_ES_SCHEME", "0"))
+po.set_eigensolver_scheme(SCHEME)
 dev = torch.device("cuda:0")
 batch = Batch.uniform(capi.MODE_TARGET, B, N)
 extra = [Batch.uniform(capi.MODE_TARGET, B, N) for _ in range(2)]   # copies: three calls in flight (below)
+for b_ in [batch] + extra:
+    b_.set_eigensolver_scheme(SCHEME)
+O_DEF = capi.default_pipeline_options(eigensolver_scheme=SCHEME)
 qs, ts, first = [], [], None
 for c in range(0, B, 5000):
     m = min(5000, B - c)
@@ -52,11 +58,11 @@ t_sel, sel = timed(lambda: batch.select(mask))
 t_wes, (qw, tw) = timed(lambda: sel.weighted_eigensolver(qr, tr, 1e-13, 10))
 t_ls, res = timed(lambda: sel.solve(qw, tw))
 # the product path: the whole chain as ONE call (pnec_hip_solve_pipeline; no host synchronisation between stages)
-t_one, (q_one, t_one_t) = timed(lambda: batch.solve_pipeline(q0, t0), reps=5)
+t_one, (q_one, t_one_t) = timed(lambda: batch.solve_pipeline(q0, t0, O_DEF), reps=5)
 one_call_equals_stages = bool(torch.equal(q_one, res.q) and torch.equal(t_one_t, res.t))
 # what the reference's odometry actually runs per frame pair: Frame2Frame forces use_nec, no refinement
 # (frame2frame.cc:127-128, quirk C2): the chain ends at the RANSAC eigensolver's pose (no InlierExtraction needed)
-o_vo = capi.default_pipeline_options(use_nec=1, use_ceres=0)
+o_vo = capi.default_pipeline_options(use_nec=1, use_ceres=0, eigensolver_scheme=SCHEME)
 t_vo, _ = timed(lambda: batch.solve_pipeline(q0, t0, o_vo), reps=5)
 # ... and with three calls in flight, each on its own stream and its own copy of the batch: the stages end in tails of a
 # few long pairs (a quarter of the RANSAC launch at this size); the next call's work fills them
@@ -69,7 +75,7 @@ def in_flight(rounds=4):
     for _ in range(rounds):
         for b_, s_ in zip(copies, streams):
             with torch.cuda.stream(s_):
-                outs.append(b_.solve_pipeline(q0, t0))
+                outs.append(b_.solve_pipeline(q0, t0, O_DEF))
     return outs
 
 
@@ -85,8 +91,8 @@ if not os.environ.get("PNEC_NO_INFLIGHT"):   # (the kernel-trace profile wants e
 # the previous call are dispatched first.  Here the previous call solved THE SAME batch, i.e. the hint is perfect: the
 # upper bound of what a stream of temporally coherent frame pairs gets from it
 batch.launch_order_hint(True)
-batch.solve_pipeline(q0, t0); torch.cuda.synchronize()
-t_hint, (q_hint, t_hint_t) = timed(lambda: batch.solve_pipeline(q0, t0), reps=5)
+batch.solve_pipeline(q0, t0, O_DEF); torch.cuda.synchronize()
+t_hint, (q_hint, t_hint_t) = timed(lambda: batch.solve_pipeline(q0, t0, O_DEF), reps=5)
 t_vo_hint, _ = timed(lambda: batch.solve_pipeline(q0, t0, o_vo), reps=5)
 hint_equal = bool(torch.equal(q_hint, q_one) and torch.equal(t_hint_t, t_one_t))
 batch.launch_order_hint(False)
@@ -109,6 +115,7 @@ for p in range(n_s):
     worst = max(worst, np.radians(po.rotational_difference_deg(s.R, po.rot_from_quat(gq))))
 print(json.dumps({
     "workload": f"{B} pairs x {N} corr, 10 % gross outliers, reference-default Options (RANSAC eigensolver, 10 weighted iterations, LS with Ceres-default termination)",
+    "eigensolver_scheme": SCHEME,
     "gpu_ms": {"nec_es (no ransac)": t_nec * 1e3, "ransac_es": t_ran * 1e3, "inlier_extraction": t_sel * 1e3,
                "weighted_es+scf": t_wes * 1e3, "ls_refinement": t_ls * 1e3},
     "gpu_pairs_per_s_full_pipeline": B / (t_ran + t_sel + t_wes + t_ls),
