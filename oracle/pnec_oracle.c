@@ -660,6 +660,8 @@ static int chol_solve5(const double A[25], const double b[5], double y[5]) {
 
 /* Ceres TrustRegionMinimizer + LevenbergMarquardtStrategy [EXT], default options. */
 /* diagnostics (test tooling): how many LM steps reached the accept / reject decision, and how many were rejected */
+static int g_lm_diagnostics = 0; /* pnec_oracle_lm_diagnostics(1) switches the counters below on */
+void pnec_oracle_lm_diagnostics(int on) { g_lm_diagnostics = on; }
 static long long g_lm_steps_evaluated = 0, g_lm_steps_rejected = 0;
 static long long g_lm_promise[2][24][2]; /* [after accepted-or-first | after rejected][decade of model_change / cost, -24 .. -1][accepted | rejected] */
 void pnec_oracle_lm_promise_histogram(long long out[96]) { memcpy(out, g_lm_promise, sizeof(g_lm_promise)); memset(g_lm_promise, 0, sizeof(g_lm_promise)); }
@@ -763,13 +765,13 @@ static int minimise(const problem_t *P, const pnec_oracle_options *o, state_t *x
       }
     }
     const double rho = (cost - cost_c) / model_cost_change;
+    if (g_lm_diagnostics) {   /* test tooling, off unless switched on: the timed baseline runs without it */
 #pragma omp atomic
-    g_lm_steps_evaluated += 1;
-    if (!(rho > o->min_relative_decrease)) {
+      g_lm_steps_evaluated += 1;
+      if (!(rho > o->min_relative_decrease)) {
 #pragma omp atomic
-      g_lm_steps_rejected += 1;
-    }
-    {
+        g_lm_steps_rejected += 1;
+      }
       const int now = rho > o->min_relative_decrease ? 0 : 1;
 #pragma omp atomic
       g_lm_transitions[prev_outcome][now] += 1;

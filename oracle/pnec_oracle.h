@@ -104,6 +104,8 @@ double pnec_oracle_cost_function(int64_t n, const double *bvs1, const double *bv
 /* diagnostics: LM steps that reached Ceres' accept / reject decision since the last reset, how many were rejected, and
  * the outcome by predecessor: out[2 + 2 a + b], a = first step | after an accepted | after a rejected, b = accepted | rejected */
 void pnec_oracle_lm_step_counts(int reset, long long out[8]);
+/* ... counted only while switched on (off by default: the timed CPU baseline carries no test tooling) */
+void pnec_oracle_lm_diagnostics(int on);
 /* pnec::common::RotationBetweenPoints (common.cc:118-124) for unit vectors; out column-major */
 void pnec_oracle_rotation_between_points(const double p1[3], const double p2[3], double out[9]);
 void pnec_oracle_unscented_transform(const double mu[3], const double cov[9], const double K_inv[9],

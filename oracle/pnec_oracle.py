@@ -66,6 +66,32 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+
+
+def use_library(path: str | None = None) -> str:
+    """Load another build of the same sources from here on (bench.py: the -march=native build made on the box the CPU
+    baseline is timed on); None: back to oracle/libpnec_oracle.so.  Returns the path in use."""
+    global _lib, _LIB_PATH
+    _LIB_PATH = path or os.path.join(_HERE, "libpnec_oracle.so")
+    _lib = None
+    lib()
+    return _LIB_PATH
+
+
+def build_native() -> str | None:
+    """`make -C oracle native` (gcc -O3 -march=native on THIS host); None when there is no compiler or the build fails."""
+    import shutil
+    if not (shutil.which("gcc") or shutil.which("cc")) or not shutil.which("make"):
+        return None
+    try:
+        subprocess.run(["make", "-C", _HERE, "native"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       timeout=300)
+    except (subprocess.SubprocessError, OSError):
+        return None
+    out = os.path.join(_HERE, "_native", "libpnec_oracle.so")
+    return out if os.path.exists(out) else None
+
+
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 _lp = C.POINTER(C.c_int64)

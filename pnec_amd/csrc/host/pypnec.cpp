@@ -282,13 +282,13 @@ PYBIND11_MODULE(pypnec, m) {
   m.def("solve", &solve, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"), py::arg("init_pose"),
         py::arg("overload") = 1, py::arg("use_ransac") = true, py::arg("use_nec") = false,
         py::arg("use_ceres") = true, py::arg("weighted_iterations") = 10, py::arg("regularization") = 1e-13,
-        py::arg("eigensolver_scheme") = 0,
+        py::arg("eigensolver_scheme") = 2,
         "PNEC::Solve for one frame pair through one of its four overloads (eigensolver_scheme: which iteration stands in "
         "for opengv's eigenvalue minimisation, include/pnec_hip.h)");
   m.def("solve_batch", &solve_batch, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"), py::arg("init_poses"),
         py::arg("use_ransac") = true, py::arg("use_nec") = false, py::arg("use_ceres") = true,
         py::arg("weighted_iterations") = 10, py::arg("regularization") = 1e-13, py::arg("devices") = std::vector<int>{},
-        py::arg("eigensolver_scheme") = 0,
+        py::arg("eigensolver_scheme") = 2,
         "PNEC::Solve for a list of frame pairs, every stage one device launch over the batch (addition); devices: the "
         "GPUs to shard the pairs over from this process (empty: the default device)");
   m.def("ceres_solver_batch", &ceres_solver_batch, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"),

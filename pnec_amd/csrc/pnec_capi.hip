@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "pnec_device.hpp"
+#include "pnec_front_shared.hpp"
 #include "pnec_solve_kernel.hpp"
 
 namespace pnec_hip {

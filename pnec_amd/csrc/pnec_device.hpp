@@ -21,8 +21,6 @@ namespace pnec_hip {
 constexpr int kWave = 64;
 constexpr int kNumAcc = 21;  // sum r^2 | J'r (5) | upper triangle of J'J (15)
 
-// eigensolver schemes 1, 2: most rounds of the weighted stage (weighted_iterations - 1) whose minimisers the front scratch holds
-constexpr int kEsMaxRounds = 15;
 __host__ __device__ constexpr int num_components(int mode) {
   return mode == PNEC_HIP_MODE_NEC ? 6 : (mode == PNEC_HIP_MODE_SYM ? 18 : 12);
 }

@@ -49,6 +49,7 @@
 #include <vector>
 
 #include "pnec_device.hpp"
+#include "pnec_front_shared.hpp"
 
 namespace pnec_hip {
 
@@ -3381,6 +3382,37 @@ hipError_t launch_frontend_selftest(double *d_out /* 192 doubles */, hipStream_t
   hipLaunchKernelGGL(eig_selftest_kernel, dim3(1), dim3(kWave), 0, stream, d_out);
   return hipGetLastError();
 }
+
+#ifdef PNEC_ISA_PROBE
+// -DPNEC_ISA_PROBE (tools/isa_front_regions.py only): the pieces of one evaluation of the eigenvalue function as kernels
+// of their own, so that their FP64 instructions can be counted in the assembly: the rotation from the Cayley vector, M from
+// the 36 sums, and the whole evaluation with and without its gradient (the difference is the gradient).
+__global__ void probe_cayley_kernel(const double *vin, double *out) {
+  const double v[3] = {vin[0], vin[1], vin[2]};
+  double R[9];
+  cayley_to_rot(v, R);
+  for (int i = 0; i < 9; ++i) out[i] = R[i];
+}
+__global__ void probe_m_kernel(const double *G, const double *Rin, double *out) {
+  double Gr[36], R[9], M[9];
+  for (int i = 0; i < 36; ++i) Gr[i] = G[i];
+  for (int i = 0; i < 9; ++i) R[i] = Rin[i];
+  sums_to_m(Gr, R, M);
+  for (int i = 0; i < 9; ++i) out[i] = M[i];
+}
+template <bool GRAD>
+__global__ void probe_value_grad_kernel(const double *G, const double *vin, double *out) {
+  __shared__ double Gs[36];
+  if (threadIdx.x < 36) Gs[threadIdx.x] = G[threadIdx.x];
+  __syncthreads();
+  const double v[3] = {vin[0], vin[1], vin[2]};
+  double g[3] = {0.0, 0.0, 0.0}, e[3] = {vin[3], vin[4], vin[5]};
+  out[0] = es_value_grad<1>(Gs, v, GRAD ? g : nullptr, nullptr, e, true);
+  out[1] = g[0]; out[2] = g[1]; out[3] = g[2]; out[4] = e[0]; out[5] = e[1]; out[6] = e[2];
+}
+template __global__ void probe_value_grad_kernel<true>(const double *, const double *, double *);
+template __global__ void probe_value_grad_kernel<false>(const double *, const double *, double *);
+#endif
 
 // ------------------------------------------------------------------------------------------
 // host side: launchers called from pnec_capi.hip
