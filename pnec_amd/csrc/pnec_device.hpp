@@ -373,80 +373,85 @@ __device__ __forceinline__ bool rows_all_finite(const double (&c)[6]) {
   return __builtin_amdgcn_ballot_w64(!(z == 0.0)) == 0ull;
 }
 
-// One 8-byte global load in the scalar-base form, destination DST (read-write operand: lanes the caller masks off keep
-// their value), 32-bit lane offset LO, scalar base PL, immediate IMM.  The base goes through an s_mov inside the
-// statement: when the compiler has just fetched PL with a VALU instruction (v_readlane from a spilled-SGPR lane,
-// v_readfirstlane), a vector-memory instruction reading that SGPR needs five wait states (CDNA ISA, "manually inserted
-// wait states") -- the compiler inserts them for its own instructions and cannot see into this text.  Scalar reads of
-// such a register are interlocked, and a scalar-written register has no such rule, so the copy is all it takes.
-// (Found the hard way: a kernel with enough scalar state to spill it addressed these loads with the register's OLD
-// contents -- an exec mask for a pointer's upper half -- and faulted, or silently read elsewhere.)
-#define PNEC_GLOBAL_LOAD_SADDR(DST, LO, PL, IMM)                                                                   \
-  do {                                                                                                           \
-    unsigned long long pnec_sbase_;                                                                              \
-    asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx2 %0, %2, %1 offset:%4"                                  \
-                 : "+v"(DST), "=&s"(pnec_sbase_)                                                                 \
-                 : "v"(LO), "s"(PL), "n"(IMM)                                                                    \
-                 : "memory");                                                                                    \
-  } while (0)
-
 // One correspondence per lane from a pair's SoA planes in memory: plane c of the pair starts at sbase + c * plane_bytes
 // (scalar registers), the lane's correspondence sits `lo` + IMM bytes into it.  (The solver's tail pass, geometry
-// (12, 1, 3), and the weighted stage's table build.)  Spelled as
-// the scalar-base form of global_load (saddr + 32-bit voffset + immediate) because the compiler, left to itself,
-// keeps a 64-bit vector address per plane and slot alive across its loops -- registers these kernels do not have: the
-// solver spilled them, the weighted stage reloaded 96 of them from scratch one by one, each in front of its load.
-// Lanes beyond the planes (`in` false) keep the zeros they came with.  The s_waitcnt carries the values as operands,
-// so nothing that reads them can be scheduled in front of it.
+// (12, 1, 3).)  Spelled as the scalar-base form of global_load (saddr + 32-bit voffset + immediate) because the
+// compiler, left to itself, keeps a 64-bit vector address per plane and slot alive across its loops -- registers these
+// kernels do not have: the solver spilled them, the weighted stage reloaded 96 of them from scratch one by one, each in
+// front of its load.  Lanes beyond the planes (`in` false) keep the zeros they came with.
+//
+// ONE asm statement issues the loads AND waits for them (round 5; until then a statement per load and a separate wait
+// statement).  To the compiler an asm statement has written its outputs when it returns: between an issue statement and
+// a later wait statement it is free to copy, spill or re-use a destination register while the load that will really
+// write it is still in flight -- it did, once, under a tighter register budget (tools/check_asm_loads.py caught it after
+// the link; that check stays as a backstop, but correctness no longer rests on it).  Inside one statement there is no
+// "between".  The s_nop covers a plane base the compiler has just fetched with a VALU instruction (v_readlane from a
+// spilled-SGPR lane, v_readfirstlane): a vector-memory instruction reading that SGPR needs five wait states (CDNA ISA,
+// "manually inserted wait states"), which the compiler inserts for its own instructions and cannot see into this text.
+#define PNEC_LD_(D, B, OFF) "global_load_dwordx2 %[" #D "], %[lo], %[" #B "] offset:" OFF "\n\t"
 template <int NC, int IMM>
 __device__ __forceinline__ void load_planes_saddr(double (&e)[NC], const char *sbase, size_t plane_bytes, unsigned lo, bool in) {
   static_assert(NC == 6 || NC == 12, "tail form: 6- and 12-plane payloads");
 #pragma unroll
   for (int c = 0; c < NC; ++c) e[c] = 0.0;
   if (in) {
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const char *pl = sbase + (size_t)c * plane_bytes;
-      PNEC_GLOBAL_LOAD_SADDR(e[c], lo, pl, IMM);
+    if constexpr (NC == 12) {
+      asm volatile("s_nop 4\n\t"
+                   PNEC_LD_(d0, b0, "%[imm]") PNEC_LD_(d1, b1, "%[imm]") PNEC_LD_(d2, b2, "%[imm]") PNEC_LD_(d3, b3, "%[imm]")
+                   PNEC_LD_(d4, b4, "%[imm]") PNEC_LD_(d5, b5, "%[imm]") PNEC_LD_(d6, b6, "%[imm]") PNEC_LD_(d7, b7, "%[imm]")
+                   PNEC_LD_(d8, b8, "%[imm]") PNEC_LD_(d9, b9, "%[imm]") PNEC_LD_(d10, b10, "%[imm]") PNEC_LD_(d11, b11, "%[imm]")
+                   "s_waitcnt vmcnt(0)"
+                   : [d0] "+v"(e[0]), [d1] "+v"(e[1]), [d2] "+v"(e[2]), [d3] "+v"(e[3]), [d4] "+v"(e[4]), [d5] "+v"(e[5]),
+                     [d6] "+v"(e[6]), [d7] "+v"(e[7]), [d8] "+v"(e[8]), [d9] "+v"(e[9]), [d10] "+v"(e[10]), [d11] "+v"(e[11])
+                   : [lo] "v"(lo), [imm] "n"(IMM), [b0] "s"(sbase), [b1] "s"(sbase + plane_bytes), [b2] "s"(sbase + 2 * plane_bytes),
+                     [b3] "s"(sbase + 3 * plane_bytes), [b4] "s"(sbase + 4 * plane_bytes), [b5] "s"(sbase + 5 * plane_bytes),
+                     [b6] "s"(sbase + 6 * plane_bytes), [b7] "s"(sbase + 7 * plane_bytes), [b8] "s"(sbase + 8 * plane_bytes),
+                     [b9] "s"(sbase + 9 * plane_bytes), [b10] "s"(sbase + 10 * plane_bytes), [b11] "s"(sbase + 11 * plane_bytes)
+                   : "memory");
+    } else {
+      asm volatile("s_nop 4\n\t"
+                   PNEC_LD_(d0, b0, "%[imm]") PNEC_LD_(d1, b1, "%[imm]") PNEC_LD_(d2, b2, "%[imm]") PNEC_LD_(d3, b3, "%[imm]")
+                   PNEC_LD_(d4, b4, "%[imm]") PNEC_LD_(d5, b5, "%[imm]")
+                   "s_waitcnt vmcnt(0)"
+                   : [d0] "+v"(e[0]), [d1] "+v"(e[1]), [d2] "+v"(e[2]), [d3] "+v"(e[3]), [d4] "+v"(e[4]), [d5] "+v"(e[5])
+                   : [lo] "v"(lo), [imm] "n"(IMM), [b0] "s"(sbase), [b1] "s"(sbase + plane_bytes), [b2] "s"(sbase + 2 * plane_bytes),
+                     [b3] "s"(sbase + 3 * plane_bytes), [b4] "s"(sbase + 4 * plane_bytes), [b5] "s"(sbase + 5 * plane_bytes)
+                   : "memory");
     }
-    if constexpr (NC == 12)
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]),
-                     "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]));
-    else
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]));
   }
 }
 
-// The same loads without the wait, for callers that want several correspondences per lane in flight together:
-// issue them all (load_planes_issue), then planes_arrived() on the FIRST set -- s_waitcnt vmcnt(0): everything issued
-// before has landed -- and planes_after() on every other set, which ties its values to a point after that wait
-// (volatile statements keep their order; readers of the values depend on these statements' outputs).
-// NOTHING may stand between the issue and the wait: to the compiler the asm statement has written its output when it
-// returns, so it is free to copy, spill or re-use that register at once -- while the load that will really write it is
-// still in flight.  (RANSAC's scoring once had its model phase in between: the late writes landed in registers that
-// held other values by then -- wrong counts at some pair sizes, rounds that never ended at others.)
-template <int NC, int IMM>
-__device__ __forceinline__ void load_planes_issue(double (&e)[NC], const char *sbase, size_t plane_bytes, unsigned lo, bool in) {
+// EIGHT correspondences per lane (sets k = 0..7: correspondence 64 k + lane of this wavefront's share, 512 k bytes into
+// each plane) of a pair's TWELVE planes, all 96 loads in flight together, in one statement with its wait (the weighted
+// stage's table build).  Only the first `nt` sets are loaded -- the sets that start inside the pair's planes (the planes
+// are padded with zeros to a multiple of 64 correspondences, so a set that starts inside lies inside; one that starts
+// beyond may lie beyond the allocation) -- skipped wave-uniformly; the others keep the zeros they came with.
+#define PNEC_SET12_(K, OFF)                                                                                        \
+  "s_cmp_le_u32 %[nt], " #K "\n\ts_cbranch_scc1 1f\n\t"                                                            \
+  PNEC_LD_(d##K##_0, b0, OFF) PNEC_LD_(d##K##_1, b1, OFF) PNEC_LD_(d##K##_2, b2, OFF) PNEC_LD_(d##K##_3, b3, OFF)   \
+  PNEC_LD_(d##K##_4, b4, OFF) PNEC_LD_(d##K##_5, b5, OFF) PNEC_LD_(d##K##_6, b6, OFF) PNEC_LD_(d##K##_7, b7, OFF)   \
+  PNEC_LD_(d##K##_8, b8, OFF) PNEC_LD_(d##K##_9, b9, OFF) PNEC_LD_(d##K##_10, b10, OFF) PNEC_LD_(d##K##_11, b11, OFF)
+#define PNEC_SET12_OUT_(K)                                                                                          \
+  [d##K##_0] "+v"(pe[K][0]), [d##K##_1] "+v"(pe[K][1]), [d##K##_2] "+v"(pe[K][2]), [d##K##_3] "+v"(pe[K][3]),       \
+  [d##K##_4] "+v"(pe[K][4]), [d##K##_5] "+v"(pe[K][5]), [d##K##_6] "+v"(pe[K][6]), [d##K##_7] "+v"(pe[K][7]),       \
+  [d##K##_8] "+v"(pe[K][8]), [d##K##_9] "+v"(pe[K][9]), [d##K##_10] "+v"(pe[K][10]), [d##K##_11] "+v"(pe[K][11])
+__device__ __forceinline__ void load_sets8x12_saddr(double (&pe)[8][12], const char *sbase, size_t plane_bytes, unsigned lo,
+                                                    unsigned nt) {
 #pragma unroll
-  for (int c = 0; c < NC; ++c) e[c] = 0.0;
-  if (in) {
+  for (int k = 0; k < 8; ++k)
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const char *pl = sbase + (size_t)c * plane_bytes;
-      PNEC_GLOBAL_LOAD_SADDR(e[c], lo, pl, IMM);
-    }
-  }
-}
-__device__ __forceinline__ void planes_arrived(double (&e)[12]) {
-  asm volatile("s_waitcnt vmcnt(0)"
-               : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]),
-                 "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]));
-}
-__device__ __forceinline__ void planes_after(double (&e)[12]) {
-  asm volatile(""
-               : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]),
-                 "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]));
+    for (int c = 0; c < 12; ++c) pe[k][c] = 0.0;
+  asm volatile("s_nop 4\n\t"
+               PNEC_SET12_(0, "0") PNEC_SET12_(1, "512") PNEC_SET12_(2, "1024") PNEC_SET12_(3, "1536")
+               PNEC_SET12_(4, "2048") PNEC_SET12_(5, "2560") PNEC_SET12_(6, "3072") PNEC_SET12_(7, "3584")
+               "1:\n\ts_waitcnt vmcnt(0)"
+               : PNEC_SET12_OUT_(0), PNEC_SET12_OUT_(1), PNEC_SET12_OUT_(2), PNEC_SET12_OUT_(3), PNEC_SET12_OUT_(4),
+                 PNEC_SET12_OUT_(5), PNEC_SET12_OUT_(6), PNEC_SET12_OUT_(7)
+               : [lo] "v"(lo), [nt] "s"(nt), [b0] "s"(sbase), [b1] "s"(sbase + plane_bytes), [b2] "s"(sbase + 2 * plane_bytes),
+                 [b3] "s"(sbase + 3 * plane_bytes), [b4] "s"(sbase + 4 * plane_bytes), [b5] "s"(sbase + 5 * plane_bytes),
+                 [b6] "s"(sbase + 6 * plane_bytes), [b7] "s"(sbase + 7 * plane_bytes), [b8] "s"(sbase + 8 * plane_bytes),
+                 [b9] "s"(sbase + 9 * plane_bytes), [b10] "s"(sbase + 10 * plane_bytes), [b11] "s"(sbase + 11 * plane_bytes)
+               : "memory", "scc");
 }
 
 // ------------------------------------------------------------------------------------------

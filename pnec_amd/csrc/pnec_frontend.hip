@@ -860,21 +860,36 @@ __constant__ float c_fib32[500 * kFibStride];  // the same table rounded to sing
 // the directions' products txx tyy tzz | 2 txy 2 txz 2 tyz, one PLANE per product (the bound test of the weighted stage
 // reads them one direction per lane: 64 consecutive doubles per load instead of 64 lines); entries 500..511 are zero
 __device__ double c_fib_prod[6][512];
-// this lane's direction 64 J + lane: its six products from the planes above, in the scalar-base form of global_load
-// (see pnec_device.hpp load_planes_saddr for why), without a wait; fib_prod_arrived(first = true) is the wait for
-// everything issued so far, (first = false) ties a later set to a point after it
-template <int J>
-__device__ __forceinline__ void fib_prod_issue(double (&p)[6], const char *planes, unsigned voff) {
+// this lane's directions 64 (J0 + j) + lane, j = 0..3: their six products each from the planes above, in the scalar-base form of
+// global_load (see pnec_device.hpp load_planes_saddr for why): 24 loads and their wait in ONE statement
+#define PNEC_FIB_SET_(J, OFF)                                                                              \
+  PNEC_LD_(f##J##_0, b0, OFF) PNEC_LD_(f##J##_1, b1, OFF) PNEC_LD_(f##J##_2, b2, OFF) PNEC_LD_(f##J##_3, b3, OFF) \
+  PNEC_LD_(f##J##_4, b4, OFF) PNEC_LD_(f##J##_5, b5, OFF)
+#define PNEC_FIB_OUT_(J)                                                                                   \
+  [f##J##_0] "+v"(fp[J][0]), [f##J##_1] "+v"(fp[J][1]), [f##J##_2] "+v"(fp[J][2]), [f##J##_3] "+v"(fp[J][3]),  \
+  [f##J##_4] "+v"(fp[J][4]), [f##J##_5] "+v"(fp[J][5])
+template <int J0>
+__device__ __forceinline__ void fib_prod_load4(double (&fp)[4][6], const char *planes, unsigned voff) {
+  static_assert(J0 == 0 || J0 == 4, "the grid's two halves");
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const char *pl = planes + (size_t)k * 512 * sizeof(double);
-    p[k] = 0.0;
-    PNEC_GLOBAL_LOAD_SADDR(p[k], voff, pl, J * 64 * 8);  // (pnec_device.hpp: the base goes through a scalar move)
-  }
-}
-__device__ __forceinline__ void fib_prod_arrived(double (&p)[6], bool first) {
-  if (first) asm volatile("s_waitcnt vmcnt(0)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]));
-  else asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]));
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) fp[j][k] = 0.0;
+  constexpr size_t pb = 512 * sizeof(double);
+  if constexpr (J0 == 0)
+    asm volatile("s_nop 4\n\t" PNEC_FIB_SET_(0, "0") PNEC_FIB_SET_(1, "512") PNEC_FIB_SET_(2, "1024") PNEC_FIB_SET_(3, "1536")
+                 "s_waitcnt vmcnt(0)"
+                 : PNEC_FIB_OUT_(0), PNEC_FIB_OUT_(1), PNEC_FIB_OUT_(2), PNEC_FIB_OUT_(3)
+                 : [lo] "v"(voff), [b0] "s"(planes), [b1] "s"(planes + pb), [b2] "s"(planes + 2 * pb), [b3] "s"(planes + 3 * pb),
+                   [b4] "s"(planes + 4 * pb), [b5] "s"(planes + 5 * pb)
+                 : "memory");
+  else
+    asm volatile("s_nop 4\n\t" PNEC_FIB_SET_(0, "2048") PNEC_FIB_SET_(1, "2560") PNEC_FIB_SET_(2, "3072") PNEC_FIB_SET_(3, "3584")
+                 "s_waitcnt vmcnt(0)"
+                 : PNEC_FIB_OUT_(0), PNEC_FIB_OUT_(1), PNEC_FIB_OUT_(2), PNEC_FIB_OUT_(3)
+                 : [lo] "v"(voff), [b0] "s"(planes), [b1] "s"(planes + pb), [b2] "s"(planes + 2 * pb), [b3] "s"(planes + 3 * pb),
+                   [b4] "s"(planes + 4 * pb), [b5] "s"(planes + 5 * pb)
+                 : "memory");
 }
 typedef float v2f __attribute__((ext_vector_type(2)));
 // 1/x to ~1e-14 (seed + one Newton step): for the direction search, whose winner is re-evaluated exactly
@@ -1444,7 +1459,7 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
       mlo_valid = false;
       search_global = false;
       search_thr = -1.0;
-      // (loads in the scalar-base form, pnec_device.hpp load_planes_issue: the compiler's own version of this
+      // (loads in the scalar-base form, pnec_device.hpp load_sets8x12_saddr: the compiler's own version of this
       // loop kept 96 precomputed 64-bit addresses in scratch and reloaded each in front of its load, one memory
       // round trip after the other -- this phase took 170 k clocks of the stage's 375 k)
       const unsigned long long b64 = reinterpret_cast<unsigned long long>(base) +
@@ -1454,19 +1469,14 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64));
       const size_t plane_bytes = (size_t)(unsigned)__builtin_amdgcn_readfirstlane(stride) * sizeof(double);
       const unsigned voff = 8u * (unsigned)lane;
-      double pe[KR][12];
-      auto issue = [&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        const int idx = (WPP > 1 ? wave * KR * kWave : 0) + lane + kWave * k;
-        load_planes_issue<12, k * kWave * 8>(pe[k], sbase, plane_bytes, voff, idx < n);
-      };
-      issue(std::integral_constant<int, 0>{}); issue(std::integral_constant<int, 1>{});
-      issue(std::integral_constant<int, 2>{}); issue(std::integral_constant<int, 3>{});
-      issue(std::integral_constant<int, 4>{}); issue(std::integral_constant<int, 5>{});
-      issue(std::integral_constant<int, 6>{}); issue(std::integral_constant<int, 7>{});
-      planes_arrived(pe[0]);
-#pragma unroll
-      for (int k = 1; k < KR; ++k) planes_after(pe[k]);
+      double pe[8][12];   // (this branch is the resident form: KR == 8)
+      {
+        // the sets of this wavefront's share that start inside the pair's planes (stride = n rounded up to 64)
+        const int first = (WPP > 1 ? wave * KR * kWave : 0);
+        const int sets = (stride - first + kWave - 1) / kWave;
+        const unsigned nt = (unsigned)__builtin_amdgcn_readfirstlane(sets < 0 ? 0 : (sets > 8 ? 8 : sets));
+        load_sets8x12_saddr(pe, sbase, plane_bytes, voff, nt);
+      }
       if (threadIdx.x == 0) PNEC_WORK_ADD(kWkWesTableCorr, n);
       // the rotation as SCALARS here (it is one per pair; every product below takes one entry of it): this is where the
       // kernel has the fewest registers -- 96 payload values in flight, the tables forming -- and as eighteen vector
@@ -1547,11 +1557,7 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
           auto half = [&](auto hc) {
             constexpr int j0 = 4 * decltype(hc)::value;
             double fp[4][6];
-            fib_prod_issue<j0 + 0>(fp[0], pb, voff); fib_prod_issue<j0 + 1>(fp[1], pb, voff);
-            fib_prod_issue<j0 + 2>(fp[2], pb, voff); fib_prod_issue<j0 + 3>(fp[3], pb, voff);
-            fib_prod_arrived(fp[0], true);
-#pragma unroll
-            for (int j = 1; j < 4; ++j) fib_prod_arrived(fp[j], false);
+            fib_prod_load4<j0>(fp, pb, voff);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
               lds.lb[WPP > 1 ? wave : 0][j0 + j][lane] = (m[0] * fp[j][0] + m[3] * fp[j][1] + m[5] * fp[j][2] + m[1] * fp[j][3] +
@@ -1847,7 +1853,7 @@ __global__ __launch_bounds__(WMAX *kWave, PNEC_WES_WAVES_PER_SIMD) void weighted
 // of the midpoint triangulation, inlier if score < threshold, adaptive bound
 // k = log(1 - 0.99) / log(1 - w^s), eigensolver re-run on the inliers; rand() replaced by a
 // counter-based hash of (seed, pair, hypothesis, draw)) ------------------------------------------
-// (kernel shape: see ransac_eigensolver_kernel below)
+// (kernel shape: see ransac2_eigensolver_kernel below)
 struct RansacArgs {
   const double *data;
   const int64_t *block_offset;
@@ -1918,15 +1924,11 @@ __device__ __forceinline__ double reprojection_score(const double (&f1)[3], cons
 // ---- RANSAC scoring: the pair's bearings in registers, one model after the other -------------------------------------
 // The first kScoreTiles x 64 correspondences of the pair (f1 | f2: six planes) are loaded ONCE per round into registers,
 // lane l holding correspondence 64 i + l of tile i (coalesced; scalar plane base + lane offset + immediate, see
-// load_planes_issue); what a larger pair has beyond them is streamed from memory per model.
+// load_planes_saddr); what a larger pair has beyond them is streamed from memory per model.
 constexpr int kScoreTiles = 8;
 struct ScoreTiles { double f[kScoreTiles][6]; };
 
-// ONE asm statement issues all 48 loads AND waits for them (round 4; until then an issue statement and a separate wait
-// statement: to the compiler an asm statement has written its outputs when it returns, so it was free to copy or spill a
-// destination register between the two -- while the load that would really write it was still in flight.  It did, the
-// first time this code was compiled under a tighter register budget: tools/check_asm_loads.py caught two scratch stores
-// of tile registers in front of the wait).  Tiles beyond the pair are branched over, wave-uniformly (a tile that starts
+// ONE asm statement issues all 48 loads AND waits for them (why: pnec_device.hpp load_planes_saddr).  Tiles beyond the pair are branched over, wave-uniformly (a tile that starts
 // inside the pair lies inside its planes: stride = n rounded up to 64, the padding reads zeros; one that starts beyond
 // it may lie beyond the allocation), their registers keep the zeros they came with.  Scalar-base form of global_load
 // (base + 32-bit lane offset + immediate; why: pnec_device.hpp load_planes_saddr); the s_nop covers a plane base the
@@ -1942,33 +1944,6 @@ struct ScoreTiles { double f[kScoreTiles][6]; };
 #define PNEC_ST_OUT(i)                                                                                              \
   [d##i##0] "+v"(P.f[i][0]), [d##i##1] "+v"(P.f[i][1]), [d##i##2] "+v"(P.f[i][2]), [d##i##3] "+v"(P.f[i][3]), \
   [d##i##4] "+v"(P.f[i][4]), [d##i##5] "+v"(P.f[i][5])
-// The two-statement form (issue, then a separate wait): what the one- and two-pair kernels have run since round 3.
-// Nothing in the source keeps the compiler from touching a destination between the two statements; what it actually
-// did is checked after every link (tools/check_asm_loads.py).  Kept for those two kernels because the one-statement
-// form below, correct in the round kernel, makes the ONE-PAIR kernel return wrong poses and run on for minutes
-// (measured on the GPU, both with EXEC masking and with branches inside the statement; that kernel is the only one
-// here with a real call -- es_minimise_quad is not inlined -- and spills 114 scalar registers; not understood, so not
-// used there).
-__device__ __forceinline__ void score_tiles_load_2s(ScoreTiles &P, const double *bs, int st, int nn, int lane) {
-  const unsigned long long b64 = reinterpret_cast<unsigned long long>(bs);
-  const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
-  const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
-  const char *sb = reinterpret_cast<const char *>(((unsigned long long)bhi << 32) | blo);
-  const size_t plane_bytes = (size_t)(unsigned)__builtin_amdgcn_readfirstlane(st) * sizeof(double);
-  const unsigned voff = 8u * (unsigned)lane;
-  auto tile = [&](auto tc) {
-    constexpr int i = decltype(tc)::value;
-    load_planes_issue<6, 8 * kWave * i>(P.f[i], sb, plane_bytes, voff, kWave * i < nn);
-  };
-  tile(std::integral_constant<int, 0>{}); tile(std::integral_constant<int, 1>{});
-  tile(std::integral_constant<int, 2>{}); tile(std::integral_constant<int, 3>{});
-  tile(std::integral_constant<int, 4>{}); tile(std::integral_constant<int, 5>{});
-  tile(std::integral_constant<int, 6>{}); tile(std::integral_constant<int, 7>{});
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(P.f[0][0]), "+v"(P.f[0][1]), "+v"(P.f[0][2]), "+v"(P.f[0][3]), "+v"(P.f[0][4]), "+v"(P.f[0][5]));
-#pragma unroll
-  for (int i = 1; i < kScoreTiles; ++i)
-    asm volatile("" : "+v"(P.f[i][0]), "+v"(P.f[i][1]), "+v"(P.f[i][2]), "+v"(P.f[i][3]), "+v"(P.f[i][4]), "+v"(P.f[i][5]));
-}
 __device__ __forceinline__ void score_tiles_load(ScoreTiles &P, const double *bs, int st, int nn, int lane) {
   static_assert(kScoreTiles == 8 && kWave == 64, "eight tiles of 64 correspondences, 512 bytes per tile and plane");
   const unsigned long long b64 = reinterpret_cast<unsigned long long>(bs);
@@ -2188,276 +2163,20 @@ __device__ __forceinline__ void compact_pair(int nc, const double *sb, int n, co
     for (int c = 0; c < nc; ++c) db[(int64_t)c * dstride + idx] = 0.0;
 }
 
-// The end of a pair's RANSAC: inliers of the best model (all correspondences when sampling is impossible), the mask,
-// their 36 sums and the first inlier (ComposeM on the inlier list starts at its second entry, C7) for
-// es_batch_kernel<kEpiTranslation>, and -- with a target -- InlierExtraction (pnec.cc:210-229) into it.
-// G: 36 doubles of LDS.  The one-pair kernel's tail (the two-pair kernel has the same arithmetic inline).
-__device__ __forceinline__ int ransac_finish_pair(const RansacArgs &a, int64_t pair, int n, int stride, const double *base,
-                                                  const double (&bR)[9], const double (&bt)[3], bool can_sample, int it,
-                                                  int lane, double *G) {
-  double acc[36];
-#pragma unroll
-  for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-  int my_count = 0, my_first = 0x7fffffff;
-  const int64_t aos0 = a.offsets[pair];
-  for (int idx = lane; idx < n; idx += kWave) {
-    const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
-    const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
-                          base[(int64_t)5 * stride + idx]};
-    bool in = true;
-    if (can_sample) in = reprojection_score(f1, f2, bR, bt) < a.threshold;
-    if (a.out_mask) a.out_mask[aos0 + idx] = in ? 1 : 0;
-    if (in) {
-      ++my_count;
-      if (idx < my_first) my_first = idx;
-      const double p[6] = {f2[0] * f2[0], f2[0] * f2[1], f2[0] * f2[2], f2[1] * f2[1], f2[1] * f2[2], f2[2] * f2[2]};
-      const double qq[6] = {f1[0] * f1[0], f1[0] * f1[1], f1[0] * f1[2], f1[1] * f1[1], f1[1] * f1[2], f1[2] * f1[2]};
-#pragma unroll
-      for (int kl = 0; kl < 6; ++kl)
-#pragma unroll
-        for (int ac = 0; ac < 6; ++ac) acc[6 * kl + ac] = __builtin_fma(p[kl], qq[ac], acc[6 * kl + ac]);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 36; ++i) {
-    const double sres = wave_allreduce_sum(acc[i]);
-    if (lane == 0) G[i] = sres;
-  }
-  const int total = (int)wave_allreduce_sum((double)my_count);
-  if (lane == 0) PNEC_WORK_ADD(kWkRansacInlierCorr, n);
-  int first = my_first;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const int o = __shfl_xor(first, off);
-    first = o < first ? o : first;
-  }
-  wave_lds_sync();
-  if (lane < 36) a.scratch.G[36 * pair + lane] = G[lane];
-  if (lane == 0) {
-    double v[3];
-    rot_to_cayley(bR, v);
-    a.scratch.v0[3 * pair] = v[0]; a.scratch.v0[3 * pair + 1] = v[1]; a.scratch.v0[3 * pair + 2] = v[2];
-    a.scratch.n_scale[pair] = (double)(total > 0 ? total : 1);
-    a.scratch.first[pair] = total > 0 ? first : -1;
-    if (a.out_count) a.out_count[pair] = total;
-    if (a.out_iterations) a.out_iterations[pair] = it;
-  }
-  if (a.sel_data) {  // InlierExtraction: this wavefront's own mask bytes back (each lane reads what it wrote)
-    if (lane == 0) {
-      a.sel_count[pair] = total;
-      if (a.sel_single_offsets) {
-        a.sel_single_offsets[0] = 0;
-        a.sel_single_offsets[1] = total;
-      }
-    }
-    compact_pair(a.nc, base, n, a.out_mask + aos0, a.sel_data + a.sel_block[pair], total, lane);
-  }
-  return total;
-}
-
-
-// ONE WAVEFRONT PER FRAME PAIR, ONE QUAD PER HYPOTHESIS: a round evaluates 16 hypotheses.  The four lanes
-// of a quad share the hypothesis' Newton iteration (es_minimise_quad: the finite-difference probes and the
-// Armijo step lengths of one evaluation) and split the correspondences when it is scored.  Everything
-// that is one value per pair -- the adaptive bound k, the best count, the iteration counter -- is wave-
-// uniform, so the sequential rule of the reference loop is scalar code.
-// Against the earlier shape (4 pairs per wavefront, one lane per hypothesis): a wavefront no longer runs a
-// second round because ONE of its four pairs needs it (~1.9 -> ~1.4 rounds per pair), the slowest of 16
-// instead of 64 Newton iterations sets the pace, and the register need is es_minimise_quad's, which fits
-// two wavefronts per SIMD -- the other wavefront now fills the latency gaps of this one's chains.
-__global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac_eigensolver_kernel(const RansacArgs a) {
-  const int lane = threadIdx.x;
-  const int hyp = lane >> 2, role = lane & 3;
-  const int64_t pair = (int64_t)blockIdx.x;
-  const int n = a.count[pair];
-  const int stride = (n + kWave - 1) & ~(kWave - 1);
-  const double *base = a.data + a.block_offset[pair];
-  __shared__ double Gh[kHypPerRound][36];  // the 36 sums of each hypothesis' sample
-  __shared__ double G[36];                 // ... of the inliers of the best model
-  __shared__ double best_model[12];        // R (9) + t (3)
-  __shared__ double models[kHypPerRound][13];  // R (9) + t (3) of the round's hypotheses (scored one after the other) + kModelCapped
-  __shared__ int sel_lds[PNEC_HIP_MAX_RANSAC_SAMPLE][kWave];  // each lane's sample (indexed dynamically: not registers)
-  double q0[4] = {a.init_q[4 * pair], a.init_q[4 * pair + 1], a.init_q[4 * pair + 2], a.init_q[4 * pair + 3]};
-  {
-    const double qn = 1.0 / sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
-    for (int k = 0; k < 4; ++k) q0[k] *= qn;
-  }
-  double R0[9], v0[3];
-  rot_from_quat(q0, R0);
-  rot_to_cayley(R0, v0);
-  const int ss = a.sample_size;  // <= PNEC_HIP_MAX_RANSAC_SAMPLE (checked by the caller)
-  const bool can_sample = n >= ss && ss >= 1;
-  int it = 0;
-  unsigned long long ph_clk[kPhCount] = {0};
-  const unsigned long long ph_start = a.trace ? __builtin_amdgcn_s_memtime() : 0ull;
-  PNEC_PHASE_BEGIN();
-  {
-    int best_count = -1;
-    double k = 1.0;
-    bool stop = !can_sample;
-    while (!stop && (double)it < k) {  // wave-uniform
-      const unsigned long long h = (unsigned long long)(it + hyp);
-      // The first round evaluates all 16 hypotheses before any bound is known.  A later round knows k: hypothesis
-      // j of the round is consumed only if it + j < k, and k can only shrink while the round is consumed -- the
-      // quads beyond ceil(k - it) would never be looked at, so they stay out (exact; it shortens the slowest-of-
-      // the-quads Newton phase of the ~40 % of pairs that need a second round, typically for two or three more)
-      // (clamped in floating point: with no inlier yet k is ~2e16 or inf, outside int's range)
-      const int needed = it == 0 ? kHypPerRound : (int)fmin(ceil(k - (double)it), (double)kHypPerRound);
-      const bool active = hyp < needed;
-      // ---- this quad's hypothesis: sample, sums, minimise, translation (the four lanes do the same up to
-      // the minimiser, which splits its evaluations over them)
-      auto sel = [&](int j) -> int & { return sel_lds[j][lane]; };
-      if (active) {
-        int m = 0;
-        unsigned long long draw = 0;
-        while (m < ss) {
-          long long idx = (long long)(rng_uniform(a.seed, a.pair_id_base + (unsigned long long)pair, h, draw++) * (double)n);
-          if (idx >= n) idx = n - 1;
-          bool dup = false;
-          for (int j = 0; j < m; ++j) dup = dup || (sel(j) == (int)idx);
-          if (!dup) sel(m++) = (int)idx;
-        }
-        if (role == 0) PNEC_WORK_ADD(kWkRansacHyps, 1);
-      }
-      double ev1[3] = {0, 0, 0};  // sum f1 (for the directional evidence)
-      {
-        // the four lanes of the quad split the sample (each gather is a round trip to memory: 3 in sequence
-        // instead of 10) and add their shares up
-        double Gl[36];
-        for (int i = 0; i < 36; ++i) Gl[i] = 0.0;
-        for (int j = role; j < (active ? ss : 0); j += 4) {
-          const int idx = sel(j);
-          const double f1[3] = {base[idx], base[(int64_t)stride + idx], base[(int64_t)2 * stride + idx]};
-          const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
-                                base[(int64_t)5 * stride + idx]};
-          const double p[6] = {f2[0] * f2[0], f2[0] * f2[1], f2[0] * f2[2], f2[1] * f2[1], f2[1] * f2[2], f2[2] * f2[2]};
-          const double qq[6] = {f1[0] * f1[0], f1[0] * f1[1], f1[0] * f1[2], f1[1] * f1[1], f1[1] * f1[2], f1[2] * f1[2]};
-          for (int kl = 0; kl < 6; ++kl)
-            for (int ac = 0; ac < 6; ++ac) Gl[6 * kl + ac] += p[kl] * qq[ac];
-          for (int c = 0; c < 3; ++c) ev1[c] += f1[c];
-        }
-#pragma unroll
-        for (int i = 0; i < 36; ++i) Gl[i] = quad_sum(Gl[i]);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) ev1[c] = quad_sum(ev1[c]);
-        if (role == 0) {
-#pragma unroll
-          for (int i = 0; i < 36; ++i) Gh[hyp][i] = Gl[i];
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      double v[3], R[9], t[3];
-      for (int c = 0; c < 3; ++c)
-        v[c] = v0[c] + (rng_uniform(a.seed, a.pair_id_base + (unsigned long long)pair, h, 1000 + c) - 0.5) * 2.0 * 0.01;
-      PNEC_PHASE_END(kRpSample);
-      // t = eigenvector of the smallest eigenvalue of M at the minimiser (sign settled by the evidence below)
-      int evals = 0;
-      const int newton_its = es_minimise_quad<1, 1>(Gh[hyp], v, (double)ss, t, active, a.trace ? &evals : nullptr, kHypothesisStepDone, kHypothesisMaxIterations);
-      PNEC_PHASE_END(kRpNewton);
-      if (a.trace) {  // diagnostics: Newton iterations of the round's 16 hypotheses (sum, max), rounds
-        const double its_sum = wave_allreduce_sum((double)newton_its) * 0.25;
-        int mx = newton_its;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
-        ph_clk[8] += (unsigned long long)its_sum;
-        ph_clk[9] += (unsigned long long)mx;
-        ph_clk[10] += 1;
-        int me = evals;   // evaluations as the wavefront executes them = those of its slowest quad
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(me, off); me = o > me ? o : me; }
-        ph_clk[11] += (unsigned long long)me;
-      }
-      cayley_to_rot(v, R);
-      {
-        // directional evidence sum t.(f1 - R f2) over the sample
-        double ev = 0.0;
-        for (int j = role; j < (active ? ss : 0); j += 4) {
-          const int idx = sel(j);
-          const double f2[3] = {base[(int64_t)3 * stride + idx], base[(int64_t)4 * stride + idx],
-                                base[(int64_t)5 * stride + idx]};
-          const double u[3] = {R[0] * f2[0] + R[1] * f2[1] + R[2] * f2[2], R[3] * f2[0] + R[4] * f2[1] + R[5] * f2[2],
-                               R[6] * f2[0] + R[7] * f2[1] + R[8] * f2[2]};
-          ev -= t[0] * u[0] + t[1] * u[1] + t[2] * u[2];
-        }
-        ev = (t[0] * ev1[0] + t[1] * ev1[1] + t[2] * ev1[2]) + quad_sum(ev);
-        if (ev < 0.0) { t[0] = -t[0]; t[1] = -t[1]; t[2] = -t[2]; }
-      }
-      PNEC_PHASE_END(kRpModel);
-      // ---- the models go to LDS; then ONE HYPOTHESIS AFTER THE OTHER, in the order of the sequential rule, is scored
-      // by the whole wavefront and consumed (model_inliers_until_beaten: a model that cannot beat the best so far is
-      // dropped after a tile or two; the rule's decisions are those of the full counts)
-      if (active && role == 0) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) models[hyp][i] = R[i];
-        models[hyp][9] = t[0]; models[hyp][10] = t[1]; models[hyp][11] = t[2];
-        models[hyp][kModelCapped] = newton_its >= kHypothesisMaxIterations ? 1.0 : 0.0;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // the pair's bearings for the scoring.  (Issue and wait back to back: a register that a load in flight will
-      // write is not the compiler's to move or spill, and it does not know -- nothing may sit between the two.)
-      ScoreTiles tiles;
-      score_tiles_load_2s(tiles, base, stride, n, lane);
-      int winner = -1;
-      for (int j = 0; j < needed; ++j) {  // (hypotheses beyond `needed` would meet it >= k: never consumed)
-        if (!((double)it < k)) { stop = true; break; }
-        double Rj[9], tj[3];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Rj[i] = models[j][i];
-        tj[0] = models[j][9]; tj[1] = models[j][10]; tj[2] = models[j][11];
-        const int cj = models[j][kModelCapped] != 0.0 ? 0 : model_inliers_until_beaten(tiles, base, stride, n, Rj, tj, a.threshold, lane, best_count);
-        if (cj > best_count) {
-          best_count = cj;
-          winner = j;
-          const double w = (double)cj / (double)n;
-          double p_no = 1.0 - pow_sample(w, ss);
-          p_no = fmax(2.220446049250313e-16, p_no);
-          p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
-          k = log(1.0 - 0.99) / log(p_no);
-        }
-        ++it;
-        if (it > a.max_iterations) { stop = true; break; }
-      }
-      PNEC_PHASE_END(kRpScore);
-      if (winner >= 0 && lane < 12) best_model[lane] = models[winner][lane];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      PNEC_PHASE_END(kRpConsume);
-    }
-  }
-  double bR[9], bt[3] = {0.0, 0.0, 1.0};
-#pragma unroll
-  for (int i = 0; i < 9; ++i) bR[i] = R0[i];
-  if (can_sample) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) bR[i] = best_model[i];
-    bt[0] = best_model[9]; bt[1] = best_model[10]; bt[2] = best_model[11];
-  }
-
-  // ---- inliers of the best model (all correspondences when sampling is impossible), the mask, their 36 sums, the
-  // first inlier -- optimizeModelCoefficients (the eigensolver on the inliers from the best model's rotation, ComposeM
-  // without the first inlier, TranslationFromM) runs in es_batch_kernel<kEpiTranslation>, sixteen pairs per wavefront --
-  // and InlierExtraction when a target is given
-  ransac_finish_pair(a, pair, n, stride, base, bR, bt, can_sample, it, lane, G);
-  if (a.trace && lane == 0) {
-    ph_clk[kRpTotal] = __builtin_amdgcn_s_memtime() - ph_start;
-    for (int k = 0; k < kPhCount; ++k) a.trace[kPhCount * pair + k] = ph_clk[k];
-  }
-}
-
-// ---- The same RANSAC, TWO PAIRS PER WAVEFRONT with the hypotheses of both in one queue (round 3) -----------------
-// In the kernel above a round's Newton phase runs at the pace of the slowest of its sixteen minimisations (phase
-// counters: 131 iterations summed over the sixteen quads, 18 for the slowest -- the quads idle half of the phase, which is
-// 60 % of the kernel).  Here a wavefront owns two pairs: a round prepares up to 32 hypotheses (sample, 36 sums, jittered
-// start: per hypothesis in LDS), the sixteen quads PULL them from one queue (es_minimise_queue: a quad that has finished
-// a minimisation re-arms on the next hypothesis of the list, whichever pair it belongs to), and the rest of the round --
-// model, scoring, the sequential consume rule -- runs per pair with quad j on hypothesis j as before.  A hypothesis'
-// arithmetic does not depend on which quad minimises it or when: masks, iteration counts and models are bit for bit
-// those of the one-pair kernel (and of the oracle's restatement).
+// ---- RANSAC kernel shape: ONE QUAD PER HYPOTHESIS, TWO PAIRS PER WAVEFRONT with the hypotheses of both in one queue ----
+// A round evaluates up to sixteen hypotheses per pair.  The four lanes of a quad share a hypothesis' minimisation (the
+// finite-difference probes and step lengths of one evaluation) and split the correspondences of its sample; everything
+// that is one value per pair -- the adaptive bound k, the best count, the iteration counter -- is wave-uniform, so the
+// sequential rule of the reference loop is scalar code.  A wavefront owns two pairs: a round prepares up to 32 hypotheses
+// (sample, 36 sums, jittered start: per hypothesis in LDS), the sixteen quads PULL them from one queue (es_minimise_queue:
+// a quad that has finished a minimisation re-arms on the next hypothesis of the list, whichever pair it belongs to) --
+// with one pair per wavefront a round's minimisations run at the pace of the slowest of sixteen and the quads idle half
+// of the phase -- and the rest of the round (model, scoring one model after the other with the exact early drop, the
+// sequential consume rule) runs per pair with quad j on hypothesis j.  A pair whose partner is done, or that has a
+// wavefront to itself (the launch's last wavefronts, a handful of pairs, the per-frame handle's one), takes the second
+// slot group for its own next sixteen hypotheses.  A hypothesis' arithmetic does not depend on which quad minimises it,
+// when, or which pair shares the wavefront.  (Until round 5 a one-pair-per-wavefront kernel existed beside this one for
+// small batches; this kernel with n_double = 0 is that shape, so it went.)
 struct Ransac2Lds {
   double Gh[2 * kHypPerRound][36];   // the 36 sums of each hypothesis' sample
   double tv[2 * kHypPerRound][3];    // its start (in) / minimiser (out) in Cayley coordinates
@@ -2902,7 +2621,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
       }
       lds_sync();
       ScoreTiles tiles;  // the pair's bearings for the scoring (issue and wait back to back, see the one-pair kernel)
-      score_tiles_load_2s(tiles, bs, st, nn, lane);
+      score_tiles_load(tiles, bs, st, nn, lane);
       int winner = -1;
       for (int j = 0; j < needed[pp]; ++j) {
         if (!((double)it[pp] < k[pp])) { stop[pp] = true; break; }
@@ -3219,29 +2938,22 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), zeros, sizeof(zeros));
   }
 #endif
-  // Two pairs per wavefront with the hypotheses of both in one queue (ransac2_eigensolver_kernel) once there are
-  // enough pairs to fill the GPU either way; a handful of pairs (the per-frame handle: one) keep a wavefront each --
-  // half the latency.  Same results, bit for bit.  PNEC_RANSAC_FORM=1|2 forces a form (A/B runs).
+  // Two pairs per wavefront once there are enough pairs to fill the GPU either way; a handful of pairs (the per-frame
+  // handle: one) keep a wavefront each -- half the latency.  Same results, bit for bit.  PNEC_RANSAC_FORM=1|2 forces one /
+  // two pairs per wavefront (A/B runs).
   static const int forced_form = [] {
     const char *ev = std::getenv("PNEC_RANSAC_FORM");
     return ev && *ev ? std::atoi(ev) : 0;
   }();
-  // (schemes 1 and 2 exist in the two-pair kernel only: a handful of pairs run it with a wavefront each, n_double = 0)
-  const bool two = scheme != 0 || (forced_form == 1 ? false : (forced_form == 2 ? true : n_pairs >= 4096));
-  hipError_t e = hipSuccess;
-  if (two) {
-    a.order = order;
-    const int64_t singles = n_pairs < 4096 && forced_form != 2 ? n_pairs & ~(int64_t)1
-                                                                : std::min<int64_t>(ransac_tail_singles(n_pairs), n_pairs) & ~(int64_t)1;  // (even: the rest pairs up)
-    a.n_double = (n_pairs - singles + 1) / 2;
-    const int64_t blocks = a.n_double + (n_pairs - std::min<int64_t>(2 * a.n_double, n_pairs));
-    if (scheme == 1) hipLaunchKernelGGL(ransac2_eigensolver_kernel<1>, dim3((unsigned)blocks), dim3(kWave), 0, stream, a);
-    else if (scheme == 2) hipLaunchKernelGGL(ransac2_eigensolver_kernel<2>, dim3((unsigned)blocks), dim3(kWave), 0, stream, a);
-    else hipLaunchKernelGGL(ransac2_eigensolver_kernel<0>, dim3((unsigned)blocks), dim3(kWave), 0, stream, a);
-  } else {
-    hipLaunchKernelGGL(ransac_eigensolver_kernel, dim3((unsigned)n_pairs), dim3(kWave), 0, stream, a);
-  }
-  e = hipGetLastError();
+  const bool two = forced_form == 1 ? false : (forced_form == 2 ? true : n_pairs >= 4096);
+  a.order = two ? order : nullptr;
+  const int64_t singles = !two ? n_pairs : std::min<int64_t>(ransac_tail_singles(n_pairs), n_pairs) & ~(int64_t)1;  // (even: the rest pairs up)
+  a.n_double = (n_pairs - singles + 1) / 2;
+  const int64_t blocks = a.n_double + (n_pairs - std::min<int64_t>(2 * a.n_double, n_pairs));
+  if (scheme == 1) hipLaunchKernelGGL(ransac2_eigensolver_kernel<1>, dim3((unsigned)blocks), dim3(kWave), 0, stream, a);
+  else if (scheme == 2) hipLaunchKernelGGL(ransac2_eigensolver_kernel<2>, dim3((unsigned)blocks), dim3(kWave), 0, stream, a);
+  else hipLaunchKernelGGL(ransac2_eigensolver_kernel<0>, dim3((unsigned)blocks), dim3(kWave), 0, stream, a);
+  hipError_t e = hipGetLastError();
   if (e == hipSuccess) {
     EsBatchArgs b;
     std::memset(&b, 0, sizeof(b));

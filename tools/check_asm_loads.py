@@ -1,20 +1,22 @@
 #!/usr/bin/env python3
-"""Build-time guard for the hand-written global loads (PNEC_GLOBAL_LOAD_SADDR, pnec_amd/csrc/pnec_device.hpp).
+"""Build-time backstop for the hand-written global loads (pnec_amd/csrc/pnec_device.hpp load_planes_saddr /
+load_sets8x12_saddr, pnec_frontend.hip score_tiles_load / fib_prod_load4).
 
-Those loads are issued by one inline-asm statement and waited for by a later one, so the compiler believes the
-destination registers are written when the issue statement returns.  It may then legally put a copy, a spill or
-a re-use of such a register between the issue and the s_waitcnt -- an instruction that would read the register
-before the load has landed, or be overwritten by it.  Nothing in the source can forbid that; this script looks at
-what the compiler actually produced and fails the build if it ever happens:
+Since round 5 every such load sits in ONE inline-asm statement together with the s_waitcnt that retires it, so the
+compiler has no place to put anything between issue and wait: correctness is by construction.  (Until then the loads
+were issued by one statement and waited for by a later one, and the compiler did once spill a destination register in
+between.)  This script keeps looking at what the compiler actually produced and fails the build if the rule is ever
+broken again -- by a future edit that splits a statement, or by the compiler's own loads:
 
-  for every `s_mov_b64 sX, sY ; global_load_dwordx2 vD, vO, sX` pair in the gfx950 code of libpnec_hip.so (the macro's
-  fingerprint), no instruction between the load and the s_waitcnt vmcnt(n) that retires it may name vD.
+  for every scalar-base `global_load_dwordx2 vD, vO, s[..]` in the device code of libpnec_hip.so, no instruction between
+  the load and the s_waitcnt vmcnt(n) that retires it may name vD.
 
 vmcnt is modelled as the in-order FIFO it is on gfx9 (every vector-memory instruction enters it; `s_waitcnt
 vmcnt(n)` leaves the youngest n outstanding).  The scan is linear through each function, which is conservative
 across branches (a load stays in flight until a wait retires it).
 
-usage: check_asm_loads.py [path/to/libpnec_hip.so]      exit status 0 = clean
+usage: check_asm_loads.py [path/to/libpnec_hip.so] [--arch gfx950] [--objdump /path/to/llvm-objdump]
+exit status 0 = clean, or nothing to check with (no llvm-objdump: the check is SKIPPED, the library stays)
 """
 import os
 import re
@@ -28,7 +30,6 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 VMEM = ("global_", "buffer_", "flat_", "scratch_", "tbuffer_")
 RE_V = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 RE_LOAD = re.compile(r"^global_load_dwordx2 v\[(\d+):(\d+)\], v\d+, (s\[\d+:\d+\])")
-RE_SMOV = re.compile(r"^s_mov_b64 (s\[\d+:\d+\]), s\[\d+:\d+\]")
 RE_VMCNT = re.compile(r"vmcnt\((\d+)\)")
 
 
@@ -62,10 +63,7 @@ def check_disassembly(lines):
         # does this instruction touch a register a macro load in flight will write?
         used = vregs(line)
         ml = RE_LOAD.match(line)
-        is_macro = False
-        if ml:
-            ms = RE_SMOV.match(prev)
-            is_macro = bool(ms) and ms.group(1) == ml.group(3)
+        is_macro = bool(ml)
         for (mac, dest, text) in fifo:
             if mac and (used & dest):
                 violations.append(f"{func}: `{line}` names v{sorted(used & dest)} while `{text}` is in flight")
@@ -84,17 +82,18 @@ def check_disassembly(lines):
     return seen, violations
 
 
-def disassemble(so_path):
+def disassemble(so_path, arch="gfx950", objdump=OBJDUMP):
+    OBJDUMP_ = objdump
     tmp = tempfile.mkdtemp(prefix="pnec_asmchk_")
     try:
         local = os.path.join(tmp, os.path.basename(so_path))
         shutil.copy(so_path, local)
-        subprocess.run([OBJDUMP, "--offloading", local], check=True, cwd=tmp, stdout=subprocess.DEVNULL,
+        subprocess.run([OBJDUMP_, "--offloading", local], check=True, cwd=tmp, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL)
         out = []
         for f in sorted(os.listdir(tmp)):
-            if "gfx950" in f:
-                r = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, f)], check=True, capture_output=True, text=True)
+            if arch in f:
+                r = subprocess.run([OBJDUMP_, "-d", os.path.join(tmp, f)], check=True, capture_output=True, text=True)
                 out.extend(r.stdout.split("\n"))
         return out
     finally:
@@ -102,14 +101,23 @@ def disassemble(so_path):
 
 
 def main():
-    so = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "pnec_amd", "libpnec_hip.so")
-    seen, bad = check_disassembly(disassemble(so))
-    print(f"check_asm_loads: {seen} hand-written loads checked in {os.path.basename(so)}, {len(bad)} violation(s)")
+    args = sys.argv[1:]
+    arch, objdump = "gfx950", OBJDUMP
+    if "--arch" in args:
+        i = args.index("--arch"); arch = args[i + 1]; del args[i:i + 2]
+    if "--objdump" in args:
+        i = args.index("--objdump"); objdump = args[i + 1]; del args[i:i + 2]
+    so = args[0] if args else os.path.join(ROOT, "pnec_amd", "libpnec_hip.so")
+    if not (os.path.isfile(objdump) and os.access(objdump, os.X_OK)):
+        print(f"check_asm_loads: SKIPPED ({objdump} not found); the loads are single statements, correct by construction")
+        return 0
+    seen, bad = check_disassembly(disassemble(so, arch, objdump))
+    print(f"check_asm_loads: {seen} scalar-base loads checked in {os.path.basename(so)} ({arch}), {len(bad)} violation(s)")
     for b in bad[:40]:
         print("  " + b)
     if seen == 0:
-        print("  no macro load recognised: the fingerprint has changed, fix this script")
-        return 2
+        print(f"  no scalar-base load found in the {arch} code object: nothing was checked (other target, or the fingerprint changed)")
+        return 0 if arch != "gfx950" else 2
     return 1 if bad else 0
 
 
