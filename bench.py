@@ -206,6 +206,11 @@ def parse_args(argv=None):
     ap.add_argument("--quick-secondary", action="store_true", help="fewer steps / a shorter stream in the secondary runs (tests)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the CPU baseline sample (0 = auto)")
     ap.add_argument("--sync-gather", action="store_true", help="gather on the solve's stream (A/B of the overlap)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="sim100k: drive all --gpus devices from THIS process through the persistent multi-device handle "
+                         "(pnec_hip_multi_*: one host thread, batch and stream per device, no collective) instead of one rank "
+                         "per GPU + an RCCL gather -- the comparison line for a SCALE run; with --share-gpu every entry of "
+                         "the device list is cuda:0")
     ap.add_argument("--dry-run-cpu", action="store_true", help="gloo + stubbed solve: exercises spawn/partition/gather without a GPU")
     ap.add_argument("--share-gpu", action="store_true",
                     help="all ranks on cuda:0 (single-GPU boxes): the real solver and the device side of the gather "
@@ -1145,9 +1150,63 @@ def run(args):
         dist.destroy_process_group()
 
 
+def run_single_process(args):
+    """One process, N devices, the persistent multi-device handle (include/pnec_hip.h pnec_hip_multi_*): the sim100k
+    workload with `--pairs` pairs PER DEVICE (weak scaling, as the rank-per-GPU form), filled once; a step = one
+    pnec_hip_multi_solve over all shards (start poses and result records cross PCIe in every step: 136 B per pair --
+    the handle's entry points take host arrays; the payload stays resident)."""
+    import torch
+
+    from pnec_amd import capi
+    from pnec_amd import simulation as sim
+    from pnec_amd.multi import MultiBatch, alloc_counters
+    N = args.gpus
+    devices = [0] * N if args.share_gpu else list(range(N))
+    P, C = args.pairs * N, args.corr
+    dev = torch.device("cuda:0")
+    f1, f2, cv, q0, t0 = [], [], [], [], []
+    for c0 in range(0, P, 10000):                        # generated on device 0 in chunks, handed over as host arrays
+        m = min(10000, P - c0)
+        g = sim.generate(m, C, seed=1 + c0, device=dev)
+        f1.append(g.bvs1.reshape(-1, 3).cpu().numpy()); f2.append(g.bvs2.reshape(-1, 3).cpu().numpy())
+        cv.append(g.covs2.reshape(-1, 3, 3).cpu().numpy()); q0.append(g.init_q.cpu().numpy()); t0.append(g.init_t.cpu().numpy())
+        del g
+    f1, f2, cv, q0, t0 = (np.concatenate(x) for x in (f1, f2, cv, q0, t0))
+    off = np.arange(P + 1, dtype=np.int64) * C
+    opts = capi.default_options(max_num_iterations=args.iters, check_convergence=0)
+    with MultiBatch(devices, capi.MODE_TARGET, P, P * C, C) as mb:
+        mb.fill(off, f1, f2, cv)
+        for _ in range(max(args.warmup, 2)):
+            res = mb.solve(q0, t0, options=opts)
+        a0 = alloc_counters()
+        t_0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = mb.solve(q0, t0, options=opts)
+        wall = (time.perf_counter() - t_0) / args.steps * 1e3
+        a1 = alloc_counters()
+        bounds = mb.bounds.tolist()
+    line = {"metric": "PNEC pose solves/sec (512 corr, 10 GN iters)", "value": P / (wall * 1e-3), "unit": "solves/s", "n_gpus": N, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {args.pairs} simulated frame pairs x {C} anisotropic-covariance correspondences per "
+                                   f"GPU, {args.iters} LM iterations", "parallelism": f"single process, {N} devices "
+                       "(pnec_hip_multi_solve: one host thread + batch + stream per device, no collective)",
+                       "devices": devices, "shard_bounds": bounds,
+                       "per_step_pcie_bytes": P * 136, "note": "start poses in and result records out cross PCIe in every "
+                       "step (host-array entry point); the payload is resident; NOT the rank-per-GPU headline form",
+                       "hip_malloc_calls_during_timed_steps": a1["hip_malloc_calls"] - a0["hip_malloc_calls"]},
+            "all_iterations_done": bool((res["iterations"] == args.iters).all())}
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if args.single_process:
+        if args.workload != "sim100k" or args.chain:
+            sys.exit("--single-process drives the sim100k refinement only")
+        sys.exit(run_single_process(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, argv))
     run(args)

@@ -91,7 +91,8 @@ typedef struct pnec_hip_options {
   int32_t waves_per_pair;                    /* 0 = auto; launch tuning: wavefronts cooperating on one solve */
   int32_t lds_corr_per_lane;                 /* launch tuning: how many of corr_per_lane live in LDS */
   int32_t reserved;                          /* 0; bit 0 (diagnostics): add the correspondence-passes this call executes --
-                                                in full / cost-only -- to pnec_hip_work_counters()[13] / [14] */
+                                                in full / cost-only -- to pnec_hip_work_counters()[13] / [14]; any other
+                                                bit set: PNEC_HIP_ERR_INVALID_ARGUMENT */
   double function_tolerance;                 /* 1e-6 */
   double gradient_tolerance;                 /* 1e-10 */
   double parameter_tolerance;                /* 1e-8 */
@@ -328,6 +329,36 @@ int pnec_hip_solve_pipeline_multi(int32_t n_devices, const int32_t *devices, int
                                   const double *init_t, const pnec_hip_pipeline_options *opt, double *out_q,
                                   double *out_t, uint8_t *out_inlier_mask, int32_t *out_inlier_count);
 
+/* The persistent form (ABI 5): a handle that keeps one capacity-shaped batch and one stream per listed device alive, for
+ * callers that solve batch after batch -- the one-shot call above creates, fills and destroys a batch per device per
+ * call.  What north_star shards is the refinement (PNECCeres::Optimize over independent frame pairs), so the handle has
+ * it (pnec_hip_multi_solve = pnec_hip_solve per shard, multi-hypothesis starts included) next to the whole chain
+ * (pnec_hip_multi_solve_pipeline = pnec_hip_solve_pipeline per shard).
+ *   create  devices[n_devices] (a device may be listed more than once); mode as pnec_hip_problem_create; the handle holds
+ *           up to max_pairs pairs / max_corr correspondences in total, no pair larger than max_pair_corr (each device's
+ *           batch is sized for max_corr / n_devices + max_pair_corr: what a partition balanced by correspondence count
+ *           can give it).
+ *   fill    HOST arrays in the reference layout (as pnec_hip_problem_fill); partitions the pairs (pnec_hip_partition),
+ *           re-shapes the device batches in place and uploads every shard from a host thread of its own.
+ *   solve / solve_pipeline   HOST arrays; every shard on its device and stream, side by side; return when all are done.
+ *           Results do not depend on the device list (RANSAC draws belong to the GLOBAL pair index).
+ * After the first call of each kind nothing is allocated (pnec_hip_alloc_counters counts the library's hipMalloc calls).
+ * Not thread-safe: one handle per calling thread. */
+typedef struct pnec_hip_multi pnec_hip_multi;
+int pnec_hip_multi_create(int32_t n_devices, const int32_t *devices, int mode, int64_t max_pairs, int64_t max_corr,
+                          int64_t max_pair_corr, pnec_hip_multi **out);
+int pnec_hip_multi_destroy(pnec_hip_multi *m);
+int32_t pnec_hip_multi_num_devices(const pnec_hip_multi *m);
+int pnec_hip_multi_bounds(const pnec_hip_multi *m, int64_t *bounds /* [n_devices + 1]: the current partition */);
+int pnec_hip_multi_fill(pnec_hip_multi *m, int64_t n_pairs, const int64_t *offsets, const double *bvs1, const double *bvs2,
+                        const double *covs, const double *covs_host);
+int pnec_hip_multi_solve(pnec_hip_multi *m, const double *init_q, const double *init_t, int32_t n_hyp, const double *hyp_t,
+                         double reg, const pnec_hip_options *opt, double *out_q, double *out_t, double *out_cost,
+                         int32_t *out_iterations, int32_t *out_status);
+int pnec_hip_multi_solve_pipeline(pnec_hip_multi *m, const double *init_q, const double *init_t,
+                                  const pnec_hip_pipeline_options *opt, double *out_q, double *out_t,
+                                  uint8_t *out_inlier_mask, int32_t *out_inlier_count);
+
 /* ---- streaming: one frame pair (or a few) per call, as the reference's odometry calls the solver ----
  * (Frame2Frame::PNECAlign -> PNEC::Solve once per frame, src/rel_pose_estimation/frame2frame.cc:122-141;
  * PNECCeres::Optimize once per pybind call, python/pypnec.cpp:55-65.)  A handle owns `slots` staging
@@ -421,6 +452,9 @@ int pnec_hip_work_counters(int device, int reset, uint64_t *out16, int32_t *comp
  * variable PNEC_HIP_CACHE_MB (default 16384, 0 disables).  This call returns the cached buffers
  * of `device` (-1: all devices) to the driver; returns the number of bytes released. */
 int64_t pnec_hip_release_cache(int device);
+/* out4: hipMalloc calls made by the library's allocator so far | requests served from its cache | blocks handed out and
+ * not yet freed | bytes sitting in the cache (all devices; for "nothing is allocated after warm-up" tests) */
+int pnec_hip_alloc_counters(uint64_t *out4);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,13 @@ SYMBOLS = [
     "pnec_hip_solve_pipeline",
     "pnec_hip_partition",
     "pnec_hip_solve_pipeline_multi",
+    "pnec_hip_multi_create",
+    "pnec_hip_multi_destroy",
+    "pnec_hip_multi_num_devices",
+    "pnec_hip_multi_bounds",
+    "pnec_hip_multi_fill",
+    "pnec_hip_multi_solve",
+    "pnec_hip_multi_solve_pipeline",
     "pnec_hip_stream_create",
     "pnec_hip_stream_destroy",
     "pnec_hip_problem_create_capacity",
@@ -83,6 +90,7 @@ SYMBOLS = [
     "pnec_hip_selftest",
     "pnec_hip_work_counters",
     "pnec_hip_release_cache",
+    "pnec_hip_alloc_counters",
 ]
 
 
@@ -199,6 +207,14 @@ def lib() -> C.CDLL:
     L.pnec_hip_work_counters.argtypes = [C.c_int, C.c_int, _vp, C.POINTER(C.c_int32)]
     L.pnec_hip_solve_pipeline_multi.argtypes = [C.c_int32, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp,
                                                 C.POINTER(PipelineOptions), _vp, _vp, _vp, _vp]
+    L.pnec_hip_multi_create.argtypes = [C.c_int32, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.POINTER(_vp)]
+    L.pnec_hip_multi_destroy.argtypes = [_vp]
+    L.pnec_hip_multi_num_devices.argtypes = [_vp]
+    L.pnec_hip_multi_bounds.argtypes = [_vp, _vp]
+    L.pnec_hip_multi_fill.argtypes = [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp]
+    L.pnec_hip_multi_solve.argtypes = [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.POINTER(Options), _vp, _vp, _vp, _vp, _vp]
+    L.pnec_hip_multi_solve_pipeline.argtypes = [_vp, _vp, _vp, C.POINTER(PipelineOptions), _vp, _vp, _vp, _vp]
+    L.pnec_hip_alloc_counters.argtypes = [_vp]
     L.pnec_hip_weighted_eigensolver.argtypes = [_vp, _vp, _vp, C.c_double, C.c_int32, _vp, _vp, C.c_int, _vp]
     L.pnec_hip_default_pipeline_options.argtypes = [C.POINTER(PipelineOptions)]
     L.pnec_hip_default_pipeline_options.restype = None

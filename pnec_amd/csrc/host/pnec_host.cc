@@ -369,7 +369,6 @@ SE3d NECCeres::Result() const { return SE3d(Orientation(), Translation()); }
 namespace rel_pose_estimation {
 
 PNEC::PNEC(const Options &options) : options_(options) {}
-PNEC::~PNEC() {}
 
 SE3d PNEC::Solve(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
                  const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose) {
@@ -723,6 +722,45 @@ std::vector<SE3d> PNEC::CeresSolverBatch(const std::vector<FramePair> &pairs,
   for (int64_t p = 0; p < B; ++p) {
     out[p] = SE3d(Quaterniond(oq[4 * p + 3], oq[4 * p], oq[4 * p + 1], oq[4 * p + 2]).toRotationMatrix(),
                   Vector3d(ot[3 * p], ot[3 * p + 1], ot[3 * p + 2]));
+    if (summaries) (*summaries)[p] = {oc[p], oi[p], os[p]};
+  }
+  return out;
+}
+
+PNEC::~PNEC() {
+  if (multi_) pnec_hip_multi_destroy(multi_);
+}
+
+std::vector<SE3d> PNEC::CeresSolverBatch(const std::vector<FramePair> &pairs, const std::vector<int> &devices,
+                                         std::vector<optimization::Summary> *summaries) {
+  const int64_t B = (int64_t)pairs.size();
+  std::vector<SE3d> out(B);
+  if (summaries) summaries->resize(B);
+  if (B == 0) return out;
+  if (devices.empty()) throw std::invalid_argument("CeresSolverBatch: empty device list");
+  const FlatBatch h(pairs);
+  const int64_t total = h.offsets[B];
+  int64_t max_pair = 0;
+  for (int64_t p = 0; p < B; ++p) max_pair = std::max(max_pair, h.offsets[p + 1] - h.offsets[p]);
+  if (!multi_ || multi_devices_ != devices || B > multi_pairs_ || total > multi_corr_ || max_pair > multi_pair_corr_) {
+    if (multi_) pnec_hip_multi_destroy(multi_);
+    multi_ = nullptr;
+    std::vector<int32_t> devs(devices.begin(), devices.end());
+    // (some head-room, so that a stream of similar batches keeps the handle)
+    multi_pairs_ = B + B / 8; multi_corr_ = total + total / 8; multi_pair_corr_ = max_pair + max_pair / 8;
+    Check(pnec_hip_multi_create((int32_t)devs.size(), devs.data(), PNEC_HIP_MODE_TARGET, multi_pairs_, multi_corr_,
+                                multi_pair_corr_, &multi_));
+    multi_devices_ = devices;
+  }
+  Check(pnec_hip_multi_fill(multi_, B, h.offsets.data(), total ? h.b1[0].data() : nullptr, total ? h.b2[0].data() : nullptr,
+                            total ? h.cv[0].data() : nullptr, nullptr));
+  std::vector<double> oq(4 * B), ot(3 * B), oc(B);
+  std::vector<int32_t> oi(B), os(B);
+  const pnec_hip_options o = optimization::SolverOptions().ToHip();   // defaults, as CeresSolver does (quirk C1)
+  Check(pnec_hip_multi_solve(multi_, h.q0.data(), h.t0.data(), 1, nullptr, options_.regularization_, &o, oq.data(), ot.data(),
+                             oc.data(), oi.data(), os.data()));
+  for (int64_t p = 0; p < B; ++p) {
+    out[p] = PoseFromQT(&oq[4 * p], &ot[3 * p]);
     if (summaries) (*summaries)[p] = {oc[p], oi[p], os[p]};
   }
   return out;

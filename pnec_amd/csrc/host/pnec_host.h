@@ -267,12 +267,23 @@ class PNEC {
   // Addition: CeresSolver for many pairs in one device launch (ragged sizes allowed).
   std::vector<SE3d> CeresSolverBatch(const std::vector<FramePair> &pairs,
                                      std::vector<optimization::Summary> *summaries = nullptr);
+  // Addition: ... over several GPUs of the node from this one process -- the path the benchmark shards (independent frame
+  // pairs, no data-path exchange) -- through the persistent multi-device handle (pnec_hip_multi_*): the handle lives in
+  // this object and is reused while the device list and the shapes fit, so a loop of calls allocates nothing.
+  std::vector<SE3d> CeresSolverBatch(const std::vector<FramePair> &pairs, const std::vector<int> &devices,
+                                     std::vector<optimization::Summary> *summaries = nullptr);
+  PNEC(const PNEC &o) : options_(o.options_) {}   // (the cached device handle is not shared: a copy makes its own)
+  PNEC &operator=(const PNEC &o) { options_ = o.options_; return *this; }
 
  private:
   SE3d SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
                  const std::vector<Matrix3d> &projected_covs, const SE3d &initial_pose,
                  std::vector<int> &inliers, common::FrameTiming *timing);
   Options options_;
+  // CeresSolverBatch(pairs, devices): the cached multi-device handle and what it was made for
+  struct pnec_hip_multi *multi_ = nullptr;
+  std::vector<int> multi_devices_;
+  int64_t multi_pairs_ = 0, multi_corr_ = 0, multi_pair_corr_ = 0;
 };
 
 }  // namespace rel_pose_estimation

@@ -92,7 +92,7 @@ arr pyceresnec(arr host_bvs, arr target_bvs, arr init_pose) {
 
 // PNEC::CeresSolver (target-frame covariances, pnec.cc:350-370) over a list of pairs, one launch.
 py::list ceres_solver_batch(py::list bvs1, py::list bvs2, py::list covs, py::list init_poses,
-                            double regularization) {
+                            double regularization, std::vector<int> devices) {
   const size_t B = bvs1.size();
   if (bvs2.size() != B || covs.size() != B || init_poses.size() != B)
     throw std::invalid_argument("all lists must have one entry per frame pair");
@@ -109,7 +109,7 @@ py::list ceres_solver_batch(py::list bvs1, py::list bvs2, py::list covs, py::lis
   {
     py::gil_scoped_release release;
     pnec::rel_pose_estimation::PNEC solver(options);
-    poses = solver.CeresSolverBatch(pairs);
+    poses = devices.empty() ? solver.CeresSolverBatch(pairs) : solver.CeresSolverBatch(pairs, devices);
   }
   py::list out;
   for (const auto &T : poses) out.append(FromPose(T));
@@ -292,6 +292,7 @@ PYBIND11_MODULE(pypnec, m) {
         "PNEC::Solve for a list of frame pairs, every stage one device launch over the batch (addition); devices: the "
         "GPUs to shard the pairs over from this process (empty: the default device)");
   m.def("ceres_solver_batch", &ceres_solver_batch, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"),
-        py::arg("init_poses"), py::arg("regularization") = 1e-13,
-        "PNEC::CeresSolver for a list of frame pairs in one device launch (addition)");
+        py::arg("init_poses"), py::arg("regularization") = 1e-13, py::arg("devices") = std::vector<int>{},
+        "PNEC::CeresSolver for a list of frame pairs in one device launch (addition); devices: the GPUs to shard the pairs "
+        "over from this process (empty: the default device)");
 }

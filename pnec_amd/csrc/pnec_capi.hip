@@ -11,6 +11,7 @@
 #include <new>
 #include <string>
 #include <unordered_map>
+#include <functional>
 #include <mutex>
 #include <vector>
 
@@ -92,6 +93,9 @@ struct pnec_hip_problem {
   int64_t front_pairs = 0;
   // which iteration the eigenvalue minimisations of the stage calls run (pnec_hip_problem_set_eigensolver_scheme)
   int es_scheme = 0;
+  // capacity-shaped batches (filled again and again): the host-space fill's AoS staging, kept and grown on demand
+  double *d_fill = nullptr;
+  int64_t fill_doubles = 0;
   // launch-order hint of the RANSAC stage (pnec_hip_problem_launch_order_hint): the last run's hypothesis counts and
   // the order made from them; order_pairs = the number of pairs d_order is a permutation of (0: none yet)
   bool order_hint = false;
@@ -168,6 +172,7 @@ std::mutex g_mem_mutex;
 std::unordered_map<void *, DevBlock> g_live;  // every block handed out
 std::vector<DevBlock> g_cache;               // free blocks kept for reuse
 size_t g_cached_bytes = 0;
+uint64_t g_n_hip_malloc = 0, g_n_cache_hit = 0;   // pnec_hip_alloc_counters
 
 size_t cache_limit_bytes() {
   static const size_t limit = [] {
@@ -213,7 +218,9 @@ hipError_t dev_alloc(T **out, size_t bytes) {
     g_cached_bytes -= b.bytes;
     g_cache[best] = g_cache.back();
     g_cache.pop_back();
+    ++g_n_cache_hit;
   } else {
+    ++g_n_hip_malloc;
     e = hipMalloc(&b.ptr, bytes);
     if (e != hipSuccess) {  // out of memory: give the cache back and try once more
       (void)hipGetLastError();
@@ -1247,6 +1254,7 @@ int pnec_hip_problem_destroy(pnec_hip_problem *p) {
     if (drained) pool_event_put(p->meta_uploaded, p->device); else (void)hipEventDestroy(p->meta_uploaded);
   }
   release(p->d_bucket_pairs);
+  release(p->d_fill);
   delete p;
   return 0;
 }
@@ -1270,9 +1278,22 @@ int pnec_hip_problem_fill(pnec_hip_problem *p, int64_t first_pair, int64_t n_pai
 
   const double *d_b1 = bvs1, *d_b2 = bvs2, *d_c = covs, *d_ch = covs_host;
   double *tmp = nullptr;
+  bool persistent_stage = false;
   if (space == PNEC_HIP_MEM_HOST && m > 0) {
     const int64_t per = 6 + (p->nc >= 12 ? 9 : 0) + (p->nc >= 18 ? 9 : 0);
-    PNEC_HIP_TRY(dev_alloc(&tmp, sizeof(double) * per * m));
+    if (p->cap_pairs > 0) {   // a batch that is re-filled: its staging stays (nothing allocated per call)
+      if (per * m > p->fill_doubles) {
+        if (p->d_fill) (void)dev_free(p->d_fill);
+        p->d_fill = nullptr;
+        p->fill_doubles = 0;
+        PNEC_HIP_TRY(dev_alloc(&p->d_fill, sizeof(double) * per * m));
+        p->fill_doubles = per * m;
+      }
+      persistent_stage = true;
+      tmp = p->d_fill;
+    } else {
+      PNEC_HIP_TRY(dev_alloc(&tmp, sizeof(double) * per * m));
+    }
     double *w = tmp;
     auto up = [&](const double *src, int64_t k, const double **dst) -> hipError_t {
       *dst = w;
@@ -1285,7 +1306,7 @@ int pnec_hip_problem_fill(pnec_hip_problem *p, int64_t first_pair, int64_t n_pai
     if (e == hipSuccess && p->nc >= 12) e = up(covs, 9, &d_c);
     if (e == hipSuccess && p->nc >= 18) e = up(covs_host, 9, &d_ch);
     if (e != hipSuccess) {
-      (void)dev_free(tmp);
+      if (!persistent_stage) (void)dev_free(tmp);
       return fail_hip(e, "hipMemcpyAsync(H2D)");
     }
   } else if (space != PNEC_HIP_MEM_DEVICE && space != PNEC_HIP_MEM_HOST) {
@@ -1312,8 +1333,8 @@ int pnec_hip_problem_fill(pnec_hip_problem *p, int64_t first_pair, int64_t n_pai
   }
   hipError_t e = hipGetLastError();
   if (tmp) {
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)dev_free(tmp);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);   // (the caller may reuse its arrays; the staging may be refilled)
+    if (!persistent_stage) (void)dev_free(tmp);
   }
   if (e != hipSuccess) return fail_hip(e, "pack_kernel");
   return 0;
@@ -1475,6 +1496,7 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
   else
     pnec_hip_default_options(&opt);
   if (opt.max_num_iterations < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "max_num_iterations < 0");
+  if (opt.reserved & ~1) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "pnec_hip_options.reserved: only bit 0 is defined");
   const int64_t S = p->n_pairs * (int64_t)n_hyp;
   if (S == 0) return 0;
   if (S > 0x7fffffffLL) return fail(PNEC_HIP_ERR_UNSUPPORTED, "more than 2^31-1 solves in one call");
@@ -2167,6 +2189,16 @@ int pnec_hip_selftest(int device) {
 #include "pnec_stream.inl"
 #include "pnec_frame.inl"
 #include "pnec_multi.inl"
+
+int pnec_hip_alloc_counters(uint64_t *out4) {
+  if (!out4) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "out is NULL");
+  std::lock_guard<std::mutex> lock(g_mem_mutex);
+  out4[0] = g_n_hip_malloc;
+  out4[1] = g_n_cache_hit;
+  out4[2] = (uint64_t)g_live.size();
+  out4[3] = (uint64_t)g_cached_bytes;
+  return 0;
+}
 
 int64_t pnec_hip_release_cache(int device) {
   std::lock_guard<std::mutex> lock(g_mem_mutex);

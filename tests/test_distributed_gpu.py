@@ -285,3 +285,83 @@ def test_default_bench_line_carries_the_other_configs_and_the_chain():
     assert chain["parity"]["inlier_masks_identical"] and [b["bound"] for b in chain["roofline"]] == ["valu_fp64", "valu_fp64", "hbm"]
     assert all(b["frac"] is not None and 0 < b["frac"] < 1 for b in chain["roofline"])
     assert chain["value"] >= chain["pairs_per_s_one_call_at_a_time"] * 0.9
+
+
+def test_persistent_multi_device_handle_is_bitwise_the_single_device_calls_and_allocates_nothing(oracle):
+    """pnec_hip_multi_* (ABI 5): the refinement -- what north_star shards -- and the whole chain through the persistent
+    handle on device lists [0, 0] and [0, 0, 0] (one GPU here: every entry is cuda:0, each with its own batch, stream and
+    host thread): bit-identical to the single-device calls, multi-hypothesis starts included; and after the first calls a
+    loop of fill + solve + solve_pipeline makes no hipMalloc (pnec_hip_alloc_counters)."""
+    import numpy as np
+    from pnec_amd import Batch, capi
+    from pnec_amd import simulation as sim
+    from pnec_amd.multi import MultiBatch, alloc_counters
+    rng = np.random.default_rng(3)
+    sizes = rng.integers(64, 600, size=96)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    g = sim.generate(len(sizes), int(sizes.max()), seed=21)
+    f1 = np.concatenate([g.bvs1[p].numpy()[:n] for p, n in enumerate(sizes)])
+    f2 = np.concatenate([g.bvs2[p].numpy()[:n] for p, n in enumerate(sizes)])
+    cv = np.concatenate([g.covs2[p].numpy()[:n] for p, n in enumerate(sizes)])
+    bad = rng.random(len(f2)) < 0.1
+    junk = rng.normal(size=(len(f2), 3))
+    f2[bad] = (junk / np.linalg.norm(junk, axis=1, keepdims=True))[bad]
+    q0, t0 = g.init_q.numpy(), g.init_t.numpy()
+    H = 4
+    hyp = rng.normal(size=(len(sizes) * H, 3)); hyp /= np.linalg.norm(hyp, axis=1, keepdims=True)
+    with Batch(capi.MODE_TARGET, off) as b:
+        b.fill(f1, f2, cv)
+        ref = b.solve(q0, t0)
+        ref_h = b.solve(q0, None, hyp_t=hyp, n_hyp=H)
+        rq, rt, rm, rc = b.solve_pipeline(q0, t0, want_inliers=True)
+    for devs in ([0, 0], [0, 0, 0]):
+        with MultiBatch(devs, capi.MODE_TARGET, len(sizes), int(off[-1]), int(sizes.max())) as mb:
+            mb.fill(off, f1, f2, cv)
+            bnd = mb.bounds
+            assert bnd[0] == 0 and bnd[-1] == len(sizes) and (np.diff(bnd) > 0).all()
+            r = mb.solve(q0, t0)
+            np.testing.assert_array_equal(r["q"], np.asarray(ref.q)); np.testing.assert_array_equal(r["t"], np.asarray(ref.t))
+            np.testing.assert_array_equal(r["iterations"], np.asarray(ref.iterations))
+            np.testing.assert_array_equal(r["status"], np.asarray(ref.status))
+            rh = mb.solve(q0, None, hyp_t=hyp, n_hyp=H)
+            np.testing.assert_array_equal(rh["q"], np.asarray(ref_h.q)); np.testing.assert_array_equal(rh["cost"], np.asarray(ref_h.cost))
+            q, t, m, c = mb.solve_pipeline(q0, t0, want_inliers=True)
+            np.testing.assert_array_equal(q, np.asarray(rq)); np.testing.assert_array_equal(t, np.asarray(rt))
+            np.testing.assert_array_equal(m, np.asarray(rm)); np.testing.assert_array_equal(c, np.asarray(rc))
+            k = 40
+            small = (off[:k + 1], f1[:off[k]], f2[:off[k]], cv[:off[k]])
+            mb.fill(*small); mb.solve(q0[:k], t0[:k]); mb.solve_pipeline(q0[:k], t0[:k])   # (the second shape's first calls)
+            a0 = alloc_counters()
+            for _ in range(4):                       # both shapes again, in the same handle
+                mb.fill(off, f1, f2, cv)
+                mb.solve(q0, t0)
+                mb.solve_pipeline(q0, t0)
+                mb.fill(*small)
+                r2 = mb.solve(q0[:k], t0[:k])
+                mb.solve_pipeline(q0[:k], t0[:k])
+            np.testing.assert_array_equal(r2["q"], np.asarray(ref.q)[:k])
+            a1 = alloc_counters()
+            assert a1["hip_malloc_calls"] == a0["hip_malloc_calls"], (a0, a1)
+    # the facade: CeresSolverBatch(pairs, devices) through the cached handle == the one-device call
+    sys.path.insert(0, os.path.join(ROOT, "pnec_amd"))
+    import pypnec
+    lists = lambda a: [a[off[p]:off[p + 1]] for p in range(len(sizes))]
+    T0 = []
+    for p in range(len(sizes)):
+        T = np.eye(4); T[:3, :3] = g.init_R[p].numpy(); T[:3, 3] = t0[p]; T0.append(T)
+    one = pypnec.ceres_solver_batch(lists(f1), lists(f2), lists(cv), T0)
+    two = pypnec.ceres_solver_batch(lists(f1), lists(f2), lists(cv), T0, devices=[0, 0])
+    for a_, b_ in zip(one, two):
+        np.testing.assert_array_equal(np.asarray(a_), np.asarray(b_))
+
+
+def test_single_process_bench_line():
+    """`bench.py --gpus 2 --single-process --share-gpu`: the multi-device handle driven by the bench (the comparison form
+    for a SCALE run) prints the contract's line, every solve done, nothing allocated inside the timed steps."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process", "--share-gpu",
+                        "--pairs", "4000", "--steps", "3", "--warmup", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 1e5 and line["all_iterations_done"]
+    assert line["config"]["hip_malloc_calls_during_timed_steps"] == 0 and line["config"]["shard_bounds"] == [0, 4000, 8000]
