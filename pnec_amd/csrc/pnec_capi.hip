@@ -1131,7 +1131,8 @@ static int problem_create_impl(int device, int mode, int64_t cap_pairs, int64_t 
   p->cap_doubles = cap_doubles;
   p->offsets.assign(offsets, offsets + n_pairs + 1);
   hipError_t e;
-  if ((e = dev_alloc(&p->d_data, sizeof(double) * std::max<int64_t>(std::max(total, cap_doubles), 1))) != hipSuccess) {
+  // (+ kDataSlackDoubles: the weighted stage's 16-byte table loads may read 512 bytes past the last pair's last plane)
+  if ((e = dev_alloc(&p->d_data, sizeof(double) * (std::max<int64_t>(std::max(total, cap_doubles), 1) + kDataSlackDoubles))) != hipSuccess) {
     pnec_hip_problem_destroy(p);
     return fail_hip(e, "hipMalloc(data)");
   }
@@ -1856,7 +1857,7 @@ static int alloc_like(pnec_hip_problem *src, hipStream_t stream, pnec_hip_proble
   d->cap_pairs = std::max(src->cap_pairs, src->n_pairs);
   d->cap_doubles = std::max(src->cap_doubles, src->data_doubles);
   const int64_t P = std::max<int64_t>(d->cap_pairs, 1);
-  hipError_t e = dev_alloc(&d->d_data, sizeof(double) * std::max<int64_t>(d->cap_doubles, 1));
+  hipError_t e = dev_alloc(&d->d_data, sizeof(double) * (std::max<int64_t>(d->cap_doubles, 1) + kDataSlackDoubles));
   if (e == hipSuccess) e = dev_alloc(&d->d_block_offset, sizeof(int64_t) * P);
   if (e == hipSuccess) e = dev_alloc(&d->d_offsets, sizeof(int64_t) * (P + 1));
   if (e == hipSuccess) e = dev_alloc(&d->d_count, sizeof(int32_t) * P);

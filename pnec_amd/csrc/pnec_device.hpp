@@ -421,37 +421,51 @@ __device__ __forceinline__ void load_planes_saddr(double (&e)[NC], const char *s
   }
 }
 
-// EIGHT correspondences per lane (sets k = 0..7: correspondence 64 k + lane of this wavefront's share, 512 k bytes into
-// each plane) of a pair's TWELVE planes, all 96 loads in flight together, in one statement with its wait (the weighted
-// stage's table build).  Only the first `nt` sets are loaded -- the sets that start inside the pair's planes (the planes
-// are padded with zeros to a multiple of 64 correspondences, so a set that starts inside lies inside; one that starts
-// beyond may lie beyond the allocation) -- skipped wave-uniformly; the others keep the zeros they came with.
-#define PNEC_SET12_(K, OFF)                                                                                        \
+// EIGHT correspondences per lane of a pair's TWELVE planes in one statement with its wait (the weighted stage's table
+// build), as FOUR sets of 16-byte loads: set K = 0..3 gives the lane correspondences 128 K + 2 lane and + 1 of this
+// wavefront's share (slots 2 K, 2 K + 1), 1024 K bytes into each plane -- 48 loads per lane.  (Until round 5: 96 8-byte
+// loads, correspondence 64 k + lane in slot k.  A wavefront can have 63 vector-memory instructions in flight: the 64th
+// waited for the first to return, so the build took two trips to memory and more -- 22 k of the pair's 80 k clocks; 48
+// fit in one.  Which lane and slot holds which correspondence changes the ORDER of the stage's sums over the pair, i.e.
+// its results in the last bits.)  Only the first `nt` sets are loaded -- the sets that start inside the pair's planes --
+// skipped wave-uniformly; the others keep the zeros they came with.  The planes are padded with zeros to a multiple of
+// 64 correspondences, a set spans 128: the last set may read 512 bytes past a plane's end -- the next plane's start, or,
+// behind the last plane, whatever follows the pair's block (the next pair, or the 64 doubles of slack every batch
+// allocation carries for this); what it reads there belongs to lanes beyond the pair, which the caller discards.
+typedef double pnec_d2_ __attribute__((ext_vector_type(2)));
+#define PNEC_LD4_(D, B, OFF) "global_load_dwordx4 %[" #D "], %[lo], %[" #B "] offset:" OFF "\n\t"
+#define PNEC_SET12X2_(K, OFF)                                                                                      \
   "s_cmp_le_u32 %[nt], " #K "\n\ts_cbranch_scc1 1f\n\t"                                                            \
-  PNEC_LD_(d##K##_0, b0, OFF) PNEC_LD_(d##K##_1, b1, OFF) PNEC_LD_(d##K##_2, b2, OFF) PNEC_LD_(d##K##_3, b3, OFF)   \
-  PNEC_LD_(d##K##_4, b4, OFF) PNEC_LD_(d##K##_5, b5, OFF) PNEC_LD_(d##K##_6, b6, OFF) PNEC_LD_(d##K##_7, b7, OFF)   \
-  PNEC_LD_(d##K##_8, b8, OFF) PNEC_LD_(d##K##_9, b9, OFF) PNEC_LD_(d##K##_10, b10, OFF) PNEC_LD_(d##K##_11, b11, OFF)
-#define PNEC_SET12_OUT_(K)                                                                                          \
-  [d##K##_0] "+v"(pe[K][0]), [d##K##_1] "+v"(pe[K][1]), [d##K##_2] "+v"(pe[K][2]), [d##K##_3] "+v"(pe[K][3]),       \
-  [d##K##_4] "+v"(pe[K][4]), [d##K##_5] "+v"(pe[K][5]), [d##K##_6] "+v"(pe[K][6]), [d##K##_7] "+v"(pe[K][7]),       \
-  [d##K##_8] "+v"(pe[K][8]), [d##K##_9] "+v"(pe[K][9]), [d##K##_10] "+v"(pe[K][10]), [d##K##_11] "+v"(pe[K][11])
-__device__ __forceinline__ void load_sets8x12_saddr(double (&pe)[8][12], const char *sbase, size_t plane_bytes, unsigned lo,
-                                                    unsigned nt) {
+  PNEC_LD4_(d##K##_0, b0, OFF) PNEC_LD4_(d##K##_1, b1, OFF) PNEC_LD4_(d##K##_2, b2, OFF) PNEC_LD4_(d##K##_3, b3, OFF)   \
+  PNEC_LD4_(d##K##_4, b4, OFF) PNEC_LD4_(d##K##_5, b5, OFF) PNEC_LD4_(d##K##_6, b6, OFF) PNEC_LD4_(d##K##_7, b7, OFF)   \
+  PNEC_LD4_(d##K##_8, b8, OFF) PNEC_LD4_(d##K##_9, b9, OFF) PNEC_LD4_(d##K##_10, b10, OFF) PNEC_LD4_(d##K##_11, b11, OFF)
+#define PNEC_SET12X2_OUT_(K)                                                                                        \
+  [d##K##_0] "+v"(x[K][0]), [d##K##_1] "+v"(x[K][1]), [d##K##_2] "+v"(x[K][2]), [d##K##_3] "+v"(x[K][3]),           \
+  [d##K##_4] "+v"(x[K][4]), [d##K##_5] "+v"(x[K][5]), [d##K##_6] "+v"(x[K][6]), [d##K##_7] "+v"(x[K][7]),           \
+  [d##K##_8] "+v"(x[K][8]), [d##K##_9] "+v"(x[K][9]), [d##K##_10] "+v"(x[K][10]), [d##K##_11] "+v"(x[K][11])
+__device__ __forceinline__ void load_sets4x12x2_saddr(double (&pe)[8][12], const char *sbase, size_t plane_bytes, unsigned lo16,
+                                                      unsigned nt) {
+  pnec_d2_ x[4][12];
 #pragma unroll
-  for (int k = 0; k < 8; ++k)
+  for (int k = 0; k < 4; ++k)
 #pragma unroll
-    for (int c = 0; c < 12; ++c) pe[k][c] = 0.0;
+    for (int c = 0; c < 12; ++c) x[k][c] = pnec_d2_{0.0, 0.0};
   asm volatile("s_nop 4\n\t"
-               PNEC_SET12_(0, "0") PNEC_SET12_(1, "512") PNEC_SET12_(2, "1024") PNEC_SET12_(3, "1536")
-               PNEC_SET12_(4, "2048") PNEC_SET12_(5, "2560") PNEC_SET12_(6, "3072") PNEC_SET12_(7, "3584")
+               PNEC_SET12X2_(0, "0") PNEC_SET12X2_(1, "1024") PNEC_SET12X2_(2, "2048") PNEC_SET12X2_(3, "3072")
                "1:\n\ts_waitcnt vmcnt(0)"
-               : PNEC_SET12_OUT_(0), PNEC_SET12_OUT_(1), PNEC_SET12_OUT_(2), PNEC_SET12_OUT_(3), PNEC_SET12_OUT_(4),
-                 PNEC_SET12_OUT_(5), PNEC_SET12_OUT_(6), PNEC_SET12_OUT_(7)
-               : [lo] "v"(lo), [nt] "s"(nt), [b0] "s"(sbase), [b1] "s"(sbase + plane_bytes), [b2] "s"(sbase + 2 * plane_bytes),
+               : PNEC_SET12X2_OUT_(0), PNEC_SET12X2_OUT_(1), PNEC_SET12X2_OUT_(2), PNEC_SET12X2_OUT_(3)
+               : [lo] "v"(lo16), [nt] "s"(nt), [b0] "s"(sbase), [b1] "s"(sbase + plane_bytes), [b2] "s"(sbase + 2 * plane_bytes),
                  [b3] "s"(sbase + 3 * plane_bytes), [b4] "s"(sbase + 4 * plane_bytes), [b5] "s"(sbase + 5 * plane_bytes),
                  [b6] "s"(sbase + 6 * plane_bytes), [b7] "s"(sbase + 7 * plane_bytes), [b8] "s"(sbase + 8 * plane_bytes),
                  [b9] "s"(sbase + 9 * plane_bytes), [b10] "s"(sbase + 10 * plane_bytes), [b11] "s"(sbase + 11 * plane_bytes)
                : "memory", "scc");
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      pe[2 * k][c] = x[k][c].x;
+      pe[2 * k + 1][c] = x[k][c].y;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

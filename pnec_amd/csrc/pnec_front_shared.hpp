@@ -4,4 +4,7 @@ namespace pnec_hip {
 // eigensolver schemes 1, 2: most rounds of the weighted stage (weighted_iterations - 1) whose minimisers the front
 // scratch holds per pair
 constexpr int kEsMaxRounds = 15;
+// every allocation of a batch's planes carries this many doubles of slack behind them: the weighted stage loads its tables
+// in 128-correspondence sets (16-byte loads), and the last set of a pair may read 64 doubles past the pair's last plane
+constexpr int kDataSlackDoubles = 64;
 }  // namespace pnec_hip

@@ -1373,25 +1373,33 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
       xpar ^= 1;
     }
   };
-  double q0[4] = {a.init_q[4 * pair], a.init_q[4 * pair + 1], a.init_q[4 * pair + 2], a.init_q[4 * pair + 3]};
+  // Everything the kernel reads per pair -- start pose, the first round's minimiser and its iteration count
+  // (es_batch_kernel's results), the pair's 36 weighted sums -- is requested HERE, in one trip to memory: read where it
+  // was first used, each was a dependent round trip of its own (~8 k clocks of the pair's 80 k: phase clocks, round 5).
+  const double *iqp = a.init_q + 4 * pair, *itp = a.init_t + 3 * pair;
+  const double *pvp = a.pre_n_es ? a.pre_v_rounds + 3 * pair : a.pre_v + 3 * pair;
+  double q0[4] = {iqp[0], iqp[1], iqp[2], iqp[3]};
+  const double t0[3] = {itp[0], itp[1], itp[2]};
+  const double pre_v0[3] = {pvp[0], pvp[1], pvp[2]};
+  const int pre_its0 = a.pre_its[pair];
+  const int pre_n_es0 = a.pre_n_es ? a.pre_n_es[pair] : 0;
+  const double g_mine = (lane < 36 && (WPP == 1 || wave == 0)) ? a.pre_G[36 * pair + lane] : 0.0;
   {
     const double qn = 1.0 / sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
     for (int k = 0; k < 4; ++k) q0[k] *= qn;
   }
   double R0[9];
   rot_from_quat(q0, R0);
-  const double t0[3] = {a.init_t[3 * pair], a.init_t[3 * pair + 1], a.init_t[3 * pair + 2]};
-  double R[9], t[3] = {t0[0], t0[1], t0[2]}, v[3];
+  double R[9], t[3] = {t0[0], t0[1], t0[2]}, v[3] = {pre_v0[0], pre_v0[1], pre_v0[2]};
 #pragma unroll
   for (int i = 0; i < 9; ++i) R[i] = R0[i];
-  rot_to_cayley(R0, v);
   unsigned long long ph_clk[kPhCount] = {0};
   const unsigned long long ph_start = a.trace ? __builtin_amdgcn_s_memtime() : 0ull;
   PNEC_PHASE_BEGIN();
   // weights come from the INITIAL pose in every iteration (C3): the 36 weighted sums never change -- they
   // were made by sums36_kernel<true> (the first round's minimisation, es_batch_kernel, needed them first);
   // here they are only read again if a later round has to minimise once more
-  if (lane < 36 && (WPP == 1 || wave == 0)) G[lane] = a.pre_G[36 * pair + lane];
+  if (lane < 36 && (WPP == 1 || wave == 0)) G[lane] = g_mine;
   pair_sync();
   PNEC_PHASE_END(kPhSums);
 
@@ -1433,14 +1441,18 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
     int newton = 0;
     if constexpr (WITH_ES) {
       if (a.pre_n_es) {  // schemes 1, 2: every round's call ran in es_batch_alt_kernel, chained
-        const double *pv = a.pre_v_rounds + 3 * ((int64_t)it * a.n_pairs + pair);
-        v[0] = pv[0]; v[1] = pv[1]; v[2] = pv[2];
-        newton = it == 0 ? a.pre_its[pair] : 1;
-        rotation_final = it + 1 >= a.pre_n_es[pair];
+        if (it == 0) {
+          v[0] = pre_v0[0]; v[1] = pre_v0[1]; v[2] = pre_v0[2];
+        } else {
+          const double *pv = a.pre_v_rounds + 3 * ((int64_t)it * a.n_pairs + pair);
+          v[0] = pv[0]; v[1] = pv[1]; v[2] = pv[2];
+        }
+        newton = it == 0 ? pre_its0 : 1;
+        rotation_final = it + 1 >= pre_n_es0;
       } else {
         if (it == 0) {  // the first round's call ran in es_batch_kernel (sixteen pairs per wavefront)
-          v[0] = a.pre_v[3 * pair]; v[1] = a.pre_v[3 * pair + 1]; v[2] = a.pre_v[3 * pair + 2];
-          newton = a.pre_its[pair];
+          v[0] = pre_v0[0]; v[1] = pre_v0[1]; v[2] = pre_v0[2];
+          newton = pre_its0;
         } else {
           newton = es_minimise_quad<1>(G, v, (double)(n > 0 ? n : 1));
         }
@@ -1468,14 +1480,14 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
           ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32)) << 32) |
           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64));
       const size_t plane_bytes = (size_t)(unsigned)__builtin_amdgcn_readfirstlane(stride) * sizeof(double);
-      const unsigned voff = 8u * (unsigned)lane;
       double pe[8][12];   // (this branch is the resident form: KR == 8)
       {
-        // the sets of this wavefront's share that start inside the pair's planes (stride = n rounded up to 64)
+        // the sets of 128 correspondences of this wavefront's share that start inside the pair's planes (stride = n rounded
+        // up to 64); slot s of lane l holds correspondence first + 128 (s / 2) + 2 l + (s & 1) (load_sets4x12x2_saddr)
         const int first = (WPP > 1 ? wave * KR * kWave : 0);
-        const int sets = (stride - first + kWave - 1) / kWave;
-        const unsigned nt = (unsigned)__builtin_amdgcn_readfirstlane(sets < 0 ? 0 : (sets > 8 ? 8 : sets));
-        load_sets8x12_saddr(pe, sbase, plane_bytes, voff, nt);
+        const int sets = (stride - first + 2 * kWave - 1) / (2 * kWave);
+        const unsigned nt = (unsigned)__builtin_amdgcn_readfirstlane(sets < 0 ? 0 : (sets > 4 ? 4 : sets));
+        load_sets4x12x2_saddr(pe, sbase, plane_bytes, 16u * (unsigned)lane, nt);
       }
       if (threadIdx.x == 0) PNEC_WORK_ADD(kWkWesTableCorr, n);
       // the rotation as SCALARS here (it is one per pair; every product below takes one entry of it): this is where the
@@ -1487,7 +1499,7 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
       for (int i = 0; i < 9; ++i) Rs[i] = to_sgpr(R[i]);
 #pragma unroll
       for (int k = 0; k < KR; ++k) {
-        const int idx = (WPP > 1 ? wave * KR * kWave : 0) + lane + kWave * k;
+        const int idx = (WPP > 1 ? wave * KR * kWave : 0) + 2 * kWave * (k / 2) + 2 * lane + (k & 1);
         const bool in = idx < n;
         corr_nb_of(pe[k], Rs, a.reg, rn[k], rB[k]);
         if (!in) {  // padding: contributes exactly 0 to every sum (n = 0, B = I)

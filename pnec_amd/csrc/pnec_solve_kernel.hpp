@@ -989,18 +989,34 @@ __device__ __forceinline__ int lm_advance_rows(double *slab, int *ist, double *u
 
 constexpr int SRC_PLANES = 0;  // the batch's SoA planes in HBM (pnec_hip_problem)
 constexpr int SRC_AOS = 1;     // the caller's arrays in the reference layout (streaming handle)
+// SRC_DUAL (round 5, an A/B form: -DPNEC_SOLVE_DUAL_AB builds + PNEC_SOLVE_DUAL=1; not instantiated otherwise): the batch's planes, TWO one-wavefront solves per block whose LM steps
+// run as ONE instruction stream -- after both wavefronts' passes (a barrier) the first wavefront advances solve 0 in its
+// lanes 0..3 and solve 1 in lanes 4..7 (lm_advance is per-lane code on an LDS slab; its only cross-lane traffic is inside
+// a quad), then a second barrier publishes both candidates.  Per pair of solves and iteration the step's ~400 issue slots
+// are paid once instead of twice; the price is two block barriers per iteration and a wavefront that waits while the
+// other steps.  Same arithmetic per solve, hence the same bits -- and 8.8 % SLOWER on the benchmark (36.68 -> 33.45 M solves/s):
+// the barriers cost more than the shared step saves.  The measured answer to the round-4 review's "one LM step for two
+// solves"; NOTES/round-5.md.
+constexpr int SRC_DUAL = 2;
 template <int MODE, int CPL, int WPP, int LDSK, bool RESIDENT, int SRC = SRC_PLANES>
-__global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void lm_solve_kernel(
+__global__ __launch_bounds__(kWave *(SRC == SRC_DUAL ? 2 : WPP), (CPL == 8 && LDSK == 0) ? 1 : 2) void lm_solve_kernel(
     const SolveArgs a) {
-  static_assert(SRC == SRC_PLANES || RESIDENT, "the AoS source is only built for the on-chip-resident geometries");
+  static_assert(SRC != SRC_AOS || RESIDENT, "the AoS source is only built for the on-chip-resident geometries");
+  constexpr bool DUAL = SRC == SRC_DUAL;
+  static_assert(!DUAL || (WPP == 1 && RESIDENT), "the dual form pairs one-wavefront resident solves");
+  constexpr int NW = DUAL ? 2 : WPP;   // wavefronts of the block
   constexpr int NC = num_components(MODE);
   constexpr int RCPL = CPL > 8 ? 8 : CPL;          // correspondences per lane resident on chip
   constexpr int TAILK = CPL - RCPL;                // ... and re-read from memory in every pass (one wavefront only)
-  static_assert(TAILK == 0 || (TAILK == 4 && WPP == 1 && RESIDENT && SRC == SRC_PLANES), "the tail form is (12, 1, 3) on the batch's planes");
+  static_assert(TAILK == 0 || (TAILK == 4 && WPP == 1 && RESIDENT && SRC != SRC_AOS), "the tail form is (12, 1, 3) on the batch's planes");
   constexpr int REGK = RESIDENT ? RCPL - LDSK : 1;  // correspondences per lane kept in registers
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const int64_t slot = xcd_contiguous_index(blockIdx.x, a.n_solves);
+  // DUAL: block b holds solves 2 b and 2 b + 1 (of the XCD-contiguous order); an odd batch's last block has one
+  const int64_t slot_raw = DUAL ? 2 * xcd_contiguous_index(blockIdx.x, (a.n_solves + 1) / 2) + (threadIdx.x >> 6)
+                                : xcd_contiguous_index(blockIdx.x, a.n_solves);
+  [[maybe_unused]] const bool exists = !DUAL || slot_raw < a.n_solves;
+  const int64_t slot = exists ? slot_raw : a.n_solves - 1;   // (a wavefront without a solve shadows the last one and writes nothing)
   const int64_t pair = a.pair_index ? (int64_t)a.pair_index[slot / a.n_hyp] : slot / a.n_hyp;
   const int64_t s = pair * a.n_hyp + slot % a.n_hyp;
   const double *__restrict__ base = nullptr;
@@ -1024,14 +1040,14 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   // the others wait at the block's barrier -- their SIMDs run other solves' wavefronts meanwhile.  (Until round 2
   // every wavefront kept a copy and advanced it identically to save that barrier: WPP x the ~400 instructions
   // of the step per iteration, 18 % of a two-wavefront solve's issue slots, 28 % of an eight-wavefront one's.)
-  __shared__ double slab_all[WPP][kSlab];
-  __shared__ double unif_all[WPP][kUnif];
-  __shared__ int ist_all[WPP][kINumI];
+  __shared__ double slab_all[NW][kSlab];
+  __shared__ double unif_all[NW][kUnif];
+  __shared__ int ist_all[NW][kINumI];
 #ifdef PNEC_ADVANCE_ROWS
   __shared__ int gidx_all[1][16 * kGatherInts];  // lm_advance_rows: each lane's row of the tables of sums
 #endif
   [[maybe_unused]] __shared__ double xw[2][WPP > 1 ? WPP : 1][kSumSlots];
-  [[maybe_unused]] __shared__ double ldata[LDSK > 0 ? WPP : 1][LDSK > 0 ? LDSK : 1][NC][LDSK > 0 ? kWave : 1];
+  [[maybe_unused]] __shared__ double ldata[LDSK > 0 ? NW : 1][LDSK > 0 ? LDSK : 1][NC][LDSK > 0 ? kWave : 1];
   double *slab = slab_all[WPP > 1 ? 0 : wave];
   double *unif = unif_all[WPP > 1 ? 0 : wave];
   int *ist = ist_all[WPP > 1 ? 0 : wave];
@@ -1044,13 +1060,13 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
                                      NC >= 18 ? a.aos_covs_host + 9 * aos0 : nullptr, n, wave * RCPL * kWave, lane, d,
                                      &ldata[LDSK > 0 ? wave : 0][0][0][0]);
   else if constexpr (RESIDENT)
-    load_resident<NC, RCPL, REGK>(base, n, stride, wave * RCPL * kWave, lane, d, &ldata[LDSK > 0 ? wave : 0][0][0][0]);
+    load_resident<NC, RCPL, REGK>(base, n, stride, (DUAL ? 0 : wave) * RCPL * kWave, lane, d, &ldata[LDSK > 0 ? wave : 0][0][0][0]);
   // how many of this wavefront's CPL slots hold any correspondence of the pair (wave-uniform): slot k
   // starts at correspondence first + 128 (k / 2) + (k & 1) (load_resident), lane 0 being the first
   [[maybe_unused]] int nslots = 0;
   if constexpr (RESIDENT) {
 #pragma unroll
-    for (int k = 0; k < RCPL; ++k) nslots += (n > wave * RCPL * kWave + slot_corr<RCPL, REGK>(k, 0)) ? 1 : 0;
+    for (int k = 0; k < RCPL; ++k) nslots += (n > (DUAL ? 0 : wave) * RCPL * kWave + slot_corr<RCPL, REGK>(k, 0)) ? 1 : 0;
   }
   // The tail (TAILK = 4): correspondences 512 .. 767 as the SECOND wavefront of (8, 2, 3) would hold them in its first
   // four register slots -- tail slot t <-> 512 + 128 (t / 2) + 2 lane + (t & 1) -- accumulated from zero in that order,
@@ -1106,16 +1122,19 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
     ist[kIStepOk] = 1;
     ist[kILast] = o.max_num_iterations <= 0 ? 1 : 0;
     ist[kIPark] = 0;
+    if constexpr (DUAL) ist[kITerm] = exists ? -1 : PNEC_HIP_TERM_MAX_ITERATIONS;   // (>= 0: this slot is done -- or was never there)
   }
   const double inv_max_radius = a.inv_max_radius, inv_min_radius = a.inv_min_radius;  // kernel arguments: scalar
   // the LDS slots arrive by DMA (vmcnt-tracked): they must have landed before the first pass reads them
-  if constexpr (RESIDENT && LDSK > 0 && SRC == SRC_PLANES) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  if constexpr (RESIDENT && LDSK > 0 && SRC != SRC_AOS) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  if constexpr (WPP > 1) __syncthreads();  // the first wavefront's start state is what all of them read
+  if constexpr (WPP > 1 || DUAL) __syncthreads();  // the first wavefront's start state is what all of them read
 
   int term;
+  [[maybe_unused]] bool alive = exists;      // DUAL: this wavefront's solve still iterates (wave-uniform)
   int n_full_passes = 0, n_cost_passes = 0;  // wave-uniform (diagnostics: SolveArgs::work)
   for (;;) {
+    if (!DUAL || alive) {
     // ---- one fused pass at the candidate: sum r^2, J'r, J'J ------------------------------
     PNEC_MARK("uniforms");
     {
@@ -1280,10 +1299,33 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
       }
     }
 
+    }  // (DUAL: the wavefront of a finished solve only keeps the barriers' count)
+
     // ---- accept / reject, trust region, next candidate: one lane
     PNEC_MARK("advance");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     int t = -1;
+    if constexpr (DUAL) {
+      __syncthreads();   // both solves' sums are in their slabs
+      if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        if (lane < 8) {   // lanes 0..3: solve 0, lanes 4..7: solve 1 -- one instruction stream for both steps
+          const int sv = lane >> 2;
+          if (ist_all[sv][kITerm] < 0) {
+            t = lm_advance<RESIDENT && kCostFirst>(slab_all[sv], ist_all[sv], unif_all[sv], o, inv_max_radius, inv_min_radius);
+            if ((lane & 3) == 0) ist_all[sv][kITerm] = t;
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
+      }
+      __syncthreads();   // the next candidates (or the verdicts) are published
+      // both wavefronts read both verdicts (written before the barrier): the loop ends for both in the same trip
+      const int t0_ = to_sgpr(ist_all[0][kITerm]), t1_ = to_sgpr(ist_all[1][kITerm]);
+      term = wave == 0 ? t0_ : t1_;
+      if (term >= 0) alive = false;
+      if (t0_ >= 0 && t1_ >= 0) break;
+      continue;
+    }
     // the chain below is latency-bound: let it win the issue arbitration against the pass of the
     // other wavefront on this SIMD, which has independent work to fill the gaps (+1.2 %)
     if constexpr (WPP == 1) {
@@ -1314,7 +1356,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   }
 
   PNEC_MARK("result");
-  if (threadIdx.x == 0) {
+  if (DUAL ? (lane == 0 && exists) : threadIdx.x == 0) {
     write_result(a, s, slab, ist[kIIter], term);
     if (a.work) {
       atomicAdd(a.work + 0, (unsigned long long)n_full_passes * (unsigned long long)n);
@@ -1329,7 +1371,7 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
         __hip_atomic_store(a.host_flag, a.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
-    if (a.trace) {
+    if (a.trace && threadIdx.x == 0) {
       unsigned hw = 0;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       unsigned xcc = 0;

@@ -1,5 +1,7 @@
 // pnec_solve_launch.inl -- included by one translation unit per residual family
 // (PNEC_SOLVE_MODE defined by the includer) so the four families compile in parallel.
+#include <cstdlib>
+
 #include "pnec_solve_kernel.hpp"
 
 namespace pnec_hip {
@@ -19,6 +21,23 @@ hipError_t PNEC_CAT(launch_solve_mode_, PNEC_SOLVE_MODE)(int cpl, int wpp, int l
                        args);
     return hipGetLastError();
   }
+  // A/B form, built only with -DPNEC_SOLVE_DUAL_AB (tools/build_variant.sh) and then switched on by PNEC_SOLVE_DUAL=1: the
+  // (8, 1, 3) geometry with two solves per block sharing one LM step (SRC_DUAL).  Measured in round 5 on the benchmark's
+  // batch, bit-identical results: 36.68 -> 33.45 M solves/s (-8.8 %) -- the two block barriers per iteration cost more
+  // than the ~16 % of issue slots the shared step saves (NOTES/round-5.md).  Not in the default library.
+#ifdef PNEC_SOLVE_DUAL_AB
+  static const bool dual = [] {
+    const char *ev = std::getenv("PNEC_SOLVE_DUAL");
+    return ev && *ev && std::atoi(ev) != 0;
+  }();
+  if (dual && cpl == 8 && wpp == 1 && ldsk == 3 && !args.trace) {
+    if constexpr (geometry_ok(MODE, 8, 1, 3)) {
+      hipLaunchKernelGGL((lm_solve_kernel<MODE, 8, 1, 3, true, SRC_DUAL>), dim3((unsigned)((args.n_solves + 1) / 2)),
+                         dim3(2 * kWave), 0, stream, args);
+      return hipGetLastError();
+    }
+  }
+#endif
 #define PNEC_LAUNCH_CASE(CPL, WPP, LDSK)                                                          \
   if (cpl == CPL && wpp == WPP && ldsk == LDSK) {                                                   \
     if constexpr (geometry_ok(MODE, CPL, WPP, LDSK)) {                                              \
