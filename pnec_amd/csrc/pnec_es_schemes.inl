@@ -16,9 +16,10 @@
 //   scheme 2 (LM): a trip evaluates F = grad f at a point (lane 0) and at its three forward-difference probes (lanes
 //     1..3): the start, then every trial point x + p -- a trial that MINPACK's test accepts has its Jacobian already.
 //     nfev is counted as Eigen counts it (1 + 4 per outer iteration + 1 per trial), so maxfev = 100 cuts where it would.
-// Decisions use IEEE sqrt and division, written as in the checker; the evaluation itself is es_value_grad's (eigenpair
-// by Rayleigh-quotient iteration from the neighbouring point's), which differs from the checker's Jacobi sweeps in the
-// last bits only.
+// Scheme 1's decisions use IEEE sqrt and division, written as in the checker (a handful per trip); scheme 2's head is forty
+// of them per trip and goes through the refined reciprocal / reciprocal square root (below).  The evaluation itself is
+// es_value_grad's (eigenpair by Rayleigh-quotient iteration from the neighbouring point's), which differs from the
+// checker's Jacobi sweeps in the last bits only.
 
 // lane r's copy of x within the quad (r: the same value in the quad's four lanes)
 __device__ __forceinline__ double quad_pick(double x, int r) {
@@ -26,36 +27,41 @@ __device__ __forceinline__ double quad_pick(double x, int r) {
   return r == 0 ? b0 : (r == 1 ? b1 : (r == 2 ? b2 : b3));
 }
 
-// ---- scheme 2's linear algebra: MINPACK lmpar on the normal equations (the checker's lmpar3, same order)
-__device__ __forceinline__ bool lm_chol3(const double (&A)[9], double (&L)[6]) {
+// ---- scheme 2's linear algebra: MINPACK lmpar on the normal equations (the checker's lmpar3, same order of operations).
+// Square roots and divisions go through v_rsq_f64 / v_rcp_f64 + refinement (fast_rsqrt / fast_rcp: <= 1 ulp from the IEEE
+// sequences, a fifth of their instructions -- this head runs once per trip on every quad, and with IEEE operations it was as
+// long as the evaluation it sits behind): the Cholesky factor is kept as its off-diagonal entries and the INVERSE diagonal.
+struct LmChol3 { double i0, l10, i1, l20, l21, i2; };
+__device__ __forceinline__ bool lm_chol3(const double (&A)[9], LmChol3 &L) {
   if (!(A[0] > 0.0)) return false;
-  L[0] = sqrt(A[0]);
-  L[1] = A[3] / L[0];
-  const double d1 = A[4] - L[1] * L[1];
+  L.i0 = fast_rsqrt(A[0]);
+  L.l10 = A[3] * L.i0;
+  const double d1 = A[4] - L.l10 * L.l10;
   if (!(d1 > 0.0)) return false;
-  L[2] = sqrt(d1);
-  L[3] = A[6] / L[0];
-  L[4] = (A[7] - L[3] * L[1]) / L[2];
-  const double d2 = A[8] - L[3] * L[3] - L[4] * L[4];
+  L.i1 = fast_rsqrt(d1);
+  L.l20 = A[6] * L.i0;
+  L.l21 = (A[7] - L.l20 * L.l10) * L.i1;
+  const double d2 = A[8] - L.l20 * L.l20 - L.l21 * L.l21;
   if (!(d2 > 0.0)) return false;
-  L[5] = sqrt(d2);
+  L.i2 = fast_rsqrt(d2);
   return true;
 }
-__device__ __forceinline__ void lm_forward(const double (&L)[6], const double (&b)[3], double (&z)[3]) {
-  z[0] = b[0] / L[0];
-  z[1] = (b[1] - L[1] * z[0]) / L[2];
-  z[2] = (b[2] - L[3] * z[0] - L[4] * z[1]) / L[5];
+__device__ __forceinline__ void lm_forward(const LmChol3 &L, const double (&b)[3], double (&z)[3]) {
+  z[0] = b[0] * L.i0;
+  z[1] = (b[1] - L.l10 * z[0]) * L.i1;
+  z[2] = (b[2] - L.l20 * z[0] - L.l21 * z[1]) * L.i2;
 }
-__device__ __forceinline__ void lm_backward(const double (&L)[6], const double (&z)[3], double (&x)[3]) {
-  x[2] = z[2] / L[5];
-  x[1] = (z[1] - L[4] * x[2]) / L[2];
-  x[0] = (z[0] - L[1] * x[1] - L[3] * x[2]) / L[0];
+__device__ __forceinline__ void lm_backward(const LmChol3 &L, const double (&z)[3], double (&x)[3]) {
+  x[2] = z[2] * L.i2;
+  x[1] = (z[1] - L.l21 * x[2]) * L.i1;
+  x[0] = (z[0] - L.l10 * x[1] - L.l20 * x[2]) * L.i0;
 }
-__device__ __forceinline__ double lm_nrm3(const double (&a)[3]) { return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+__device__ __forceinline__ double lm_nrm3(const double (&a)[3]) { return fast_sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
 __device__ __forceinline__ void lm_par3(const double (&A)[9], const double (&b)[3], const double (&diag)[3], double delta,
-                                     double &par, double (&x)[3]) {
+                                        double &par, double (&x)[3]) {
   const double dwarf = 2.2250738585072014e-308;
-  double L[6], z[3], wa1[3], wa2[3];
+  LmChol3 L;
+  double z[3], wa1[3], wa2[3];
   const bool full_rank = lm_chol3(A, L);
   double dxnorm, fp, parl = 0.0, paru, gnorm, temp;
   if (full_rank) {
@@ -69,26 +75,28 @@ __device__ __forceinline__ void lm_par3(const double (&A)[9], const double (&b)[
   dxnorm = lm_nrm3(wa2);
   fp = dxnorm - delta;
   if (full_rank && fp <= 0.1 * delta) { par = 0.0; return; }
+  const double inv_delta = fast_rcp(delta);
   if (full_rank) {
+    const double inv_dx = fast_rcp(dxnorm);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) wa1[j] = diag[j] * (wa2[j] / dxnorm);
+    for (int j = 0; j < 3; ++j) wa1[j] = diag[j] * (wa2[j] * inv_dx);
     lm_forward(L, wa1, z);
-    temp = lm_nrm3(z);
-    parl = fp / delta / temp / temp;
+    parl = fp * inv_delta * fast_rcp(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
   } else {
     fp = delta;
   }
 #pragma unroll
-  for (int j = 0; j < 3; ++j) wa1[j] = b[j] / diag[j];
+  for (int j = 0; j < 3; ++j) wa1[j] = b[j] * fast_rcp(diag[j]);
   gnorm = lm_nrm3(wa1);
-  paru = gnorm / delta;
-  if (paru == 0.0) paru = dwarf / fmin(delta, 0.1);
+  paru = gnorm * inv_delta;
+  if (paru == 0.0) paru = dwarf * fast_rcp(fmin(delta, 0.1));
   par = fmax(par, parl);
   par = fmin(par, paru);
-  if (par == 0.0) par = gnorm / dxnorm;
+  if (par == 0.0) par = gnorm * fast_rcp(dxnorm);
   for (int iter = 1;; ++iter) {
     if (par == 0.0) par = fmax(dwarf, 0.001 * paru);
-    double Ap[9], Lp[6];
+    double Ap[9];
+    LmChol3 Lp;
 #pragma unroll
     for (int i = 0; i < 9; ++i) Ap[i] = A[i];
 #pragma unroll
@@ -105,11 +113,11 @@ __device__ __forceinline__ void lm_par3(const double (&A)[9], const double (&b)[
     temp = fp;
     fp = dxnorm - delta;
     if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) || iter == 10) break;
+    const double inv_dx = fast_rcp(dxnorm);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) wa1[j] = diag[j] * (wa2[j] / dxnorm);
+    for (int j = 0; j < 3; ++j) wa1[j] = diag[j] * (wa2[j] * inv_dx);
     lm_forward(Lp, wa1, z);
-    temp = lm_nrm3(z);
-    const double parc = fp / delta / temp / temp;
+    const double parc = fp * inv_delta * fast_rcp(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
     if (fp > 0.0) parl = fmax(parl, par);
     if (fp < 0.0) paru = fmin(paru, par);
     par = fmax(parl, par + parc);
@@ -250,12 +258,13 @@ __device__ __forceinline__ int es_minimise_queue_alt(int n_tasks, const int *tli
         double gp[3], ep[3] = {eb[0], eb[1], eb[2]};
         (void)es_value_grad<1, true>(G, p, gp, nullptr, ep, l_state != kInit);
         double f1[3], Jn[9], e0[3];
+        const double ih[3] = {fast_rcp(h[0]), fast_rcp(h[1]), fast_rcp(h[2])};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           f1[r] = quad_broadcast<0>(gp[r]);
-          Jn[3 * r + 0] = (quad_broadcast<1>(gp[r]) - f1[r]) / h[0];
-          Jn[3 * r + 1] = (quad_broadcast<2>(gp[r]) - f1[r]) / h[1];
-          Jn[3 * r + 2] = (quad_broadcast<3>(gp[r]) - f1[r]) / h[2];
+          Jn[3 * r + 0] = (quad_broadcast<1>(gp[r]) - f1[r]) * ih[0];
+          Jn[3 * r + 1] = (quad_broadcast<2>(gp[r]) - f1[r]) * ih[1];
+          Jn[3 * r + 2] = (quad_broadcast<3>(gp[r]) - f1[r]) * ih[2];
           e0[r] = quad_broadcast<0>(ep[r]);
         }
         bool new_outer = false;  // a Jacobian has just become the current one: run the head of an outer iteration
@@ -271,22 +280,23 @@ __device__ __forceinline__ int es_minimise_queue_alt(int n_tasks, const int *tli
         } else {
           ++l_nfev;
           const double fnorm1 = lm_nrm3(f1);
+          const double inv_fn = fast_rcp(l_fnorm);
           double actred = -1.0;
-          if (0.1 * fnorm1 < l_fnorm) actred = 1.0 - (fnorm1 / l_fnorm) * (fnorm1 / l_fnorm);
+          if (0.1 * fnorm1 < l_fnorm) actred = 1.0 - (fnorm1 * inv_fn) * (fnorm1 * inv_fn);
           const double Jp[3] = {lJ[0] * lp[0] + lJ[1] * lp[1] + lJ[2] * lp[2], lJ[3] * lp[0] + lJ[4] * lp[1] + lJ[5] * lp[2],
                                 lJ[6] * lp[0] + lJ[7] * lp[1] + lJ[8] * lp[2]};
-          const double t1 = lm_nrm3(Jp) / l_fnorm, t2 = sqrt(l_par) * l_pnorm / l_fnorm;
+          const double t1 = lm_nrm3(Jp) * inv_fn, t2 = fast_sqrt(l_par) * l_pnorm * inv_fn;
           const double temp1 = t1 * t1, temp2 = t2 * t2;
           const double prered = temp1 + temp2 / 0.5, dirder = -(temp1 + temp2);
-          const double ratio = (prered != 0.0) ? actred / prered : 0.0;
+          const double ratio = (prered != 0.0) ? actred * fast_rcp(prered) : 0.0;
           if (ratio <= 0.25) {
             double temp = 0.5;
-            if (actred < 0.0) temp = 0.5 * dirder / (dirder + 0.5 * actred);
+            if (actred < 0.0) temp = 0.5 * dirder * fast_rcp(dirder + 0.5 * actred);
             if (0.1 * fnorm1 >= l_fnorm || temp < 0.1) temp = 0.1;
-            l_delta = temp * fmin(l_delta, l_pnorm / 0.1);
-            l_par /= temp;
+            l_delta = temp * fmin(l_delta, l_pnorm * 10.0);
+            l_par *= fast_rcp(temp);
           } else if (!(l_par != 0.0 && ratio < 0.75)) {
-            l_delta = l_pnorm / 0.5;
+            l_delta = l_pnorm * 2.0;
             l_par = 0.5 * l_par;
           }
           const bool accepted = ratio >= 1e-4;
@@ -322,7 +332,7 @@ __device__ __forceinline__ int es_minimise_queue_alt(int n_tasks, const int *tli
           // ---- head of an outer iteration (Eigen's minimizeOneStep up to its inner loop)
           l_nfev += 4;  // NumericalDiff<..., Forward>::df: f(x) again and the three probes
 #pragma unroll
-          for (int j = 0; j < 3; ++j) wa2[j] = sqrt(lJ[j] * lJ[j] + lJ[3 + j] * lJ[3 + j] + lJ[6 + j] * lJ[6 + j]);
+          for (int j = 0; j < 3; ++j) wa2[j] = fast_sqrt(lJ[j] * lJ[j] + lJ[3 + j] * lJ[3 + j] + lJ[6 + j] * lJ[6 + j]);
           if (l_iter == 1) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) ldiag[j] = (wa2[j] == 0.0) ? 1.0 : wa2[j];
@@ -344,9 +354,10 @@ __device__ __forceinline__ int es_minimise_queue_alt(int n_tasks, const int *tli
           if (new_outer) {
             double gnorm = 0.0;
             if (l_fnorm != 0.0) {
+              const double inv_f = fast_rcp(l_fnorm);
 #pragma unroll
               for (int j = 0; j < 3; ++j)
-                if (wa2[j] != 0.0) gnorm = fmax(gnorm, fabs(b[j] / l_fnorm / wa2[j]));
+                if (wa2[j] != 0.0) gnorm = fmax(gnorm, fabs(b[j] * inv_f * fast_rcp(wa2[j])));
             }
             l_gnorm = gnorm;
             if (gnorm <= 0.0) { l_info = 4; done = true; }
