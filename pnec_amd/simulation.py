@@ -261,12 +261,14 @@ def generate(n_pairs: int, n_corr: int, noise_type: str = "anisotropic_inhomogen
 
 
 def generate_kitti_like(n_pairs: int, mean_corr: int = 500, seed: int = 1,
-                        device: str | torch.device = "cpu", counts=None):
+                        device: str | torch.device = "cpu", counts=None, cov_model: str = "klt"):
     """KITTI-like SYNTHETIC stream (no KITTI data exists in this environment): forward motion
     (t ~ +z, the (theta,phi) chart's singular direction, Appendix C12), small yaw, pinhole
     fx = 718.856 on a 1241x376 image (data/config_kitti00-02.yaml:8-11), ragged track counts.
     Returns (offsets int64 [B+1] numpy, bvs1 [M,3], bvs2 [M,3], covs2 [M,3,3], R_gt, t_gt,
-    init_q [B,4], init_t [B,3]).  counts: optional int64 [B] pair sizes (else drawn here)."""
+    init_q [B,4], init_t [B,3]).  counts: optional int64 [B] pair sizes (else drawn here).
+    cov_model: "klt" (default since round 5) draws the 2x2 image covariances from the reference's KLT patch model,
+    "simulator" from the simulator's anisotropic model (rounds 1-4)."""
     dev = torch.device(device)
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
@@ -297,16 +299,46 @@ def generate_kitti_like(n_pairs: int, mean_corr: int = 500, seed: int = 1,
     P2 = torch.einsum("mji,mj->mi", R_gt[pair], P - t_gt[pair])
     p1 = torch.stack([(u - cx), (v - cy), torch.full((M,), fx, **f64)], -1)
     p2 = P2 / P2[:, 2:3] * fx
-    # KLT-like anisotropic covariances, ~0.2 px std
-    alpha = U(M) * math.pi
-    beta = (U(M) + 1.0) / 2.0
-    scale = 0.04 * (U(M) + 0.5)
-    ca, sa = torch.cos(alpha), torch.sin(alpha)
-    rot = torch.stack([ca, -sa, sa, ca], -1).reshape(M, 2, 2)
-    dg = torch.zeros(M, 2, 2, **f64)
-    dg[:, 0, 0] = beta
-    dg[:, 1, 1] = 1 - beta
-    cov2d = scale[:, None, None] * (rot @ dg @ rot.transpose(-1, -2))
+    if cov_model == "klt":
+        # The reference's KLT covariance model (include/features/tracking/pnec_patch.h:128-136,
+        # klt_patch_optical_flow.h:377,458): image covariance = top-left 2x2 of the inverse SE(2) Gauss-Newton Hessian of
+        # the tracked patch / uncertainty_scaling (10).  H_se2 = sum_i J_i' J_i over the pattern's pixels with
+        # J_i = g_i' [I | (-y_i, x_i)'] (image gradient g_i, pattern offset (x_i, y_i)).  Synthetic patches: 52 pixels on
+        # rings of radius 1..4 px (the size of the reference's pattern), gradients g_i = Rot(alpha) diag(1, sqrt(rho)) z_i,
+        # z_i ~ N(0, I) -- an oriented texture of anisotropy rho ~ U(0.15, 1) (edges to corners) -- in units in which the
+        # patch's mean gradient energy is 1; the missing image-noise variance is one global scale (the PNEC weights do not
+        # see it), calibrated here so that the tracking noise drawn from these covariances has a std of ~0.15..0.4 px.
+        NPAT = 52
+        ring = torch.arange(NPAT, **f64)
+        rad = 1.0 + 3.0 * (ring % 4) / 3.0
+        ang = 2.0 * math.pi * ring / NPAT * 4.0 + 0.4 * (ring % 4)
+        px, py = rad * torch.cos(ang), rad * torch.sin(ang)
+        alpha = U(M) * math.pi
+        rho = 0.15 + 0.85 * U(M)
+        cov2d = torch.empty(M, 2, 2, **f64)
+        step = 1 << 18
+        for m0 in range(0, M, step):
+            m1 = min(M, m0 + step)
+            zg = torch.randn(m1 - m0, NPAT, 2, generator=g, **f64)
+            ca, sa = torch.cos(alpha[m0:m1])[:, None], torch.sin(alpha[m0:m1])[:, None]
+            u0, u1 = zg[..., 0], zg[..., 1] * torch.sqrt(rho[m0:m1])[:, None]
+            gx, gy = ca * u0 - sa * u1, sa * u0 + ca * u1
+            jr = -gx * py + gy * px                                    # d residual / d angle
+            J = torch.stack([gx, gy, jr], -1)                          # [m, NPAT, 3]
+            H = J.transpose(-1, -2) @ J
+            cov2d[m0:m1] = torch.linalg.inv(H)[:, :2, :2] / 10.0 * (0.02 * 10.0 * NPAT)
+    else:
+        # the simulator's anisotropic-inhomogeneous model (standard_experiments.cc:99-119), ~0.2 px std
+        alpha = U(M) * math.pi
+        beta = (U(M) + 1.0) / 2.0
+        scale = 0.04 * (U(M) + 0.5)
+        ca, sa = torch.cos(alpha), torch.sin(alpha)
+        rot = torch.stack([ca, -sa, sa, ca], -1).reshape(M, 2, 2)
+        dg = torch.zeros(M, 2, 2, **f64)
+        dg[:, 0, 0] = beta
+        dg[:, 1, 1] = 1 - beta
+        cov2d = scale[:, None, None] * (rot @ dg @ rot.transpose(-1, -2))
+    cov2d = 0.5 * (cov2d + cov2d.transpose(-1, -2))
     a, b, d = cov2d[:, 0, 0], cov2d[:, 1, 0], cov2d[:, 1, 1]
     l00 = torch.sqrt(a); l10 = b / l00; l11 = torch.sqrt(d - l10 * l10)
     z = torch.randn(M, 2, generator=g, **f64)

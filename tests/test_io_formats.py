@@ -1,5 +1,6 @@
 """Data formats either side of the path: the reference simulator's experiment
 CSVs, run_simulation's result tables and the odometry pose stream."""
+import json
 import os
 
 import numpy as np
@@ -180,3 +181,88 @@ int main(int argc, char **argv) {
     assert out == TIMING_TXT
     assert open(tmp_path / "timing.txt").read() == TIMING_TXT
     assert io.read_timing_file(tmp_path / "timing.txt").shape == (2, 9)
+
+
+def test_tracks_validator_and_converter_from_the_simulator_folder(tmp_path):
+    """pnec_amd/tracks.py (SURVEY 8f row 4 / VERDICT r4 item 8): a simulator folder of the reference
+    (experiments.cc:131-172) -> a tracks file through `python -m pnec_amd.tracks from-experiments`; the validator CLI
+    accepts it and names what is wrong with broken ones (non-unit bearings, asymmetric / indefinite covariances, rows that
+    pair different track ids, pairs below the minimum count); loading the file gives back exactly what was converted."""
+    import subprocess
+    import sys
+
+    from pnec_amd import simulation as sim
+    from pnec_amd import tracks as tk
+    rng = np.random.default_rng(3)
+    E, N = 5, 40
+    poses_1 = np.tile(np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float64), (E, 1))
+    poses_2 = poses_1.copy()
+    points_1, points_2, covs_1, covs_2 = [], [], [], []
+    for e in range(E):
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        ang = 0.2 * rng.random()
+        poses_2[e, :3], poses_2[e, 3] = ax * np.sin(ang / 2), np.cos(ang / 2)
+        poses_2[e, 4:] = rng.normal(size=3) * 0.3
+        p1 = np.column_stack([rng.uniform(-300, 300, N), rng.uniform(-200, 200, N), np.full(N, 800.0)])
+        p2 = p1 + np.column_stack([rng.normal(size=(N, 2)) * 2.0, np.zeros(N)])
+        c = np.zeros((N, 3, 3))
+        a = rng.uniform(0.5, 1.5, N); b = rng.uniform(-0.3, 0.3, N); d = rng.uniform(0.5, 1.5, N)
+        c[:, 0, 0], c[:, 0, 1], c[:, 1, 0], c[:, 1, 1] = a, b, b, d
+        points_1.append(p1); points_2.append(p2); covs_1.append(c.copy()); covs_2.append(c)
+    folder = tmp_path / "exp"
+    folder.mkdir()
+    io.write_experiments(str(folder), poses_1, poses_2, points_1, points_2, covs_1, covs_2)
+    out = str(tmp_path / "tracks.npz")
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "pnec_amd.tracks", "from-experiments", str(folder), out], capture_output=True,
+                       text=True, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-1500:]
+    r = subprocess.run([sys.executable, "-m", "pnec_amd.tracks", "check", out], capture_output=True, text=True, env=env, cwd=ROOT)
+    rep = json.loads(r.stdout)
+    assert r.returncode == 0 and rep["ok"] and rep["pairs"] == E and rep["correspondences"] == E * N and rep["matched_ids_equal"]
+    tr = tk.load_tracks(out)
+    ref = tk.from_experiments(str(folder))
+    for k in ("bvs1", "bvs2", "covs", "init_q", "init_t"):
+        np.testing.assert_array_equal(np.asarray(getattr(tr, k)), np.asarray(getattr(ref, k)))
+    assert tk.sizes_of(out).tolist() == [N] * E
+    # the frame-2 covariance is the reference's UnscentedTransform of the 2x2 image covariance (pinned by goldens elsewhere)
+    import torch
+    back = io.read_experiments(str(folder))     # (the CSVs hold %g values: the file is the data)
+    want = sim.unscented_bearing_cov(torch.from_numpy(back["points_2"][0]), torch.from_numpy(back["covs_2"][0][:, :2, :2])).numpy()
+    np.testing.assert_array_equal(np.asarray(tr.covs)[:N], want)
+    # broken files: every defect is named
+    def broken(**kw):
+        t = tk.load_tracks(out)
+        for k, f in kw.items():
+            setattr(t, k, f(np.array(getattr(t, k))))
+        return tk.check(t, min_corr=10)
+    assert any("not unit length" in p for p in broken(bvs1=lambda a: a * 1.001)["problems"])
+    def asym(c):
+        c[:, 0, 1] += 1e-6 * np.abs(c).max(); return c
+    assert any("not symmetric" in p for p in broken(covs=asym)["problems"])
+    assert any("positive semi-definite" in p for p in broken(covs=lambda c: -c)["problems"])
+    assert any("different track ids" in p for p in broken(ids2=lambda i: np.roll(i, 1))["problems"])
+    assert any("fewer than" in p for p in tk.check(tk.load_tracks(out), min_corr=N + 1)["problems"])
+    bad = str(tmp_path / "bad.npz")
+    np.savez(bad, offsets=np.array([0, 3]), bvs1=np.zeros((2, 3)))
+    r = subprocess.run([sys.executable, "-m", "pnec_amd.tracks", "check", bad], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert r.returncode == 1 and not json.loads(r.stdout)["ok"]
+
+
+def test_kitti_like_covariances_follow_the_klt_patch_model():
+    """generate_kitti_like draws its 2x2 image covariances from the reference's KLT model (top-left block of the inverse
+    SE(2) patch Hessian / 10: pnec_patch.h:128-136, klt_patch_optical_flow.h:377,458) since round 5: symmetric positive
+    definite, anisotropic (oriented texture), tracking noise of a fraction of a pixel; the simulator's model stays
+    selectable and the set is a function of the seed."""
+    from pnec_amd import simulation as sim
+    from pnec_amd import tracks as tk
+    a = sim.generate_kitti_like(6, 200, seed=4)
+    b = sim.generate_kitti_like(6, 200, seed=4)
+    c = sim.generate_kitti_like(6, 200, seed=4, cov_model="simulator")
+    assert np.array_equal(a[3].numpy(), b[3].numpy()) and not np.array_equal(a[3].numpy(), c[3].numpy())
+    rep = tk.check(tk.Tracks(a[0], a[1], a[2], a[3], a[6], a[7]))
+    assert rep["ok"], rep["problems"]
+    w = np.linalg.eigvalsh(a[3].numpy())
+    px_std = np.sqrt(w[:, 2]) * 718.856
+    assert 0.03 < np.median(px_std) < 0.5 and np.median(w[:, 2] / w[:, 1]) > 1.3     # anisotropic, sub-pixel
