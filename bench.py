@@ -122,9 +122,30 @@ def chain_stage_rooflines(counts, stage_ms, payload_bytes, inlier_payload_bytes,
     return out
 
 
+# the front stages' device code: what the flop model above was counted from and what the committed work counts were taken on
+FRONT_KERNEL_SOURCES = ("pnec_frontend.hip", "pnec_es_schemes.inl", "pnec_device.hpp", "pnec_front_shared.hpp")
+# sha256 (front_sources_sha256) of the sources the FLOP_* table above was last derived from / cross-checked against
+# (tools/isa_front_regions.py); tests/test_bench_launch_cpu.py fails when the sources move on without it
+FRONT_FLOP_MODEL_STAMP = "unstamped"
+
+
+def front_sources_sha256():
+    """Identity of the front stages' device code (comments and layout stripped), like kernel_sources_sha256."""
+    d = os.path.join(ROOT, "pnec_amd", "csrc")
+    h = hashlib.sha256()
+    for f in FRONT_KERNEL_SOURCES:
+        h.update(f.encode())
+        h.update(_strip_comments(open(os.path.join(d, f), "r").read()).encode())
+    return h.hexdigest()
+
+
 def load_chain_counts(name, pairs, corr):
+    """The committed work counts of a bench workload -- only if they were taken on THIS front-stage code and workload."""
     try:
-        c = json.load(open(os.path.join(ROOT, "profiles", "chain_work_latest.json")))["workloads"][name]
+        j = json.load(open(os.path.join(ROOT, "profiles", "chain_work_latest.json")))
+        if j.get("frontend_sources_sha256") != front_sources_sha256():
+            return None
+        c = j["workloads"][name]
         return c if (c["pairs"], c["correspondences"]) == (pairs, corr) else None
     except (OSError, KeyError, ValueError):
         return None
@@ -1015,7 +1036,14 @@ def run(args):
             line["shared_gpu"] = {"ranks": n_ranks, "note": "every rank on cuda:0 (plumbing run on a one-GPU box: real "
                                   "solver, partition and device-side gather with world > 1; gloo over pinned host records "
                                   "because RCCL refuses two ranks on one device) -- NOT a scaling measurement",
-                                  "collectives_issued": gather.collectives}
+                                  "collectives_issued": gather.collectives,
+                                  # where a step's wall time goes on rank 0 (all steps incl. warm-up, per collective): the
+                                  # gloo gather itself (which also waits for the other rank to arrive) and the wait for
+                                  # the step's records to reach pinned memory (= for this rank's kernels to have run:
+                                  # two processes on one device do not run their kernels side by side, the device is
+                                  # time-sliced between their queues)
+                                  "host_collective_ms_per_collective": 1e3 * gather.host_collective_s / max(1, gather.collectives),
+                                  "wait_for_own_records_ms_per_collective": 1e3 * gather.host_copy_wait_s / max(1, gather.collectives)}
         if cpu:
             # the gathered "cost" column must be the global pair index, in order, from the LAST step
             assert torch.equal(gathered[:, 7], torch.arange(sh.total_pairs, dtype=torch.float64))

@@ -48,8 +48,9 @@ hipError_t launch_weighted_eigensolver(int, const double *, const int64_t *, con
                                        int32_t *, double *, int32_t *, hipStream_t, int);
 hipError_t launch_frontend_selftest(double *, hipStream_t);
 // scratch of the front stages, per pair (pnec_frontend.hip FrontScratch)
-// (+ 3 kEsMaxRounds doubles and one int per pair: the weighted stage's chained minimisations under eigensolver schemes 1, 2)
-constexpr int64_t kFrontDoublesPerPair = 43 + 3 * kEsMaxRounds, kFrontIntsPerPair = 3;
+// (+ 3 kEsMaxRounds doubles and one int per pair: the weighted stage's chained minimisations under eigensolver schemes 1, 2;
+//  + two ints per pair: the list of the RANSAC stage's second launch and its length)
+constexpr int64_t kFrontDoublesPerPair = 43 + 3 * kEsMaxRounds, kFrontIntsPerPair = 5;
 }  // namespace pnec_hip
 
 using namespace pnec_hip;

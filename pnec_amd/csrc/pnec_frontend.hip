@@ -1015,8 +1015,12 @@ struct FrontScratch {
   int32_t *first;   // [P]    correspondence ComposeM leaves out (C7), -1: none
   double *v_rounds; // [kEsMaxRounds,P,3] schemes 1, 2: the weighted stage's minimiser of every round
   int32_t *n_es;    // [P]    ... and how many rounds have one
+  // the RANSAC stage's two launches (ransac2_eigensolver_kernel PHASE 1 / 2): the rule's state per pair lives in the
+  // v_rounds region (free until the weighted stage), the list of pairs that go on and its length behind the ints
+  double *st_k, *st_it, *st_best, *st_model;
+  int32_t *st_list, *st_count;
 };
-// per pair: 36 + 3 + 1 + 3 + 3 kEsMaxRounds doubles and 3 ints (pnec_capi.hip sizes the buffers: kFrontDoublesPerPair /
+// per pair: 36 + 3 + 1 + 3 + 3 kEsMaxRounds doubles and 5 ints (pnec_capi.hip sizes the buffers: kFrontDoublesPerPair /
 // kFrontIntsPerPair)
 FrontScratch front_scratch(double *d, int32_t *i, int64_t P) {
   FrontScratch f;
@@ -1028,6 +1032,12 @@ FrontScratch front_scratch(double *d, int32_t *i, int64_t P) {
   f.its = i;
   f.first = i + P;
   f.n_es = i + 2 * P;
+  f.st_k = d + 43 * P;
+  f.st_it = d + 44 * P;
+  f.st_best = d + 45 * P;
+  f.st_model = d + 46 * P;   // .. 58 P (of the 45 P the v_rounds region has)
+  f.st_list = i + 3 * P;
+  f.st_count = i + 4 * P;    // (one int; the region is sized 5 P)
   return f;
 }
 
@@ -1890,6 +1900,10 @@ struct RansacArgs {
   int64_t *sel_single_offsets; // a batch of ONE pair: its AoS offsets [0, m]
   // two-pair form: the pairs in launch order (null: as they lie in the batch); see ransac_order_kernel
   const int32_t *order;
+  // two launches (PHASE 1 / 2 of ransac2_eigensolver_kernel): where the sequential rule of a pair stands after its first
+  // round -- it, best count, k, the best model (R | t) -- and the list of the pairs that go on
+  double *st_k, *st_it, *st_best, *st_model;   // [P], [P], [P], [P,12]
+  int32_t *st_list, *st_count;                 // [P], [1]
   // two-pair form: blocks [0, n_double) take the pairs 2 b, 2 b + 1 (of the launch order), blocks from n_double on ONE
   // pair each, 2 n_double + (b - n_double): the launch's last wavefronts are short ones (see ransac_tail_singles)
   int64_t n_double;
@@ -2377,25 +2391,49 @@ __device__ __forceinline__ int es_minimise_queue(int n_tasks, const int *tlist, 
 
 // SCHEME: which iteration minimises a hypothesis' eigenvalue (0: es_minimise_queue; 1, 2: es_minimise_queue_alt, where
 // every hypothesis is scored -- there is no cap that voids a model).
-template <int SCHEME>
+// PHASE (an A/B form of round 5, -DPNEC_RANSAC_TWO_LAUNCH_AB: the stage as TWO launches; the default library only has
+// PHASE 0): 0 = a pair's whole RANSAC in this launch; 1 = its FIRST
+// round only -- a pair that is done after it (six in ten at 10 % mismatches) is finished here, the others leave where
+// their sequential rule stands (RansacArgs::st_*) and their index in a list; 2 = the listed pairs, two per wavefront by a
+// grid-stride loop, from that state to the end.  Why: a launch ends with its slowest wavefronts, and in ONE launch the
+// pairs that need a second and third round sit wherever the batch has them -- the ones dispatched late end it late (a
+// quarter of the launch was that tail; the opt-in launch-order hint cured it with knowledge from an earlier call).  The
+// first rounds are all alike (no tail to speak of), and the long pairs start TOGETHER at the top of the second launch.
+// A hypothesis' arithmetic does not depend on the launch it runs in: same bits as PHASE 0 -- and measured 8 % slower: the
+// first rounds of other pairs are what fills the long pairs' tails in ONE launch (launch_ransac_eigensolver).
+template <int SCHEME, int PHASE>
 __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eigensolver_kernel(const RansacArgs a) {
   const int lane = threadIdx.x;
   const int hyp = lane >> 2, role = lane & 3;
   __shared__ Ransac2Lds lds;
   const int ss = a.sample_size;  // <= PNEC_HIP_MAX_RANSAC_SAMPLE (checked by the caller)
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  const int64_t n_listed = PHASE == 2 ? (int64_t)*a.st_count : 0;
+  for (int64_t work = (int64_t)blockIdx.x; PHASE != 2 || 2 * work < n_listed; work += (int64_t)gridDim.x) {
   // ---- the two pairs' wave-uniform state
   int64_t pair[2];
   int n[2], stride[2], it[2] = {0, 0}, best_count[2] = {-1, -1};
   const double *base[2];
   double k[2] = {1.0, 1.0}, v0[2][3], R0[2][9];
   bool stop[2], can_sample[2], exists[2];
+  [[maybe_unused]] bool unfinished[2] = {false, false};   // PHASE 1: the pair goes on in the second launch
+  [[maybe_unused]] int rounds_done = 0;
   bool lent = false;  // slot 1 works for slot 0's pair (its second sixteen hypotheses of a round)
 #pragma unroll
   for (int pp = 0; pp < 2; ++pp) {
-    const int64_t blk = (int64_t)blockIdx.x;
-    pair[pp] = blk < a.n_double ? 2 * blk + pp : a.n_double + blk;   // (= 2 n_double + (blk - n_double) for slot 0)
-    exists[pp] = pair[pp] < a.n_pairs && (blk < a.n_double || pp == 0);
-    if (a.order && exists[pp]) pair[pp] = a.order[pair[pp]];
+    const int64_t blk = work;
+    if constexpr (PHASE == 2) {
+      exists[pp] = 2 * blk + pp < n_listed;
+      pair[pp] = exists[pp] ? (int64_t)a.st_list[2 * blk + pp] : 0;
+    } else {
+      pair[pp] = blk < a.n_double ? 2 * blk + pp : a.n_double + blk;   // (= 2 n_double + (blk - n_double) for slot 0)
+      exists[pp] = pair[pp] < a.n_pairs && (blk < a.n_double || pp == 0);
+      if (a.order && exists[pp]) pair[pp] = a.order[pair[pp]];
+    }
     const int64_t pq = exists[pp] ? pair[pp] : 0;
     n[pp] = exists[pp] ? a.count[pq] : 0;
     stride[pp] = (n[pp] + kWave - 1) & ~(kWave - 1);
@@ -2407,16 +2445,20 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
     rot_to_cayley(R0[pp], v0[pp]);
     can_sample[pp] = exists[pp] && n[pp] >= ss && ss >= 1;
     stop[pp] = !can_sample[pp];
+    if constexpr (PHASE == 2) {   // from where the first launch left the pair's rule
+      if (exists[pp]) {
+        it[pp] = (int)a.st_it[pq];
+        best_count[pp] = (int)a.st_best[pq];
+        k[pp] = a.st_k[pq];
+        if (lane < 12) lds.best_model[pp][lane] = a.st_model[12 * pq + lane];
+      }
+    }
   }
+  if constexpr (PHASE == 2) lds_sync();
   unsigned long long ph_clk[kPhCount] = {0};
   const unsigned long long ph_start = a.trace ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long rt_start = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   PNEC_PHASE_BEGIN();
-  auto lds_sync = [&]() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
   for (;;) {
     bool go[2];
     int needed[2];
@@ -2424,6 +2466,15 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
     for (int pp = 0; pp < 2; ++pp) {
       go[pp] = !stop[pp] && (double)it[pp] < k[pp];
       if (!go[pp]) stop[pp] = true;
+    }
+    if constexpr (PHASE == 1) {
+      if (rounds_done == 1) {   // the first round is consumed: who goes on does so in the second launch
+        // (a slot that was lent holds no pair of its own: the pair is slot 0's)
+        unfinished[0] = go[0];
+        unfinished[1] = go[1] && !lent;
+        break;
+      }
+      ++rounds_done;
     }
     // ---- A pair whose partner is done takes the partner's slot as well: from its next round on, slot 1 works on the
     // pair's SECOND sixteen hypotheses of the round (it + 16 ...), consumed after slot 0's by the same sequential rule.
@@ -2694,6 +2745,19 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
 #pragma unroll
   for (int pp = 0; pp < 2; ++pp) {
     if (!exists[pp]) continue;
+    if constexpr (PHASE == 1) {
+      if (unfinished[pp]) {   // leave the rule's state and the pair's index for the second launch
+        const int64_t pq = pair[pp];
+        if (lane < 12) a.st_model[12 * pq + lane] = lds.best_model[pp][lane];
+        if (lane == 0) {
+          a.st_it[pq] = (double)it[pp];
+          a.st_best[pq] = (double)best_count[pp];
+          a.st_k[pq] = k[pp];
+          a.st_list[atomicAdd(a.st_count, 1)] = (int32_t)pq;
+        }
+        continue;
+      }
+    }
     const double *bs = base[pp];
     const int st = stride[pp], nn = n[pp];
     double bR[9], bt[3] = {0.0, 0.0, 1.0};
@@ -2762,6 +2826,9 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
     }
     if (a.sel_data)  // InlierExtraction (this wavefront's own mask bytes back: each lane reads what it wrote)
       compact_pair(a.nc, bs, nn, a.out_mask + aos0, a.sel_data + a.sel_block[pair[pp]], total, lane);
+  }
+  if constexpr (PHASE != 2) break;
+  lds_sync();   // (the next two pairs of the list reuse the LDS)
   }
 }
 
@@ -2962,9 +3029,44 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   const int64_t singles = !two ? n_pairs : std::min<int64_t>(ransac_tail_singles(n_pairs), n_pairs) & ~(int64_t)1;  // (even: the rest pairs up)
   a.n_double = (n_pairs - singles + 1) / 2;
   const int64_t blocks = a.n_double + (n_pairs - std::min<int64_t>(2 * a.n_double, n_pairs));
-  if (scheme == 1) hipLaunchKernelGGL(ransac2_eigensolver_kernel<1>, dim3((unsigned)blocks), dim3(kWave), 0, stream, a);
-  else if (scheme == 2) hipLaunchKernelGGL(ransac2_eigensolver_kernel<2>, dim3((unsigned)blocks), dim3(kWave), 0, stream, a);
-  else hipLaunchKernelGGL(ransac2_eigensolver_kernel<0>, dim3((unsigned)blocks), dim3(kWave), 0, stream, a);
+  // The stage as TWO launches (first rounds, then the pairs that go on: the kernel's PHASE 1 / 2) is an A/B form, built only
+  // with -DPNEC_RANSAC_TWO_LAUNCH_AB and then switched on by PNEC_RANSAC_LAUNCHES=2: bit-identical and, measured in round 5,
+  // 8 % SLOWER at 10 % mismatches (1.72 -> 1.86 ms per 20 000 pairs; 14.9 -> 15.9 ms at 30 %) -- in one launch the slots
+  // that finished pairs free go to other pairs' first rounds at once, which is what fills the long pairs' tails; two
+  // launches put a barrier there (NOTES/round-5.md).
+#ifdef PNEC_RANSAC_TWO_LAUNCH_AB
+  static const int forced_launches = [] {
+    const char *ev = std::getenv("PNEC_RANSAC_LAUNCHES");
+    return ev && *ev ? std::atoi(ev) : 0;
+  }();
+  const bool split = !a.trace && forced_launches == 2;
+#else
+  constexpr bool split = false;
+#endif
+  a.st_k = a.scratch.st_k; a.st_it = a.scratch.st_it; a.st_best = a.scratch.st_best; a.st_model = a.scratch.st_model;
+  a.st_list = a.scratch.st_list; a.st_count = a.scratch.st_count;
+  const dim3 g1((unsigned)blocks), bl(kWave);
+#ifdef PNEC_RANSAC_TWO_LAUNCH_AB
+  // (the second launch: as many blocks as there could be listed pairs -- the hardware hands them out as slots free up; a
+  //  block beyond the list's end leaves at once.  A fixed grid looping over the list would tie long pairs to blocks.)
+  const dim3 g2((unsigned)std::max<int64_t>(1, (n_pairs + 1) / 2));
+#define PNEC_RANSAC_LAUNCH(S)                                                                                 \
+  if (!split) {                                                                                               \
+    hipLaunchKernelGGL((ransac2_eigensolver_kernel<S, 0>), g1, bl, 0, stream, a);                             \
+  } else {                                                                                                    \
+    hipError_t em = hipMemsetAsync(a.st_count, 0, sizeof(int32_t), stream);                                   \
+    if (em != hipSuccess) return em;                                                                          \
+    hipLaunchKernelGGL((ransac2_eigensolver_kernel<S, 1>), g1, bl, 0, stream, a);                             \
+    hipLaunchKernelGGL((ransac2_eigensolver_kernel<S, 2>), g2, bl, 0, stream, a);                             \
+  }
+#else
+  (void)split;
+#define PNEC_RANSAC_LAUNCH(S) hipLaunchKernelGGL((ransac2_eigensolver_kernel<S, 0>), g1, bl, 0, stream, a);
+#endif
+  if (scheme == 1) { PNEC_RANSAC_LAUNCH(1) }
+  else if (scheme == 2) { PNEC_RANSAC_LAUNCH(2) }
+  else { PNEC_RANSAC_LAUNCH(0) }
+#undef PNEC_RANSAC_LAUNCH
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) {
     EsBatchArgs b;

@@ -112,6 +112,8 @@ class RecordGather:
         self.next_slot = 0
         self.last = None
         self.collectives = 0      # collectives issued (bookkeeping for the tests)
+        self.host_collective_s = 0.0   # host_staged: wall time this rank spent inside its collectives (incl. waiting for
+        self.host_copy_wait_s = 0.0    # the slowest rank), and waiting for the records' copy into pinned memory
         if self.cuda:
             self.device = torch.device(device)
             self.side = torch.cuda.Stream(device=self.device)
@@ -131,8 +133,13 @@ class RecordGather:
     def _complete(self, slot: int) -> None:
         """host_staged: run the collective of a slot whose device-to-host copy was enqueued earlier."""
         if self.host_staged and self.pending[slot]:
+            import time
+            t0 = time.perf_counter()
             self.gathered[slot].synchronize()      # the copy into pinned memory has landed
+            t1 = time.perf_counter()
             self.last = self._collective(self.pinned[slot])
+            self.host_copy_wait_s += t1 - t0
+            self.host_collective_s += time.perf_counter() - t1
             self.pending[slot] = False
 
     def acquire(self) -> int:

@@ -148,6 +148,28 @@ def test_profiled_counters_are_dropped_when_the_device_code_changed(tmp_path, mo
         "profiles/traffic_latest.json is stale: re-run tools/profile_bench.sh + tools/make_traffic_json.py"
 
 
+def test_front_flop_model_and_work_counts_belong_to_the_committed_front_stage_code():
+    """The chain's stage rooflines multiply committed work counts (profiles/chain_work_latest.json, a -DPNEC_WORK_COUNT run) by
+    a flop table in bench.py: both carry the sha256 of the front-stage sources they were made on, a line never uses stale
+    counts, and the commit fails here when pnec_frontend.hip moves on without them (the table priced a
+    gradient the kernel no longer computed).  The table's straight-line pieces are cross-checked against the compiled code."""
+    import json
+    import bench
+    cur = bench.front_sources_sha256()
+    committed = json.load(open(os.path.join(ROOT, "profiles", "chain_work_latest.json")))
+    assert committed.get("frontend_sources_sha256") == cur, \
+        "profiles/chain_work_latest.json is stale: rebuild the counting library and re-run tools/count_chain_work.py"
+    assert bench.FRONT_FLOP_MODEL_STAMP == cur, \
+        "bench.py's FLOP_* table was derived on other front-stage code: re-derive it (tools/isa_front_regions.py) and re-stamp"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_front_regions
+    r = isa_front_regions.count()
+    straight = r["cayley"]["flop"] + r["m"]["flop"] + (r["with_gradient"]["flop"] - r["value_only"]["flop"])
+    model = 47 + 411 + 292
+    assert abs(straight - model) <= 0.10 * model, (straight, model, r)
+    assert bench.FLOP_ES_POINT == model + 274 and bench.FLOP_ES_QUAD_EVAL == 4 * bench.FLOP_ES_POINT + 160
+
+
 def test_chain_stage_rooflines_from_committed_work_counts():
     """bench.py --chain prints one roofline block per stage: algorithmic flop = committed work counts
     (profiles/chain_work_latest.json, taken by a -DPNEC_WORK_COUNT build) x the flop model, over the live stage time.

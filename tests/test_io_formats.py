@@ -266,3 +266,54 @@ def test_kitti_like_covariances_follow_the_klt_patch_model():
     w = np.linalg.eigvalsh(a[3].numpy())
     px_std = np.sqrt(w[:, 2]) * 718.856
     assert 0.03 < np.median(px_std) < 0.5 and np.median(w[:, 2] / w[:, 1]) > 1.3     # anisotropic, sub-pixel
+
+
+@pytest.mark.gpu
+def test_tracks_file_from_the_converter_solves_like_the_in_memory_arrays(tmp_path):
+    """a tracks file written by the converter, loaded back (whole and as two shards), gives the refinement and the whole
+    chain exactly the bits the in-memory arrays give; and `bench.py --workload kitti_all --tracks` runs on it"""
+    import subprocess
+    import sys
+
+    from pnec_amd import Batch, capi
+    from pnec_amd import tracks as tk
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = sim.generate(12, 120, seed=8)
+    E, N = 12, 120
+    poses_1 = np.tile(np.array([0, 0, 0, 1, 0, 0, 0], dtype=np.float64), (E, 1))
+    poses_2 = np.concatenate([g.q_gt.numpy() if hasattr(g, "q_gt") else sim.matrix_to_quaternion_xyzw(g.R_gt).numpy(), g.t_gt.numpy()], 1)
+    rng = np.random.default_rng(1)
+    p1 = [np.column_stack([rng.uniform(-300, 300, N), rng.uniform(-200, 200, N), np.full(N, 800.0)]) for _ in range(E)]
+    # frame-2 image points of the same landmarks under the pose (depth 5): what the simulator writes
+    p2, c2 = [], []
+    for e in range(E):
+        R, t = io.quat_xyzw_to_matrix(poses_2[e, :4]), poses_2[e, 4:]
+        X = p1[e] / 800.0 * 5.0
+        Y = (R.T @ (X - t).T).T
+        p2.append(np.column_stack([Y[:, 0] / Y[:, 2] * 800.0 + rng.normal(size=N) * 0.5, Y[:, 1] / Y[:, 2] * 800.0 + rng.normal(size=N) * 0.5, np.full(N, 800.0)]))
+        c = np.zeros((N, 3, 3)); c[:, 0, 0] = 0.3; c[:, 1, 1] = 0.2; c[:, 0, 1] = c[:, 1, 0] = 0.05
+        c2.append(c)
+    folder = tmp_path / "exp"; folder.mkdir()
+    io.write_experiments(str(folder), poses_1, poses_2, p1, p2, c2, c2)
+    mem = tk.from_experiments(str(folder))
+    path = str(tmp_path / "t.npz")
+    tk.save_tracks(path, mem)
+    assert tk.check(tk.load_tracks(path))["ok"]
+
+    def solve(tr):
+        with Batch(capi.MODE_TARGET, tr.offsets) as b:
+            b.fill(np.asarray(tr.bvs1), np.asarray(tr.bvs2), np.asarray(tr.covs))
+            r = b.solve(np.asarray(tr.init_q), np.asarray(tr.init_t))
+            q, t = b.solve_pipeline(np.asarray(tr.init_q), np.asarray(tr.init_t))
+            return np.asarray(r.q), np.asarray(r.t), np.asarray(q), np.asarray(t)
+    a = solve(mem)
+    b = solve(tk.load_tracks(path))
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    s0, s1 = solve(tk.load_tracks(path, 0, 5)), solve(tk.load_tracks(path, 5, 12))
+    np.testing.assert_array_equal(np.concatenate([s0[0], s1[0]]), a[0])       # the refinement does not depend on the sharding
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "kitti_all", "--tracks", path, "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["data"].startswith("tracks:") and line["value"] > 0

@@ -57,7 +57,9 @@ def count(batch, q0, t0):
 
 
 dev = torch.device("cuda:0")
-result = {"what": "algorithmic work per stage, counted by a -DPNEC_WORK_COUNT build (tools/count_chain_work.py)", "workloads": {}}
+import bench  # noqa: E402  (the identity of the front-stage sources the counts belong to)
+result = {"what": "algorithmic work per stage, counted by a -DPNEC_WORK_COUNT build (tools/count_chain_work.py)",
+          "frontend_sources_sha256": bench.front_sources_sha256(), "workloads": {}}
 # (1) bench.py --workload kitti_all --chain (synthetic stand-in, 10 % gross mismatches)
 sizes = tk.kitti_all_sizes()
 tr = tk.kitti_all_shard(0, len(sizes), device=dev, outlier_frac=0.10)
