@@ -126,7 +126,7 @@ def chain_stage_rooflines(counts, stage_ms, payload_bytes, inlier_payload_bytes,
 FRONT_KERNEL_SOURCES = ("pnec_frontend.hip", "pnec_es_schemes.inl", "pnec_device.hpp", "pnec_front_shared.hpp")
 # sha256 (front_sources_sha256) of the sources the FLOP_* table above was last derived from / cross-checked against
 # (tools/isa_front_regions.py); tests/test_bench_launch_cpu.py fails when the sources move on without it
-FRONT_FLOP_MODEL_STAMP = "unstamped"
+FRONT_FLOP_MODEL_STAMP = "294cfa43c72fe5739d3aa27093559944234c9740c30d3217506481375ff049c8"
 
 
 def front_sources_sha256():

@@ -49,9 +49,10 @@
  *    of the minimiser (1e-5 rad), which is the one place where the choice is visible above the 1e-6 rad bar.
  *    ge_main2's "wrong minimum" branch (|cayley| < 0.01 and the second eigenvalue > 0.001 -> restart from a start
  *    disturbed by +-0.3, +-0.6 after three trials, at most five trials) is restated too, behind its own switch and OFF
- *    by default: for the central problem with unit bearings the second eigenvalue of M is ~0.1 N, so the test fires
- *    for EVERY small rotation -- all of KITTI -- and sends the descent off from a start 0.3 away
- *    (tests/test_opengv_schemes.py shows it); it only makes sense for the 4x4 generalised problem it was written for.
+ *    by default: for the central problem with unit bearings the second eigenvalue of M is 1e-4..5e-4 per
+ *    correspondence (0.01..0.5 on KITTI-like pairs of 100..1000 points), so the test can never be satisfied: for EVERY small rotation -- all of KITTI -- all five trials are spent and the end of the last one, a
+ *    descent started up to 0.6 away, is returned (five times the work for nothing; tests/test_opengv_schemes.py shows
+ *    it); it only makes sense for the 4x4 generalised problem it was written for.
  *
  *  Recalled and NOT reproduced (documented deviations of the RANSAC restatement in pnec_oracle_frontend.c, all inside
  *  the statistical noise of opengv's rand() draws): EigensolverSacProblem::getSelectedDistancesToModel writes the

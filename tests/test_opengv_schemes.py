@@ -93,21 +93,33 @@ def test_where_each_scheme_stops(oracle, scheme):
 
 def test_ge_main2_restart_branch_cannot_belong_to_the_central_solver(oracle, scheme):
     """ge_main2's "wrong minimum" test -- |cayley| < 0.01 and the second eigenvalue > 0.001 -> start again from a point
-    disturbed by +-0.3 -- fires for EVERY small rotation of the central problem (unit bearings: the second eigenvalue of M
-    is ~0.1 N), i.e. for all KITTI-like pairs, and throws the descent off; with the branch off (the default) the same
-    pairs end at the minimiser.  Why the branch is restated but not used (oracle/pnec_oracle_opengv.c)."""
+    disturbed by +-0.3 (+-0.6 from the fourth trial), five trials at most -- can never be satisfied by the central problem:
+    with unit bearings the second eigenvalue of M is 1e-4..5e-4 per correspondence (0.03..0.13 here), so for EVERY small rotation (all KITTI-like pairs) all five
+    trials are spent and what comes back is the end of a descent started up to 0.6 away, not the first (undisturbed)
+    one's.  Why the branch is restated but not used (oracle/pnec_oracle_opengv.c)."""
+    import ctypes as C
+    L = oracle.lib()
+    L.pnec_oracle_es_descent_restarts.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint64, C.c_uint64,
+                                                  C.POINTER(C.c_int)]
     scheme(1)
-    worse = 0
-    for f1, f2, R0 in _kitti_like(oracle, 6, 300, 9):
-        G = oracle.sums36(f1, f2)
+    tested = 0
+    for f1, f2, R0 in _kitti_like(oracle, 12, 300, 9):
+        G = np.ascontiguousarray(oracle.sums36(f1, f2))
         v0 = oracle.rot_to_cayley(R0)
-        assert np.linalg.norm(v0) < 0.01 and oracle.es_value_grad_sums(G, v0)[3] > 0.001   # the test's two conditions hold at once
-        oracle.set_eigensolver_restart(False); R_plain, _ = oracle.eigensolver(f1, f2, R0)
-        oracle.set_eigensolver_restart(True); R_rst, _ = oracle.eigensolver(f1, f2, R0)
-        scheme(0); R_n, _ = oracle.eigensolver(f1, f2, R0); scheme(1)
-        assert _angle(oracle, R_plain, R_n) < 1e-3
-        worse += _angle(oracle, R_rst, R_n) > 10 * _angle(oracle, R_plain, R_n) + 1e-9
-    assert worse >= 1   # five disturbed trials never "find" a second eigenvalue below 0.001: the last trial's end is returned
+        if np.linalg.norm(v0) >= 0.006:      # (frame-to-frame yaw of up to 0.02 rad: most pairs, not all, stay below 0.01)
+            continue
+        tested += 1
+        assert oracle.es_value_grad_sums(G, v0)[3] > 0.001 * 10     # the second eigenvalue: tens of times the test's bound
+        v_plain, _, _ = oracle.es_descent(G, v0)
+        v = np.array(v0)
+        trials = C.c_int()
+        L.pnec_oracle_es_descent_restarts(G.ctypes.data_as(C.POINTER(C.c_double)), v.ctypes.data_as(C.POINTER(C.c_double)), 1, 0,
+                                          C.byref(trials))
+        assert trials.value == 5                       # never "found": every trial fails the second-eigenvalue test
+        assert not np.array_equal(v, v_plain)          # ... and the last, disturbed trial's end is what comes back
+        assert np.linalg.norm(v - v_plain) < 1e-2      # (on clean data the descent finds its way back to the basin: the
+                                                       #  branch costs five descents, it does not buy anything)
+    assert tested >= 3
 
 
 def test_chain_honours_the_scheme_and_scores_every_hypothesis(oracle, scheme):
