@@ -909,13 +909,11 @@ struct FrontArgs {
   unsigned long long *trace;  // null, or [n_pairs, 8] clocks per phase of the weighted kernel (PNEC_HIP_TRACE_FRONT)
   double reg;
   int weighted_iterations;
-  // weighted stage: the 36 weighted sums [n_pairs,36], and the first round's eigenvalue minimisation
-  // (es_batch_kernel): its minimiser [n_pairs,3] and Newton iteration count [n_pairs]
-  const double *pre_G, *pre_v;
+  // weighted stage: ALL its eigenvalue minimisations ran before it, chained (es_batch_kernel / es_batch_alt_kernel) --
+  // the first call's iteration count [n_pairs], round r's minimiser of pair p at pre_v_rounds[3 (r n_pairs + p)], and
+  // how many rounds of the pair have one (after those the rotation is final) at pre_n_es[p]
   const int32_t *pre_its;
-  // eigensolver schemes 1, 2: ALL the stage's minimisations ran in es_batch_alt_kernel, chained -- round r's minimiser
-  // of pair p at pre_v_rounds[3 (r n_pairs + p)], and how many rounds of the pair have one (after those the rotation is
-  // final) at pre_n_es[p]; null under scheme 0
+  const int32_t *order;    // [n_pairs] the pair block b takes (weighted_order_place), or null: pair b
   const double *pre_v_rounds;
   const int32_t *pre_n_es;
   int64_t n_pairs;
@@ -1019,6 +1017,9 @@ struct FrontScratch {
   // v_rounds region (free until the weighted stage), the list of pairs that go on and its length behind the ints
   double *st_k, *st_it, *st_best, *st_model;
   int32_t *st_list, *st_count;
+  // the weighted stage's launch order (same ints, free by then): wo_order[b] = the pair block b of the weighted kernel
+  // takes, wo_count[0 / 1] = pairs placed from the front / from the back so far
+  int32_t *wo_order, *wo_count;
 };
 // per pair: 36 + 3 + 1 + 3 + 3 kEsMaxRounds doubles and 5 ints (pnec_capi.hip sizes the buffers: kFrontDoublesPerPair /
 // kFrontIntsPerPair)
@@ -1038,6 +1039,8 @@ FrontScratch front_scratch(double *d, int32_t *i, int64_t P) {
   f.st_model = d + 46 * P;   // .. 58 P (of the 45 P the v_rounds region has)
   f.st_list = i + 3 * P;
   f.st_count = i + 4 * P;    // (one int; the region is sized 5 P)
+  f.wo_order = i + 3 * P;
+  f.wo_count = i + 4 * P;    // (two ints)
   return f;
 }
 
@@ -1072,6 +1075,7 @@ __global__ __launch_bounds__(kWave) void sums36_kernel(const FrontArgs a, const 
     out.v0[3 * pair] = v[0]; out.v0[3 * pair + 1] = v[1]; out.v0[3 * pair + 2] = v[2];
     out.n_scale[pair] = (double)(n > 0 ? n : 1);
     out.first[pair] = n > 0 ? 0 : -1;  // ComposeM starts at i = 1 (C7)
+    if (WEIGHTED && pair == 0) out.wo_count[0] = out.wo_count[1] = 0;  // (es_batch_kernel, the next launch, counts)
   }
 }
 
@@ -1123,11 +1127,45 @@ __device__ __forceinline__ void es_batch_translation_epilogue(const EsBatchArgs 
   }
 }
 
+// The weighted kernel's launch order.  A launch ends with its slowest pair, and the slow pairs of that kernel are the ones
+// whose translation is barely observable: the cost is nearly flat along a second direction, the bound prunes little of the
+// Fibonacci grid (the full-grid search: 6-12 times a median pair's clocks) and the SCF wanders through all its rounds.
+// Dispatched in index order, 1-2 % of such pairs left the last THIRD of a 20 000-pair launch to a few dozen wavefronts
+// (slots busy on average: 1 090 of 2 048; round 5, tools/analyse_weighted_trace.py).  How flat the cost is shows BEFORE that
+// kernel runs: smallest / second eigenvalue of the weighted M at the first minimiser (the top 5 % by that ratio held 298 of
+// the 302 pairs that took more than three medians).  So the pairs above a fixed ratio are placed from the front of the
+// order and the others from the back -- one atomic per pair, no sort; the order inside the two classes is whatever the
+// atomics give (it decides WHEN a pair runs, never what comes out: every pair writes its own records).
+constexpr double kWeightedLongRatio = 1e-3;
+// called by the whole wavefront; `place`: this lane holds a pair (and its eigenvalues w).  One atomic per class and
+// WAVEFRONT (one per pair, all on two addresses, cost the launch 150 us per 20 000 pairs)
+__device__ __forceinline__ void weighted_order_place(const FrontScratch &s, int64_t n_pairs, bool place, int64_t pair,
+                                                     const double (&w)[3]) {
+  const int lane = (int)threadIdx.x & (kWave - 1);
+  const bool long_pair = place && !(w[0] < kWeightedLongRatio * w[1]);  // (a NaN counts as long: nothing is known about it)
+  const bool short_pair = place && !long_pair;
+  const unsigned long long ml = __builtin_amdgcn_ballot_w64(long_pair), ms = __builtin_amdgcn_ballot_w64(short_pair);
+  int base_l = 0, base_s = 0;
+  if (lane == 0) {
+    if (ml != 0ull) base_l = atomicAdd(&s.wo_count[0], __builtin_popcountll(ml));
+    if (ms != 0ull) base_s = atomicAdd(&s.wo_count[1], __builtin_popcountll(ms));
+  }
+  base_l = __builtin_amdgcn_readfirstlane(base_l);
+  base_s = __builtin_amdgcn_readfirstlane(base_s);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (long_pair) s.wo_order[base_l + __builtin_popcountll(ml & below)] = (int32_t)pair;
+  if (short_pair) s.wo_order[n_pairs - 1 - base_s - __builtin_popcountll(ms & below)] = (int32_t)pair;
+}
+
 // sixteen pairs per wavefront, one per quad: minimise lambda_min(M(R)) from v0; kEpiTranslation: then the
 // rotation as a quaternion and the translation = eigenvector of the smallest eigenvalue of M without the
 // correspondence ComposeM skips
+// kEpiNone (the weighted stage): ALL of the stage's minimisations, chained -- the weights never change (C3), so a later
+// round minimises the same function from the previous round's result, and a call that ended for any other reason than
+// the iteration cap leaves nothing to do: normally ONE call per pair; a pair at the cap goes on (the other quads idle
+// through it), `rounds` calls at most.  Round r's minimiser at v_rounds[r], the number of rounds that have one at n_es.
 template <int EPI>
-__global__ __launch_bounds__(kWave, 2) void es_batch_kernel(const EsBatchArgs a) {
+__global__ __launch_bounds__(kWave, 2) void es_batch_kernel(const EsBatchArgs a, int rounds) {
   const int lane = threadIdx.x;
   const int quad = lane >> 2;
   __shared__ double Gs[16][36];
@@ -1143,13 +1181,32 @@ __global__ __launch_bounds__(kWave, 2) void es_batch_kernel(const EsBatchArgs a)
   const bool mine = first_pair + quad < a.n_pairs;
   const int64_t pair = mine ? first_pair + quad : a.n_pairs - 1;
   double v[3] = {a.s.v0[3 * pair], a.s.v0[3 * pair + 1], a.s.v0[3 * pair + 2]};
+  int it = 0, n_es = 0;
+  bool going = mine;
+  for (int r = 0; r < (EPI == kEpiNone ? rounds : 1); ++r) {
+    if (r > 0 && __builtin_amdgcn_ballot_w64(going) == 0ull) break;
+    const double v_in[3] = {v[0], v[1], v[2]};
 #ifdef PNEC_WORK_COUNT
-  int evals_here = 0;
-  const int it = es_minimise_quad<1, 3>(Gs[quad], v, a.s.n_scale[pair], nullptr, true, &evals_here);   // (TAG 3: counted here)
-  if (mine && (lane & 3) == 0) PNEC_WORK_ADD(EPI == kEpiNone ? kWkEsFirstEvals : kWkEsTailEvals, evals_here);
+    int evals_here = 0;
+    const int it_r = es_minimise_quad<1, 3>(Gs[quad], v, a.s.n_scale[pair], nullptr, true, &evals_here);   // (TAG 3: counted here)
+    if (going && (lane & 3) == 0) PNEC_WORK_ADD(EPI == kEpiNone ? kWkEsFirstEvals : kWkEsTailEvals, evals_here);
 #else
-  const int it = es_minimise_quad<1, 2>(Gs[quad], v, a.s.n_scale[pair]);
+    const int it_r = es_minimise_quad<1, 2>(Gs[quad], v, a.s.n_scale[pair]);
 #endif
+    if (r == 0) it = it_r;
+    if (!going) {  // a quad that only kept the others company
+      v[0] = v_in[0]; v[1] = v_in[1]; v[2] = v_in[2];
+      continue;
+    }
+    if constexpr (EPI == kEpiNone) {
+      if ((lane & 3) == 0) {
+        double *dst = a.s.v_rounds + 3 * ((int64_t)r * a.n_pairs + pair);
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2];
+      }
+      n_es = r + 1;
+      going = it_r >= kNewtonMaxIterations;
+    }
+  }
 #ifdef PNEC_FRONT_DEBUG
   if (mine && (lane & 3) == 0) {
     atomicMax(&g_dbg[12], (unsigned long long)it);
@@ -1159,10 +1216,14 @@ __global__ __launch_bounds__(kWave, 2) void es_batch_kernel(const EsBatchArgs a)
   }
 #endif
   if constexpr (EPI == kEpiNone) {
+    double M[9], w[3], V[9];
+    es_value_grad<1>(Gs[quad], v, nullptr, M);
+    sym_eig3(M, w, V);
     if (mine && (lane & 3) == 0) {
-      a.s.v[3 * pair] = v[0]; a.s.v[3 * pair + 1] = v[1]; a.s.v[3 * pair + 2] = v[2];
+      a.s.n_es[pair] = n_es;
       a.s.its[pair] = it;
     }
+    weighted_order_place(a.s, a.n_pairs, mine && (lane & 3) == 0, pair, w);
   } else {
     es_batch_translation_epilogue(a, Gs[quad], v, pair, mine, it, lane);
   }
@@ -1243,10 +1304,17 @@ __global__ __launch_bounds__(kWave, 2) void es_batch_alt_kernel(const EsBatchArg
       }
       wave_lds_sync();
     }
+    double M[9], w[3], V[9];
+    {
+      const double vq[3] = {lds.tv[quad][0], lds.tv[quad][1], lds.tv[quad][2]};
+      es_value_grad<1>(lds.Gs[quad], vq, nullptr, M);
+      sym_eig3(M, w, V);
+    }
     if (mine && (lane & 3) == 0) {
       a.s.n_es[pair] = n_es;
       a.s.its[pair] = it_first;
     }
+    weighted_order_place(a.s, a.n_pairs, mine && (lane & 3) == 0, pair, w);
     return;
   }
   double v[3] = {lds.tv[quad][0], lds.tv[quad][1], lds.tv[quad][2]};
@@ -1327,7 +1395,6 @@ __device__ double obj_fun_pair(const double *base, int n, int stride, const doub
 // The LDS of a block (one struct for whatever forms its kernel can run, so it is the largest, not the sum):
 template <int WMAX>
 struct WeightedLds {
-  double G[36];          // the pair's 36 weighted sums
   double cand[21][3];    // streaming form: the directions of a batch
   // exchange between the wavefronts of a pair: [buffer][wavefront][value]; the buffers alternate so that a
   // wavefront that runs ahead into the next exchange cannot overwrite what another has yet to read
@@ -1340,15 +1407,13 @@ struct WeightedLds {
   float cost32p[WMAX > 1 ? WMAX : 1][WMAX > 1 ? 512 : 1];  // ... each wavefront's share of those
 };
 template <bool RES, int WPP, typename Lds>
-__device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
+__device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds, const int64_t pair) {
   static_assert(WPP == 1 || RES, "several wavefronts per pair exist for the resident form only");
-  const int64_t pair = blockIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
   [[maybe_unused]] const int wave = threadIdx.x >> 6;
   const int n = a.count[pair];
   const int stride = (n + kWave - 1) & ~(kWave - 1);
   const double *base = a.data + a.block_offset[pair];
-  double *G = lds.G;
   [[maybe_unused]] double (*cand)[3] = lds.cand;
   [[maybe_unused]] auto &xch = lds.xch;
   [[maybe_unused]] int xpar = 0;
@@ -1383,17 +1448,16 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
       xpar ^= 1;
     }
   };
-  // Everything the kernel reads per pair -- start pose, the first round's minimiser and its iteration count
-  // (es_batch_kernel's results), the pair's 36 weighted sums -- is requested HERE, in one trip to memory: read where it
-  // was first used, each was a dependent round trip of its own (~8 k clocks of the pair's 80 k: phase clocks, round 5).
+  // Everything the kernel reads per pair -- start pose, the first round's minimiser, its iteration count and the number
+  // of rounds that have one (es_batch_kernel's results) -- is requested HERE, in one trip to memory: read where it was
+  // first used, each was a dependent round trip of its own (~8 k clocks of the pair's 80 k: phase clocks, round 5).
   const double *iqp = a.init_q + 4 * pair, *itp = a.init_t + 3 * pair;
-  const double *pvp = a.pre_n_es ? a.pre_v_rounds + 3 * pair : a.pre_v + 3 * pair;
+  const double *pvp = a.pre_v_rounds + 3 * pair;
   double q0[4] = {iqp[0], iqp[1], iqp[2], iqp[3]};
   const double t0[3] = {itp[0], itp[1], itp[2]};
   const double pre_v0[3] = {pvp[0], pvp[1], pvp[2]};
   const int pre_its0 = a.pre_its[pair];
-  const int pre_n_es0 = a.pre_n_es ? a.pre_n_es[pair] : 0;
-  const double g_mine = (lane < 36 && (WPP == 1 || wave == 0)) ? a.pre_G[36 * pair + lane] : 0.0;
+  const int pre_n_es0 = a.pre_n_es[pair];
   {
     const double qn = 1.0 / sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);
     for (int k = 0; k < 4; ++k) q0[k] *= qn;
@@ -1405,12 +1469,11 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
   for (int i = 0; i < 9; ++i) R[i] = R0[i];
   unsigned long long ph_clk[kPhCount] = {0};
   const unsigned long long ph_start = a.trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  [[maybe_unused]] const unsigned long long ph_start_real = a.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   PNEC_PHASE_BEGIN();
-  // weights come from the INITIAL pose in every iteration (C3): the 36 weighted sums never change -- they
-  // were made by sums36_kernel<true> (the first round's minimisation, es_batch_kernel, needed them first);
-  // here they are only read again if a later round has to minimise once more
-  if (lane < 36 && (WPP == 1 || wave == 0)) G[lane] = g_mine;
-  pair_sync();
+  // (weights come from the INITIAL pose in every iteration (C3): the 36 weighted sums never change, so every eigenvalue
+  // minimisation of the stage ran before this kernel, chained in es_batch_kernel; until round 5 the ones after the first
+  // ran here -- a Newton iteration that one pair in thousands entered and every pair paid 224 B/lane of scratch for)
   PNEC_PHASE_END(kPhSums);
 
   constexpr int KR = RES ? 8 : 1;
@@ -1450,24 +1513,13 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
     // final and later rounds only redo the translation (newton = 0: "did not move").
     int newton = 0;
     if constexpr (WITH_ES) {
-      if (a.pre_n_es) {  // schemes 1, 2: every round's call ran in es_batch_alt_kernel, chained
-        if (it == 0) {
-          v[0] = pre_v0[0]; v[1] = pre_v0[1]; v[2] = pre_v0[2];
-        } else {
-          const double *pv = a.pre_v_rounds + 3 * ((int64_t)it * a.n_pairs + pair);
-          v[0] = pv[0]; v[1] = pv[1]; v[2] = pv[2];
-        }
-        newton = it == 0 ? pre_its0 : 1;
-        rotation_final = it + 1 >= pre_n_es0;
-      } else {
-        if (it == 0) {  // the first round's call ran in es_batch_kernel (sixteen pairs per wavefront)
-          v[0] = pre_v0[0]; v[1] = pre_v0[1]; v[2] = pre_v0[2];
-          newton = pre_its0;
-        } else {
-          newton = es_minimise_quad<1>(G, v, (double)(n > 0 ? n : 1));
-        }
-        rotation_final = newton < kNewtonMaxIterations;
+      if (it > 0 && it < pre_n_es0) {
+        const double *pv = a.pre_v_rounds + 3 * ((int64_t)it * a.n_pairs + pair);
+        v[0] = pv[0]; v[1] = pv[1]; v[2] = pv[2];
       }
+      // (beyond the pair's last call -- the streaming form's later rounds -- the rotation stays: newton = 0)
+      newton = it == 0 ? pre_its0 : (it < pre_n_es0 ? 1 : 0);
+      rotation_final = it + 1 >= pre_n_es0;
     }
     if (it == 0) first_iterations = newton;
     PNEC_PHASE_END(kPhNewton);
@@ -1833,6 +1885,7 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
     if (a.out_iterations) a.out_iterations[pair] = first_iterations;
     if (a.trace) {
       ph_clk[kPhTotal] = __builtin_amdgcn_s_memtime() - ph_start;
+      ph_clk[7] = (ph_start_real & 0xffffffffull) | (__builtin_amdgcn_s_memrealtime() << 32);  // start | end, 100 MHz
       for (int k = 0; k < kPhCount; ++k) a.trace[kPhCount * pair + k] = ph_clk[k];
     }
   }
@@ -1847,25 +1900,26 @@ __device__ __forceinline__ void weighted_pair(const FrontArgs &a, Lds &lds) {
 template <bool RES>
 __global__ __launch_bounds__(kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigensolver_kernel(const FrontArgs a) {
   __shared__ WeightedLds<1> lds;
-  weighted_pair<RES, 1>(a, lds);
+  weighted_pair<RES, 1>(a, lds, a.order ? (int64_t)a.order[blockIdx.x] : (int64_t)blockIdx.x);
 }
 template <int WMAX>
 __global__ __launch_bounds__(WMAX *kWave, PNEC_WES_WAVES_PER_SIMD) void weighted_eigensolver_mixed_kernel(const FrontArgs a) {
   __shared__ WeightedLds<WMAX> lds;
-  const int n = a.count[blockIdx.x];
+  const int64_t pair = a.order ? (int64_t)a.order[blockIdx.x] : (int64_t)blockIdx.x;
+  const int n = a.count[pair];
   const int wave = threadIdx.x >> 6;
   if (n <= 8 * kWave) {
-    if (wave < 1) weighted_pair<true, 1>(a, lds);
+    if (wave < 1) weighted_pair<true, 1>(a, lds, pair);
   } else if (n <= 16 * kWave) {
-    if (wave < 2) weighted_pair<true, 2>(a, lds);
+    if (wave < 2) weighted_pair<true, 2>(a, lds, pair);
   } else if (WMAX >= 4 && n <= 32 * kWave) {
     if constexpr (WMAX >= 4) {
-      if (wave < 4) weighted_pair<true, 4>(a, lds);
+      if (wave < 4) weighted_pair<true, 4>(a, lds, pair);
     }
   } else if (WMAX >= 8 && n <= 64 * kWave) {
-    if constexpr (WMAX >= 8) weighted_pair<true, 8>(a, lds);
+    if constexpr (WMAX >= 8) weighted_pair<true, 8>(a, lds, pair);
   } else {
-    if (wave < 1) weighted_pair<false, 1>(a, lds);
+    if (wave < 1) weighted_pair<false, 1>(a, lds, pair);
   }
 }
 
@@ -2892,7 +2946,7 @@ static void launch_es_batch_translation(const EsBatchArgs &b, int scheme, hipStr
   const dim3 grid(es_batch_blocks(b.n_pairs)), block(kWave);
   if (scheme == 1) hipLaunchKernelGGL((es_batch_alt_kernel<kEpiTranslation, 1>), grid, block, 0, stream, b, 1);
   else if (scheme == 2) hipLaunchKernelGGL((es_batch_alt_kernel<kEpiTranslation, 2>), grid, block, 0, stream, b, 1);
-  else hipLaunchKernelGGL(es_batch_kernel<kEpiTranslation>, grid, block, 0, stream, b);
+  else hipLaunchKernelGGL(es_batch_kernel<kEpiTranslation>, grid, block, 0, stream, b, 1);
 }
 
 hipError_t launch_select(int nc, const double *src, const int64_t *src_block, const int64_t *src_offsets,
@@ -3371,7 +3425,7 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
     else if (scheme == 2)
       hipLaunchKernelGGL((es_batch_alt_kernel<kEpiNone, 2>), dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, stream, b, rounds);
     else
-      hipLaunchKernelGGL(es_batch_kernel<kEpiNone>, dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, stream, b);
+      hipLaunchKernelGGL(es_batch_kernel<kEpiNone>, dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, stream, b, rounds);
     if ((e = hipGetLastError()) != hipSuccess) return e;
 #ifdef PNEC_FRONT_DEBUG
     {
@@ -3385,14 +3439,11 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
     }
 #endif
   }
-  a.pre_G = sc.G;
-  a.pre_v = sc.v;
   a.pre_its = sc.its;
+  a.order = std::getenv("PNEC_WES_INDEX_ORDER") ? nullptr : sc.wo_order;  // (A/B: the launch in index order)
   a.n_pairs = n_pairs;
-  if (scheme != 0) {
-    a.pre_v_rounds = sc.v_rounds;
-    a.pre_n_es = sc.n_es;
-  }
+  a.pre_v_rounds = sc.v_rounds;
+  a.pre_n_es = sc.n_es;
   // PNEC_HIP_TRACE_FRONT=1: per-phase clocks of every pair, averaged and printed to stderr (diagnostics;
   // synchronises, never set it for timed runs)
   const char *tr = std::getenv("PNEC_HIP_TRACE_FRONT");
@@ -3415,6 +3466,12 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
       double m[kPhCount] = {0};
       for (int64_t p = 0; p < n_pairs; ++p)
         for (int k = 0; k < kPhCount; ++k) m[k] += (double)h[(size_t)(kPhCount * p + k)];
+      if (tr[0] == '/' || tr[0] == '.') {  // a path: the raw [n_pairs, kPhCount] records of this launch (overwritten per launch)
+        if (std::FILE *fp = std::fopen(tr, "wb")) {
+          std::fwrite(h.data(), sizeof(unsigned long long), h.size(), fp);
+          std::fclose(fp);
+        }
+      }
       static const char *names[kPhCount] = {"sums36", "newton", "tables", "search", "cur_cost", "scf", "total", "-", "-", "-", "-", "-"};
       std::fprintf(stderr, "weighted_eigensolver phases (mean s_memtime clocks per pair, %lld pairs):", (long long)n_pairs);
       for (int k = 0; k < kPhTotal + 1; ++k) std::fprintf(stderr, " %s=%.0f", names[k], m[k] / (double)n_pairs);
