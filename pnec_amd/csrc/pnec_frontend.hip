@@ -3440,14 +3440,17 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
 #endif
   }
   a.pre_its = sc.its;
-  a.order = std::getenv("PNEC_WES_INDEX_ORDER") ? nullptr : sc.wo_order;  // (A/B: the launch in index order)
+  {
+    const char *io = std::getenv("PNEC_WES_INDEX_ORDER");  // (A/B: =1 launches in index order)
+    a.order = (io && *io && *io != '0') ? nullptr : sc.wo_order;
+  }
   a.n_pairs = n_pairs;
   a.pre_v_rounds = sc.v_rounds;
   a.pre_n_es = sc.n_es;
   // PNEC_HIP_TRACE_FRONT=1: per-phase clocks of every pair, averaged and printed to stderr (diagnostics;
   // synchronises, never set it for timed runs)
   const char *tr = std::getenv("PNEC_HIP_TRACE_FRONT");
-  if (tr && *tr && n_max <= 8 * kWave) {
+  if (tr && *tr && n_max <= 64 * kWave) {
     e = hipMalloc(&a.trace, sizeof(unsigned long long) * kPhCount * (size_t)n_pairs);
     if (e != hipSuccess) return e;
   }
