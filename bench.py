@@ -126,7 +126,7 @@ def chain_stage_rooflines(counts, stage_ms, payload_bytes, inlier_payload_bytes,
 FRONT_KERNEL_SOURCES = ("pnec_frontend.hip", "pnec_es_schemes.inl", "pnec_device.hpp", "pnec_front_shared.hpp")
 # sha256 (front_sources_sha256) of the sources the FLOP_* table above was last derived from / cross-checked against
 # (tools/isa_front_regions.py); tests/test_bench_launch_cpu.py fails when the sources move on without it
-FRONT_FLOP_MODEL_STAMP = "294cfa43c72fe5739d3aa27093559944234c9740c30d3217506481375ff049c8"
+FRONT_FLOP_MODEL_STAMP = "1f029785a5576a9984c7697011f92fe78173b557d75e631e4550c262890928e9"
 
 
 def front_sources_sha256():
@@ -1080,7 +1080,7 @@ def run(args):
                              "note": "one pnec_hip_solve_pipeline call per step and rank; `roofline` has one block per stage "
                                      "(stage times from the same chain run stage by stage on rank 0; algorithmic flop from the "
                                      "committed work counts, profiles/chain_work_latest.json); stage kernels: "
-                                     "profiles/r04_full_pipeline_kernels.md"}
+                                     "profiles/r05_full_pipeline_kernels.md"}
         else:
             kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
             batch = sh.batch
