@@ -103,6 +103,8 @@ int main(int argc, char **argv) {
       options.use_nec_ = true;
       options.use_ceres_ = false;
     }
+    // optional 5th argument: the eigensolver scheme (include/pnec_hip.h; the facade's default is 2)
+    if (argc > 5) options.eigensolver_scheme_ = std::atoi(argv[5]);
     pnec::rel_pose_estimation::PNEC pnec_solver(options);
     const pnec::SE3d init(pnec::Quaterniond(0.975, 0.1, -0.14, 0.115).normalized().toRotationMatrix(),
                           pnec::Vector3d(0.28, -0.22, 0.92).normalized());
@@ -124,12 +126,12 @@ int main(int argc, char **argv) {
     }
     std::sort(us.begin(), us.end());
     std::printf("{\"call\": \"PNEC::Solve, %s, "
-                "host arrays in, pose + inliers out\", \"correspondences\": %d, \"inliers\": %zu, \"reps\": %d, "
+                "host arrays in, pose + inliers out\", \"eigensolver_scheme\": %d, \"correspondences\": %d, \"inliers\": %zu, \"reps\": %d, "
                 "\"median_us\": %.1f, \"p10_us\": %.1f, \"p90_us\": %.1f, \"checksum\": %.6f, \"frame_timing_us\": \"%s\"}\n",
                 vo ? "the odometry's forced Options (use_nec, no refinement: RANSAC eigensolver only)"
                    : (timed ? "reference-default Options, the TIMED overload (stage by stage, FrameTiming filled)"
                             : "reference-default Options (RANSAC eigensolver, weighted eigensolver + SCF, refinement)"),
-                n, n_inl, reps, us[us.size() / 2], us[us.size() / 10], us[us.size() * 9 / 10], sink / reps,
+                options.eigensolver_scheme_, n, n_inl, reps, us[us.size() / 2], us[us.size() / 10], us[us.size() * 9 / 10], sink / reps,
                 timed ? last_timing.TimingRowUs().c_str() : "");
     return 0;
   }

@@ -549,6 +549,46 @@ def test_weighted_eigensolver_ragged_batch_forms_device_vs_oracle(oracle):
         assert abs(abs(tw[p] @ tt) - 1) < 1e-8, n
 
 
+def test_weighted_stage_launch_order_and_chained_minimisations_on_degenerate_pairs(oracle, monkeypatch):
+    """Round 5: (a) every eigenvalue minimisation of the weighted stage runs before the weighted kernel, chained (a call
+    that ended at the iteration cap is followed by another from its result); (b) the kernel takes the pairs in an order
+    made from the flatness of their minimum, long pairs first.  Neither may change a bit of what comes out.  The set:
+    1 200 pairs of 5..11 correspondences, noise up to 0.5, starts up to |v| ~ 1 (about one in ten first calls ends at the
+    cap there) -- far outside the use case, where a Newton iteration's end depends on the last bits of its start, so the
+    agreement with the checker's sequential twin is exact-to-rounding only for the near starts and a share for the far."""
+    rng = np.random.default_rng(5)
+    F1, F2, C2, sizes, Q, T, VS = [], [], [], [], [], [], []
+    for _ in range(1200):
+        n = int(rng.integers(5, 12))
+        f1 = rng.normal(size=(n, 3)); f1[:, 2] = abs(f1[:, 2]) + 1; f1 /= np.linalg.norm(f1, axis=1, keepdims=True)
+        f2 = f1 + rng.normal(size=(n, 3)) * rng.choice([1e-3, 1e-2, 1e-1, 0.5]); f2 /= np.linalg.norm(f2, axis=1, keepdims=True)
+        vs = rng.choice([0.01, 0.3, 1.0])
+        A = rng.normal(size=(n, 3, 3)) * 1e-3
+        t = rng.normal(size=3)
+        F1.append(f1); F2.append(f2); C2.append(A @ A.transpose(0, 2, 1) + 1e-7 * np.eye(3)); sizes.append(n); VS.append(vs)
+        Q.append(oracle.quat_from_rot(oracle.cayley_to_rot(rng.normal(size=3) * vs))); T.append(t / np.linalg.norm(t))
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    f1, f2, c2, q0, t0, VS = np.concatenate(F1), np.concatenate(F2), np.concatenate(C2), np.array(Q), np.array(T), np.array(VS)
+    res = {}
+    for index_order in ("0", "1"):
+        monkeypatch.setenv("PNEC_WES_INDEX_ORDER", index_order)   # (read at every launch: "1" = blocks take pairs in index order)
+        with Batch(capi.MODE_TARGET, off) as b:
+            b.fill(f1, f2, c2)
+            res[index_order] = b.weighted_eigensolver(q0, t0, 1e-13, 10)
+    monkeypatch.delenv("PNEC_WES_INDEX_ORDER")
+    np.testing.assert_array_equal(res["0"][0], res["1"][0])
+    np.testing.assert_array_equal(res["0"][1], res["1"][1])
+    qw, tw = res["0"]
+    err = np.empty(len(sizes))
+    for p in range(len(sizes)):
+        sl = slice(off[p], off[p + 1])
+        Rt, _ = oracle.weighted_eigensolver(f1[sl], f2[sl], c2[sl], oracle.rot_from_quat(q0[p]), t0[p], 1e-13, 10, device_early_exits=True)
+        err[p] = _rot_err(oracle, _quat_to_R(qw[p]), Rt)
+    assert np.isfinite(err).all()
+    assert err[VS == 0.01].max() <= 1e-7
+    assert (err[VS == 0.3] <= 1e-8).mean() >= 0.9 and (err[VS == 1.0] <= 1e-8).mean() >= 0.7
+
+
 def test_ransac_eigensolver_and_inlier_selection_device_vs_oracle(oracle):
     """SURVEY 8f row 2 with RANSAC (pnec.cc:239-272) + InlierExtraction (pnec.cc:210-229): same
     counter-based draws on both sides -> same inlier sets, same rotations"""

@@ -28,7 +28,8 @@ python tools/verify_pipeline.py 100000 > $OUT/pipeline_parity_100k.json 2> $OUT/
 python tools/verify_eigensolver_schemes.py 2000 > $OUT/odometry_options_parity.json 2> /dev/null
 python tools/bench_streaming.py > $OUT/streaming.json 2> /dev/null
 # 6. one PNEC::Solve per frame through the facade (default options / the odometry's / the timed overload)
-for n in 100 512 700 2000; do for m in "" vo timed; do ./pnec_amd/pnec_host_demo $n solve_latency 300 $m 2>/dev/null | tail -1 >> $OUT/solve_latency.jsonl; done; done
+rm -f $OUT/solve_latency.jsonl
+for n in 100 512 700 2000; do for m in default vo timed; do for s in 2 0; do ./pnec_amd/pnec_host_demo $n solve_latency 300 $m $s 2>/dev/null | tail -1 >> $OUT/solve_latency.jsonl; done; done; done
 # 7. the two-ranks-on-one-GPU run under a kernel trace (what the 7x per step is made of)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_2ranks -o t -- python $REPO/bench.py --gpus 2 --share-gpu --workload kitti_all --chain --steps 6 --warmup 2 > $OUT/trace_2ranks.log 2>&1
