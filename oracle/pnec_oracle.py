@@ -280,6 +280,15 @@ def set_eigensolver_scheme(scheme: int) -> None:
     L.pnec_oracle_set_eigensolver_scheme(int(scheme))
 
 
+def set_ransac_frozen_rules(on: bool) -> None:
+    """RANSAC under scheme 0 with the round-3 rules: every hypothesis scored, 50 iterations for a hypothesis' minimisation
+    (pnec_oracle_frontend.c); OFF by default"""
+    L = lib()
+    L.pnec_oracle_set_ransac_frozen_rules.argtypes = [C.c_int]
+    L.pnec_oracle_set_ransac_frozen_rules.restype = None
+    L.pnec_oracle_set_ransac_frozen_rules(int(bool(on)))
+
+
 def set_eigensolver_restart(on: bool) -> None:
     """scheme 1 only: ge_main2's disturbed-restart loop around the descent (off by default; pnec_oracle_opengv.c)"""
     L = lib()

@@ -258,6 +258,12 @@ static int solve3_spd(const double H[9], const double b[3], double x[3]) {
  * tooling; a process-wide switch: set it before, not during, a batch call. */
 static int g_es_scheme = 0;
 void pnec_oracle_set_eigensolver_scheme(int scheme) { g_es_scheme = scheme; }
+/* RANSAC under scheme 0 with the rules of round 3 ("frozen"): every hypothesis is scored, whatever its minimisation did
+ * (opengv scores every model), and a hypothesis' minimisation may take the 50 iterations of any other.  OFF by default:
+ * the device's rule since round 4 -- a hypothesis still moving after 25 iterations yields no model -- is what the parity
+ * tests compare with; ON to measure what that rule changes (tools/verify_eigensolver_schemes.py). */
+static int g_ransac_frozen_rules = 0;
+void pnec_oracle_set_ransac_frozen_rules(int on) { g_ransac_frozen_rules = on; }
 int pnec_oracle_get_eigensolver_scheme(void) { return g_es_scheme; }
 static int g_es_info; /* scheme 2: Eigen's status of the calling thread's last minimisation (5 = maxfev reached) */
 static int g_es_nfev;
@@ -664,14 +670,15 @@ int pnec_oracle_ransac_eigensolver(int64_t n, const double *bvs1, const double *
     for (int c = 0; c < 3; ++c)
       v[c] = v0[c] + (pnec_oracle_rng_uniform(seed, pair_id, (uint64_t)it, 1000 + c) - 0.5) * 2.0 * 0.01;
     es_data D = {sample_size, s1, s2};
-    const int newton_its = eigensolver_cayley_tol(&D, v, ES_HYPOTHESIS_STEP_DONE, ES_HYPOTHESIS_MAX_ITERATIONS);
+    const int hyp_cap = g_ransac_frozen_rules ? ES_MAX_ITERATIONS : ES_HYPOTHESIS_MAX_ITERATIONS;
+    const int newton_its = eigensolver_cayley_tol(&D, v, ES_HYPOTHESIS_STEP_DONE, hyp_cap);
     pnec_oracle_cayley_to_rot(v, R);
     es_model_translation(sample_size, s1, s2, R, t);
     /* a minimisation that was cut off yields no model: the rule consumes the hypothesis with a count of zero (why: the
      * device's kHypothesisMaxIterations -- cut off, two floating-point realisations of the iteration stand at different
      * points of a walk that did not converge, and would score differently) */
     int count = 0;
-    const int cut_off = g_es_scheme == 0 && newton_its >= ES_HYPOTHESIS_MAX_ITERATIONS; /* (schemes 1, 2: every hypothesis
+    const int cut_off = !g_ransac_frozen_rules && g_es_scheme == 0 && newton_its >= hyp_cap; /* (schemes 1, 2: every hypothesis
                                                                                               is scored, as opengv does) */
     for (int64_t i = 0; i < n && !cut_off; ++i)
       count += pnec_oracle_reprojection_score(bvs1 + 3 * i, bvs2 + 3 * i, R, t) < threshold;

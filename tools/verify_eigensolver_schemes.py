@@ -100,7 +100,23 @@ for c in (0, 1, 2):
             "default_options_rotation_diff_rad_after_refinement": st(angles(r["q_df"], o["q"])),
             "no_ransac_clean_data_rotation_diff_rad": st(angles(r["q_plain"], plain)),
         }
+# the device's scheme 0 against the checker with the round-3 RANSAC rules (every hypothesis scored, 50 iterations): what
+# the 25-iteration rule for hypotheses (a cut-off minimisation yields no model) changes
 po.set_eigensolver_scheme(0)
+po.set_ransac_frozen_rules(True)
+o = po.solve_chain_batch(off, f1, f2, cv, g.init_q.cpu().numpy(), seed=1, num_threads=po.max_threads())
+po.set_ransac_frozen_rules(False)
+r = devr[0]
+same = (o["mask"].reshape(P, N) == r["m_vo"].reshape(P, N).astype(bool)).all(axis=1)
+a_vo = angles(r["q_vo"], o["es_q"])
+out["device_0_vs_checker_0_with_round3_ransac_rules"] = {
+    "rules": "every hypothesis scored, a hypothesis' minimisation may take 50 iterations (oracle: pnec_oracle_set_ransac_frozen_rules)",
+    "inlier_masks_identical": int(same.sum()),
+    "ransac_iteration_counts_identical": int((r["its"] == o["ransac_iterations"]).sum()),
+    "odometry_options_rotation_diff_rad": st(a_vo),
+    "odometry_options_rotation_diff_rad_pairs_with_identical_masks": st(a_vo[same]) if same.any() else None,
+    "default_options_rotation_diff_rad_after_refinement": st(angles(r["q_df"], o["q"])),
+}
 for d in (1, 2):
     out["device_vs_device"][f"device_{d}_vs_device_0"] = {
         "odometry_options_rotation_diff_rad": st(angles(devr[d]["q_vo"], devr[0]["q_vo"])),
