@@ -11,7 +11,7 @@ python tools/summarize_profile.py gpurun_out/prof_r05 profiles/r05_kernel.md "$N
 cp gpurun_out/prof_r05/stats/bench_kernel_stats.csv profiles/r05_kernel_rocprofv3_kernel_stats.csv
 python tools/summarize_pipeline_profile.py gpurun_out/prof_pipeline_r05 profiles/r05_full_pipeline_kernels.md $G/pipeline_scheme0.json $G/pipeline_100k.json $G/pipeline_pmc.txt "$NOTE"
 cp gpurun_out/prof_pipeline_r05/pipe_kernel_stats.csv profiles/r05_full_pipeline_rocprofv3_kernel_stats.csv
-for f in bench bench_kitti bench_kitti_chain pipeline_100k pipeline_kitti pipeline_parity_100k streaming odometry_options_parity \
+for f in bench bench_kitti bench_kitti_chain pipeline_100k pipeline_kitti pipeline_parity_100k streaming odometry_options_parity odometry_options_parity_30pct_mismatches \
          bench_single_process_1x bench_single_process_2x; do cp $G/$f.json profiles/r05_$f.json; done
 for s in 0 1 2; do cp $G/pipeline_scheme$s.json profiles/r05_pipeline_stages_scheme$s.json; done
 cp $G/bench_kitti_chain_1.json profiles/r05_bench_kitti_chain_one_at_a_time.json

@@ -26,6 +26,7 @@ python tools/bench_modes.py 100000 > $OUT/residual_families.jsonl 2> /dev/null
 python tools/verify_full_batch.py 100000 target > $OUT/full_batch_parity.jsonl 2> /dev/null
 python tools/verify_pipeline.py 100000 > $OUT/pipeline_parity_100k.json 2> $OUT/pipeline_parity_100k.err
 python tools/verify_eigensolver_schemes.py 2000 > $OUT/odometry_options_parity.json 2> /dev/null
+python tools/verify_eigensolver_schemes.py 2000 0.3 > $OUT/odometry_options_parity_30pct_mismatches.json 2> /dev/null
 python tools/bench_streaming.py > $OUT/streaming.json 2> /dev/null
 # 6. one PNEC::Solve per frame through the facade (default options / the odometry's / the timed overload)
 rm -f $OUT/solve_latency.jsonl

@@ -10,7 +10,7 @@ For 2 000 pairs x 512 correspondences with 10 % gross mismatches this prints, fo
   * default options: rotation difference after the refinement;
   * use_ransac_ = false on the same pairs WITHOUT the mismatches: rotation difference of the plain eigensolver.
 The diagonal d == c is the parity statement (device against its sequential twin); the off-diagonal entries say how far
-apart the three recollections are -- i.e. what is at stake in the choice.   python tools/verify_eigensolver_schemes.py [pairs]"""
+apart the three recollections are -- i.e. what is at stake in the choice.   python tools/verify_eigensolver_schemes.py [pairs] [share of mismatches]"""
 import json
 import os
 import sys
@@ -26,10 +26,11 @@ from pnec_amd import simulation as sim
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 N = 512
+OUTLIERS = float(sys.argv[2]) if len(sys.argv) > 2 else 0.10   # share of gross mismatches
 dev = torch.device("cuda:0")
 g = sim.generate(P, N, seed=1, device=dev)
 clean2 = g.bvs2.clone()
-bad = torch.rand(P, N, device=dev, generator=torch.Generator(device=dev).manual_seed(0)) < 0.10
+bad = torch.rand(P, N, device=dev, generator=torch.Generator(device=dev).manual_seed(0)) < OUTLIERS
 rnd = torch.randn(P, N, 3, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
 g.bvs2 = torch.where(bad[..., None], rnd / rnd.norm(dim=-1, keepdim=True), g.bvs2)
 NAMES = {0: "newton", 1: "descent [EXT]", 2: "lm, reduced Cayley [EXT]"}
@@ -76,7 +77,7 @@ f1, f2, cv = (x.cpu().numpy() for x in (g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1
 f2c = clean2.reshape(-1, 3).cpu().numpy()
 R0 = g.init_R.cpu().numpy()
 off = np.arange(P + 1, dtype=np.int64) * N
-out = {"pairs": P, "corr": N, "outliers": 0.10, "oracle_threads": po.max_threads(), "schemes": NAMES,
+out = {"pairs": P, "corr": N, "outliers": OUTLIERS, "oracle_threads": po.max_threads(), "schemes": NAMES,
        "what": __doc__.split("\n\n")[1].replace("\n", " "), "device_vs_checker": {}, "device_vs_device": {},
        "device_pairs_per_s_at_this_size": {str(d): {"odometry_options": devr[d]["vo_pairs_per_s"], "default_options": devr[d]["df_pairs_per_s"]}
                                            for d in devr}}
