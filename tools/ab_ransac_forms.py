@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """RANSAC-stage forms against each other on one box: the whole chain over a ragged batch (the shapes of
 tests/test_chain_scale_gpu.py's bitwise test) or a uniform one, with the form forced through PNEC_RANSAC_FORM
-(1 one pair per wavefront, 2 two pairs, 3 split at the eigenvalue minimisation; read once per process, so one
+(1 one pair per wavefront, 2 two pairs -- the split form, 3, was removed in round 5; read once per process, so one
 process per form).  Prints a digest of (q, t, mask, count) and the time per call.
    PNEC_RANSAC_FORM=3 python tools/ab_ransac_forms.py ragged 6001 | uniform 20000 [outlier_fraction]"""
 import hashlib
