@@ -50,7 +50,6 @@ hipError_t launch_frontend_selftest(double *, hipStream_t);
 // scratch of the front stages, per pair (pnec_frontend.hip FrontScratch)
 // (+ 3 kEsMaxRounds doubles and one int per pair: the weighted stage's chained minimisations under eigensolver schemes 1, 2;
 //  + two ints per pair: the list of the RANSAC stage's second launch and its length)
-constexpr int64_t kFrontDoublesPerPair = 43 + 3 * kEsMaxRounds, kFrontIntsPerPair = 5;
 }  // namespace pnec_hip
 
 using namespace pnec_hip;
@@ -976,8 +975,8 @@ int ensure_front(pnec_hip_problem *p) {
     p->d_front = nullptr;
     p->d_front_i = nullptr;
     p->front_pairs = 0;
-    PNEC_HIP_TRY(dev_alloc(&p->d_front, sizeof(double) * kFrontDoublesPerPair * P));
-    PNEC_HIP_TRY(dev_alloc(&p->d_front_i, sizeof(int32_t) * kFrontIntsPerPair * P));
+    PNEC_HIP_TRY(dev_alloc(&p->d_front, sizeof(double) * (size_t)kFrontDoublesPerPair * P));
+    PNEC_HIP_TRY(dev_alloc(&p->d_front_i, sizeof(int32_t) * ((size_t)kFrontIntsPerPair * P + kFrontCounterInts)));
     p->front_pairs = P;
   }
   return 0;

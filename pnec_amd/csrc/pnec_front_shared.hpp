@@ -7,4 +7,9 @@ constexpr int kEsMaxRounds = 15;
 // every allocation of a batch's planes carries this many doubles of slack behind them: the weighted stage loads its tables
 // in 128-correspondence sets (16-byte loads), and the last set of a pair may read 64 doubles past the pair's last plane
 constexpr int kDataSlackDoubles = 64;
+// the front stages' scratch of a batch of P pairs: doubles and ints per pair, plus a few ints of counters behind the ints
+// (front_scratch in pnec_frontend.hip lays them out, pnec_capi.hip allocates them)
+constexpr int kFrontDoublesPerPair = 43 + 3 * kEsMaxRounds;
+constexpr int kFrontIntsPerPair = 4;
+constexpr int kFrontCounterInts = 16;
 }  // namespace pnec_hip

@@ -1021,8 +1021,9 @@ struct FrontScratch {
   // takes, wo_count[0 / 1] = pairs placed from the front / from the back so far
   int32_t *wo_order, *wo_count;
 };
-// per pair: 36 + 3 + 1 + 3 + 3 kEsMaxRounds doubles and 5 ints (pnec_capi.hip sizes the buffers: kFrontDoublesPerPair /
-// kFrontIntsPerPair)
+// per pair kFrontDoublesPerPair = 36 + 3 + 1 + 3 + 3 kEsMaxRounds doubles and kFrontIntsPerPair ints, and kFrontCounterInts
+// ints of counters behind those (pnec_front_shared.hpp; pnec_capi.hip allocates them -- until round 5 the counters sat
+// in a fifth per-pair region, i.e. past the end of a one-pair batch's five ints)
 FrontScratch front_scratch(double *d, int32_t *i, int64_t P) {
   FrontScratch f;
   f.G = d;
@@ -1038,9 +1039,10 @@ FrontScratch front_scratch(double *d, int32_t *i, int64_t P) {
   f.st_best = d + 45 * P;
   f.st_model = d + 46 * P;   // .. 58 P (of the 45 P the v_rounds region has)
   f.st_list = i + 3 * P;
-  f.st_count = i + 4 * P;    // (one int; the region is sized 5 P)
+  int32_t *counters = i + (int64_t)kFrontIntsPerPair * P;
+  f.st_count = counters;     // (one int)
   f.wo_order = i + 3 * P;
-  f.wo_count = i + 4 * P;    // (two ints)
+  f.wo_count = counters + 2; // (two ints)
   return f;
 }
 
