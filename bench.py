@@ -153,7 +153,7 @@ def load_chain_counts(name, pairs, corr):
 
 def executed_passes(batch, q0, t0, opts, capi, **solve_kw):
     """How many correspondence-passes ONE launch of the refinement over `batch` executes, in full and cost-only: one extra,
-    untimed launch with the diagnostics flag set (pnec_hip_options.reserved bit 0 -> pnec_hip_work_counters[13], [14]).
+    untimed launch with the diagnostics flag set (PNEC_HIP_OPT_COUNT_PASSES in pnec_hip_options.flags -> pnec_hip_work_counters[13], [14]).
     The kernel skips the Jacobian of a candidate whose step it expects to be rejected and evaluates a solve's last
     candidate at the iteration cap cost-only, so the number of full passes is a property of the data; with the same
     inputs the counted launch executes exactly what the timed ones do."""
@@ -166,7 +166,7 @@ def executed_passes(batch, q0, t0, opts, capi, **solve_kw):
     torch.cuda.synchronize()
     capi.check(L.pnec_hip_work_counters(batch.device, 1, out.ctypes.data, C.byref(flag)))
     o2 = capi.Options.from_buffer_copy(bytes(opts))
-    o2.reserved = 1
+    o2.flags = 1
     batch.solve(q0, t0, options=o2, **solve_kw)
     torch.cuda.synchronize()
     capi.check(L.pnec_hip_work_counters(batch.device, 1, out.ctypes.data, C.byref(flag)))
@@ -630,7 +630,7 @@ def secondary_lines(device, capi, quick=False):
     from pnec_amd import simulation as sim
     from pnec_amd import tracks as tk
     out = []
-    cores = po.max_threads()
+    cores = po.usable_threads()   # (capped by the cgroup quota: 128 OpenMP threads on a 16-CPU quota run slower than 32)
 
     def guarded(fn):
         try:

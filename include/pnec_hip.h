@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define PNEC_HIP_ABI_VERSION 5
+#define PNEC_HIP_ABI_VERSION 6
 #define PNEC_HIP_MAX_RANSAC_SAMPLE 16 /* largest Options::ransac_sample_size_ the RANSAC kernel is built for */
 
 typedef enum pnec_hip_status {
@@ -90,9 +90,9 @@ typedef struct pnec_hip_options {
   int32_t corr_per_lane;                     /* 0 = auto; launch tuning: correspondences held per lane */
   int32_t waves_per_pair;                    /* 0 = auto; launch tuning: wavefronts cooperating on one solve */
   int32_t lds_corr_per_lane;                 /* launch tuning: how many of corr_per_lane live in LDS */
-  int32_t reserved;                          /* 0; bit 0 (diagnostics): add the correspondence-passes this call executes --
-                                                in full / cost-only -- to pnec_hip_work_counters()[13] / [14]; any other
-                                                bit set: PNEC_HIP_ERR_INVALID_ARGUMENT */
+  int32_t flags;                             /* 0; a set of PNEC_HIP_OPT_* bits (below); an undefined bit:
+                                                PNEC_HIP_ERR_INVALID_ARGUMENT.  (ABI <= 5 called this field `reserved`
+                                                and defined bit 0 only.) */
   double function_tolerance;                 /* 1e-6 */
   double gradient_tolerance;                 /* 1e-10 */
   double parameter_tolerance;                /* 1e-8 */
@@ -103,6 +103,21 @@ typedef struct pnec_hip_options {
   double min_lm_diagonal;                    /* 1e-6 */
   double max_lm_diagonal;                    /* 1e32 */
 } pnec_hip_options;
+
+/* pnec_hip_options.flags */
+#define PNEC_HIP_OPT_COUNT_PASSES 1 /* diagnostics: add the correspondence-passes this call executes -- in full /
+                                        cost-only -- to pnec_hip_work_counters()[13] / [14] */
+#define PNEC_HIP_OPT_JACOBIAN_NUMERIC_CENTRAL 2
+/* VERIFICATION mode (ABI 6): differentiate the way the reference does -- ceres::NumericDiffCostFunction<Functor, CENTRAL,
+ * 1, 1, 1, 4> (src/optimization/pnec_ceres.cc:84-97; nec_ceres.cc:82-93): per AMBIENT parameter x_j of (theta, phi, qx, qy,
+ * qz, qw) the residual at x_j +- h, h = max(sqrt(eps), 1e-6 |x_j|), J_j = (r+ - r-) / (2 h), the quaternion perturbed
+ * component-wise WITHOUT renormalisation (toRotationMatrix of a non-unit quaternion), then the 1x4 block through
+ * EigenQuaternionManifold::PlusJacobian (4x3) [EXT] -- instead of the closed-form Jacobian.  Thirteen residual evaluations
+ * per correspondence and pass, streamed from HBM (no on-chip residency, one 8-wavefront block per solve): ~20x slower
+ * than the production kernel, and not meant to be anything else.  It exists so that the device can follow the reference's
+ * TRAJECTORY on solves that are not converged when they stop (fixed iteration counts from far-off starts), where the
+ * rounding of the difference quotient -- not the derivative -- decides the last digits of every step.  pnec_hip_solve
+ * only (the streaming handle returns PNEC_HIP_ERR_UNSUPPORTED). */
 
 typedef struct pnec_hip_problem pnec_hip_problem; /* opaque: a batch of pairs resident in HBM */
 
@@ -150,7 +165,10 @@ int pnec_hip_problem_reshape(pnec_hip_problem *p, int64_t n_pairs, const int64_t
  * 3 doubles, covs 9 doubles column-major per correspondence), pointing at the first
  * correspondence of `first_pair`.  `covs` is the single array of Optimize(bvs1,bvs2,covs,..)
  * [frame 2 for TARGET, frame 1 for HOST] or covs_2 of the symmetric overload; `covs_host` is
- * covs_1 of the symmetric overload (NULL otherwise).  space = where those arrays live. */
+ * covs_1 of the symmetric overload (NULL otherwise).  space = where those arrays live.
+ * HOST space stages the arrays in HBM first (15 / 24 doubles per correspondence on top of the 12 / 18 of the planes): a
+ * capacity-shaped batch keeps that staging between calls while it is <= 256 MB (per-frame handles: nothing allocated per
+ * call); larger stagings are borrowed from the library's buffer cache for the call (pnec_hip_release_cache frees it). */
 int pnec_hip_problem_fill(pnec_hip_problem *p, int64_t first_pair, int64_t n_pairs,
                           const double *bvs1, const double *bvs2, const double *covs,
                           const double *covs_host, int space, void *stream);
@@ -186,7 +204,10 @@ int pnec_hip_problem_mode(const pnec_hip_problem *p);
 int pnec_hip_problem_device(const pnec_hip_problem *p);
 /* The scheme the STAGE calls on this batch use (pnec_hip_nec_eigensolver, pnec_hip_ransac_eigensolver,
  * pnec_hip_weighted_eigensolver; default NEWTON).  pnec_hip_solve_pipeline takes its own from the options.  Under
- * DESCENT / LM weighted_iterations is limited to 16. */
+ * DESCENT weighted_iterations is limited to 16 (a minimiser is kept per round; more: PNEC_HIP_ERR_UNSUPPORTED).  NEWTON
+ * and LM run a further minimisation only while the previous one stopped at its evaluation cap (the weights never change
+ * from round to round, pnec.cc:297-300), at most 15 of them per pair: a pair still at the cap then keeps that rotation
+ * for the remaining rounds.  A batch handed out by pnec_hip_problem_select_view follows its source's scheme. */
 int pnec_hip_problem_set_eigensolver_scheme(pnec_hip_problem *p, int32_t scheme);
 int pnec_hip_problem_eigensolver_scheme(const pnec_hip_problem *p);
 
@@ -443,7 +464,7 @@ int pnec_hip_selftest(int device);
  * (tools/count_chain_work.py builds and runs one); the production build compiles the counting out and reports
  * *compiled_in = 0 and zeros.  Entries [13] and [14] work in every build: the correspondence-passes the refinement
  * executed in full (residual, weight, Jacobian, normal equations) and cost-only (after a rejected step and at the iteration
- * cap) in the pnec_hip_solve calls made with pnec_hip_options.reserved bit 0 set.  Waits for the device. */
+ * cap) in the pnec_hip_solve calls made with PNEC_HIP_OPT_COUNT_PASSES in pnec_hip_options.flags.  Waits for the device. */
 int pnec_hip_work_counters(int device, int reset, uint64_t *out16, int32_t *compiled_in);
 
 /* The library keeps freed device buffers for reuse (batches are created and destroyed per frame or per

@@ -393,6 +393,9 @@ static void quat_plus_jacobian(const double q[4], double P[12]) {
   P[9] = -q[0]; P[10] = -q[1]; P[11] = -q[2];
 }
 
+static double g_numeric_step_scale = 1.0;
+void pnec_oracle_set_numeric_step_scale(double s) { g_numeric_step_scale = s > 0.0 ? s : 1.0; }
+
 /* NumericDiffCostFunction<..., CENTRAL, 1, 1, 1, 4> [EXT]: per ambient parameter
  * h = max(sqrt(eps), 1e-6 |x_j|), J_j = (f(x + h e_j) - f(x - h e_j)) / (2h); the quaternion is
  * perturbed component-wise with no renormalisation; the manifold's plus-Jacobian then maps
@@ -400,8 +403,10 @@ static void quat_plus_jacobian(const double q[4], double P[12]) {
 static void numeric_row(int mode, const double f1[3], const double f2[3], const double *cov2,
                         const double *cov1, double reg, double theta, double phi,
                         const double q[4], const double P[12], double *r, double J[5]) {
-  const double kMinStep = 1.4901161193847656e-08; /* sqrt(DBL_EPSILON) */
-  const double kRel = 1e-6;
+  /* g_numeric_step_scale (1.0; test tooling): the same derivative through a slightly different step -- what the result
+   * owes to the ROUNDING of the difference quotient rather than to the derivative it approximates */
+  const double kMinStep = 1.4901161193847656e-08 * g_numeric_step_scale; /* sqrt(DBL_EPSILON) */
+  const double kRel = 1e-6 * g_numeric_step_scale;
   *r = pnec_oracle_residual(mode, f1, f2, cov2, cov1, reg, theta, phi, q);
   {
     const double h = fmax(kMinStep, fabs(theta) * kRel);
@@ -662,7 +667,12 @@ static int chol_solve5(const double A[25], const double b[5], double y[5]) {
 /* diagnostics (test tooling): how many LM steps reached the accept / reject decision, and how many were rejected */
 static int g_lm_diagnostics = 0; /* pnec_oracle_lm_diagnostics(1) switches the counters below on */
 void pnec_oracle_lm_diagnostics(int on) { g_lm_diagnostics = on; }
-static long long g_lm_steps_evaluated = 0, g_lm_steps_rejected = 0;
+static long long g_lm_steps_evaluated = 0, g_lm_steps_rejected = 0, g_lm_invalid_steps = 0;
+long long pnec_oracle_lm_invalid_steps(int reset) {
+  const long long v = g_lm_invalid_steps;
+  if (reset) g_lm_invalid_steps = 0;
+  return v;
+}
 static long long g_lm_promise[2][24][2]; /* [after accepted-or-first | after rejected][decade of model_change / cost, -24 .. -1][accepted | rejected] */
 void pnec_oracle_lm_promise_histogram(long long out[96]) { memcpy(out, g_lm_promise, sizeof(g_lm_promise)); memset(g_lm_promise, 0, sizeof(g_lm_promise)); }
 static long long g_lm_transitions[3][2]; /* [first step | after an accepted step | after a rejected step][accepted | rejected] */
@@ -703,6 +713,11 @@ static int minimise(const problem_t *P, const pnec_oracle_options *o, state_t *x
   RESCALE();
   double x_norm = state_norm(x);
   double radius = o->initial_trust_region_radius, decrease_factor = 2.0;
+  /* step_is_successful = 1 at iteration zero [EXT, recalled]: TrustRegionMinimizer::IterationZero() ends with
+   * iteration_summary_.step_is_valid = iteration_summary_.step_is_successful = true, so the first
+   * FinalizeIterationAndCheckIfMinimizerCanContinue() tests the gradient tolerance at the START point -- Ceres 1.x made
+   * that test explicitly in front of its loop, and a solve started at a stationary point still reports
+   * "Gradient tolerance reached" after iteration 0 alone. */
   int reuse_diagonal = 0, num_invalid = 0, step_is_successful = 1;
   int term;
   int prev_outcome = 0; /* diagnostics: 0 first step, 1 after an accepted, 2 after a rejected one */
@@ -741,9 +756,14 @@ static int minimise(const problem_t *P, const pnec_oracle_options *o, state_t *x
       if (++num_invalid >= o->max_num_consecutive_invalid_steps) {
         term = PNEC_ORACLE_TERM_INVALID_STEPS; break;
       }
-      radius /= decrease_factor;
-      decrease_factor *= 2.0;
+      /* [EXT, recalled] TrustRegionMinimizer::HandleInvalidStep -> LevenbergMarquardtStrategy::StepIsInvalid():
+       * radius_ *= 0.5; reuse_diagonal_ = true; -- decrease_factor_ belongs to StepRejected() alone */
+      radius *= 0.5;
       reuse_diagonal = 1;
+      if (g_lm_diagnostics) {
+#pragma omp atomic
+        g_lm_invalid_steps += 1;
+      }
       continue;
     }
     num_invalid = 0;

@@ -104,6 +104,13 @@ double pnec_oracle_cost_function(int64_t n, const double *bvs1, const double *bv
 /* diagnostics: LM steps that reached Ceres' accept / reject decision since the last reset, how many were rejected, and
  * the outcome by predecessor: out[2 + 2 a + b], a = first step | after an accepted | after a rejected, b = accepted | rejected */
 void pnec_oracle_lm_step_counts(int reset, long long out[8]);
+/* ... and the steps that were INVALID (linear solve failed / model change <= 0: HandleInvalidStep) */
+long long pnec_oracle_lm_invalid_steps(int reset);
+/* Test tooling: multiply the central-difference step h = max(sqrt(eps), 1e-6 |x|) by `s` (default 1).  The derivative the
+ * quotient approximates does not change (truncation error ~ h^2 f''' ~ 1e-16); its rounding error (~ eps |r| / h ~ 1e-8
+ * relative) does.  Two runs that differ only in s show how far a solve's END POINT depends on that rounding -- i.e. on
+ * the compiler, libm and FMA contraction of whoever builds the reference -- and not on the mathematics. */
+void pnec_oracle_set_numeric_step_scale(double s);
 /* ... counted only while switched on (off by default: the timed CPU baseline carries no test tooling) */
 void pnec_oracle_lm_diagnostics(int on);
 /* pnec::common::RotationBetweenPoints (common.cc:118-124) for unit vectors; out column-major */

@@ -131,6 +131,10 @@ def lib() -> C.CDLL:
                                                  C.POINTER(Options), C.c_int, _dp, _dp, _dp, _ip,
                                                  _ip]
         _lib.pnec_oracle_max_threads.restype = C.c_int
+        _lib.pnec_oracle_lm_invalid_steps.argtypes = [C.c_int]
+        _lib.pnec_oracle_lm_invalid_steps.restype = C.c_longlong
+        _lib.pnec_oracle_lm_diagnostics.argtypes = [C.c_int]
+        _lib.pnec_oracle_set_numeric_step_scale.argtypes = [C.c_double]
         _lib.pnec_oracle_rotation_between_points.argtypes = [_dp, _dp, _dp]
         _lib.pnec_oracle_rotation_between_points.restype = None
         _lib.pnec_oracle_unscented_transform.argtypes = [_dp, _dp, _dp, C.c_double, C.c_int, _dp]
@@ -470,7 +474,7 @@ def solve_chain_batch(offsets, bvs1, bvs2, covs, init_q, seed=1, first_pair_id=0
     ip = lambda a: a.ctypes.data_as(_ip)
     lib().pnec_oracle_solve_chain_batch(P, off.ctypes.data_as(_lp), b1p, b2p, cp, q0p, seed, first_pair_id,
                                         max_ransac_iterations, sample_size, threshold, reg, weighted_iterations,
-                                        num_threads or max_threads(), dp(es_q), dp(es_t),
+                                        num_threads or usable_threads(), dp(es_q), dp(es_t),
                                         mask.ctypes.data_as(C.POINTER(C.c_uint8)), ip(cnt), ip(rit), dp(w_q), dp(w_t),
                                         dp(q), dp(t), ip(lit), ip(lst))
     return dict(es_q=es_q, es_t=es_t, mask=mask[:M].astype(bool), inlier_count=cnt, ransac_iterations=rit, w_q=w_q,
@@ -617,6 +621,39 @@ def solve_batch(mode, offsets, bvs1, bvs2, covs2_9, covs1_9, reg, init_q, init_t
 
 def max_threads() -> int:
     return lib().pnec_oracle_max_threads()
+
+
+def usable_threads() -> int:
+    """Threads worth starting: the OpenMP maximum capped by the affinity mask and by TWICE the cgroup CPU quota (the GPU
+    boxes show 256 logical CPUs, an OpenMP maximum of 128 and a quota of 16 CPUs: bench.py's scaling table there reads
+    8 / 16 / 32 / 64 / 128 threads -> best at 32, 128 threads at less than half of that)."""
+    n = max_threads()
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, 2 * int(round(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def lm_invalid_steps(reset: bool = True) -> int:
+    """Invalid LM steps (Ceres' HandleInvalidStep branch) counted since the last reset; lm_diagnostics(True) first."""
+    return int(lib().pnec_oracle_lm_invalid_steps(1 if reset else 0))
+
+
+def lm_diagnostics(on: bool) -> None:
+    lib().pnec_oracle_lm_diagnostics(1 if on else 0)
+
+
+def set_numeric_step_scale(s: float) -> None:
+    """Scale the central-difference step of the numeric Jacobian (1.0 = the reference's); see pnec_oracle.h."""
+    lib().pnec_oracle_set_numeric_step_scale(float(s))
 
 
 # --------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PNEC_HIP_LIB: load an alternative build of the same ABI (kernel A/B experiments only)
 LIB_PATH = os.environ.get("PNEC_HIP_LIB") or os.path.join(_HERE, "libpnec_hip.so")
 
-ABI_VERSION = 5  # PNEC_HIP_ABI_VERSION of include/pnec_hip.h this binding was written against
+ABI_VERSION = 6  # PNEC_HIP_ABI_VERSION of include/pnec_hip.h this binding was written against
 MODE_NEC, MODE_TARGET, MODE_HOST, MODE_SYM = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 # pnec_hip_eigensolver_scheme: which iteration stands in for opengv's eigenvalue minimisation (include/pnec_hip.h)
@@ -94,6 +94,10 @@ SYMBOLS = [
 ]
 
 
+OPT_COUNT_PASSES = 1               # pnec_hip_options.flags: PNEC_HIP_OPT_COUNT_PASSES
+OPT_JACOBIAN_NUMERIC_CENTRAL = 2   # ... PNEC_HIP_OPT_JACOBIAN_NUMERIC_CENTRAL (verification mode)
+
+
 class Options(C.Structure):
     """``pnec_hip_options``: the ceres::Solver::Options subset + launch tuning."""
 
@@ -105,7 +109,7 @@ class Options(C.Structure):
         ("corr_per_lane", C.c_int32),
         ("waves_per_pair", C.c_int32),
         ("lds_corr_per_lane", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
         ("function_tolerance", C.c_double),
         ("gradient_tolerance", C.c_double),
         ("parameter_tolerance", C.c_double),

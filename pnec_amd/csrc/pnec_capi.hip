@@ -1018,7 +1018,7 @@ void pnec_hip_default_options(pnec_hip_options *o) {
   o->corr_per_lane = 0;
   o->waves_per_pair = 0;
   o->lds_corr_per_lane = 0;
-  o->reserved = 0;
+  o->flags = 0;
   o->function_tolerance = 1e-6;
   o->gradient_tolerance = 1e-10;
   o->parameter_tolerance = 1e-8;
@@ -1282,7 +1282,10 @@ int pnec_hip_problem_fill(pnec_hip_problem *p, int64_t first_pair, int64_t n_pai
   bool persistent_stage = false;
   if (space == PNEC_HIP_MEM_HOST && m > 0) {
     const int64_t per = 6 + (p->nc >= 12 ? 9 : 0) + (p->nc >= 18 ? 9 : 0);
-    if (p->cap_pairs > 0) {   // a batch that is re-filled: its staging stays (nothing allocated per call)
+    // a batch that is re-filled keeps its staging (nothing allocated per call: the per-frame and streaming handles) --
+    // up to 256 MB; beyond that the staging is ~1.25 x the payload (6 GB for 100k x 512) and is borrowed from the
+    // library's buffer cache per call instead, so that it is shared by every batch on the device, not held by each
+    if (p->cap_pairs > 0 && per * m * (int64_t)sizeof(double) <= (256ll << 20)) {
       if (per * m > p->fill_doubles) {
         if (p->d_fill) (void)dev_free(p->d_fill);
         p->d_fill = nullptr;
@@ -1497,7 +1500,14 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
   else
     pnec_hip_default_options(&opt);
   if (opt.max_num_iterations < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "max_num_iterations < 0");
-  if (opt.reserved & ~1) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "pnec_hip_options.reserved: only bit 0 is defined");
+  if (opt.flags & ~(PNEC_HIP_OPT_COUNT_PASSES | PNEC_HIP_OPT_JACOBIAN_NUMERIC_CENTRAL))
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "pnec_hip_options.flags: undefined bit set");
+  const bool numeric = (opt.flags & PNEC_HIP_OPT_JACOBIAN_NUMERIC_CENTRAL) != 0;
+  if (numeric) {   // verification mode: the streaming form, whatever the tuning fields say
+    opt.corr_per_lane = 0;
+    opt.waves_per_pair = kStreamWaves;
+    opt.lds_corr_per_lane = 0;
+  }
   const int64_t S = p->n_pairs * (int64_t)n_hyp;
   if (S == 0) return 0;
   if (S > 0x7fffffffLL) return fail(PNEC_HIP_ERR_UNSUPPORTED, "more than 2^31-1 solves in one call");
@@ -1516,7 +1526,8 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
   a.reg = reg;
   a.opt = opt;
   finish_args(a);
-  if (opt.reserved & 1) {   // diagnostics: count the passes this call executes (pnec_hip_work_counters)
+  a.numeric_jacobian = numeric ? 1 : 0;
+  if (opt.flags & PNEC_HIP_OPT_COUNT_PASSES) {   // diagnostics: count the passes this call executes (pnec_hip_work_counters)
     if (int rc = solve_work_buffer(p->device, &a.work)) return rc;
   }
 
@@ -1753,6 +1764,7 @@ int pnec_hip_problem_set_eigensolver_scheme(pnec_hip_problem *p, int32_t scheme)
   if (scheme < PNEC_HIP_ES_NEWTON || scheme > PNEC_HIP_ES_LM)
     return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "eigensolver scheme: 0 (Newton), 1 (descent) or 2 (LM)");
   p->es_scheme = scheme;
+  if (p->sel_view) p->sel_view->es_scheme = scheme;   // a view handed out earlier follows its source
   return 0;
 }
 int pnec_hip_problem_eigensolver_scheme(const pnec_hip_problem *p) { return p ? p->es_scheme : 0; }
@@ -1766,8 +1778,10 @@ int pnec_hip_weighted_eigensolver(pnec_hip_problem *p, const double *init_q, con
                                   double reg, int32_t weighted_iterations, double *out_q, double *out_t,
                                   int space, void *stream) {
   if (weighted_iterations < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "weighted_iterations < 0");
-  if (p && p->es_scheme != PNEC_HIP_ES_NEWTON && weighted_iterations - 1 > kEsMaxRounds)
-    return fail(PNEC_HIP_ERR_UNSUPPORTED, "eigensolver schemes 1 and 2 hold at most 16 weighted_iterations");
+  // DESCENT moves the rotation in every round and keeps a minimiser per round (kEsMaxRounds of them); NEWTON and LM
+  // chain calls only while one ends at its evaluation cap, and freeze a pair's rotation after kEsMaxRounds such calls
+  if (p && p->es_scheme == PNEC_HIP_ES_DESCENT && weighted_iterations - 1 > kEsMaxRounds)
+    return fail(PNEC_HIP_ERR_UNSUPPORTED, "eigensolver scheme 1 (descent) holds at most 16 weighted_iterations");
   return run_front_stage(p, true, init_q, init_t, reg, weighted_iterations, out_q, out_t, space, stream);
 }
 
@@ -1996,7 +2010,7 @@ int pnec_hip_problem_select(pnec_hip_problem *src, const uint8_t *mask, int spac
   return 0;
 }
 
-// the refinement's pass counters (pnec_hip_options.reserved bit 0): two 64-bit sums per device, allocated on first use
+// the refinement's pass counters (PNEC_HIP_OPT_COUNT_PASSES): two 64-bit sums per device, allocated on first use
 static unsigned long long *g_solve_work[64] = {nullptr};
 static int solve_work_buffer(int device, unsigned long long **out) {
   if (device < 0 || device >= 64) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "device index out of range");
@@ -2021,7 +2035,7 @@ int pnec_hip_work_counters(int device, int reset, uint64_t *out16, int32_t *comp
   for (int i = 0; i < 16; ++i) out16[i] = (uint64_t)c[i];
   if (compiled_in) *compiled_in = in;
   // [13], [14]: correspondence-passes the refinement executed in full / cost-only, for calls made with
-  // pnec_hip_options.reserved bit 0 set (any build)
+  // PNEC_HIP_OPT_COUNT_PASSES set (any build)
   if (device >= 0 && device < 64 && g_solve_work[device]) {
     unsigned long long w[2] = {0, 0};
     PNEC_HIP_TRY(hipDeviceSynchronize());
@@ -2064,6 +2078,8 @@ int pnec_hip_problem_select_view(pnec_hip_problem *src, const uint8_t *mask, int
     d_mask = src->d_mask;
   }
   if (int rc = select_into(src, d_mask, stream, src->sel_view)) return rc;
+  // the view runs the stages the way its source would NOW (the scheme may have been changed since the view was made)
+  src->sel_view->es_scheme = src->es_scheme;
   if (space == PNEC_HIP_MEM_HOST) PNEC_HIP_TRY(hipStreamSynchronize(stream));  // (the caller may reuse `mask`)
   *out = src->sel_view;
   return 0;

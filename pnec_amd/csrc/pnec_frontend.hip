@@ -3421,7 +3421,7 @@ hipError_t launch_weighted_eigensolver(int device, const double *data, const int
       (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), zeros, sizeof(zeros), 12 * sizeof(unsigned long long));
     }
 #endif
-    const int rounds = std::min(weighted_iterations - 1, kEsMaxRounds);  // (the ABI refuses more under schemes 1, 2)
+    const int rounds = std::min(weighted_iterations - 1, kEsMaxRounds);  // (the ABI refuses more under scheme 1; 0 and 2 freeze a pair still at its cap)
     if (scheme == 1)
       hipLaunchKernelGGL((es_batch_alt_kernel<kEpiNone, 1>), dim3(es_batch_blocks(n_pairs)), dim3(kWave), 0, stream, b, rounds);
     else if (scheme == 2)

@@ -171,7 +171,7 @@ int pnec_hip_multi_fill(pnec_hip_multi *m, int64_t n_pairs, const int64_t *offse
   if (int rc = pnec_hip_partition(n_pairs, offsets, n, m->bounds.data())) return rc;
   m->n_pairs = n_pairs;
   for (int32_t r = 0; r <= n; ++r) m->corr0[(size_t)r] = offsets[m->bounds[(size_t)r]];
-  return multi_run(m, [&](size_t d) -> int {
+  const int rc = multi_run(m, [&](size_t d) -> int {
     const int64_t a = m->bounds[d], cnt = m->bounds[d + 1] - a, c0 = m->corr0[d];
     std::vector<int64_t> off((size_t)cnt + 1);
     for (int64_t p = 0; p <= cnt; ++p) off[(size_t)p] = offsets[a + p] - c0;
@@ -180,6 +180,20 @@ int pnec_hip_multi_fill(pnec_hip_multi *m, int64_t n_pairs, const int64_t *offse
     return pnec_hip_problem_fill(m->probs[d], 0, cnt, bvs1 + 3 * c0, bvs2 + 3 * c0, covs ? covs + 9 * c0 : nullptr,
                                  covs_host ? covs_host + 9 * c0 : nullptr, PNEC_HIP_MEM_HOST, m->streams[d]);
   }, "pnec_hip_multi_fill");
+  if (rc) {
+    // a shard that could not be shaped or filled (e.g. a pair beyond max_pair_corr outgrew its device's batch) leaves
+    // the others with the NEW partition: the handle would index the caller's arrays with bounds its shards do not have.
+    // Empty it instead -- every shard zero pairs, bounds zero -- so that a solve after a failed fill is a no-op.
+    const std::string msg = g_last_error;
+    const int64_t none[1] = {0};
+    for (size_t d = 0; d < m->probs.size(); ++d)
+      if (m->probs[d]) (void)pnec_hip_problem_reshape(m->probs[d], 0, none, m->streams[d]);
+    std::fill(m->bounds.begin(), m->bounds.end(), 0);
+    std::fill(m->corr0.begin(), m->corr0.end(), 0);
+    m->n_pairs = 0;
+    return fail(rc, msg);
+  }
+  return 0;
 }
 
 int pnec_hip_multi_solve(pnec_hip_multi *m, const double *init_q, const double *init_t, int32_t n_hyp, const double *hyp_t,

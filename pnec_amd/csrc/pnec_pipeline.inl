@@ -226,8 +226,8 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
   if (o.weighted_iterations < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "weighted_iterations < 0");
   if (o.eigensolver_scheme < PNEC_HIP_ES_NEWTON || o.eigensolver_scheme > PNEC_HIP_ES_LM)
     return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "eigensolver_scheme: 0 (Newton), 1 (descent) or 2 (LM)");
-  if (o.eigensolver_scheme != PNEC_HIP_ES_NEWTON && !o.use_nec && o.weighted_iterations - 1 > kEsMaxRounds)
-    return fail(PNEC_HIP_ERR_UNSUPPORTED, "eigensolver schemes 1 and 2 hold at most 16 weighted_iterations");
+  if (o.eigensolver_scheme == PNEC_HIP_ES_DESCENT && !o.use_nec && o.weighted_iterations - 1 > kEsMaxRounds)
+    return fail(PNEC_HIP_ERR_UNSUPPORTED, "eigensolver scheme 1 (descent) holds at most 16 weighted_iterations");
   if (!o.use_nec && p->mode != PNEC_HIP_MODE_TARGET)
     return fail(PNEC_HIP_ERR_UNSUPPORTED, "the PNEC chain needs a TARGET-mode problem (bearings + frame-2 covariances)");
   if (o.use_ransac && (o.max_ransac_iterations < 0 || o.ransac_sample_size < 1))

@@ -70,10 +70,10 @@ struct SolveArgs {
   int32_t *out_iterations;      // [n_solves] or null
   int32_t *out_status;          // [n_solves] or null
   unsigned long long *trace;    // null, or [n_blocks,4]: s_memtime at start / payload on chip / end, hw id
-  unsigned long long *work;     // null, or [2]: correspondence-passes executed in full / cost-only (pnec_hip_options.reserved bit 0)
+  unsigned long long *work;     // null, or [2]: correspondence-passes executed in full / cost-only (PNEC_HIP_OPT_COUNT_PASSES)
   int64_t n_solves;
   int32_t n_hyp;
-  int32_t pad_;
+  int32_t numeric_jacobian;     // PNEC_HIP_OPT_JACOBIAN_NUMERIC_CENTRAL (verification; streaming form only)
   // SRC_AOS (streaming handle, pnec_stream.hip): the pairs are read straight from the caller's arrays in
   // the REFERENCE layout (bvs 3 doubles, covs 9 doubles column-major per correspondence) -- pinned host
   // memory mapped into the device, so one launch ingests, solves and reports without a staging copy
@@ -638,8 +638,9 @@ __device__ __forceinline__ int lm_advance(double *slab, int *ist, double *unif, 
       valid = valid && (model_change > 0.0);
       if (!valid) {
         if (++num_invalid >= o.max_num_consecutive_invalid_steps) { term = PNEC_HIP_TERM_INVALID_STEPS; break; }
-        inv_radius = inv_radius * dec;
-        dec = 2.0 * dec;
+        // [EXT, recalled] TrustRegionMinimizer::HandleInvalidStep -> LevenbergMarquardtStrategy::StepIsInvalid():
+        // radius *= 0.5, reuse_diagonal = true -- NOT the rejected-step rule: decrease_factor stays as it is
+        inv_radius = 2.0 * inv_radius;
         reuse_diagonal = 1;
         continue;
       }
@@ -918,8 +919,9 @@ __device__ __forceinline__ int lm_advance_rows(double *slab, int *ist, double *u
       valid = valid && (model_change > 0.0);
       if (!valid) {
         if (++num_invalid >= o.max_num_consecutive_invalid_steps) { term = PNEC_HIP_TERM_INVALID_STEPS; break; }
-        inv_radius = inv_radius * dec;
-        dec = 2.0 * dec;
+        // [EXT, recalled] TrustRegionMinimizer::HandleInvalidStep -> LevenbergMarquardtStrategy::StepIsInvalid():
+        // radius *= 0.5, reuse_diagonal = true -- NOT the rejected-step rule: decrease_factor stays as it is
+        inv_radius = 2.0 * inv_radius;
         reuse_diagonal = 1;
         continue;
       }
@@ -978,6 +980,64 @@ __device__ __forceinline__ int lm_advance_rows(double *slab, int *ist, double *u
     ist[kIStepOk] = step_ok;
   }
   return term;
+}
+
+// ---- PNEC_HIP_OPT_JACOBIAN_NUMERIC_CENTRAL: the reference's own differentiation, for verification --------------------
+// ceres::NumericDiffCostFunction<Functor, CENTRAL, 1, 1, 1, 4> (pnec_ceres.cc:84-97) [EXT, SURVEY Appendix B]: per ambient
+// parameter x_j of (theta, phi, qx, qy, qz, qw): h = max(sqrt(eps), 1e-6 |x_j|), J_j = (r(x + h e_j) - r(x - h e_j)) / 2h;
+// the quaternion's components are perturbed one by one WITHOUT renormalisation (the functor's toRotationMatrix is
+// Eigen's un-normalised formula, rot_from_quat), and EigenQuaternionManifold::PlusJacobian (4x3) maps the 1x4 block to
+// the tangent space.  Twelve perturbed poses per pass: lane j < 12 of the first wavefront makes pose j = 2 * parameter +
+// (0: plus, 1: minus) and leaves its R | t (12 doubles) and 1 / (2 h) in LDS; every lane then evaluates its
+// correspondences' residual at the centre and at the twelve poses.
+constexpr int kNumPoses = 12;
+__device__ __forceinline__ void numeric_poses(const double *slab, int lane, double (*nu)[12], double *inv2h) {
+  if (lane < kNumPoses) {
+    const int prm = lane >> 1;
+    double x[6] = {slab[kThetaC], slab[kPhiC], slab[kQc + 0], slab[kQc + 1], slab[kQc + 2], slab[kQc + 3]};
+    const double xv = prm == 0 ? x[0] : (prm == 1 ? x[1] : (prm == 2 ? x[2] : (prm == 3 ? x[3] : (prm == 4 ? x[4] : x[5]))));
+    const double h = fmax(1.4901161193847656e-08, fabs(xv) * 1e-6);
+    const double xp = (lane & 1) ? xv - h : xv + h;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = (k == prm) ? xp : x[k];
+    double u[kUnif];
+    const double q[4] = {x[2], x[3], x[4], x[5]};
+    pose_uniforms(x[0], x[1], q, u);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) nu[lane][i] = u[i];
+    if ((lane & 1) == 0) inv2h[prm] = 1.0 / h / 2.0;
+  }
+}
+template <int MODE>
+__device__ __forceinline__ void eval_corr_numeric(const double (&e)[num_components(MODE)], const PassUniforms &U,
+                                                  const double (*nu)[12], const double *inv2h, const double *qc,
+                                                  double reg, double &r, double (&J)[5]) {
+  double kk;
+  eval_cost<MODE>(e, U, reg, r, kk);
+  double Ja[6];
+#pragma unroll 1
+  for (int prm = 0; prm < 6; ++prm) {
+    double rr[2];
+#pragma unroll
+    for (int sgn = 0; sgn < 2; ++sgn) {
+      PassUniforms V;
+      const double *u = nu[2 * prm + sgn];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) V.R[i] = u[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) V.t[i] = u[9 + i];
+      eval_cost<MODE>(e, V, reg, rr[sgn], kk);
+    }
+    Ja[prm] = (rr[0] - rr[1]) * inv2h[prm];
+  }
+  J[0] = Ja[0];
+  J[1] = Ja[1];
+  // PlusJacobian of q (xyzw) [EXT]: rows x, y, z, w; columns delta_xyz.  The pass's rotation columns are for
+  // R <- Exp(omega) R, omega = 2 delta: half the manifold's (lm_advance doubles them back).
+  const double qx = qc[0], qy = qc[1], qz = qc[2], qw = qc[3];
+  J[2] = 0.5 * (Ja[2] * qw + Ja[3] * -qz + Ja[4] * qy + Ja[5] * -qx);
+  J[3] = 0.5 * (Ja[2] * qz + Ja[3] * qw + Ja[4] * -qx + Ja[5] * -qy);
+  J[4] = 0.5 * (Ja[2] * -qy + Ja[3] * qx + Ja[4] * qw + Ja[5] * -qz);
 }
 
 // region markers for tools/isa_mix.py --regions (assembly comments; compiled in only on request)
@@ -1047,6 +1107,8 @@ __global__ __launch_bounds__(kWave *(SRC == SRC_DUAL ? 2 : WPP), (CPL == 8 && LD
   __shared__ int gidx_all[1][16 * kGatherInts];  // lm_advance_rows: each lane's row of the tables of sums
 #endif
   [[maybe_unused]] __shared__ double xw[2][WPP > 1 ? WPP : 1][kSumSlots];
+  [[maybe_unused]] __shared__ double nunif[RESIDENT ? 1 : kNumPoses][12];   // numeric Jacobian: R | t of the perturbed poses
+  [[maybe_unused]] __shared__ double ninv2h[8];
   [[maybe_unused]] __shared__ double ldata[LDSK > 0 ? NW : 1][LDSK > 0 ? LDSK : 1][NC][LDSK > 0 ? kWave : 1];
   double *slab = slab_all[WPP > 1 ? 0 : wave];
   double *unif = unif_all[WPP > 1 ? 0 : wave];
@@ -1206,12 +1268,19 @@ __global__ __launch_bounds__(kWave *(SRC == SRC_DUAL ? 2 : WPP), (CPL == 8 && LD
         if constexpr (RESIDENT) {
           pass_resident<MODE, REGK, LDSK>(d, &ldata[LDSK > 0 ? wave : 0][0][0][0], nslots, lane, U, reg, acc);
         } else {
+          const bool numeric = a.numeric_jacobian != 0;   // (kernel argument: uniform)
+          if (numeric) {
+            // the candidate was published behind a block barrier: its perturbed poses, made once, behind another
+            if (wave == 0) numeric_poses(slab, lane, nunif, ninv2h);
+            __syncthreads();
+          }
           for (int idx = threadIdx.x; idx < stride; idx += kWave * WPP) {
             double e[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) e[c] = base[(int64_t)c * stride + idx];
             double r, J[5];
-            eval_corr<MODE>(e, U, reg, r, J);
+            if (numeric) eval_corr_numeric<MODE>(e, U, nunif, ninv2h, slab + kQc, reg, r, J);
+            else eval_corr<MODE>(e, U, reg, r, J);
             accumulate(r, J, acc);
           }
         }

@@ -191,6 +191,11 @@ int pnec_hip_stream_submit(pnec_hip_stream *s, int mode, int64_t n_pairs, const 
   pnec_hip_options opt;
   if (opt_in) opt = *opt_in; else pnec_hip_default_options(&opt);
   if (opt.max_num_iterations < 0) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "max_num_iterations < 0");
+  if (opt.flags & ~(PNEC_HIP_OPT_COUNT_PASSES | PNEC_HIP_OPT_JACOBIAN_NUMERIC_CENTRAL))
+    return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "pnec_hip_options.flags: undefined bit set");
+  if (opt.flags & PNEC_HIP_OPT_JACOBIAN_NUMERIC_CENTRAL)
+    return fail(PNEC_HIP_ERR_UNSUPPORTED, "the numeric-Jacobian verification mode is a pnec_hip_solve option "
+                                          "(the streaming handle's AoS-source kernels are the resident forms only)");
   // the handle picks each pair's geometry from the auto-tuner's ladder (the only AoS-source kernels built), so a
   // forced geometry cannot be honoured here: refuse it rather than silently run something else
   if (opt.corr_per_lane != 0 || opt.waves_per_pair != 0 || opt.lds_corr_per_lane != 0)

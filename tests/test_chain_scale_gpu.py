@@ -38,76 +38,153 @@ def _angles(q_a, q_b):
     return 2.0 * np.arctan2(np.linalg.norm(v, axis=1), d)
 
 
-def test_one_call_chain_matches_the_oracle_chain_over_20000_pairs(oracle):
-    cores = oracle.max_threads()
-    P, N = (20_000 if cores >= 32 else 4_000), 512      # ~11 ms of oracle per pair and thread
-    dev = torch.device("cuda:0")
-    g = sim.generate(P, N, seed=1, device=dev)
-    bad = torch.rand(P, N, device=dev, generator=torch.Generator(device=dev).manual_seed(0)) < 0.10
-    rnd = torch.randn(P, N, 3, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
-    g.bvs2 = torch.where(bad[..., None], rnd / rnd.norm(dim=-1, keepdim=True), g.bvs2)
-    with Batch.uniform(capi.MODE_TARGET, P, N) as b:
-        b.fill(g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3))
-        q, t, mask, cnt = b.solve_pipeline(g.init_q, g.init_t, want_inliers=True)          # the product call
+def _check_chain_against_oracle(oracle, es_scheme, off, f1, f2, cv, q0, t0, label):
+    """The one-call chain on the device under `es_scheme` against the checker's chain under the same scheme, over the
+    pairs (off, f1, f2, cv: device tensors; q0, t0 start poses).  Scheme 0 (damped Newton): every pair identical up to a
+    handful that are re-derived from the device's own intermediates.  Scheme 2 (the facade's default: MINPACK-style LM on
+    the reduced-Cayley gradient): the same, except that the iteration ITSELF stalls on a flat valley of |grad| where M's
+    two smallest eigenvalues lie close (about 1 % of pairs) and ends at a point its rounding picks -- such a pair must be
+    one where the CHECKER's own minimisation ended in a stall (MINPACK info 1) or at maxfev (5), or where the device's
+    result is not a stationary point either: explained, not tolerated blindly (the rule of
+    tests/test_opengv_schemes.py::test_whole_chain_device_vs_checker_2000_pairs, here at scale)."""
+    cores = oracle.usable_threads()
+    P = len(off) - 1
+    po = capi.default_pipeline_options(eigensolver_scheme=es_scheme)
+    with Batch(capi.MODE_TARGET, off) as b:
+        b.fill(f1, f2, cv)
+        q, t, mask, cnt = b.solve_pipeline(q0, t0, options=po, want_inliers=True)          # the product call
         # the same chain stage by stage (bit-identical by construction; its intermediates explain outliers)
-        qr, tr, mask_s, cnt_s, its = b.ransac_eigensolver(g.init_q, seed=1)
+        b.set_eigensolver_scheme(es_scheme)
+        qr, tr, mask_s, cnt_s, its = b.ransac_eigensolver(q0, seed=1)
         sel = b.select(mask_s)
         qw, tw = sel.weighted_eigensolver(qr, tr, 1e-13, 10)
         res = sel.solve(qw, tw)
         sel.close()
     torch.cuda.synchronize()
     assert torch.equal(q, res.q) and torch.equal(t, res.t) and torch.equal(mask, mask_s) and torch.equal(cnt, cnt_s)
-    gq, gmask = q.cpu().numpy(), mask.cpu().numpy().reshape(P, N).astype(bool)
-    f1, f2, cv = (x.cpu().numpy() for x in (g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3)))
-    off = np.arange(P + 1, dtype=np.int64) * N
-    o = oracle.solve_chain_batch(off, f1, f2, cv, g.init_q.cpu().numpy(), seed=1, num_threads=cores)
-    omask = o["mask"].reshape(P, N)
-    same_mask = (omask == gmask).all(axis=1)
-    ang = _angles(gq, o["q"])
-    report = {"pairs": P, "corr": N, "oracle_threads": cores,
-              "inlier_masks_identical": int(same_mask.sum()),
-              "ransac_iteration_counts_identical": int((its.cpu().numpy() == o["ransac_iterations"]).sum()),
-              "ls_iteration_counts_identical": int((res.iterations.cpu().numpy() == o["ls_iterations"]).sum()),
-              "median_rot_diff_rad": float(np.median(ang)), "p99_rot_diff_rad": float(np.percentile(ang, 99)),
-              "max_rot_diff_rad": float(ang.max()), "pairs_over_1e-6_rad": int((ang > TOL).sum()), "explained": []}
-    assert same_mask.mean() >= 0.9999, report
-    assert np.percentile(ang, 99) <= 1e-10, report
-    over = np.flatnonzero(ang > TOL)
-    assert len(over) <= 3, report
-    gqr, gtr, gqw, gtw = (x.cpu().numpy() for x in (qr, tr, qw, tw))
-    git = res.iterations.cpu().numpy()
-    for p in over:
-        sl = slice(off[p], off[p + 1])
-        m = gmask[p]
-        if not same_mask[p]:
-            # the RANSAC stage chose another hypothesis: the oracle's weighted stage + refinement from the
-            # DEVICE's inliers and eigensolver pose must land on the device's final pose
-            Rw, tww = oracle.weighted_eigensolver(f1[sl][m], f2[sl][m], cv[sl][m], oracle.rot_from_quat(gqr[p]), gtr[p])
-            s = oracle.solve(oracle.MODE_TARGET, f1[sl][m], f2[sl][m], cv[sl][m], None, 1e-13, oracle.quat_from_rot(Rw),
-                             tww, oracle.default_options())
-            kind = "ransac hypothesis bifurcation"
+    gq, gmask = q.cpu().numpy(), mask.cpu().numpy().astype(bool)
+    f1, f2, cv = (x.cpu().numpy() for x in (f1, f2, cv))
+    q0h = q0.cpu().numpy()
+    oracle.set_eigensolver_scheme(es_scheme)
+    try:
+        o = oracle.solve_chain_batch(off, f1, f2, cv, q0h, seed=1, num_threads=cores)
+        omask = o["mask"]
+        same_mask = np.array([(omask[off[p]:off[p + 1]] == gmask[off[p]:off[p + 1]]).all() for p in range(P)])
+        ang = _angles(gq, o["q"])
+        ang_es = _angles(qr.cpu().numpy(), o["es_q"])
+        report = {"what": label, "eigensolver_scheme": es_scheme, "pairs": P, "corr_min_max": [int(np.diff(off).min()), int(np.diff(off).max())],
+                  "oracle_threads": cores, "inlier_masks_identical": int(same_mask.sum()),
+                  "ransac_iteration_counts_identical": int((its.cpu().numpy() == o["ransac_iterations"]).sum()),
+                  "ls_iteration_counts_identical": int((res.iterations.cpu().numpy() == o["ls_iterations"]).sum()),
+                  "median_rot_diff_rad": float(np.median(ang)), "p99_rot_diff_rad": float(np.percentile(ang, 99)),
+                  "max_rot_diff_rad": float(ang.max()), "pairs_over_1e-6_rad": int((ang > TOL).sum()),
+                  "eigensolver_stage_pairs_over_1e-8_rad_with_identical_masks": int((same_mask & (ang_es > 1e-8)).sum()),
+                  "explained": []}
+        gqr, gtr, gqw, gtw = (x.cpu().numpy() for x in (qr, tr, qw, tw))
+        git = res.iterations.cpu().numpy()
+        L = oracle.lib()
+
+        def stall(p):
+            """scheme 2: the checker's own eigensolver call on this pair's inliers ended in a stall (1) or at maxfev (5), or
+            the device's eigensolver-stage rotation is not a stationary point of the function it minimises"""
+            sl = slice(off[p], off[p + 1])
+            _, _, m, _ = oracle.ransac_eigensolver(f1[sl], f2[sl], oracle.rot_from_quat(q0h[p]), seed=1, pair_id=int(p))
+            if L.pnec_oracle_es_last_info() in (1, 5):
+                return True
+            G = oracle.sums36(f1[sl][m], f2[sl][m])
+            grad = oracle.es_value_grad_sums(G, oracle.rot_to_cayley(oracle.rot_from_quat(gqr[p])), reduced=True)[1]
+            return bool(np.abs(grad).max() > 1e-9 * (off[p + 1] - off[p]))
+
+        if es_scheme == 0:
+            assert same_mask.mean() >= 0.9999, report
+            assert np.percentile(ang, 99) <= 1e-10, report
+            over = np.flatnonzero(ang > TOL)
+            assert len(over) <= max(3, P // 5000), report
         else:
-            # identical inliers, refinement stopped elsewhere: the oracle's refinement from the DEVICE's
-            # weighted-stage pose must reproduce the device's iteration count (+-1) and pose
-            s = oracle.solve(oracle.MODE_TARGET, f1[sl][m], f2[sl][m], cv[sl][m], None, 1e-13, gqw[p], gtw[p],
-                             oracle.default_options())
-            kind = "refinement stopping rule on an ill-conditioned pair"
-            assert abs(int(s.iterations) - int(git[p])) <= 1, (p, s.iterations, git[p], report)
-        d = float(np.radians(oracle.rotational_difference_deg(s.R, oracle.rot_from_quat(gq[p]))))
-        report["explained"].append({"pair": int(p), "kind": kind, "rot_diff_rad": float(ang[p]),
-                                    "rot_diff_rad_from_the_devices_own_intermediate": d,
-                                    "ls_iterations_device_oracle": [int(git[p]), int(o["ls_iterations"][p])]})
-        assert d <= TOL, report
+            assert same_mask.mean() >= 0.998, report
+            assert np.percentile(ang[same_mask], 99) <= 1e-8, report
+            over = np.flatnonzero(same_mask & (ang > TOL))
+            assert len(over) <= 0.002 * P, report
+            # the eigensolver stage by itself (what the odometry's options return): beyond 1e-8 only where the iteration stalls
+            far = np.flatnonzero(same_mask & (ang_es > 1e-8))
+            assert len(far) <= 0.015 * P, report
+            unexplained = [int(p) for p in far if not stall(int(p))]
+            report["eigensolver_stage_unexplained"] = unexplained
+            assert not unexplained, report
+        for p in over:
+            sl = slice(off[p], off[p + 1])
+            m = gmask[sl]
+            if not same_mask[p]:
+                # the RANSAC stage chose another hypothesis: the oracle's weighted stage + refinement from the
+                # DEVICE's inliers and eigensolver pose must land on the device's final pose
+                Rw, tww = oracle.weighted_eigensolver(f1[sl][m], f2[sl][m], cv[sl][m], oracle.rot_from_quat(gqr[p]), gtr[p])
+                s = oracle.solve(oracle.MODE_TARGET, f1[sl][m], f2[sl][m], cv[sl][m], None, 1e-13, oracle.quat_from_rot(Rw),
+                                 tww, oracle.default_options())
+                kind = "ransac hypothesis bifurcation"
+            elif es_scheme != 0 and ang_es[p] > 1e-8:
+                # identical inliers, the eigensolver stage already apart (a stall, checked above): the oracle's weighted
+                # stage + refinement from the DEVICE's eigensolver pose must land on the device's final pose
+                Rw, tww = oracle.weighted_eigensolver(f1[sl][m], f2[sl][m], cv[sl][m], oracle.rot_from_quat(gqr[p]), gtr[p])
+                s = oracle.solve(oracle.MODE_TARGET, f1[sl][m], f2[sl][m], cv[sl][m], None, 1e-13, oracle.quat_from_rot(Rw),
+                                 tww, oracle.default_options())
+                kind = "eigensolver iteration stalled (MINPACK info 1 / 5 on the checker's side, or a non-stationary end)"
+            else:
+                # identical inliers, refinement stopped elsewhere: the oracle's refinement from the DEVICE's
+                # weighted-stage pose must reproduce the device's iteration count (+-1) and pose
+                s = oracle.solve(oracle.MODE_TARGET, f1[sl][m], f2[sl][m], cv[sl][m], None, 1e-13, gqw[p], gtw[p],
+                                 oracle.default_options())
+                kind = "refinement stopping rule on an ill-conditioned pair"
+                assert abs(int(s.iterations) - int(git[p])) <= 1, (p, s.iterations, git[p], report)
+            d = float(np.radians(oracle.rotational_difference_deg(s.R, oracle.rot_from_quat(gq[p]))))
+            report["explained"].append({"pair": int(p), "kind": kind, "rot_diff_rad": float(ang[p]),
+                                        "rot_diff_rad_from_the_devices_own_intermediate": d,
+                                        "ls_iterations_device_oracle": [int(git[p]), int(o["ls_iterations"][p])]})
+            assert d <= TOL, report
+    finally:
+        oracle.set_eigensolver_scheme(0)
     # every pair that is NOT beyond the tolerance is, well, within it (the north star's bar)
-    assert (np.delete(ang, over) <= TOL).all()
+    if es_scheme == 0:
+        assert (np.delete(ang, over) <= TOL).all()
+    else:
+        assert (np.delete(ang, np.concatenate([over, np.flatnonzero(~same_mask)])) <= TOL).all()
     out = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "chain_parity_at_scale.json"), "w") as f:
+        with open(os.path.join(out, f"chain_parity_at_scale_{label}_scheme{es_scheme}.json"), "w") as f:
             json.dump(report, f)
     except OSError:
         pass
     print(json.dumps(report))
+    return report
+
+
+@pytest.mark.parametrize("es_scheme", [0, 2])
+def test_one_call_chain_matches_the_oracle_chain_over_20000_pairs(oracle, es_scheme):
+    """20 000 x 512, 10 % gross mismatches, the reference's default Options -- under the C ABI's default eigensolver scheme
+    (0) and under the facade's (2, the restatement believed to be what opengv runs)."""
+    cores = oracle.usable_threads()                       # (the cgroup quota, not the host's CPU count)
+    P, N = (20_000 if cores >= 32 else 4_000), 512      # ~11 ms of oracle per pair and thread
+    dev = torch.device("cuda:0")
+    g = sim.generate(P, N, seed=1, device=dev)
+    bad = torch.rand(P, N, device=dev, generator=torch.Generator(device=dev).manual_seed(0)) < 0.10
+    rnd = torch.randn(P, N, 3, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    g.bvs2 = torch.where(bad[..., None], rnd / rnd.norm(dim=-1, keepdim=True), g.bvs2)
+    off = np.arange(P + 1, dtype=np.int64) * N
+    _check_chain_against_oracle(oracle, es_scheme, off, g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3),
+                                g.init_q, g.init_t, "sim20k")
+
+
+def test_kitti_like_ragged_chain_under_the_facades_default_scheme(oracle):
+    """BASELINE configs 3 / 5's stand-in (all KITTI 00-10 frame pairs, ragged, 10 % gross mismatches; a quarter of them on a
+    small box) through the one-call chain under eigensolver scheme 2 -- what a user of the C++ facade gets -- against the
+    checker's scheme-2 chain."""
+    from pnec_amd import tracks as tk
+    cores = oracle.usable_threads()
+    P_all = int(len(tk.kitti_all_sizes()))
+    P = P_all if cores >= 32 else P_all // 4
+    tr = tk.kitti_all_shard(0, P, device=torch.device("cuda:0"), outlier_frac=0.10)
+    _check_chain_against_oracle(oracle, 2, np.asarray(tr.offsets, dtype=np.int64), tr.bvs1, tr.bvs2, tr.covs,
+                                tr.init_q.contiguous(), tr.init_t.contiguous(), "kitti_all")
 
 
 def test_two_pairs_per_wavefront_ransac_is_bitwise_the_one_pair_form():

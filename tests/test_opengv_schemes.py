@@ -257,7 +257,7 @@ def test_whole_chain_device_vs_checker_2000_pairs(oracle, scheme, s, options):
     import torch
     from pnec_amd import Batch, capi
     from tests.test_chain_scale_gpu import _angles
-    cores = oracle.max_threads()
+    cores = oracle.usable_threads()
     P, N = (2000 if cores >= 16 else 400), 256
     g = _chain_data(P, N, 0.0 if options == "no_ransac" else 0.10)
     po = capi.default_pipeline_options(eigensolver_scheme=s)
@@ -324,3 +324,45 @@ def test_whole_chain_device_vs_checker_2000_pairs(oracle, scheme, s, options):
     elif options == "default":
         af = _angles(q.cpu().numpy(), ref["q"])[ok_mask]
         assert np.percentile(af, 99) <= 1e-8 and (af > 1e-6).sum() <= 2, (np.percentile(af, 99), af.max())
+
+
+@gpu
+def test_cached_inlier_view_follows_its_sources_scheme(oracle):
+    """pnec_hip_problem_select_view hands out the batch's CACHED InlierExtraction target; the scheme of the stage calls on
+    it must be the source's at the time of the call -- also when the source's scheme was changed after the view had been
+    made (round-5 advisor finding: the view kept the scheme it was allocated with), and in both orders of the two calls."""
+    import torch
+    from pnec_amd import Batch, capi
+    P, N = 64, 256
+    g = _chain_data(P, N, 0.10)
+    with Batch.uniform(capi.MODE_TARGET, P, N) as b:
+        b.fill(g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3))
+        qr, tr, mask, cnt, its = b.ransac_eigensolver(g.init_q, seed=1)
+        want = {}
+        for s in (0, 2):                                  # fresh, uncached targets made under the scheme
+            b.set_eigensolver_scheme(s)
+            sel = b.select(mask)
+            assert capi.lib().pnec_hip_problem_eigensolver_scheme(sel._h) == s
+            want[s] = sel.weighted_eigensolver(qr, tr, 1e-13, 10)
+            sel.close()
+        assert not torch.equal(want[0][0], want[2][0])    # the schemes are told apart by this data
+        b.set_eigensolver_scheme(0)
+        v = b.select(mask, view=True)                     # the cached view is made under scheme 0 ...
+        assert torch.equal(v.weighted_eigensolver(qr, tr, 1e-13, 10)[0], want[0][0])
+        b.set_eigensolver_scheme(2)                       # ... the source changes its scheme: the view in hand follows
+        assert capi.lib().pnec_hip_problem_eigensolver_scheme(v._h) == 2
+        assert torch.equal(v.weighted_eigensolver(qr, tr, 1e-13, 10)[0], want[2][0])
+        v = b.select(mask, view=True)                     # ... and so does the next view
+        assert torch.equal(v.weighted_eigensolver(qr, tr, 1e-13, 10)[0], want[2][0])
+        b.set_eigensolver_scheme(0)
+        v = b.select(mask, view=True)
+        assert torch.equal(v.weighted_eigensolver(qr, tr, 1e-13, 10)[0], want[0][0])
+        # scheme 2 no longer refuses more than 16 weighted iterations (its rounds end at the first converged call)
+        b.set_eigensolver_scheme(2)
+        v = b.select(mask, view=True)
+        q20, _ = v.weighted_eigensolver(qr, tr, 1e-13, 20)
+        assert torch.isfinite(q20).all()
+        b.set_eigensolver_scheme(1)
+        v = b.select(mask, view=True)
+        with pytest.raises(Exception, match="at most 16"):
+            v.weighted_eigensolver(qr, tr, 1e-13, 20)

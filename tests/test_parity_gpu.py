@@ -842,7 +842,7 @@ def test_cost_only_pass_after_a_rejected_step_counts_and_changes_no_bit(oracle):
     """Round 4: a candidate that follows a rejected step (or whose model promises less than the cost can resolve) is
     evaluated cost-only first -- Ceres' own order: residuals, then the Jacobian once the step is accepted -- and in full
     only if its step turns out accepted.  Results must be those of the reference-faithful oracle (iteration counts and
-    codes equal: every decision is the same), and the pass counters (pnec_hip_options.reserved bit 0 ->
+    codes equal: every decision is the same), and the pass counters (PNEC_HIP_OPT_COUNT_PASSES ->
     pnec_hip_work_counters[13], [14]) must show that fewer than iterations + 1 full passes per solve ran in the
     fixed-iteration mode, where the solves sit at their noise floor for most of their ten iterations."""
     import ctypes as C
@@ -857,7 +857,7 @@ def test_cost_only_pass_after_a_rejected_step_counts_and_changes_no_bit(oracle):
             opts = capi.default_options(max_num_iterations=mi, check_convergence=conv)
             plain = b.solve(g.init_q, g.init_t, options=opts)
             capi.check(L.pnec_hip_work_counters(0, 1, cnt.ctypes.data, C.byref(flag)))
-            counted_opts = capi.default_options(max_num_iterations=mi, check_convergence=conv, reserved=1)
+            counted_opts = capi.default_options(max_num_iterations=mi, check_convergence=conv, flags=1)
             counted = b.solve(g.init_q, g.init_t, options=counted_opts)
             torch.cuda.synchronize()
             capi.check(L.pnec_hip_work_counters(0, 1, cnt.ctypes.data, C.byref(flag)))

@@ -18,7 +18,7 @@ for conv,mi in ((0,10),(1,50)):
         torch.cuda.synchronize(); ms=(time.perf_counter()-t)/5*1e3
         cnt=np.zeros(16,dtype=np.uint64); flag=C.c_int32(0)
         capi.check(capi.lib().pnec_hip_work_counters(0,1,cnt.ctypes.data,C.byref(flag)))
-        o2=capi.default_options(max_num_iterations=mi,check_convergence=conv,reserved=1)
+        o2=capi.default_options(max_num_iterations=mi,check_convergence=conv,flags=1)
         b.solve(g.init_q,None,options=o2,hyp_t=hyp,n_hyp=H); torch.cuda.synchronize()
         capi.check(capi.lib().pnec_hip_work_counters(0,1,cnt.ctypes.data,C.byref(flag)))
         print(json.dumps({"lib":os.environ.get("PNEC_HIP_LIB","default")[-40:],"conv":conv,"ms":ms,"its_mean":float(r.iterations.double().mean()),"full_passes_per_solve":float(cnt[13])/(Bp*H*N),"cost_passes_per_solve":float(cnt[14])/(Bp*H*N), "launch":b.describe_launch(opts)}))

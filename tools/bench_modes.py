@@ -88,7 +88,7 @@ for name, mode, omode in (("NEC", capi.MODE_NEC, po.MODE_NEC), ("PNEC target", c
     flag = C.c_int32(0)
     capi.check(capi.lib().pnec_hip_work_counters(0, 1, cnt.ctypes.data, C.byref(flag)))
     o2 = capi.Options.from_buffer_copy(bytes(opts))
-    o2.reserved = 1
+    o2.flags = 1
     batch.solve(q0, t0, reg=reg, options=o2)
     torch.cuda.synchronize()
     capi.check(capi.lib().pnec_hip_work_counters(0, 1, cnt.ctypes.data, C.byref(flag)))
