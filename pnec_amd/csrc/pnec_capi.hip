@@ -18,6 +18,7 @@
 #include "pnec_device.hpp"
 #include "pnec_front_shared.hpp"
 #include "pnec_solve_kernel.hpp"
+#include "pnec_solve_group_kernel.hpp"
 
 namespace pnec_hip {
 // one translation unit per residual family (pnec_solve_<family>.hip)
@@ -25,6 +26,11 @@ hipError_t launch_solve_mode_0(int, int, int, bool, const SolveArgs &, hipStream
 hipError_t launch_solve_mode_1(int, int, int, bool, const SolveArgs &, hipStream_t);
 hipError_t launch_solve_mode_2(int, int, int, bool, const SolveArgs &, hipStream_t);
 hipError_t launch_solve_mode_3(int, int, int, bool, const SolveArgs &, hipStream_t);
+// the multi-hypothesis form (pnec_solve_group_kernel.hpp): one block per (pair, group of hypotheses)
+hipError_t launch_solve_group_mode_0(int, int, int, const SolveArgs &, hipStream_t);
+hipError_t launch_solve_group_mode_1(int, int, int, const SolveArgs &, hipStream_t);
+hipError_t launch_solve_group_mode_2(int, int, int, const SolveArgs &, hipStream_t);
+hipError_t launch_solve_group_mode_3(int, int, int, const SolveArgs &, hipStream_t);
 
 // pnec_stream_<family>.hip: the same kernels reading the reference's AoS arrays (streaming handle)
 hipError_t launch_solve_aos_mode_0(int, int, int, const SolveArgs &, hipStream_t);
@@ -1566,7 +1572,23 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
     a.out_status = p->d_stage_i + S;
   }
 
+  // several hypotheses per pair on a several-wavefront geometry: the block-per-(pair, group of hypotheses) form -- the
+  // pair's payload loaded once per group, one LM step for the whole group (bit-identical results).  PNEC_SOLVE_GROUPS=0
+  // keeps the one-solve-per-block launch (A/B, and the bit-identity test).
+  static const bool use_groups = [] {
+    const char *ev = std::getenv("PNEC_SOLVE_GROUPS");
+    return !(ev && *ev == '0');
+  }();
   auto launch_on = [&](const Geometry &gg, const SolveArgs &aa, hipStream_t st) -> hipError_t {
+    if (use_groups && aa.n_hyp > 1 && gg.resident && gg.wpp >= 2 && !aa.trace && !aa.numeric_jacobian &&
+        group_geometry_ok(p->mode, gg.cpl, gg.wpp, gg.ldsk)) {
+      switch (p->mode) {
+        case PNEC_HIP_MODE_NEC: return launch_solve_group_mode_0(gg.cpl, gg.wpp, gg.ldsk, aa, st);
+        case PNEC_HIP_MODE_TARGET: return launch_solve_group_mode_1(gg.cpl, gg.wpp, gg.ldsk, aa, st);
+        case PNEC_HIP_MODE_HOST: return launch_solve_group_mode_2(gg.cpl, gg.wpp, gg.ldsk, aa, st);
+        default: return launch_solve_group_mode_3(gg.cpl, gg.wpp, gg.ldsk, aa, st);
+      }
+    }
     switch (p->mode) {
       case PNEC_HIP_MODE_NEC: return launch_solve_mode_0(gg.cpl, gg.wpp, gg.ldsk, gg.resident, aa, st);
       case PNEC_HIP_MODE_TARGET: return launch_solve_mode_1(gg.cpl, gg.wpp, gg.ldsk, gg.resident, aa, st);

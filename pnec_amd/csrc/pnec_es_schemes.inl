@@ -124,7 +124,8 @@ __device__ __forceinline__ void lm_par3(const double (&A)[9], const double (&b)[
   }
 }
 
-template <int SCHEME>
+// WK: which work counter the quad-evaluations belong to (a -DPNEC_WORK_COUNT build only; tools/count_chain_work.py)
+template <int SCHEME, int WK = kWkRansacEvals>
 __device__ __forceinline__ int es_minimise_queue_alt(int n_tasks, const int *tlist, const double (*Gtab)[36], double (*tv)[3],
                                                      double (*te)[3], int *tits, int *tflag) {
   static_assert(SCHEME == 1 || SCHEME == 2, "scheme 0 is es_minimise_queue / es_minimise_quad");
@@ -159,8 +160,12 @@ __device__ __forceinline__ int es_minimise_queue_alt(int n_tasks, const int *tli
   };
   if (quad < n_tasks) arm(tlist[quad]);
   const double kSqrtEps = 1.4901161193847656e-08, kEps = 2.220446049250313e-16;
+  [[maybe_unused]] int my_evals = 0;
   for (;;) {
     ++trips;
+#ifdef PNEC_WORK_COUNT
+    if (!done) ++my_evals;
+#endif
     if (!done) {
       const double *G = Gtab[slot];
       int role = role_of_lane;
@@ -401,5 +406,8 @@ __device__ __forceinline__ int es_minimise_queue_alt(int n_tasks, const int *tli
     next += __builtin_popcountll(fb);
     if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
   }
+#ifdef PNEC_WORK_COUNT
+  if (role_of_lane == 0) PNEC_WORK_ADD(WK, my_evals);
+#endif
   return trips;
 }

@@ -1272,7 +1272,7 @@ __global__ __launch_bounds__(kWave, 2) void es_batch_alt_kernel(const EsBatchArg
   wave_lds_sync();
   int it_first = 0;
   if constexpr (EPI == kEpiTranslation) {
-    es_minimise_queue_alt<SCHEME>(n_mine, lds.tlist, lds.Gs, lds.tv, lds.te, lds.tits, lds.tflag);
+    es_minimise_queue_alt<SCHEME, kWkEsTailEvals>(n_mine, lds.tlist, lds.Gs, lds.tv, lds.te, lds.tits, lds.tflag);
     wave_lds_sync();
     it_first = lds.tits[quad];
   } else {
@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(kWave, 2) void es_batch_alt_kernel(const EsBatchArg
         }
       }
       wave_lds_sync();
-      es_minimise_queue_alt<SCHEME>(n_tasks, lds.tlist, lds.Gs, lds.tv, lds.te, lds.tits, lds.tflag);
+      es_minimise_queue_alt<SCHEME, kWkEsFirstEvals>(n_tasks, lds.tlist, lds.Gs, lds.tv, lds.te, lds.tits, lds.tflag);
       wave_lds_sync();
       if (going) {
         if ((lane & 3) == 0) {

@@ -3,6 +3,7 @@
 #include <cstdlib>
 
 #include "pnec_solve_kernel.hpp"
+#include "pnec_solve_group_kernel.hpp"
 
 namespace pnec_hip {
 
@@ -49,6 +50,32 @@ hipError_t PNEC_CAT(launch_solve_mode_, PNEC_SOLVE_MODE)(int cpl, int wpp, int l
     }                                                                                               \
   }
   PNEC_FOR_EACH_GEOMETRY(PNEC_LAUNCH_CASE)
+#undef PNEC_LAUNCH_CASE
+  return hipErrorInvalidConfiguration;
+}
+#endif
+
+// The multi-hypothesis form (pnec_solve_group_kernel.hpp): one block per (pair, group of WPP hypotheses).  The
+// several-wavefront geometries of the ladders; bit-identical to the one-solve-per-block launch above.
+#ifndef PNEC_SOLVE_AOS
+hipError_t PNEC_CAT(launch_solve_group_mode_, PNEC_SOLVE_MODE)(int cpl, int wpp, int ldsk, const SolveArgs &args,
+                                                               hipStream_t stream) {
+  constexpr int MODE = PNEC_SOLVE_MODE;
+  if (wpp < 2 || args.n_hyp < 1) return hipErrorInvalidConfiguration;
+  const int64_t groups = (args.n_hyp + wpp - 1) / wpp;
+  const int64_t blocks = (args.n_solves / args.n_hyp) * groups;
+  if (blocks > 0x7fffffffLL) return hipErrorInvalidConfiguration;
+  const dim3 grid((unsigned)blocks);
+#define PNEC_LAUNCH_CASE(CPL, WPP, LDSK)                                                               \
+  if (cpl == CPL && wpp == WPP && ldsk == LDSK) {                                                        \
+    if constexpr (group_geometry_ok(MODE, CPL, WPP, LDSK)) {                                             \
+      hipLaunchKernelGGL((lm_solve_group_kernel<MODE, CPL, WPP, LDSK>), grid, dim3(kWave * WPP), 0, stream, args); \
+      return hipGetLastError();                                                                          \
+    } else {                                                                                             \
+      return hipErrorInvalidConfiguration;                                                               \
+    }                                                                                                    \
+  }
+  PNEC_FOR_EACH_GROUP_GEOMETRY(PNEC_LAUNCH_CASE)
 #undef PNEC_LAUNCH_CASE
   return hipErrorInvalidConfiguration;
 }

@@ -880,3 +880,40 @@ def test_cost_only_pass_after_a_rejected_step_counts_and_changes_no_bit(oracle):
                                  1e-13, g.init_q[p].cpu().numpy(), g.init_t[p].cpu().numpy(), oo)
                 assert rit[p] == s.iterations and rst[p] == s.status, p
                 assert _rot_err(oracle, _quat_to_R(rq[p]), s.R) <= 1e-8, p
+
+
+@pytest.mark.parametrize("mode,n_corr,H", [(capi.MODE_TARGET, 4096, 19), (capi.MODE_TARGET, 3000, 8), (capi.MODE_TARGET, 1500, 5),
+                                           (capi.MODE_TARGET, 900, 7), (capi.MODE_NEC, 2100, 6), (capi.MODE_HOST, 1100, 3),
+                                           (capi.MODE_SYM, 700, 9), (capi.MODE_SYM, 2048, 10)])
+def test_multi_hypothesis_group_form_is_bitwise_the_one_solve_per_block_form(mode, n_corr, H):
+    """n_hyp > 1 on a several-wavefront geometry runs lm_solve_group_kernel: one block per (pair, group of WPP hypotheses),
+    the payload loaded once, one LM step for the whole group in the quads of the first wavefront.  Same arithmetic in the
+    same order per solve, so every (pair, hypothesis) must come out BIT FOR BIT as the same solve made alone (n_hyp = 1: the
+    one-solve-per-block kernel) -- poses, costs, iteration counts, termination codes; with H not a multiple of the group
+    size (short last group), in the throughput configuration and with Ceres' convergence tests (hypotheses of one group
+    end at different iterations), and from starts 180 degrees off."""
+    P = 5
+    g = sim.generate(P, n_corr, seed=4000 + n_corr, device="cuda:0")
+    c2, c1 = (None, None) if mode == capi.MODE_NEC else (g.covs2.reshape(-1, 3, 3), None)
+    if mode == capi.MODE_SYM:
+        c1 = (g.covs2.roll(1, dims=1) * 0.8).reshape(-1, 3, 3).contiguous()
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(11)
+    hyp = torch.randn(P * H, 3, generator=gen, dtype=torch.float64, device="cuda:0")
+    hyp = hyp / hyp.norm(dim=1, keepdim=True)
+    hyp[::H] = g.init_t
+    with Batch.uniform(mode, P, n_corr) as b:
+        b.fill(g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), c2, c1)
+        for kw in (dict(max_num_iterations=10, check_convergence=0), dict(), dict(max_num_iterations=0)):
+            opts = capi.default_options(**kw)
+            launch = b.describe_launch(opts)
+            assert launch["waves_per_pair"] >= 2, launch
+            res = b.solve(g.init_q, None, options=opts, hyp_t=hyp, n_hyp=H)
+            torch.cuda.synchronize()
+            for h in range(H):
+                one = b.solve(g.init_q, None, options=opts, hyp_t=hyp[h::H].contiguous(), n_hyp=1)
+                for name in ("q", "t", "cost", "iterations", "status"):
+                    got, want = getattr(res, name)[h::H], getattr(one, name)
+                    assert torch.equal(got, want), (kw, h, name, got, want)
+            if kw == dict():
+                assert len(set(res.iterations.cpu().numpy().tolist())) > 1     # the groups did hold solves of different lengths

@@ -17,13 +17,15 @@ f2 = torch.where(bad[:, None], rnd / rnd.norm(dim=-1, keepdim=True), f2)
 off = offsets.cpu().numpy() if hasattr(offsets, "cpu") else np.asarray(offsets)
 with Batch(capi.MODE_TARGET, off) as b:
     b.fill(f1, f2, c2)
+    SCHEME = int(os.environ.get("PNEC_ES_SCHEME", "0"))   # include/pnec_hip.h pnec_hip_eigensolver_scheme
+    O = capi.default_pipeline_options(eigensolver_scheme=SCHEME)
     def run():
-        return b.solve_pipeline(q0, t0)
+        return b.solve_pipeline(q0, t0, O)
     run(); torch.cuda.synchronize()
     ts = []
     for _ in range(5):
         t = time.perf_counter(); run(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
     ms = float(np.median(ts)) * 1e3
 n = np.diff(off)
-print(json.dumps({"workload": "KITTI-like SYNTHETIC stream, %d ragged pairs (%d..%d correspondences, mean %.0f), 10 %% gross outliers, reference-default Options, one call" % (P, n.min(), n.max(), n.mean()),
+print(json.dumps({"eigensolver_scheme": SCHEME, "workload": "KITTI-like SYNTHETIC stream, %d ragged pairs (%d..%d correspondences, mean %.0f), 10 %% gross outliers, reference-default Options, one call" % (P, n.min(), n.max(), n.mean()),
                   "pairs_over_512": int((n > 512).sum()), "one_call_ms": ms, "pairs_per_s": P / ms * 1e3}))

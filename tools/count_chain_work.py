@@ -38,7 +38,8 @@ def counters(reset=True):
     return {n: int(out[i]) for i, n in enumerate(NAMES)}
 
 
-def count(batch, q0, t0):
+def count(batch, q0, t0, scheme=0):
+    batch.set_eigensolver_scheme(scheme)
     counters()
     qr, tr, mask, cnt, its = batch.ransac_eigensolver(q0, seed=1)
     torch.cuda.synchronize()
@@ -65,9 +66,10 @@ sizes = tk.kitti_all_sizes()
 tr = tk.kitti_all_shard(0, len(sizes), device=dev, outlier_frac=0.10)
 with Batch(capi.MODE_TARGET, tr.offsets) as b:
     b.fill(tr.bvs1, tr.bvs2, tr.covs)
-    c = count(b, tr.init_q.contiguous(), tr.init_t.contiguous())
-c.update({"pairs": int(len(sizes)), "correspondences": int(sizes.sum()), "outliers": 0.10})
-result["workloads"]["kitti_all_chain"] = c
+    for sch in (0, 2):
+        c = count(b, tr.init_q.contiguous(), tr.init_t.contiguous(), sch)
+        c.update({"pairs": int(len(sizes)), "correspondences": int(sizes.sum()), "outliers": 0.10, "eigensolver_scheme": sch})
+        result["workloads"]["kitti_all_chain" + ("" if sch == 0 else f"_scheme{sch}")] = c
 del tr
 # (2) tools/bench_pipeline.py 20000: 20 000 x 512, 10 % gross outliers
 B, N = 20000, 512
@@ -82,8 +84,9 @@ for c0 in range(0, B, 5000):
     g.bvs2 = torch.where(bad[..., None], rnd, g.bvs2)
     batch.fill(g.bvs1.reshape(-1, 3), g.bvs2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3), first_pair=c0, n_pairs=m)
     qs.append(g.init_q); ts.append(g.init_t)
-c = count(batch, torch.cat(qs), torch.cat(ts))
-c.update({"pairs": B, "correspondences": B * N, "outliers": 0.10})
-result["workloads"]["sim20k_chain"] = c
+for sch in (0, 2):
+    c = count(batch, torch.cat(qs), torch.cat(ts), sch)
+    c.update({"pairs": B, "correspondences": B * N, "outliers": 0.10, "eigensolver_scheme": sch})
+    result["workloads"]["sim20k_chain" + ("" if sch == 0 else f"_scheme{sch}")] = c
 batch.close()
 print(json.dumps(result, indent=1))

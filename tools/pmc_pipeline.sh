@@ -5,8 +5,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/pmcpipe_$TAG
 mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
 CMD="python $REPO/tools/bench_pipeline.py $B"
-rocprofv3 --kernel-trace --kernel-include-regex "eigensolver" --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/a -o b -- $CMD > $OUT/a.log 2>&1
-rocprofv3 --kernel-trace --kernel-include-regex "eigensolver" --pmc SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAIT_ANY SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/b -o b -- $CMD > $OUT/b.log 2>&1
+rocprofv3 --kernel-trace --kernel-include-regex "eigensolver|es_batch|sums36" --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/a -o b -- $CMD > $OUT/a.log 2>&1
+rocprofv3 --kernel-trace --kernel-include-regex "eigensolver|es_batch|sums36" --pmc SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAIT_ANY SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/b -o b -- $CMD > $OUT/b.log 2>&1
 python3 - <<PY
 import csv,glob,collections
 v=collections.defaultdict(lambda: collections.defaultdict(list))

@@ -72,10 +72,12 @@ def study(Bp=64, N=4096, H=64, seed=9, hyp_seed=5, device="cuda:0"):
         res["oracle_numeric"] = cpu(po.JAC_NUMERIC_CENTRAL)
         res["oracle_numeric_step_x_1p001"] = cpu(po.JAC_NUMERIC_CENTRAL, 1.0 + 2.0 ** -10)
         res["oracle_analytic"] = cpu(po.JAC_ANALYTIC)
+        SCALES = (1.0 + 2.0 ** -10, 1.0 - 2.0 ** -10, 1.0 + 2.0 ** -7, 2.0, 0.5)
+        others = [cpu(po.JAC_NUMERIC_CENTRAL, sc)[0] for sc in SCALES]
 
         def d(a, b):
             return quat_angles(res[a][0], res[b][0])
-        floor = d("oracle_numeric", "oracle_numeric_step_x_1p001")
+        floor = np.max(np.stack([quat_angles(res["oracle_numeric"][0], oq) for oq in others]), axis=0)
         line = {"configuration": name, "n_solves": Bp, "pairs": f"{Bp} x {N}, hypothesis (7 p + 3) % {H} of pair p"}
         for a, b in (("device_analytic", "oracle_numeric"), ("device_numeric", "oracle_numeric"),
                      ("device_analytic", "oracle_analytic"), ("oracle_analytic", "oracle_numeric"),
@@ -96,6 +98,11 @@ def study(Bp=64, N=4096, H=64, seed=9, hyp_seed=5, device="cuda:0"):
             line[f"{a}__unstable_solves_distance_over_reference_self_distance_max"] = float(ratio.max()) if ratio.size else None
         line["reference_self_distance_unstable_solves_max_rad"] = float(floor[~stable].max()) if (~stable).any() else None
         line["lm_iterations_mean_device"] = float(res["device_analytic"][1].mean())
+        line["step_scales_of_the_self_distance"] = list(SCALES)
+        line["per_solve"] = {"reference_self_distance_rad": floor.tolist(),
+                             "device_analytic_vs_oracle_numeric_rad": d("device_analytic", "oracle_numeric").tolist(),
+                             "device_numeric_vs_oracle_numeric_rad": d("device_numeric", "oracle_numeric").tolist(),
+                             "device_analytic_vs_oracle_analytic_rad": d("device_analytic", "oracle_analytic").tolist()}
         out.append(line)
     return out
 
