@@ -1073,9 +1073,19 @@ def run(args):
     gathered = gather.drain()
     fence()
     elapsed = time.perf_counter() - t_start
+    per_rank = None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # every rank's own numbers, for the line (after the timed region): wall time of its K steps, device time of one step's
+        # launches (events on its stream), device time of the side stream's pack + collective per step, its pairs
+        mine = torch.tensor([elapsed,
+                             float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)])) if ev0 else float("nan"),
+                             gather.device_ms_per_collective() or float("nan"), float(my_pairs)],
+                            dtype=torch.float64, device=tmax.device)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = torch.stack(allr).cpu().numpy()
         elapsed = float(tmax.item())
     one_at_a_time = None
     if in_flight > 1 and world == 1:   # the same steps one after the other on one stream, for the record
@@ -1112,6 +1122,15 @@ def run(args):
         # digest of the gathered records of the last step (q, t, cost, iterations, status per pair, in pair order):
         # equal across rank counts for the strong-scaling workloads, whose pairs do not depend on the sharding
         line["records_sha256"] = hashlib.sha256(gathered.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+        if per_rank is not None:
+            # a SCALE run diagnoses itself: `value` is the slowest rank's wall time; here is every rank's
+            line["per_rank"] = {"wall_ms_per_step": [float(x) / args.steps * 1e3 for x in per_rank[:, 0]],
+                                "kernel_ms": [None if np.isnan(x) else float(x) for x in per_rank[:, 1]],
+                                "gather_ms": [None if np.isnan(x) else float(x) for x in per_rank[:, 2]],
+                                "pairs": [int(x) for x in per_rank[:, 3]],
+                                "note": "kernel_ms: device time of one step's launches (events on the rank's stream); gather_ms: "
+                                        "device time of the side stream's pack + collective of one step (it overlaps the next "
+                                        "step's launches); wall_ms_per_step: the rank's own clock around its K steps"}
         if args.share_gpu and not cpu:
             line["shared_gpu"] = {"ranks": n_ranks, "note": "every rank on cuda:0 (plumbing run on a one-GPU box: real "
                                   "solver, partition and device-side gather with world > 1; gloo over pinned host records "
@@ -1273,8 +1292,53 @@ def run_single_process(args):
     from pnec_amd.multi import MultiBatch, alloc_counters
     N = args.gpus
     devices = [0] * N if args.share_gpu else list(range(N))
-    P, C = args.pairs * N, args.corr
     dev = torch.device("cuda:0")
+    if args.workload == "kitti_all":
+        # the strong-scaling workload through the handle: the SAME pairs, start poses, options and record layout as the
+        # rank-per-GPU form gathers, so that `records_sha256` of the two launchers can be compared on the day an N-GPU box
+        # runs both (the results do not depend on the device list: tests/test_distributed_gpu.py)
+        from pnec_amd import tracks as tk
+        sizes = tk.kitti_all_sizes()
+        Pk = int(len(sizes))
+        tr = tk.kitti_all_shard(0, Pk, device=dev, outlier_frac=args.outliers if args.chain else 0.0)
+        f1, f2, cv = tr.bvs1.cpu().numpy(), tr.bvs2.cpu().numpy(), tr.covs.cpu().numpy()
+        q0, t0 = tr.init_q.cpu().numpy(), tr.init_t.cpu().numpy()
+        off = np.asarray(tr.offsets, dtype=np.int64)
+        del tr
+        popts = capi.default_pipeline_options(eigensolver_scheme=args.es_scheme)
+        ropts = capi.default_options()
+        with MultiBatch(devices, capi.MODE_TARGET, Pk, int(off[-1]), int(sizes.max())) as mb:
+            mb.fill(off, f1, f2, cv)
+
+            def one():
+                if args.chain:
+                    q, t, _m, cnt = mb.solve_pipeline(q0, t0, options=popts, want_inliers=True)
+                    return np.concatenate([q, t, np.zeros((Pk, 1)), cnt[:, None].astype(np.float64), np.zeros((Pk, 1))], axis=1)
+                r = mb.solve(q0, t0, reg=1e-13, options=ropts)
+                return np.concatenate([r["q"], r["t"], r["cost"][:, None], r["iterations"][:, None].astype(np.float64),
+                                       r["status"][:, None].astype(np.float64)], axis=1)
+            for _ in range(max(args.warmup, 2)):
+                rec = one()
+            t_0 = time.perf_counter()
+            for _ in range(args.steps):
+                rec = one()
+            wall = (time.perf_counter() - t_0) / args.steps * 1e3
+            bounds = mb.bounds.tolist()
+        line = {"metric": ("PNEC::Solve frame pairs/sec, whole chain (all KITTI 00-10 pairs, ragged, reference-default Options)" if args.chain
+                           else "PNEC pose solves/sec (all KITTI 00-10 pairs, ragged, Ceres-default termination)"),
+                "value": Pk / (wall * 1e-3), "unit": "pairs/s" if args.chain else "solves/s", "n_gpus": 1 if args.share_gpu else N,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic KITTI-like (no KITTI data in this environment)",
+                "config": {"workload": "configs[4]: all KITTI 00-10 frame pairs (23 190 ragged pairs, synthetic stand-in)" +
+                                       (f", whole chain, eigensolver scheme {args.es_scheme}" if args.chain else ", refinement"),
+                           "parallelism": f"single process, {N} devices (pnec_hip_multi_*: one host thread + batch + stream per "
+                                          "device, no collective; host arrays in and out)", "devices": devices, "shard_bounds": bounds},
+                "records_sha256": hashlib.sha256(np.ascontiguousarray(rec).tobytes()).hexdigest(),
+                "records_note": "the digest of the per-pair records [q t cost iterations status] in pair order: the same "
+                                "number `bench.py --gpus N --workload kitti_all [--chain]` prints for its gathered records"}
+        print(json.dumps(line), flush=True)
+        return 0
+    P, C = args.pairs * N, args.corr
     f1, f2, cv, q0, t0 = [], [], [], [], []
     for c0 in range(0, P, 10000):                        # generated on device 0 in chunks, handed over as host arrays
         m = min(10000, P - c0)
@@ -1315,8 +1379,8 @@ def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
     if args.single_process:
-        if args.workload != "sim100k" or args.chain:
-            sys.exit("--single-process drives the sim100k refinement only")
+        if args.chain and args.workload != "kitti_all":
+            sys.exit("--chain goes with --workload kitti_all")
         sys.exit(run_single_process(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, argv))

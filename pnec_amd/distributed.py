@@ -121,6 +121,7 @@ class RecordGather:
             self.gathered = [None] * self.SLOTS
             self.pinned = [None] * self.SLOTS     # host_staged: the slot's records on the host
             self.pending = [False] * self.SLOTS   # host_staged: copy enqueued, collective not yet run
+            self.timing = []                      # (start, end) events around the side stream's pack + collective, last 64
 
     def _collective(self, rec: torch.Tensor):
         self.collectives += 1
@@ -157,6 +158,8 @@ class RecordGather:
         self.solved[slot].record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.solved[slot])
+            t_begin = torch.cuda.Event(enable_timing=True)
+            t_begin.record(self.side)
             rec = pack_records(res)
             if self.host_staged:
                 if self.pinned[slot] is None or self.pinned[slot].shape != rec.shape:
@@ -165,9 +168,20 @@ class RecordGather:
                 self.pending[slot] = True
             else:
                 self.last = self._collective(rec)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=True)
             ev.record(self.side)
             self.gathered[slot] = ev
+            self.timing.append((t_begin, ev))
+            if len(self.timing) > 64:
+                del self.timing[0]
+
+    def device_ms_per_collective(self):
+        """Mean device time (ms) of the side stream's work per step -- pack the records + the collective (device form) or
+        the copy into pinned memory (host_staged) -- over the last <= 64 submits; call after drain().  None on CPU."""
+        if not self.cuda or not self.timing:
+            return None
+        self.side.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in self.timing]))
 
     def drain(self):
         if self.cuda:

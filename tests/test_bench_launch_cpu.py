@@ -210,3 +210,33 @@ def test_a_rank_that_never_arrives_gives_a_json_error_line_not_a_hang():
     assert line["value"] is None and line["n_gpus"] == 2 and ("init_process_group" in line["error"] or "did not finish" in line["error"])
     pre = json.loads(next(l for l in r.stderr.splitlines() if l.startswith('{"preflight"')))["preflight"]
     assert pre["backend"] == "gloo" and pre["world_size"] == 2 and "HSA_ENABLE_IPC_MODE_LEGACY" in pre
+
+
+def test_world_size_8_dry_run_of_the_chain_workload_as_the_driver_launches_it():
+    """The first real N > 1 run will be the driver's (`python -m torch.distributed.run --nproc-per-node 8 bench.py
+    --gpus 8 ...`): rehearse its launcher, partition, ragged gather and order check with EIGHT ranks on gloo (stubbed
+    solve) for the strong-scaling chain workload -- and the self-diagnosis fields of the line: every rank's own wall
+    time and pair count, the digest of the gathered records."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+              "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "8", "--steps", "2",
+              "--warmup", "1", "--workload", "kitti_all", "--chain", "--dry-run-cpu"])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["launcher"] == "torch.distributed.run"
+    sizes = d["config"]["pairs_per_rank"]
+    assert len(sizes) == 8 and sum(sizes) == 23190 and min(sizes) > 2000
+    c = d["config"]["corr_per_rank"]
+    assert max(c) - min(c) <= 2 * 700          # balanced by correspondence count to within a couple of pairs
+    assert d["records_in_order"] is True       # rank 0 checked global order, step stamp and owner of every record
+    pr = d["per_rank"]
+    assert pr["pairs"] == sizes and len(pr["wall_ms_per_step"]) == 8 and all(x > 0 for x in pr["wall_ms_per_step"])
+    assert pr["kernel_ms"] == [None] * 8 and pr["gather_ms"] == [None] * 8     # (no device in a dry run)
+    assert len(d["records_sha256"]) == 64
+    # the same workload with two ranks gathers the same records (the stub's records depend on the global pair index
+    # and the step only): the digest does not depend on the number of ranks, except for the owner column
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    d1 = _run([sys.executable, BENCH, "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "kitti_all", "--chain",
+               "--dry-run-cpu"], env)
+    assert d1["config"]["pairs_per_rank"] == [23190]

@@ -365,3 +365,28 @@ def test_single_process_bench_line():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["value"] > 1e5 and line["all_iterations_done"]
     assert line["config"]["hip_malloc_calls_during_timed_steps"] == 0 and line["config"]["shard_bounds"] == [0, 4000, 8000]
+
+
+@pytest.mark.parametrize("chain", [False, True])
+def test_both_launchers_print_the_same_records_digest_on_the_strong_scaling_workload(chain):
+    """For the day an N-GPU box runs both: `bench.py --gpus N --workload kitti_all [--chain]` (one rank per GPU, one
+    gather) and `... --single-process` (one process, the persistent multi-device handle) print `records_sha256`, the digest
+    of the per-pair result records in pair order.  Here, with one GPU: the rank form with one rank, with two ranks sharing
+    cuda:0 (gloo over pinned records), and the handle on the device list [0, 0] -- one and the same digest, whatever the
+    sharding (RANSAC draws belong to the GLOBAL pair index)."""
+    import json
+    extra = ["--chain", "--in-flight", "1"] if chain else []
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "kitti_all", "--steps", "2", "--warmup", "1",
+            "--no-cpu-baseline"] + extra
+    digests = {}
+    for name, more in (("one rank", []), ("two ranks on cuda:0", ["--gpus", "2", "--share-gpu"]),
+                       ("handle [0, 0]", ["--gpus", "2", "--share-gpu", "--single-process"])):
+        r = subprocess.run(base + more, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert "error" not in line, (name, line)
+        digests[name] = line["records_sha256"]
+        if name == "two ranks on cuda:0":
+            pr = line["per_rank"]
+            assert len(pr["kernel_ms"]) == 2 and all(x and x > 0 for x in pr["kernel_ms"]) and sum(pr["pairs"]) == 23190
+    assert len(set(digests.values())) == 1, digests
