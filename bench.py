@@ -933,7 +933,59 @@ def secondary_lines(device, capi, quick=False):
                                                          "kitti_all entry"},
                 "parity": {"bitwise_equal_to_the_batched_call": bool(np.array_equal(gq, np.asarray(ref.q))), "n_pairs": Ps}}
 
-    for fn in (kitti_all_refinement, kitti_all_chain, multi_hypothesis, kitti00_streamed):
+    def kitti00_per_frame_chain():
+        # The reference's ACTUAL call pattern (VERDICT r5 "missing" 5): one PNEC::Solve -- the whole chain -- per frame, each
+        # start pose depending on the previous frame's result (FrameProcessing::ProcessFrame, src/odometry/frame_processing.cc:
+        # 57-145: prev_rel_rotation -> Frame2Frame::Align -> PNECAlign, frame2frame.cc:122-141 -> PNEC::Solve): nothing of
+        # frame k + 1 can start before frame k's pose is back on the host.  pnec_hip_frame_solve on a persistent handle.
+        from pnec_amd.frame import FrameSolver
+        Ps = 400 if quick else 4541
+        offsets, f1, f2, c2, R_gt, t_gt, q0, t0 = sim.generate_kitti_like(Ps, mean_corr=500, seed=3)
+        f1, f2, c2 = (x.numpy() for x in (f1, f2, c2))
+        offsets = np.asarray(offsets, dtype=np.int64)
+        out = {}
+        for name, kw in (("default", dict()), ("odometry", dict(use_nec=1, use_ceres=0))):
+            inits_q, inits_t, gq = np.zeros((Ps, 4)), np.zeros((Ps, 3)), np.zeros((Ps, 4))
+            with FrameSolver(max_corr=int(np.diff(offsets).max()), device=device.index) as fs:
+                o = capi.default_pipeline_options(eigensolver_scheme=2, **kw)
+                for rep in range(2):                   # the first pass warms the handle
+                    q_prev, t_prev = np.array([0.0, 0.0, 0.0, 1.0]), np.array([0.0, 0.0, 1.0])
+                    t_0 = time.perf_counter()
+                    for pp in range(Ps):
+                        a, e = offsets[pp], offsets[pp + 1]
+                        # (RANSAC draws as pair pp of the sequence, so that the batched call below draws the same)
+                        o.first_pair_id = pp
+                        inits_q[pp], inits_t[pp] = q_prev, t_prev
+                        q_prev, t_prev, _m, _c = fs.solve(f1[a:e], f2[a:e], c2[a:e], q_prev, t_prev, o)
+                        gq[pp] = q_prev
+                    wall = time.perf_counter() - t_0
+            # the same frames, with the start poses the sequence produced, as ONE batched call: bit for bit the same poses
+            with Batch(capi.MODE_TARGET, offsets, device=device.index) as b:
+                b.fill(f1, f2, c2)
+                bq, _bt = b.solve_pipeline(inits_q, inits_t, options=capi.default_pipeline_options(eigensolver_scheme=2, **kw))
+            gt_err = _quat_angles(gq, np.stack([po.quat_from_rot(R) for R in R_gt.numpy()]))
+            out[name] = {"frames_per_s": Ps / wall, "us_per_frame": wall / Ps * 1e6,
+                         "bitwise_equal_to_the_batched_call": bool(np.array_equal(gq, np.asarray(bq))),
+                         "median_rot_err_rad_vs_ground_truth": float(np.median(gt_err))}
+        d = out["default"]
+        return {"workload": f"configs[2], the reference's call pattern: a KITTI-00-like sequence of {Ps} consecutive frames "
+                            "(synthetic stand-in, ~500 ragged correspondences), ONE PNEC::Solve (whole chain, reference-default "
+                            "Options, eigensolver scheme 2) per frame through pnec_hip_frame_solve, every start pose = the "
+                            "previous frame's result (sequentially dependent: frame_processing.cc:57-145); host arrays in, pose "
+                            "out, includes the Python loop",
+                "value": d["frames_per_s"], "unit": "pairs/s", "ms_per_step": d["us_per_frame"] * 1e-3,
+                "us_per_frame": d["us_per_frame"],
+                "odometry_options": {"what": "use_nec, no refinement -- what Frame2Frame forces (frame2frame.cc:127-128)", **out["odometry"]},
+                "roofline": {"bound": "latency", "note": "one frame = one wavefront's worth of sequential work per stage (RANSAC "
+                                                         "hypotheses' minimisations one trip after the other); bounded by dependent-"
+                                                         "instruction latency and four launches, not by a device roof"},
+                "parity": {"bitwise_equal_to_the_batched_call": bool(d["bitwise_equal_to_the_batched_call"] and
+                                                                     out["odometry"]["bitwise_equal_to_the_batched_call"]),
+                           "n_pairs": Ps, "median_rot_err_rad_vs_ground_truth": d["median_rot_err_rad_vs_ground_truth"],
+                           "note": "the batched call's parity against the oracle's chain: the chain entry above and "
+                                   "tests/test_chain_scale_gpu.py"}}
+
+    for fn in (kitti_all_refinement, kitti_all_chain, multi_hypothesis, kitti00_streamed, kitti00_per_frame_chain):
         guarded(fn)
     return out
 

@@ -276,7 +276,7 @@ def test_default_bench_line_carries_the_other_configs_and_the_chain():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["metric"].startswith("PNEC pose solves/sec") and line["value"] > 1e6 and "roofline" in line and "cpu_baseline" in line
     sec = line["secondary"]
-    assert len(sec) == 4 and not any("error" in e for e in sec), [e.get("error") for e in sec]
+    assert len(sec) == 5 and not any("error" in e for e in sec), [e.get("error") for e in sec]
     for e in sec:
         assert e["value"] > 0 and e["unit"] in ("solves/s", "pairs/s") and e["ms_per_step"] > 0 and "roofline" in e
         p = e["parity"]
