@@ -126,7 +126,7 @@ def chain_stage_rooflines(counts, stage_ms, payload_bytes, inlier_payload_bytes,
 FRONT_KERNEL_SOURCES = ("pnec_frontend.hip", "pnec_es_schemes.inl", "pnec_device.hpp", "pnec_front_shared.hpp")
 # sha256 (front_sources_sha256) of the sources the FLOP_* table above was last derived from / cross-checked against
 # (tools/isa_front_regions.py); tests/test_bench_launch_cpu.py fails when the sources move on without it
-FRONT_FLOP_MODEL_STAMP = "bb17c2281718072d9fee7f2ffeee698b1d08829bedf5d4ddb79a4a29dc11e0a1"
+FRONT_FLOP_MODEL_STAMP = "cd29963804527ac4b3ea2f2bc99f34f6bc6d8a13b9486e3d3a669da17293171f"
 
 
 def front_sources_sha256():
