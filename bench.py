@@ -943,21 +943,25 @@ def secondary_lines(device, capi, quick=False):
         offsets, f1, f2, c2, R_gt, t_gt, q0, t0 = sim.generate_kitti_like(Ps, mean_corr=500, seed=3)
         f1, f2, c2 = (x.numpy() for x in (f1, f2, c2))
         offsets = np.asarray(offsets, dtype=np.int64)
+        # the caller's arrays as the reference holds them (std::vector<Eigen::Matrix3d>: column-major 3x3), made once
+        c9 = np.ascontiguousarray(np.transpose(c2, (0, 2, 1)).reshape(-1, 9))
         out = {}
         for name, kw in (("default", dict()), ("odometry", dict(use_nec=1, use_ceres=0))):
             inits_q, inits_t, gq = np.zeros((Ps, 4)), np.zeros((Ps, 3)), np.zeros((Ps, 4))
             with FrameSolver(max_corr=int(np.diff(offsets).max()), device=device.index) as fs:
                 o = capi.default_pipeline_options(eigensolver_scheme=2, **kw)
+                mask_buf = np.zeros(int(np.diff(offsets).max()), dtype=np.uint8)
+                gt = np.zeros((Ps, 3))
                 for rep in range(2):                   # the first pass warms the handle
-                    q_prev, t_prev = np.array([0.0, 0.0, 0.0, 1.0]), np.array([0.0, 0.0, 1.0])
+                    inits_q[0], inits_t[0] = (0.0, 0.0, 0.0, 1.0), (0.0, 0.0, 1.0)
                     t_0 = time.perf_counter()
                     for pp in range(Ps):
-                        a, e = offsets[pp], offsets[pp + 1]
+                        a, e = int(offsets[pp]), int(offsets[pp + 1])
                         # (RANSAC draws as pair pp of the sequence, so that the batched call below draws the same)
                         o.first_pair_id = pp
-                        inits_q[pp], inits_t[pp] = q_prev, t_prev
-                        q_prev, t_prev, _m, _c = fs.solve(f1[a:e], f2[a:e], c2[a:e], q_prev, t_prev, o)
-                        gq[pp] = q_prev
+                        fs.solve_raw(e - a, f1[a:e], f2[a:e], c9[a:e], inits_q[pp], inits_t[pp], o, gq[pp], gt[pp], mask_buf)
+                        if pp + 1 < Ps:                # the next frame starts from this frame's result
+                            inits_q[pp + 1], inits_t[pp + 1] = gq[pp], gt[pp]
                     wall = time.perf_counter() - t_0
             # the same frames, with the start poses the sequence produced, as ONE batched call: bit for bit the same poses
             with Batch(capi.MODE_TARGET, offsets, device=device.index) as b:

@@ -41,6 +41,17 @@ class FrameSolver:
     def __exit__(self, *exc):
         self.close()
 
+    def solve_raw(self, n: int, bvs1, bvs2, covs9, init_q, init_t, options, out_q, out_t, out_mask) -> int:
+        """The same call without any marshalling, for per-frame loops: every array is float64 (uint8 for the mask),
+        C-contiguous and of the right shape already -- bvs* [n,3], covs9 [n,9] COLUMN-MAJOR 3x3 (or None), init_q [4],
+        init_t [3], out_q [4], out_t [3], out_mask [>= n]; `options` a capi.PipelineOptions.  Returns the inlier count."""
+        cnt = C.c_int32(0)
+        capi.check(self._lib.pnec_hip_frame_solve(self._h, n, bvs1.ctypes.data, bvs2.ctypes.data,
+                                                  None if covs9 is None else covs9.ctypes.data, init_q.ctypes.data,
+                                                  init_t.ctypes.data, C.byref(options), out_q.ctypes.data, out_t.ctypes.data,
+                                                  out_mask.ctypes.data, C.byref(cnt)))
+        return int(cnt.value)
+
     def solve(self, bvs1, bvs2, covs, init_q, init_t, options: capi.PipelineOptions | None = None):
         """-> (q [4] xyzw, t [3], inlier_mask [n] bool, inlier_count).  bvs* [n,3]; covs [n,3,3] (symmetric) or
         [n,9] column-major, or None with use_nec; init_q xyzw."""
