@@ -1580,8 +1580,9 @@ int pnec_hip_solve(pnec_hip_problem *p, const double *init_q, const double *init
     return !(ev && *ev == '0');
   }();
   auto launch_on = [&](const Geometry &gg, const SolveArgs &aa, hipStream_t st) -> hipError_t {
-    if (use_groups && aa.n_hyp > 1 && gg.resident && gg.wpp >= 2 && !aa.trace && !aa.numeric_jacobian &&
-        group_geometry_ok(p->mode, gg.cpl, gg.wpp, gg.ldsk)) {
+    if (use_groups && aa.n_hyp > 1 && gg.resident && !aa.trace && !aa.numeric_jacobian &&
+        (gg.wpp >= 2 ? group_geometry_ok(p->mode, gg.cpl, gg.wpp, gg.ldsk)
+                     : pairhyp_geometry_ok(p->mode, gg.cpl, gg.wpp, gg.ldsk))) {
       switch (p->mode) {
         case PNEC_HIP_MODE_NEC: return launch_solve_group_mode_0(gg.cpl, gg.wpp, gg.ldsk, aa, st);
         case PNEC_HIP_MODE_TARGET: return launch_solve_group_mode_1(gg.cpl, gg.wpp, gg.ldsk, aa, st);

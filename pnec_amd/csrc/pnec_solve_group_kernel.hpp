@@ -206,4 +206,157 @@ __global__ __launch_bounds__(kWave *WPP, (CPL == 8 && LDSK == 0) ? 1 : 2) void l
   }
 }
 
+// ---- one wavefront per pair (N <= 512 ...): TWO hypotheses of the pair per wavefront -------------------------------------
+// The same idea where a solve is ONE wavefront (the (1..8, 1, *) geometries): the wavefront keeps the pair's payload and
+// walks two of its hypotheses -- two passes against the resident data, then BOTH LM steps at once, hypothesis h in quad h
+// (lm_advance is per-lane code whose only cross-lane traffic stays inside a quad) -- so the ~400 issue slots of a step are
+// paid once per two solves, with no barrier at all: what round 5's SRC_DUAL form (two solves of DIFFERENT pairs per block)
+// bought with two block barriers per iteration and lost to them.  Two is what fits: the second hypothesis' state (880 B)
+// still leaves eight wavefronts per CU beside the (8, 1, 3) payload (8 x 20 192 B <= 160 KB; a third would not).
+// Bit-identical to one solve per block.
+constexpr int kPairHyp = 2;
+#define PNEC_FOR_EACH_PAIRHYP_GEOMETRY(X) X(1, 1, 0) X(2, 1, 0) X(4, 1, 0) X(8, 1, 3) X(8, 1, 0)
+__host__ __device__ constexpr bool pairhyp_geometry_ok(int mode, int cpl, int wpp, int ldsk) {
+  if (wpp != 1 || !geometry_ok(mode, cpl, wpp, ldsk)) return false;
+#define PNEC_PH_MATCH(CPL, WPP, LDSK) if (cpl == CPL && ldsk == LDSK) return true;
+  PNEC_FOR_EACH_PAIRHYP_GEOMETRY(PNEC_PH_MATCH)
+#undef PNEC_PH_MATCH
+  return false;
+}
+
+template <int MODE, int CPL, int LDSK>
+__global__ __launch_bounds__(kWave, (CPL == 8 && LDSK == 0) ? 1 : 2) void lm_solve_pairhyp_kernel(const SolveArgs a) {
+  constexpr int G = kPairHyp;
+  constexpr int NC = num_components(MODE);
+  constexpr int REGK = CPL - LDSK;
+  const int lane = threadIdx.x;
+  const int groups_per_pair = (a.n_hyp + G - 1) / G;
+  const int64_t n_pairs_here = a.n_solves / a.n_hyp;
+  const int64_t logical = xcd_contiguous_index(blockIdx.x, n_pairs_here * groups_per_pair);
+  const int64_t pslot = logical / groups_per_pair;
+  const int h0 = (int)(logical % groups_per_pair) * G;
+  const int nh = (a.n_hyp - h0) < G ? (a.n_hyp - h0) : G;
+  const int64_t pair = a.pair_index ? (int64_t)a.pair_index[pslot] : pslot;
+  const double *__restrict__ base = a.data + a.block_offset[pair];
+  const int n = a.count[pair];
+  const int stride = (n + kWave - 1) & ~(kWave - 1);
+  const pnec_hip_options &o = a.opt;
+  const double reg = a.reg;
+
+  __shared__ double slab_all[G][kSlab];
+  __shared__ double unif_all[G][kUnif];
+  __shared__ int ist_all[G][kINumI];
+  [[maybe_unused]] __shared__ double ldata[LDSK > 0 ? LDSK : 1][NC][LDSK > 0 ? kWave : 1];
+
+  double d[REGK][NC];
+  load_resident<NC, CPL, REGK>(base, n, stride, 0, lane, d, &ldata[0][0][0]);
+  int nslots = 0;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) nslots += (n > slot_corr<CPL, REGK>(k, 0)) ? 1 : 0;
+
+  if ((lane & 3) == 0 && (lane >> 2) < G) {
+    const int h = lane >> 2;
+    double *slab = slab_all[h];
+    int *ist = ist_all[h];
+    if (h < nh) {
+      const int64_t s = pair * a.n_hyp + h0 + h;
+      double th, ph;
+      const double *t0 = a.hyp_t ? a.hyp_t + 3 * s : a.init_t + 3 * pair;
+      angles_from_vec(t0[0], t0[1], t0[2], th, ph);
+      double q[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        q[k] = a.init_q[pair * 4 + k];
+        slab[kQc + k] = q[k];
+      }
+      slab[kThetaC] = th;
+      slab[kPhiC] = ph;
+      pose_uniforms(th, ph, q, unif_all[h]);
+    }
+    ist[kIIter] = 0;
+    ist[kIFirst] = 1;
+    ist[kIReuseDiag] = 0;
+    ist[kINumInvalid] = 0;
+    ist[kIStepOk] = 1;
+    ist[kILast] = o.max_num_iterations <= 0 ? 1 : 0;
+    ist[kIPark] = 0;
+    ist[kITerm] = h < nh ? -1 : PNEC_HIP_TERM_MAX_ITERATIONS;
+  }
+  const double inv_max_radius = a.inv_max_radius, inv_min_radius = a.inv_min_radius;
+  if constexpr (LDSK > 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the DMA'd LDS slots have landed
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  wave_sync();
+
+  int n_full_passes = 0, n_cost_passes = 0;
+  for (;;) {
+#pragma unroll 1
+    for (int h = 0; h < G; ++h) {
+      if (to_sgpr(ist_all[h][kITerm]) >= 0) continue;
+      const double *unif = unif_all[h];
+      PassUniforms U;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) U.R[i] = to_sgpr(unif[i]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) U.t[i] = to_sgpr(unif[9 + i]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) U.bth[i] = to_sgpr(unif[12 + i]);
+      U.bph[0] = -U.t[1];
+      U.bph[1] = U.t[0];
+      U.bph[2] = 0.0;
+      double c[6];
+      const bool cost_only = to_sgpr(ist_all[h][kILast]) != 0;
+      n_cost_passes += cost_only ? 1 : 0;
+      n_full_passes += cost_only ? 0 : 1;
+      if (cost_only) {
+        double a0 = 0.0, z = 0.0;
+        pass_cost_resident<MODE, REGK, LDSK>(d, &ldata[0][0][0], nslots, lane, U, reg, a0, z);
+        c[0] = wave_reduce_acc0_row0(a0);
+        c[1] = __builtin_amdgcn_ballot_w64(!(z == 0.0)) == 0ull ? 0.0 : __builtin_nan("");
+        c[2] = c[3] = c[4] = c[5] = 0.0;
+      } else {
+        double acc[kNumAcc];
+#pragma unroll
+        for (int k = 0; k < kNumAcc; ++k) acc[k] = 0.0;
+        pass_resident<MODE, REGK, LDSK>(d, &ldata[0][0][0], nslots, lane, U, reg, acc);
+        wave_reduce21_rows(acc, c);
+      }
+      double *cand_sums = slab_all[h] + kSums + (to_sgpr(ist_all[h][kIPark]) ^ 1) * kSumSlots;
+      const bool fin = rows_all_finite(c);
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cand_sums[(lane >> 4) * 6 + i] = c[i];
+        if (lane == 0) slab_all[h][kSumsFinite] = fin ? 1.0 : 0.0;
+      }
+    }
+    // ---- both steps at once: hypothesis h in quad h
+    wave_sync();
+    {
+      const int h = lane >> 2;
+      __builtin_amdgcn_s_setprio(3);
+      if (h < G && ist_all[h][kITerm] < 0) {
+        const int t = lm_advance<kCostFirst>(slab_all[h], ist_all[h], unif_all[h], o, inv_max_radius, inv_min_radius);
+        if ((lane & 3) == 0) ist_all[h][kITerm] = t;
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    wave_sync();
+    bool going = false;
+#pragma unroll
+    for (int h = 0; h < G; ++h) going = going || to_sgpr(ist_all[h][kITerm]) < 0;
+    if (!going) break;
+  }
+  if ((lane & 3) == 0 && (lane >> 2) < nh) {
+    const int h = lane >> 2;
+    write_result(a, pair * a.n_hyp + h0 + h, slab_all[h], ist_all[h][kIIter], ist_all[h][kITerm]);
+  }
+  if (lane == 0 && a.work) {
+    atomicAdd(a.work + 0, (unsigned long long)n_full_passes * (unsigned long long)n);
+    atomicAdd(a.work + 1, (unsigned long long)n_cost_passes * (unsigned long long)n);
+  }
+}
+
 }  // namespace pnec_hip

@@ -61,7 +61,24 @@ hipError_t PNEC_CAT(launch_solve_mode_, PNEC_SOLVE_MODE)(int cpl, int wpp, int l
 hipError_t PNEC_CAT(launch_solve_group_mode_, PNEC_SOLVE_MODE)(int cpl, int wpp, int ldsk, const SolveArgs &args,
                                                                hipStream_t stream) {
   constexpr int MODE = PNEC_SOLVE_MODE;
-  if (wpp < 2 || args.n_hyp < 1) return hipErrorInvalidConfiguration;
+  if (args.n_hyp < 1) return hipErrorInvalidConfiguration;
+  if (wpp == 1) {   // one wavefront per pair: two hypotheses of the pair per wavefront (lm_solve_pairhyp_kernel)
+    const int64_t groups1 = (args.n_hyp + kPairHyp - 1) / kPairHyp;
+    const int64_t blocks1 = (args.n_solves / args.n_hyp) * groups1;
+    if (blocks1 > 0x7fffffffLL) return hipErrorInvalidConfiguration;
+#define PNEC_LAUNCH_CASE(CPL, WPP, LDSK)                                                                  \
+  if (cpl == CPL && ldsk == LDSK) {                                                                         \
+    if constexpr (pairhyp_geometry_ok(MODE, CPL, 1, LDSK)) {                                                \
+      hipLaunchKernelGGL((lm_solve_pairhyp_kernel<MODE, CPL, LDSK>), dim3((unsigned)blocks1), dim3(kWave), 0, stream, args); \
+      return hipGetLastError();                                                                             \
+    } else {                                                                                                \
+      return hipErrorInvalidConfiguration;                                                                  \
+    }                                                                                                       \
+  }
+    PNEC_FOR_EACH_PAIRHYP_GEOMETRY(PNEC_LAUNCH_CASE)
+#undef PNEC_LAUNCH_CASE
+    return hipErrorInvalidConfiguration;
+  }
   const int64_t groups = (args.n_hyp + wpp - 1) / wpp;
   const int64_t blocks = (args.n_solves / args.n_hyp) * groups;
   if (blocks > 0x7fffffffLL) return hipErrorInvalidConfiguration;

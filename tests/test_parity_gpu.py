@@ -884,10 +884,14 @@ def test_cost_only_pass_after_a_rejected_step_counts_and_changes_no_bit(oracle):
 
 @pytest.mark.parametrize("mode,n_corr,H", [(capi.MODE_TARGET, 4096, 19), (capi.MODE_TARGET, 3000, 8), (capi.MODE_TARGET, 1500, 5),
                                            (capi.MODE_TARGET, 900, 7), (capi.MODE_NEC, 2100, 6), (capi.MODE_HOST, 1100, 3),
-                                           (capi.MODE_SYM, 700, 9), (capi.MODE_SYM, 2048, 10)])
+                                           (capi.MODE_SYM, 700, 9), (capi.MODE_SYM, 2048, 10),
+                                           # one wavefront per pair: two hypotheses of the pair per wavefront (lm_solve_pairhyp_kernel)
+                                           (capi.MODE_TARGET, 512, 7), (capi.MODE_TARGET, 100, 4), (capi.MODE_TARGET, 40, 3),
+                                           (capi.MODE_NEC, 512, 5), (capi.MODE_HOST, 300, 2), (capi.MODE_SYM, 450, 3)])
 def test_multi_hypothesis_group_form_is_bitwise_the_one_solve_per_block_form(mode, n_corr, H):
     """n_hyp > 1 on a several-wavefront geometry runs lm_solve_group_kernel: one block per (pair, group of WPP hypotheses),
-    the payload loaded once, one LM step for the whole group in the quads of the first wavefront.  Same arithmetic in the
+    the payload loaded once, the group's LM steps at the same time (one per wavefront); on a one-wavefront geometry
+    lm_solve_pairhyp_kernel: two hypotheses of the pair per wavefront, both steps at once in two quads.  Same arithmetic in the
     same order per solve, so every (pair, hypothesis) must come out BIT FOR BIT as the same solve made alone (n_hyp = 1: the
     one-solve-per-block kernel) -- poses, costs, iteration counts, termination codes; with H not a multiple of the group
     size (short last group), in the throughput configuration and with Ceres' convergence tests (hypotheses of one group
@@ -907,7 +911,7 @@ def test_multi_hypothesis_group_form_is_bitwise_the_one_solve_per_block_form(mod
         for kw in (dict(max_num_iterations=10, check_convergence=0), dict(), dict(max_num_iterations=0)):
             opts = capi.default_options(**kw)
             launch = b.describe_launch(opts)
-            assert launch["waves_per_pair"] >= 2, launch
+            assert (launch["waves_per_pair"] >= 2) == (n_corr > 768 or (mode == capi.MODE_SYM and n_corr > 512)), launch
             res = b.solve(g.init_q, None, options=opts, hyp_t=hyp, n_hyp=H)
             torch.cuda.synchronize()
             for h in range(H):
