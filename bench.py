@@ -1240,7 +1240,8 @@ def run(args):
                                      "committed work counts, profiles/chain_work_latest.json); stage kernels: "
                                      "profiles/r06_full_pipeline_kernels_scheme2.md"}
         else:
-            kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+            step_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
+            kernel_ms = float(np.mean(step_ms))
             batch = sh.batch
             payload = batch.payload_bytes                      # bytes the kernel must read once
             iters_done = res.iterations.to(torch.float64)
@@ -1291,6 +1292,10 @@ def run(args):
                 "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": why,
                 "kernel_ms": kernel_ms,
+                # the spread over the K timed launches: a box whose clocks move shows here (round 6: two boxes at 2.72 ms, one at
+                # 3.03 ms mean whose rocprofv3 trace of the same command read 2.72 min / 2.90 mean); `achieved` / `frac` use the
+                # MEAN, as the contract says
+                "kernel_ms_min_median_max": [float(np.min(step_ms)), float(np.median(step_ms)), float(np.max(step_ms))],
                 "algorithmic_bytes_per_launch": payload,
                 "note": "register-resident design: the payload (96 B/correspondence) is read from HBM "
                         "once per solve, not once per pass, so the kernel is FP64-VALU-bound, not "
