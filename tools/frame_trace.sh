@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/s2/frame
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/s2/frame -o f -- $R/pnec_amd/pnec_host_demo 512 solve_latency 50 > $R/gpurun_out/s2/frame/run.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/s2/frame -o f -- $R/pnec_amd/pnec_host_demo 512 solve_latency 50 ${FRAME_MODE:-default} ${FRAME_SCHEME:-2} > $R/gpurun_out/s2/frame/run.log 2>&1
 python3 - <<PY
 import csv,glob
 f=glob.glob("$R/gpurun_out/s2/frame/**/f_kernel_trace.csv", recursive=True)[0]
