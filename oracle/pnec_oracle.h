@@ -9,7 +9,9 @@
  * PARITY STATUS: "parity unpinned" for the optimiser trajectory.
  *   - The objective (residual + propagated-variance weight) IS pinned: it is
  *     checked against golden vectors produced by importing the reference's
- *     scripts/pnec/common.py (tests/golden/make_golden.py, tests/test_oracle_golden.py).
+ *     scripts/pnec/common.py (tests/golden/make_golden.py, tests/test_oracle_golden.py) --
+ *     Target and NEC directly; Host and Symmetrical through the Python's target energy at the
+ *     transformed inputs where it is their denominator (residual_forms_golden.npz, round 6).
  *   - The Gauss-Newton/LM arithmetic lives in Ceres Solver, which is neither
  *     vendored under /root/reference nor consistently pinned (Dockerfile:17 says
  *     1.13.0, src/optimization/pnec_ceres.cc:103 needs the Manifold API, >= 2.1),

@@ -142,6 +142,59 @@ def main():
                         obj_Ai=Ai, obj_Bi=Bi, obj_X=X, obj_out=obj)
     print(f"wrote {idx} energy cases, math goldens")
 
+    # ---- HOST and SYMMETRIC residuals (pnec_residual.h:50-83, :106-150), pinned through the reference's TARGET energy ----
+    # The reference's Python has no Host / Symmetrical energy.  But its target energy evaluates
+    #     (t' [fi]x R fi')^2 / (t' [fi]x R S R' [fi]x' t + reg)
+    # for whatever it is given, and the C++ Host functor's denominator is exactly that form at fi := R f1, R := I, S := cov
+    # (pnec_residual.h:63-70: bv_1_hat = Skew(R bv_1); bv_1_hat cov bv_1_hat'), the Symmetrical functor's second term the
+    # same at fi := R f2, S := cov_1 (:128-140).  The numerator of all three functors is t . (f1 x R f2); the vector handed
+    # over as fi' is chosen so that the Python's numerator t' [fi]x fi' equals it: fi' = n (t x fi) / |t x fi|^2.  So:
+    #   host energy   = pnec_energy_rotations(I, t, R f1, fi', cov, reg)                      (one call over all k)
+    #   symmetric r^2 = N / (N / E_target + N / E_second - reg), per correspondence, with N = nec_energy_rotations
+    #                   (the squared numerator), E_target and E_second the Python's one-correspondence energies
+    # -- every number on the right is what a function of scripts/pnec/common.py returned.
+    forms = {}
+    fidx = 0
+    eye = np.eye(3).reshape(1, 1, 3, 3)
+    for seed in (11, 12):
+        for k in (12, 40):
+            rng = np.random.default_rng(5000 + 10 * seed + k)
+            f1 = random_bearings(rng, k)
+            f2 = random_bearings(rng, k)
+            cov2 = random_bearing_covs(rng, f2, True)      # frame-2 covariances (target term)
+            cov1 = random_bearing_covs(rng, f1, True)      # frame-1 covariances (host functor / symmetric second term)
+            for reg in (1e-13, 1e-10):
+                for _pose in range(3):
+                    R = random_rotation(rng)
+                    t = rng.normal(size=3)
+                    t /= np.linalg.norm(t)
+                    n = np.einsum("i,ki->k", t, np.cross(f1, f2 @ R.T))          # t . (f1 x R f2)
+                    # HOST: cov = the single covariance array of Optimize(..., frame = Host): frame 1's
+                    a = f1 @ R.T
+                    ta = np.cross(t, a)
+                    x = n[:, None] * ta / np.sum(ta * ta, axis=1, keepdims=True)
+                    host = float(rc.pnec_energy_rotations(eye, t, a, x, cov1, reg)[0, 0])
+                    # SYMMETRIC, per correspondence
+                    b = f2 @ R.T
+                    tb = np.cross(t, b)
+                    xb = n[:, None] * tb / np.sum(tb * tb, axis=1, keepdims=True)
+                    r2 = np.zeros(k)
+                    for i in range(k):
+                        N = float(rc.nec_energy_rotations(R.reshape(1, 1, 3, 3), t, f1[i:i + 1], f2[i:i + 1])[0, 0])
+                        Et = float(rc.pnec_energy_rotations(R.reshape(1, 1, 3, 3), t, f1[i:i + 1], f2[i:i + 1], cov2[i:i + 1], reg)[0, 0])
+                        Es = float(rc.pnec_energy_rotations(eye, t, b[i:i + 1], xb[i:i + 1], cov1[i:i + 1], reg)[0, 0])
+                        r2[i] = N / (N / Et + N / Es - reg)
+                    key = f"form{fidx:03d}"
+                    forms[key + "_f1"], forms[key + "_f2"] = f1, f2
+                    forms[key + "_cov1"], forms[key + "_cov2"] = cov1, cov2
+                    forms[key + "_R"], forms[key + "_t"], forms[key + "_reg"] = R, t, np.array(reg)
+                    forms[key + "_host_energy"] = np.array(host)
+                    forms[key + "_sym_r2"] = r2
+                    fidx += 1
+    forms["n_cases"] = np.array(fidx)
+    np.savez_compressed(os.path.join(HERE, "residual_forms_golden.npz"), **forms)
+    print(f"wrote {fidx} host / symmetric residual cases")
+
 
 if __name__ == "__main__":
     main()

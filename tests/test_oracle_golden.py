@@ -44,6 +44,38 @@ def test_energy_matches_reference_python(oracle, golden_dir):
     assert n_checked == 36 * 4
 
 
+def _form_cases(golden_dir):
+    z = np.load(f"{golden_dir}/residual_forms_golden.npz")
+    for i in range(int(z["n_cases"])):
+        k = f"form{i:03d}_"
+        yield {n: z[k + n] for n in ("f1", "f2", "cov1", "cov2", "R", "t", "reg", "host_energy", "sym_r2")}
+
+
+def test_host_and_symmetric_residuals_match_numbers_the_reference_python_returned(oracle, golden_dir):
+    """PNECResidualHost and PNECSymmetrical (pnec_residual.h:50-83, :106-150; the symmetric one is what pypnec.pyceres runs)
+    against tests/golden/residual_forms_golden.npz: the reference's Python has no energy of their own, but its TARGET
+    energy IS their denominator at transformed inputs (fi := R f1 resp. R f2, R := I, S := the frame-1 covariance) -- the
+    fixture holds what scripts/pnec/common.py returned for those inputs, combined per correspondence for the symmetric
+    form (tests/golden/make_golden.py says how).  The C restatement and the numpy restatement must both match."""
+    n_host = n_sym = 0
+    for c in _form_cases(golden_dir):
+        reg, R, t = float(c["reg"]), c["R"], c["t"]
+        got = oracle.energy(oracle.MODE_HOST, c["f1"], c["f2"], c["cov1"], None, reg, R, t)
+        assert got == pytest.approx(float(c["host_energy"]), rel=1e-9)
+        assert oracle.energy_numpy(oracle.MODE_HOST, c["f1"], c["f2"], c["cov1"], None, reg, R, t) == pytest.approx(float(c["host_energy"]), rel=1e-9)
+        n_host += 1
+        q = oracle.quat_from_rot(R)
+        th, ph = oracle.angles_from_vec(t)
+        c2, c1 = oracle.covs_to_colmajor9(c["cov2"]), oracle.covs_to_colmajor9(c["cov1"])
+        for i in range(len(c["f1"])):
+            r = oracle.residual(oracle.MODE_SYM, c["f1"][i], c["f2"][i], c2[i], c1[i], reg, th, ph, q)
+            assert r * r == pytest.approx(float(c["sym_r2"][i]), rel=1e-8, abs=1e-30)
+            n_sym += 1
+        got = oracle.energy(oracle.MODE_SYM, c["f1"], c["f2"], c["cov2"], c["cov1"], reg, R, t)
+        assert got == pytest.approx(float(c["sym_r2"].sum()), rel=1e-9)
+    assert n_host == 24 and n_sym == 24 // 2 * (12 + 40)
+
+
 def test_functor_variants_against_literal_numpy(oracle):
     """Host / Target / Symmetric / NEC functors (pnec_residual.h:66-70,97-102,133-140)."""
     rng = np.random.default_rng(5)

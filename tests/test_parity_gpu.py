@@ -87,6 +87,31 @@ def test_objective_matches_reference_goldens(golden_dir):
     assert checked == 36 * 8
 
 
+def test_host_and_symmetric_objectives_match_numbers_the_reference_python_returned(golden_dir):
+    """The DEVICE's 1/2 sum r^2 for the Host and Symmetrical functors (max_num_iterations = 0 returns the cost at the start
+    pose) against tests/golden/residual_forms_golden.npz -- numbers scripts/pnec/common.py returned for the transformed
+    inputs at which its target energy is those functors' (tests/golden/make_golden.py)."""
+    from oracle import pnec_oracle as po
+    z = np.load(f"{golden_dir}/residual_forms_golden.npz")
+    opts = capi.default_options(max_num_iterations=0)
+    n = int(z["n_cases"])
+    for i in range(n):
+        k = f"form{i:03d}_"
+        f1, f2, c1, c2, R, t = (z[k + a] for a in ("f1", "f2", "cov1", "cov2", "R", "t"))
+        reg = float(z[k + "reg"])
+        q0, t0 = po.quat_from_rot(R)[None], t[None]
+        off = np.array([0, len(f1)], dtype=np.int64)
+        with Batch(capi.MODE_HOST, off) as b:
+            b.fill(f1, f2, c1)
+            res = b.solve(q0, t0, reg=reg, options=opts)
+        np.testing.assert_allclose(2.0 * res.cost, [float(z[k + "host_energy"])], rtol=1e-9)
+        with Batch(capi.MODE_SYM, off) as b:
+            b.fill(f1, f2, c2, c1)
+            res = b.solve(q0, t0, reg=reg, options=opts)
+        np.testing.assert_allclose(2.0 * res.cost, [float(z[k + "sym_r2"].sum())], rtol=1e-9)
+    assert n == 24
+
+
 @pytest.mark.parametrize("mode", [capi.MODE_NEC, capi.MODE_TARGET, capi.MODE_HOST, capi.MODE_SYM])
 @pytest.mark.parametrize("n_corr", [10, 100, 512])
 def test_lm_parity_with_oracle(oracle, mode, n_corr):
