@@ -1,3 +1,6 @@
+"""One whole-chain PNEC::Solve per call from Python (pnec_amd.frame.FrameSolver.solve_raw, no marshalling): the C++ demo's
+kind of pair (simulated, 512 correspondences) under schemes 2 and 0, then 300 frames of the bench's KITTI-like sequence
+under scheme 2 -- to tell the Python loop's cost (~10 us) from the workload's (NOTES/round-6.md 6).  Run on the GPU box."""
 import sys, os, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
