@@ -637,6 +637,82 @@ def chain_stage_times(batch, q0, t0, reps=3):
     return acc, res, sel, sel_payload
 
 
+def lockstep_sequences(device, capi, tk, quick=False, check_steps=12, scheme=2):
+    """The KITTI-like set's sequences advanced side by side: -> dict(wall_s, steps, sequences, pairs, q [P,4] in the set's
+    pair order, bitwise_equal_to_one_call_per_frame, n_compared)."""
+    import torch
+
+    from pnec_amd import Batch
+    from pnec_amd.frame import FrameSolver
+    frames = tk.KITTI_FRAMES if not quick else tuple(max(2, f // 12) for f in tk.KITTI_FRAMES)
+    sizes = tk.kitti_all_sizes(frames=frames)
+    P = int(len(sizes))
+    tr = tk.kitti_all_shard(0, P, device=device, frames=frames, outlier_frac=0.10)
+    seq = np.asarray(tr.sequence)
+    lens = np.array([f - 1 for f in frames])
+    order = np.argsort(-lens, kind="stable")                   # longest sequence first: the running ones are a prefix
+    start = np.concatenate([[0], np.cumsum(lens)])
+    T = int(lens.max())
+    step_pairs = [np.array([start[s] + k for s in order if lens[s] > k], dtype=np.int64) for k in range(T)]
+    off = np.asarray(tr.offsets, dtype=np.int64)
+    # the correspondences regrouped step by step (a gather on the device, once): step k's pairs are contiguous
+    flat = np.concatenate(step_pairs)
+    cnt = np.diff(off)[flat]
+    src = torch.as_tensor(np.concatenate([np.arange(off[p], off[p + 1]) for p in flat]), device=device)
+    f1, f2, cv = tr.bvs1[src].contiguous(), tr.bvs2[src].contiguous(), tr.covs[src].contiguous()
+    step_off = np.concatenate([[0], np.cumsum([len(sp) for sp in step_pairs])])
+    corr_off = np.concatenate([[0], np.cumsum(cnt)])
+    S = len(frames)
+    q_out = torch.zeros(P, 4, dtype=torch.float64, device=device)
+    flat_t = torch.as_tensor(flat, device=device)
+    popts = capi.default_pipeline_options(eigensolver_scheme=scheme)
+    wall = None
+    with Batch.with_capacity(capi.MODE_TARGET, S, int(S * (np.diff(off).max() + 64)), device=device.index) as b:
+        for rep in range(2):                                   # the first pass warms the batch's scratch
+            q_prev = torch.zeros(S, 4, dtype=torch.float64, device=device)
+            q_prev[:, 3] = 1.0
+            t_prev = torch.zeros(S, 3, dtype=torch.float64, device=device)
+            t_prev[:, 2] = 1.0
+            outs = []
+            torch.cuda.synchronize()
+            t_0 = time.perf_counter()
+            for k in range(T):
+                a, e = int(step_off[k]), int(step_off[k + 1])
+                n = e - a
+                ca, ce = int(corr_off[a]), int(corr_off[e])
+                b.reshape(np.concatenate([[0], np.cumsum(cnt[a:e])]))
+                b.fill(f1[ca:ce], f2[ca:ce], cv[ca:ce])
+                popts.first_pair_id = a                        # RANSAC draws keyed by the pair's place in this order
+                q_prev, t_prev = b.solve_pipeline(q_prev[:n].contiguous(), t_prev[:n].contiguous(), options=popts)
+                outs.append(q_prev)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t_0
+        q_steps = torch.cat(outs)
+    q_out[flat_t] = q_steps
+    # the same frames one call per frame, for the first steps of every sequence: same start poses, same pair ids
+    equal, n_cmp = True, 0
+    q_steps_h = q_steps.cpu().numpy()
+    f1h, f2h = f1.cpu().numpy(), f2.cpu().numpy()
+    c9 = np.ascontiguousarray(np.transpose(cv.cpu().numpy(), (0, 2, 1)).reshape(-1, 9))
+    with FrameSolver(max_corr=int(np.diff(off).max()), device=device.index) as fs:
+        o1 = capi.default_pipeline_options(eigensolver_scheme=scheme)
+        oq, ot, mask = np.zeros(4), np.zeros(3), np.zeros(int(np.diff(off).max()), dtype=np.uint8)
+        prev = {}
+        for k in range(min(check_steps, T)):
+            a, e = int(step_off[k]), int(step_off[k + 1])
+            for i in range(e - a):
+                j = a + i
+                qi, ti = prev.get(i, (np.array([0.0, 0.0, 0.0, 1.0]), np.array([0.0, 0.0, 1.0])))
+                o1.first_pair_id = j
+                ca, ce = int(corr_off[j]), int(corr_off[j + 1])
+                fs.solve_raw(ce - ca, f1h[ca:ce], f2h[ca:ce], c9[ca:ce], qi, ti, o1, oq, ot, mask)
+                equal = equal and bool(np.array_equal(oq, q_steps_h[j]))
+                prev[i] = (oq.copy(), ot.copy())
+                n_cmp += 1
+    return {"wall_s": wall, "steps": T, "sequences": S, "pairs": P, "q": q_out, "bitwise_equal_to_one_call_per_frame": equal,
+            "n_compared": n_cmp}
+
+
 def secondary_lines(device, capi, quick=False):
     """BASELINE configs 3, 4, 5 and the whole PNEC::Solve chain on this GPU, each {workload, value, unit, ms_per_step,
     roofline, parity}; an entry that fails reports its error instead of taking the headline down with it."""
@@ -989,7 +1065,28 @@ def secondary_lines(device, capi, quick=False):
                            "note": "the batched call's parity against the oracle's chain: the chain entry above and "
                                    "tests/test_chain_scale_gpu.py"}}
 
-    for fn in (kitti_all_refinement, kitti_all_chain, multi_hypothesis, kitti00_streamed, kitti00_per_frame_chain):
+    def kitti_all_sequences_in_lockstep():
+        # configs[4] the way an odometry would run it on ONE device: the eleven sequences advance side by side -- the
+        # reference fans them out as processes (scripts/parallel_kitti.sh:60-69) -- one batched PNEC::Solve per time step over
+        # the sequences still running, and every start pose is the previous step's result of the same sequence
+        # (frame_processing.cc:57-145) WITHOUT leaving the device: step k + 1's call takes step k's output tensors as its
+        # init poses, everything is enqueued on one stream, the host never waits for a pose.
+        res = lockstep_sequences(device, capi, tk, quick)
+        return {"workload": "configs[4] as eleven odometry runs in lockstep on one GPU: all KITTI 00-10 frame pairs (23 190, synthetic "
+                            "stand-in, 10 % gross mismatches), one batched whole-chain PNEC::Solve (scheme 2) per time step over the "
+                            "sequences still running, every start pose = the previous step's result of that sequence, chained ON THE "
+                            "DEVICE (no host round trip between steps)",
+                "value": res["pairs"] / res["wall_s"], "unit": "pairs/s", "ms_per_step": res["wall_s"] / res["steps"] * 1e3,
+                "time_steps": res["steps"], "sequences": res["sequences"], "pairs": res["pairs"],
+                "roofline": {"bound": "latency", "note": "a time step is a batch of <= 11 pairs: one wavefront per pair and stage, five "
+                                                         "dependent launches; bounded by a stage's sequential trips, not by a device roof"},
+                "parity": {"bitwise_equal_to_one_call_per_frame": res["bitwise_equal_to_one_call_per_frame"],
+                           "n_pairs_compared": res["n_compared"],
+                           "note": "the first steps of every sequence re-run one frame per call (pnec_hip_frame_solve) with the same "
+                                   "start poses and RANSAC pair ids"}}
+
+    for fn in (kitti_all_refinement, kitti_all_chain, multi_hypothesis, kitti00_streamed, kitti00_per_frame_chain,
+               kitti_all_sequences_in_lockstep):
         guarded(fn)
     return out
 

@@ -69,6 +69,36 @@ class Batch:
     def uniform(cls, mode: int, n_pairs: int, n_corr: int, device: int = 0) -> "Batch":
         return cls(mode, np.arange(n_pairs + 1, dtype=np.int64) * n_corr, device)
 
+    @classmethod
+    def with_capacity(cls, mode: int, max_pairs: int, max_corr: int, device: int = 0) -> "Batch":
+        """A batch that is shaped again and again without allocating (pnec_hip_problem_create_capacity): room for up to
+        max_pairs pairs / max_corr correspondences in total, created empty; give it a shape with reshape(), then fill."""
+        b = cls.__new__(cls)
+        b._lib = capi.lib()
+        b.mode, b.device = int(mode), int(device)
+        h = C.c_void_p()
+        capi.check(b._lib.pnec_hip_problem_create_capacity(b.device, b.mode, int(max_pairs), int(max_corr), C.byref(h)))
+        b._h = h
+        b.n_pairs = 0
+        b._offsets = np.zeros(1, dtype=np.int64)
+        return b
+
+    def reshape(self, offsets) -> "Batch":
+        """A new shape for a capacity batch (pnec_hip_problem_reshape), asynchronous on torch's current stream: work queued
+        earlier still sees the old shape; the planes hold garbage until filled."""
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        stream = None
+        try:
+            import torch
+            if torch.cuda.is_available():
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+        except ImportError:
+            pass
+        capi.check(self._lib.pnec_hip_problem_reshape(self._h, len(off) - 1, off.ctypes.data, stream))
+        self._offsets = off
+        self.n_pairs = len(off) - 1
+        return self
+
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

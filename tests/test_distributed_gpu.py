@@ -276,11 +276,11 @@ def test_default_bench_line_carries_the_other_configs_and_the_chain():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["metric"].startswith("PNEC pose solves/sec") and line["value"] > 1e6 and "roofline" in line and "cpu_baseline" in line
     sec = line["secondary"]
-    assert len(sec) == 5 and not any("error" in e for e in sec), [e.get("error") for e in sec]
+    assert len(sec) == 6 and not any("error" in e for e in sec), [e.get("error") for e in sec]
     for e in sec:
         assert e["value"] > 0 and e["unit"] in ("solves/s", "pairs/s") and e["ms_per_step"] > 0 and "roofline" in e
         p = e["parity"]
-        assert p.get("max_rot_err_rad", 0.0) <= 1e-6 and p.get("bitwise_equal_to_the_batched_call", True)
+        assert p.get("max_rot_err_rad", 0.0) <= 1e-6 and p.get("bitwise_equal_to_the_batched_call", True) and p.get("bitwise_equal_to_one_call_per_frame", True)
     chain = sec[1]
     assert chain["parity"]["inlier_masks_identical"] and [b["bound"] for b in chain["roofline"]] == ["valu_fp64", "valu_fp64", "hbm"]
     assert all(b["frac"] is not None and 0 < b["frac"] < 1 for b in chain["roofline"])

@@ -116,3 +116,21 @@ def test_capacity_shaped_batch_reshapes_without_reallocating_and_matches_fresh_b
     finally:
         L.pnec_hip_problem_destroy(h)
     torch.cuda.synchronize()
+
+
+def test_sequences_in_lockstep_with_device_chained_starts_equal_one_call_per_frame():
+    """bench.py's `kitti_all_sequences_in_lockstep`: the sequences of the KITTI-like set advance side by side, one batched
+    whole-chain call per time step on a capacity batch that is re-shaped and re-filled per step (Batch.with_capacity /
+    reshape), every start pose the previous step's OUTPUT TENSOR of the same sequence -- nothing returns to the host
+    between steps.  A short version (sequence lengths / 12): every pose of the first 12 steps equals, bit for bit, the
+    same frame solved alone through pnec_hip_frame_solve with the same start pose and RANSAC pair id; all poses finite,
+    every sequence ran to its end."""
+    import torch
+    import bench
+    from pnec_amd import capi
+    from pnec_amd import tracks as tk
+    r = bench.lockstep_sequences(torch.device("cuda:0"), capi, tk, quick=True, check_steps=12)
+    assert r["bitwise_equal_to_one_call_per_frame"] and r["n_compared"] >= 12 * 9
+    assert r["sequences"] == 11 and r["pairs"] == sum(max(2, f // 12) - 1 for f in tk.KITTI_FRAMES)
+    q = r["q"]
+    assert bool(torch.isfinite(q).all()) and float(((q * q).sum(-1) - 1).abs().max()) < 1e-12
