@@ -2,13 +2,13 @@
 """Several t-hat starts per pair on pairs that fit ONE wavefront (N <= 512): hypothesis-solves/s for H = 1, 2, 4, 16 at a
 fixed number of solves (100 000), ten LM iterations.  With PNEC_SOLVE_GROUPS=0 every (pair, hypothesis) is a block of its
 own (round 5); by default two hypotheses of a pair share a wavefront (lm_solve_pairhyp_kernel).
-   python tools/bench_multihyp_small.py [corr] [solves]"""
+   python tools/bench_multihyp_small.py [corr] [solves]   (also for larger pairs: the several-wavefront group form)"""
 import json, os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from pnec_amd import Batch, capi, simulation as sim
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-S = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
+S = int(sys.argv[2]) if len(sys.argv) > 2 else max(4096, 100_000 * 512 // max(N, 512))
 dev = torch.device("cuda:0")
 out = {"corr": N, "solves": S, "PNEC_SOLVE_GROUPS": os.environ.get("PNEC_SOLVE_GROUPS", "1"), "rates_M_per_s": {}}
 opts = capi.default_options(max_num_iterations=10, check_convergence=0)
