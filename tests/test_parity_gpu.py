@@ -946,3 +946,33 @@ def test_multi_hypothesis_group_form_is_bitwise_the_one_solve_per_block_form(mod
                     assert torch.equal(got, want), (kw, h, name, got, want)
             if kw == dict():
                 assert len(set(res.iterations.cpu().numpy().tolist())) > 1     # the groups did hold solves of different lengths
+
+
+def test_multi_hypothesis_on_a_ragged_batch_runs_every_form_side_by_side():
+    """A ragged batch is solved as one launch per geometry in use (side streams, a table of the pairs each launch covers).
+    With several starts per pair that means, in ONE call: two hypotheses per wavefront on the small pairs
+    (lm_solve_pairhyp_kernel), the one-solve-per-block kernel on the pairs of 513..768 (the tail form (12, 1, 3) has no
+    multi-hypothesis twin), and a block per pair and group of 2 / 4 / 8 hypotheses on the larger ones
+    (lm_solve_group_kernel) -- every (pair, hypothesis) bit for bit the same solve made alone."""
+    sizes = np.array([40, 64, 100, 300, 512, 513, 700, 768, 769, 1024, 1500, 2048, 2100, 4096, 17, 511, 3000, 640], dtype=np.int64)
+    P, H = len(sizes), 5
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    g = sim.generate(P, int(sizes.max()), seed=777, device="cuda:0")
+    keep = torch.arange(int(sizes.max()), device="cuda:0")[None, :] < torch.as_tensor(sizes, device="cuda:0")[:, None]
+    f1, f2, cv = g.bvs1[keep], g.bvs2[keep], g.covs2[keep]
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(3)
+    hyp = torch.randn(P * H, 3, generator=gen, dtype=torch.float64, device="cuda:0")
+    hyp = hyp / hyp.norm(dim=1, keepdim=True)
+    hyp[::H] = g.init_t
+    with Batch(capi.MODE_TARGET, off) as b:
+        b.fill(f1, f2, cv)
+        for kw in (dict(max_num_iterations=10, check_convergence=0), dict()):
+            opts = capi.default_options(**kw)
+            res = b.solve(g.init_q, None, options=opts, hyp_t=hyp, n_hyp=H)
+            torch.cuda.synchronize()
+            for h in range(H):
+                one = b.solve(g.init_q, None, options=opts, hyp_t=hyp[h::H].contiguous(), n_hyp=1)
+                for name in ("q", "t", "cost", "iterations", "status"):
+                    assert torch.equal(getattr(res, name)[h::H], getattr(one, name)), (kw, h, name)
+            assert torch.isfinite(res.q).all()
