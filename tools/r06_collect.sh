@@ -19,6 +19,7 @@ cp $G/pipeline_pmc_scheme2.txt profiles/r06_pipeline_pmc_scheme2.txt
 cp $G/bench.json profiles/r06_bench.json
 cp $G/config4_group_form_ab.jsonl profiles/r06_config4_group_form_ab.jsonl
 cp $G/numeric_jacobian_config4.jsonl profiles/r06_numeric_jacobian_config4.jsonl
+[ -f $G/config4_pmc.txt ] && cp $G/config4_pmc.txt profiles/r06_config4_pmc.txt
 for s in 0 1 2; do cp $G/pipeline_scheme$s.json profiles/r06_pipeline_stages_scheme$s.json; done
 for f in bench_kitti bench_kitti_chain bench_kitti_chain_scheme0 pipeline_100k pipeline_kitti pipeline_parity_100k streaming odometry_options_parity \
          bench_single_process_1x bench_single_process_2x; do [ -f $G/$f.json ] && cp $G/$f.json profiles/r06_$f.json; done

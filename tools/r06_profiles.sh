@@ -19,6 +19,7 @@ bash tools/pmc_pipeline.sh r06 > $OUT/pipeline_pmc.txt 2>&1
 # 3. config 4 (multi-hypothesis): one-solve-per-block against the group form, same box
 for g in 0 1; do PNEC_SOLVE_GROUPS=$g python tools/ab_config4.py 2>/dev/null | grep '^{' | sed "s/^{/{\"PNEC_SOLVE_GROUPS\": $g, /"; done > $OUT/config4_group_form_ab.jsonl
 python tools/verify_numeric_jacobian.py $OUT/numeric_jacobian_config4.jsonl > /dev/null 2>&1
+bash tools/pmc_config4.sh r06 > $OUT/config4_pmc.txt 2>&1
 if [ -z "$QUICK" ]; then
 python tools/bench_pipeline.py 100000 512 2 > $OUT/pipeline_100k.json 2> /dev/null
 PNEC_ES_SCHEME=2 python tools/bench_pipeline_kitti.py > $OUT/pipeline_kitti.json 2> /dev/null
