@@ -69,13 +69,13 @@ FLOP_PER_CORR_COST_PASS = 67
 # iterations per hypothesis, where a model is dropped); it is counted once by a -DPNEC_WORK_COUNT build of the library
 # (tools/count_chain_work.py -> profiles/chain_work_latest.json) and combined here with the live stage times.
 # One evaluation of the eigenvalue function at ONE point (es_value_grad): the rotation from the Cayley vector 47, M from the
-# 36 sums 411, the smallest eigenpair by Rayleigh-quotient iteration ~274 (2.9 steps on average, counted in round 4), the
-# gradient 292 = e x r_l 27 + three q_k = (sum_l G_kl y_l) x e 189 + 1 / (1 + |v|^2) 13 + the contraction with dR/dv 63
-# (round 4's commit 2b406fe contracts dN_j . Q term by term: 63 flop where the three explicit matrices took ~165; until
-# round 5 this constant still said 391 for the gradient).  Cross-check against the compiled code: tools/isa_front_regions.py
-# counts the FP64 instructions of the pieces as kernels of their own -- rotation 51, M 390, gradient (evaluation with minus
-# without) 356 flop: the straight-line pieces within 6 % of the model's 750 (tests/test_bench_launch_cpu.py holds it there).
-FLOP_ES_POINT = 47 + 411 + 274 + 292
+# 36 sums 339 (compose_m, round 6: M = S + S', six blocks x 18 FMA + three x 18 FMA + 9 halvings + 6 additions; the block
+# form until then took 411), the smallest eigenpair by Rayleigh-quotient iteration ~274 (2.9 steps on average, counted in
+# round 4), the gradient 292 = e x r_l 27 + three q_k = (sum_l G_kl y_l) x e 189 + 1 / (1 + |v|^2) 13 + the contraction
+# with dR/dv 63.  Cross-check against the compiled code: tools/isa_front_regions.py counts the FP64 instructions of the
+# pieces as kernels of their own -- rotation 51, M 339, gradient (evaluation with minus without) 327 flop: the
+# straight-line pieces within 6 % of the model's 678 (tests/test_bench_launch_cpu.py holds it there).
+FLOP_ES_POINT = 47 + 339 + 274 + 292
 FLOP_ES_QUAD_EVAL = 4 * FLOP_ES_POINT + 160   # a quad's trip: four points + the iteration's head
 FLOP_SCORE_CORR = 117                # reprojection score of one correspondence against one model
 FLOP_INLIER_CORR = 117 + 84          # ... + its 36 sums when it is an inlier
@@ -126,7 +126,7 @@ def chain_stage_rooflines(counts, stage_ms, payload_bytes, inlier_payload_bytes,
 FRONT_KERNEL_SOURCES = ("pnec_frontend.hip", "pnec_es_schemes.inl", "pnec_device.hpp", "pnec_front_shared.hpp")
 # sha256 (front_sources_sha256) of the sources the FLOP_* table above was last derived from / cross-checked against
 # (tools/isa_front_regions.py); tests/test_bench_launch_cpu.py fails when the sources move on without it
-FRONT_FLOP_MODEL_STAMP = "cd29963804527ac4b3ea2f2bc99f34f6bc6d8a13b9486e3d3a669da17293171f"
+FRONT_FLOP_MODEL_STAMP = "7d90b195df45536446d4c882d70e6162c27ea6cf7063674104421128bbab5409"
 
 
 def front_sources_sha256():

@@ -366,13 +366,55 @@ __device__ __forceinline__ void cross3(const double (&a)[3], const double (&b)[3
   c[2] = a[0] * b[1] - a[1] * b[0];
 }
 
+// M = sum_kl [r_k]x G_kl [r_l]x' from the 36 sums and the columns r_k of the rotation, as M = S + S' with
+//   S = sum_k [r_k]x C_k,   C_k = G_kk [r_k / 2]x' + sum_{l > k} G_kl [r_l]x'
+// (X_lk = X_kl' because the blocks are symmetric, and X_kk is symmetric).  Row i of G [b]x' is b x (row i of G), column j
+// of [a]x C is a x (column j of C): every term is a cross product ACCUMULATED into its target -- two fused multiply-adds
+// per component and nothing else: 6 blocks x 18 + 3 x 18 + 9 halvings + 6 additions = 177 instructions.  (Until round 6
+// block by block, X_kl = [r_k]x G_kl [r_l]x' for k <= l and M += X_kl (+ X_kl') with the sums of the blocks as separate
+// additions and a symmetrisation at the end: 310.)  The same matrix, symmetric by construction; last bits differ.
+__device__ __forceinline__ void compose_m(const double (&Gr)[36], const double (&r)[3][3], double (&M)[9]) {
+  double S[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) S[i] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double Ck[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Ck[i][0] = Ck[i][1] = Ck[i][2] = 0.0;
+#pragma unroll
+    for (int l = k; l < 3; ++l) {
+      const double *Gp = Gr + 6 * s3(k, l);
+      const double h = (l == k) ? 0.5 : 1.0;
+      const double rx = h * r[l][0], ry = h * r[l][1], rz = h * r[l][2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double g0 = Gp[s3(i, 0)], g1 = Gp[s3(i, 1)], g2 = Gp[s3(i, 2)];   // row i of the symmetric G_kl
+        Ck[i][0] = __builtin_fma(ry, g2, __builtin_fma(-rz, g1, Ck[i][0]));
+        Ck[i][1] = __builtin_fma(rz, g0, __builtin_fma(-rx, g2, Ck[i][1]));
+        Ck[i][2] = __builtin_fma(rx, g1, __builtin_fma(-ry, g0, Ck[i][2]));
+      }
+    }
+    const double kx = r[k][0], ky = r[k][1], kz = r[k][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double c0 = Ck[0][j], c1 = Ck[1][j], c2 = Ck[2][j];              // column j of C_k
+      S[j] = __builtin_fma(ky, c2, __builtin_fma(-kz, c1, S[j]));
+      S[3 + j] = __builtin_fma(kz, c0, __builtin_fma(-kx, c2, S[3 + j]));
+      S[6 + j] = __builtin_fma(kx, c1, __builtin_fma(-ky, c0, S[6 + j]));
+    }
+  }
+  M[0] = S[0] + S[0]; M[4] = S[4] + S[4]; M[8] = S[8] + S[8];
+  M[1] = M[3] = S[1] + S[3];
+  M[2] = M[6] = S[2] + S[6];
+  M[5] = M[7] = S[5] + S[7];
+}
+
 // lambda_min(M(R(v))) from the 36 sums, optionally its gradient w.r.t. the Cayley vector (e' dM e).
 // M_out (row-major) is the composed matrix.  The 36 sums are read as G[i * GS]: GS = 1 for a
 // table shared by the wavefront, GS = 64 for one table per lane interleaved in LDS (RANSAC).
 //   M = sum_kl [r_k]x G_kl [r_l]x'   (G_kl symmetric 3x3, G_lk = G_kl)
-//     = sum_k X_kk + sum_{k<l} (X_kl + X_kl'),   X_kl = [r_k]x G_kl [r_l]x'
-// with the skew products written as cross products: row j of [a]x G is a x g_j (g_j = row j of the
-// symmetric G, transposed into place), and row i of T [b]x' is b x T_i.
+//   composed by compose_m above.
 // ew (optional): on entry the eigenvector of the smallest eigenvalue at a nearby point (`warm`), on
 // exit the one at this point -- Rayleigh-quotient iteration from it instead of Jacobi sweeps from
 // scratch (sym_eig3_min_rqi; falls back to the sweeps when it cannot vouch for the result).
@@ -404,44 +446,7 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
     r[k][0] = R[k]; r[k][1] = R[3 + k]; r[k][2] = R[6 + k];
   }
   double M[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) M[i] = 0.0;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-#pragma unroll
-    for (int l = k; l < 3; ++l) {
-      const double *Gp = Gr + 6 * s3(k, l);
-      // T = [r_k]x G: column j of T = r_k x (column j of G); stored by columns
-      double Tc[3][3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const double gj[3] = {Gp[s3(0, j)], Gp[s3(1, j)], Gp[s3(2, j)]};
-        cross3(r[k], gj, Tc[j]);
-      }
-      // X = T [r_l]x': row i of X = r_l x (row i of T)
-      double X[3][3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const double Ti[3] = {Tc[0][i], Tc[1][i], Tc[2][i]};
-        cross3(r[l], Ti, X[i]);
-      }
-      if (k == l) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) M[3 * i + j] += X[i][j];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) M[3 * i + j] += X[i][j] + X[j][i];
-      }
-    }
-  }
-  // symmetrise (rounding)
-  M[1] = M[3] = 0.5 * (M[1] + M[3]);
-  M[2] = M[6] = 0.5 * (M[2] + M[6]);
-  M[5] = M[7] = 0.5 * (M[5] + M[7]);
+  compose_m(Gr, r, M);
   if (M_out) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) M_out[i] = M[i];
@@ -495,8 +500,8 @@ __device__ double es_value_grad(const double *G, const double (&v)[3], double *g
     for (int l = 0; l < 3; ++l) {
       const double *Gp = Gr + 6 * s3(k, l);
 #pragma unroll
-      for (int a = 0; a < 3; ++a)
-        z[a] += Gp[s3(a, 0)] * y[l][0] + Gp[s3(a, 1)] * y[l][1] + Gp[s3(a, 2)] * y[l][2];
+      for (int a = 0; a < 3; ++a)   // (one chain of fused multiply-adds per component: round 6)
+        z[a] = __builtin_fma(Gp[s3(a, 0)], y[l][0], __builtin_fma(Gp[s3(a, 1)], y[l][1], __builtin_fma(Gp[s3(a, 2)], y[l][2], z[a])));
     }
     cross3(z, e, q[k]);
   }
@@ -534,31 +539,7 @@ __device__ __forceinline__ void sums_to_m(const double (&Gr)[36], const double (
   for (int k = 0; k < 3; ++k) {
     r[k][0] = R[k]; r[k][1] = R[3 + k]; r[k][2] = R[6 + k];
   }
-#pragma unroll
-  for (int i = 0; i < 9; ++i) M[i] = 0.0;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-#pragma unroll
-    for (int l = k; l < 3; ++l) {
-      const double *Gp = Gr + 6 * s3(k, l);
-      double Tc[3][3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const double gj[3] = {Gp[s3(0, j)], Gp[s3(1, j)], Gp[s3(2, j)]};
-        cross3(r[k], gj, Tc[j]);
-      }
-      double X[3][3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const double Ti[3] = {Tc[0][i], Tc[1][i], Tc[2][i]};
-        cross3(r[l], Ti, X[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) M[3 * i + j] += (k == l) ? X[i][j] : X[i][j] + X[j][i];
-    }
-  }
+  compose_m(Gr, r, M);
 }
 
 // 3x3 Cholesky solve with reciprocal square roots (v_rsq_f64 + refinement) in place of the IEEE

@@ -165,7 +165,7 @@ def test_front_flop_model_and_work_counts_belong_to_the_committed_front_stage_co
     import isa_front_regions
     r = isa_front_regions.count()
     straight = r["cayley"]["flop"] + r["m"]["flop"] + (r["with_gradient"]["flop"] - r["value_only"]["flop"])
-    model = 47 + 411 + 292
+    model = 47 + 339 + 292
     assert abs(straight - model) <= 0.10 * model, (straight, model, r)
     assert bench.FLOP_ES_POINT == model + 274 and bench.FLOP_ES_QUAD_EVAL == 4 * bench.FLOP_ES_POINT + 160
 

@@ -3,7 +3,7 @@
 pnec_frontend.hip): the file is compiled to assembly with -DPNEC_ISA_PROBE, which adds four tiny kernels -- the rotation
 from the Cayley vector, M from the 36 sums, the whole evaluation with and without its gradient -- and their FP64
 instructions are counted (v_fma / v_fmac = 2 flop, v_mul / v_add / v_rcp / v_rsq = 1).  This is the cross-check of
-bench.py's flop model FLOP_ES_POINT = Cayley 47 + M 411 + eigenpair ~274 + gradient 290: the straight-line pieces must
+bench.py's flop model FLOP_ES_POINT = Cayley 47 + M 339 + eigenpair ~274 + gradient 292: the straight-line pieces must
 come out at the model's numbers (the eigenpair part is a loop; its static count is one trip of each of its paths and is
 printed for reference only); `--json` prints {"cayley":, "m":, "gradient":, "evaluation_static":} for the CPU test
 (tests/test_bench_launch_cpu.py).   python tools/isa_front_regions.py [--json]"""
