@@ -57,8 +57,8 @@ __device__ __forceinline__ void lm_backward(const LmChol3 &L, const double (&z)[
   x[0] = (z[0] - L.l10 * x[1] - L.l20 * x[2]) * L.i0;
 }
 __device__ __forceinline__ double lm_nrm3(const double (&a)[3]) { return fast_sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
-__device__ __forceinline__ void lm_par3(const double (&A)[9], const double (&b)[3], const double (&diag)[3], double delta,
-                                        double &par, double (&x)[3]) {
+__device__ __forceinline__ double lm_par3(const double (&A)[9], const double (&b)[3], const double (&diag)[3], double delta,
+                                          double par, double (&x)[3]) {
   const double dwarf = 2.2250738585072014e-308;
   LmChol3 L;
   double z[3], wa1[3], wa2[3];
@@ -74,7 +74,7 @@ __device__ __forceinline__ void lm_par3(const double (&A)[9], const double (&b)[
   for (int j = 0; j < 3; ++j) wa2[j] = diag[j] * x[j];
   dxnorm = lm_nrm3(wa2);
   fp = dxnorm - delta;
-  if (full_rank && fp <= 0.1 * delta) { par = 0.0; return; }
+  if (full_rank && fp <= 0.1 * delta) return 0.0;
   const double inv_delta = fast_rcp(delta);
   if (full_rank) {
     const double inv_dx = fast_rcp(dxnorm);
@@ -103,7 +103,7 @@ __device__ __forceinline__ void lm_par3(const double (&A)[9], const double (&b)[
     for (int j = 0; j < 3; ++j) Ap[4 * j] += par * diag[j] * diag[j];
     if (!lm_chol3(Ap, Lp)) {
       x[0] = x[1] = x[2] = 0.0;
-      return;
+      return par;
     }
     lm_forward(Lp, b, z);
     lm_backward(Lp, z, x);
@@ -122,6 +122,7 @@ __device__ __forceinline__ void lm_par3(const double (&A)[9], const double (&b)[
     if (fp < 0.0) paru = fmin(paru, par);
     par = fmax(parl, par + parc);
   }
+  return par;
 }
 
 // WK: which work counter the quad-evaluations belong to (a -DPNEC_WORK_COUNT build only; tools/count_chain_work.py)
@@ -371,7 +372,7 @@ __device__ __forceinline__ int es_minimise_queue_alt(int n_tasks, const int *tli
           }
           if (!done) {
             double pl[3];
-            lm_par3(A, b, ldiag, l_delta, l_par, pl);
+            l_par = lm_par3(A, b, ldiag, l_delta, l_par, pl);
 #pragma unroll
             for (int j = 0; j < 3; ++j) lp[j] = -pl[j];
             const double dp[3] = {ldiag[0] * lp[0], ldiag[1] * lp[1], ldiag[2] * lp[2]};

@@ -153,30 +153,36 @@ __device__ void sym_eig3_impl(const double (&A_in)[9], double (&w)[3], double (&
       }
     }
   }
-  const double d[3] = {A[0], A[4], A[8]};
-  int i0 = 0, i1 = 1, i2 = 2;
-  if (d[i0] > d[i1]) { const int t = i0; i0 = i1; i1 = t; }
-  if (d[i1] > d[i2]) { const int t = i1; i1 = i2; i2 = t; }
-  if (d[i0] > d[i1]) { const int t = i0; i0 = i1; i1 = t; }
-  const int idx[3] = {i0, i1, i2};
-  double Vs[9];
+  // ascending eigenvalues, their columns moved with them: three compare-and-swaps on (value, column) with selects (an
+  // index permutation applied to V afterwards reads V by a run-time index, which puts the matrix in scratch memory)
+  double d0 = A[0], d1 = A[4], d2 = A[8];
+  double c0[3] = {V[0], V[3], V[6]}, c1[3] = {V[1], V[4], V[7]}, c2[3] = {V[2], V[5], V[8]};
+  auto cswap = [](double &da, double &db, double (&ca)[3], double (&cb)[3]) {
+    const bool sw = da > db;
+    const double ta = sw ? db : da, tb = sw ? da : db;
+    da = ta; db = tb;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const int j = idx[c];
-    const double v0 = (j == 0) ? V[0] : (j == 1 ? V[1] : V[2]);
-    const double v1 = (j == 0) ? V[3] : (j == 1 ? V[4] : V[5]);
-    const double v2 = (j == 0) ? V[6] : (j == 1 ? V[7] : V[8]);
-    w[c] = (j == 0) ? d[0] : (j == 1 ? d[1] : d[2]);
-    double big = v0;
-    if (fabs(v1) > fabs(big)) big = v1;
-    if (fabs(v2) > fabs(big)) big = v2;
+    for (int r = 0; r < 3; ++r) {
+      const double xa = sw ? cb[r] : ca[r], xb = sw ? ca[r] : cb[r];
+      ca[r] = xa; cb[r] = xb;
+    }
+  };
+  cswap(d0, d1, c0, c1);
+  cswap(d1, d2, c1, c2);
+  cswap(d0, d1, c0, c1);
+  auto put = [&](int c, double dv, const double (&col)[3]) {
+    w[c] = dv;
+    double big = col[0];
+    if (fabs(col[1]) > fabs(big)) big = col[1];
+    if (fabs(col[2]) > fabs(big)) big = col[2];
     const double sg = big < 0.0 ? -1.0 : 1.0;
-    Vs[c] = sg * v0;
-    Vs[3 + c] = sg * v1;
-    Vs[6 + c] = sg * v2;
-  }
-#pragma unroll
-  for (int i = 0; i < 9; ++i) V[i] = Vs[i];
+    V[c] = sg * col[0];
+    V[3 + c] = sg * col[1];
+    V[6 + c] = sg * col[2];
+  };
+  put(0, d0, c0);
+  put(1, d1, c1);
+  put(2, d2, c2);
 }
 __device__ void sym_eig3(const double (&A)[9], double (&w)[3], double (&V)[9]) { sym_eig3_impl<false>(A, w, V); }
 
@@ -911,6 +917,18 @@ enum : int { kPhSums = 0, kPhNewton, kPhTables, kPhSearch, kPhCost, kPhScf, kPhT
     }                                                                       \
   } while (0)
 
+// (the largest-diagonal cases are written out per i: indexing R by a run-time i put the CALLER's rotation -- nine doubles
+// that live across the whole kernel -- into scratch memory, loaded and stored once per outer iteration)
+template <int I>
+__device__ __forceinline__ void quat_from_rot_case(const double (&R)[9], double (&q)[4]) {
+  constexpr int J = (I + 1) % 3, K = (J + 1) % 3;
+  double t = sqrt(R[4 * I] - R[4 * J] - R[4 * K] + 1.0);
+  q[I] = 0.5 * t;
+  t = 0.5 / t;
+  q[3] = (R[3 * K + J] - R[3 * J + K]) * t;
+  q[J] = (R[3 * J + I] + R[3 * I + J]) * t;
+  q[K] = (R[3 * K + I] + R[3 * I + K]) * t;
+}
 __device__ __forceinline__ void quat_from_rot_dev(const double (&R)[9], double (&q)[4]) {
   const double tr = R[0] + R[4] + R[8];
   if (tr > 0.0) {
@@ -924,15 +942,9 @@ __device__ __forceinline__ void quat_from_rot_dev(const double (&R)[9], double (
     int i = 0;
     if (R[4] > R[0]) i = 1;
     if (R[8] > (i == 0 ? R[0] : R[4])) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    double t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
-    double qq[4];
-    qq[i] = 0.5 * t;
-    t = 0.5 / t;
-    qq[3] = (R[3 * k + j] - R[3 * j + k]) * t;
-    qq[j] = (R[3 * j + i] + R[3 * i + j]) * t;
-    qq[k] = (R[3 * k + i] + R[3 * i + k]) * t;
-    q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
+    if (i == 0) quat_from_rot_case<0>(R, q);
+    else if (i == 1) quat_from_rot_case<1>(R, q);
+    else quat_from_rot_case<2>(R, q);
   }
 }
 

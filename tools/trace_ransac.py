@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What the long wavefronts of the RANSAC launch are made of (runs on the GPU box): the pipeline benchmark's batch, one
 RANSAC call with PNEC_HIP_TRACE_FRONT=<path> (raw per-pair phase records), joined with the pairs' hypothesis counts.
-usage: trace_ransac.py [pairs] [out.json]"""
+usage: [PNEC_ES_SCHEME=0|1|2] trace_ransac.py [pairs] [out.json]"""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -14,6 +14,7 @@ from pnec_amd import Batch, capi, simulation as sim
 N = 512
 dev = torch.device("cuda:0")
 batch = Batch.uniform(capi.MODE_TARGET, B, N)
+batch.set_eigensolver_scheme(int(os.environ.get("PNEC_ES_SCHEME", "0")))
 qs = []
 for c in range(0, B, 5000):
     m = min(5000, B - c)
