@@ -675,31 +675,56 @@ __global__ __launch_bounds__(kWave) void mask_count_kernel(const uint8_t *__rest
   }
 }
 
-// exclusive prefix sum of the pair sizes -> AoS offsets [n+1] (one workgroup; n is at most a few 1e5)
+// exclusive prefix sum of the pair sizes -> AoS offsets [n+1] (one workgroup; n is at most a few 1e5).  Segments of
+// 32 x 1024 pairs: each thread takes up to 32 consecutive sizes, ALL of them requested before the first is used; the 1024
+// partial sums are scanned by shuffles inside the sixteen wavefronts + one scan of their totals.  (Until round 6: one
+// dependent load after the other per thread, twice, and thread 0 walking the 1024 partial sums alone -- ~40 us on the
+// chain's critical path in every call.)
 __global__ __launch_bounds__(1024) void offsets_scan_kernel(const int32_t *__restrict__ count,
                                                             int64_t *__restrict__ offsets, int64_t n) {
-  __shared__ long long part[1024];
-  const int t = threadIdx.x;
-  const int64_t per = (n + 1023) / 1024, a = std::min<int64_t>(n, per * t), b = std::min<int64_t>(n, a + per);
-  long long sacc = 0;
-  for (int64_t i = a; i < b; ++i) sacc += count[i];
-  part[t] = sacc;
-  __syncthreads();
-  if (t == 0) {
-    long long run = 0;
-    for (int i = 0; i < 1024; ++i) {
-      const long long v = part[i];
-      part[i] = run;
-      run += v;
+  constexpr int kPer = 32;
+  __shared__ long long wave_tot[17];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  long long carry = 0;
+  for (int64_t seg = 0; seg < n; seg += (int64_t)kPer * 1024) {
+    const int64_t m = std::min<int64_t>(n - seg, (int64_t)kPer * 1024);
+    const int64_t per = (m + 1023) / 1024, a = seg + std::min<int64_t>(m, per * t), b = seg + std::min<int64_t>(m, per * (t + 1));
+    int32_t c[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) c[k] = (a + k < b) ? count[a + k] : 0;
+    long long sacc = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) sacc += c[k];
+    long long inc = sacc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const long long o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
     }
-    offsets[n] = run;
+    __syncthreads();   // (the previous segment's totals have been read)
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+      const long long w = lane < 16 ? wave_tot[lane] : 0ll;
+      long long winc = w;
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const long long o = __shfl_up(winc, d, 64);
+        if (lane >= d) winc += o;
+      }
+      if (lane < 16) wave_tot[lane] = winc - w;
+      if (lane == 15) wave_tot[16] = winc;
+    }
+    __syncthreads();
+    long long run = carry + wave_tot[wave] + inc - sacc;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      if (a + k < b) offsets[a + k] = run;
+      run += c[k];
+    }
+    carry += wave_tot[16];
   }
-  __syncthreads();
-  long long run = part[t];
-  for (int64_t i = a; i < b; ++i) {
-    offsets[i] = run;
-    run += count[i];
-  }
+  if (t == 0) offsets[n] = carry;
 }
 
 // ---- device self-test kernels (cross-lane reduction, 5x5 solve) ---------------------------

@@ -2968,30 +2968,77 @@ hipError_t launch_select(int nc, const double *src, const int64_t *src_block, co
 // that did not (the finished partner's slot group is lent to the long pair); the rest follow in batch order.  Any
 // content of `prev` gives a permutation; results do not depend on the order (draws belong to the pair's global index).
 __global__ __launch_bounds__(1024) void ransac_order_kernel(const int32_t *prev, int64_t n, int32_t *order) {
-  __shared__ int c_long[1024], c_rest[1024];
-  __shared__ int total_long;
-  const int tid = (int)threadIdx.x;
-  const int64_t chunk = (n + 1023) / 1024, lo = tid * chunk, hi = lo + chunk < n ? lo + chunk : n;
-  int nl = 0, nr = 0;
-  for (int64_t i = lo; i < hi; ++i) { if (prev[i] > kHypPerRound) ++nl; else ++nr; }
-  c_long[tid] = nl; c_rest[tid] = nr;
-  __syncthreads();
-  if (tid == 0) {
-    int al = 0, ar = 0;
-    for (int t = 0; t < 1024; ++t) { const int l = c_long[t], r = c_rest[t]; c_long[t] = al; c_rest[t] = ar; al += l; ar += r; }
-    total_long = al;
-  }
-  __syncthreads();
-  const int64_t L = total_long, R = n - L, paired = L < R ? L : R;
-  int64_t il = c_long[tid], ir = c_rest[tid];
-  for (int64_t i = lo; i < hi; ++i) {
-    if (prev[i] > kHypPerRound) {
-      const int64_t pos = il < paired ? 2 * il : paired + il;   // (more long pairs than others: the surplus after the mixed wavefronts)
-      order[pos] = (int32_t)i; ++il;
-    } else {
-      const int64_t pos = ir < paired ? 2 * ir + 1 : paired + ir;
-      order[pos] = (int32_t)i; ++ir;
+  // Two passes over segments of 32 x 1024 pairs, each thread up to 32 consecutive pairs whose counts are ALL requested
+  // before the first is used: (1) how many long pairs there are; (2) every pair's place.  The 1024 per-thread counts are
+  // scanned by shuffles inside the sixteen wavefronts + one scan of their totals.  (Until round 6: one dependent load
+  // after the other per thread and thread 0 walking the 1024 counts alone, ~40 us.)
+  constexpr int kPer = 32;
+  __shared__ int wave_tot[17];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto scan = [&](int v, int &excl, int &total) {
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
     }
+    __syncthreads();
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+      const int w = lane < 16 ? wave_tot[lane] : 0;
+      int winc = w;
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const int o = __shfl_up(winc, d, 64);
+        if (lane >= d) winc += o;
+      }
+      if (lane < 16) wave_tot[lane] = winc - w;
+      if (lane == 15) wave_tot[16] = winc;
+    }
+    __syncthreads();
+    excl = wave_tot[wave] + inc - v;
+    total = wave_tot[16];
+  };
+  int64_t L = 0;
+  for (int64_t seg = 0; seg < n; seg += (int64_t)kPer * 1024) {
+    const int64_t m = n - seg < (int64_t)kPer * 1024 ? n - seg : (int64_t)kPer * 1024;
+    const int64_t per = (m + 1023) / 1024, lo = seg + (per * tid < m ? per * tid : m), hi = seg + (per * (tid + 1) < m ? per * (tid + 1) : m);
+    int nl = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) nl += (lo + k < hi && prev[lo + k] > kHypPerRound) ? 1 : 0;
+    int excl, total;
+    scan(nl, excl, total);
+    L += total;
+  }
+  const int64_t R = n - L, paired = L < R ? L : R;
+  int64_t long_before = 0;
+  for (int64_t seg = 0; seg < n; seg += (int64_t)kPer * 1024) {
+    const int64_t m = n - seg < (int64_t)kPer * 1024 ? n - seg : (int64_t)kPer * 1024;
+    const int64_t per = (m + 1023) / 1024, lo = seg + (per * tid < m ? per * tid : m), hi = seg + (per * (tid + 1) < m ? per * (tid + 1) : m);
+    bool is_long[kPer];
+    int nl = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      is_long[k] = lo + k < hi && prev[lo + k] > kHypPerRound;
+      nl += is_long[k] ? 1 : 0;
+    }
+    int excl, total;
+    scan(nl, excl, total);
+    int64_t il = long_before + excl, ir = lo - il;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      if (lo + k < hi) {
+        if (is_long[k]) {
+          const int64_t pos = il < paired ? 2 * il : paired + il;   // (more long pairs than others: the surplus after the mixed wavefronts)
+          order[pos] = (int32_t)(lo + k); ++il;
+        } else {
+          const int64_t pos = ir < paired ? 2 * ir + 1 : paired + ir;
+          order[pos] = (int32_t)(lo + k); ++ir;
+        }
+      }
+    }
+    long_before += total;
   }
 }
 

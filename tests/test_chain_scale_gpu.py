@@ -292,3 +292,44 @@ def test_launch_order_hint_changes_the_dispatch_order_and_no_bit(oracle):
     q_n, t_n, m_n, c_n = batch.solve_pipeline(g2.init_q, g2.init_t, want_inliers=True)
     assert torch.equal(q_h, q_n) and torch.equal(t_h, t_n) and torch.equal(m_h, m_n) and torch.equal(c_h, c_n)
     batch.close()
+
+
+@pytest.mark.gpu
+def test_offsets_and_launch_order_beyond_one_scan_segment():
+    """The two one-workgroup index kernels walk the pairs in segments of 32 x 1024 (offsets_scan_kernel: AoS offsets of an
+    InlierExtraction target; ransac_order_kernel: the hinted launch order): batches of more pairs than one segment -- the
+    offsets are the running sum of the kept counts, and the hinted RANSAC call returns the unhinted one's bits (an order
+    that is not a permutation loses or repeats pairs)."""
+    import torch
+    from pnec_amd import Batch, capi
+    from pnec_amd import simulation as sim
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    P = 70001
+    sizes = rng.integers(3, 10, size=P)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    M = int(off[-1])
+    f = rng.standard_normal((2, M, 3))
+    f /= np.linalg.norm(f, axis=2, keepdims=True)
+    mask = (rng.random(M) < 0.6).astype(np.uint8)
+    with Batch(capi.MODE_NEC, off) as b:
+        b.fill(f[0], f[1], None)
+        sel = b.select(mask)
+        kept = np.add.reduceat(mask.astype(np.int64), off[:-1])
+        assert np.array_equal(sel.offsets, np.concatenate([[0], np.cumsum(kept)]))
+        sel.close()
+    P2, N2 = 40000, 48
+    g = sim.generate(P2, N2, seed=3, device=dev)
+    bad = torch.rand(P2, N2, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) < 0.3
+    rnd = torch.randn(P2, N2, 3, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    b2 = torch.where(bad[..., None], rnd / rnd.norm(dim=-1, keepdim=True), g.bvs2)
+    batch = Batch.uniform(capi.MODE_TARGET, P2, N2)
+    batch.fill(g.bvs1.reshape(-1, 3), b2.reshape(-1, 3), g.covs2.reshape(-1, 3, 3))
+    ref = batch.ransac_eigensolver(g.init_q, seed=1)
+    assert int((ref[4] > 16).sum()) > P2 // 20
+    batch.launch_order_hint(True)
+    for _ in range(2):
+        out = batch.ransac_eigensolver(g.init_q, seed=1)
+        for x, y in zip(out, ref):
+            assert torch.equal(x, y)
+    batch.close()
