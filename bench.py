@@ -510,7 +510,7 @@ def kernel_sources_sha256():
             # lists of sources / headers / host targets, which cannot change the device code of this kernel
             keep, cont = [], False
             for ln in text.splitlines():
-                if cont or re.match(r"\s*(HIPCC|ARCH|CXXFLAGS)\s*[?:+]?=", ln):
+                if cont or re.match(r"\s*(HIPCC|ARCH|CXXFLAGS|CXXBASE|SCHED_\w+)\s*[?:+]?=", ln):
                     keep.append(" ".join(ln.split()))
                     cont = ln.rstrip().endswith("\\")
                 else:
