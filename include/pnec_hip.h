@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define PNEC_HIP_ABI_VERSION 6
+#define PNEC_HIP_ABI_VERSION 7
 #define PNEC_HIP_MAX_RANSAC_SAMPLE 16 /* largest Options::ransac_sample_size_ the RANSAC kernel is built for */
 
 typedef enum pnec_hip_status {
@@ -211,6 +211,23 @@ int pnec_hip_problem_device(const pnec_hip_problem *p);
 int pnec_hip_problem_set_eigensolver_scheme(pnec_hip_problem *p, int32_t scheme);
 int pnec_hip_problem_eigensolver_scheme(const pnec_hip_problem *p);
 
+/* RANSAC variants (ABI 7): a set of bits for pnec_hip_pipeline_options.ransac_flags (the chain) and
+ * pnec_hip_problem_set_ransac_flags (what pnec_hip_ransac_eigensolver on the batch runs with; default 0).
+ *   PNEC_HIP_RANSAC_CHAINED_STARTS  [EXT, recalled: opengv is not in the reference tree]  opengv's
+ *     EigensolverSacProblem::getSelectedDistancesToModel leaves the model it scores in the adapter
+ *     (_adapter.setR12(model.rotation)), and computeModelCoefficients starts from _adapter.getR12() + jitter: hypothesis
+ *     h + 1 starts from the rotation of the last model scored, not from the initial rotation the call site hands over once
+ *     (src/rel_pose_estimation/pnec.cc:235-252).  A sequential dependence between hypotheses: with this bit a round is
+ *     ONE hypothesis per pair (sixteen side by side without) and the stage costs 20-60x (600 pairs x 256, 25 % gross
+ *     mismatches: 1.4 -> 30 ms under scheme 0, 2.2 -> 131 ms under scheme 2); the draws (sample, jitter) of hypothesis h
+ *     are the same either way, the hypothesis counts grow (a contaminated sample's minimum is a poor start for the next
+ *     one).  A FIDELITY switch, checked against the CPU checker's same switch (tests/test_opengv_schemes.py: masks and
+ *     counts identical for 97-99 % of the pairs over chains of 100+ dependent hypotheses); off by default because the
+ *     difference is inside the noise of opengv's rand(). */
+#define PNEC_HIP_RANSAC_CHAINED_STARTS 1
+int pnec_hip_problem_set_ransac_flags(pnec_hip_problem *p, int32_t flags);
+int pnec_hip_problem_ransac_flags(const pnec_hip_problem *p);
+
 /* Run InitValues + Optimize + Result for every solve of the batch, entirely on the device.
  *   init_q  [n_pairs,4] xyzw     starting orientation per pair (used as given)
  *   init_t  [n_pairs,3]          starting translation per pair (any non-zero vector; ignored if hyp_t)
@@ -308,7 +325,8 @@ typedef struct pnec_hip_pipeline_options {
                                     NECCeresSolver default-construct theirs (pnec.cc:355,399) */
   int32_t eigensolver_scheme;    /* 0     pnec_hip_eigensolver_scheme: which iteration every eigenvalue minimisation of
                                           the chain runs (ABI 5) */
-  int32_t reserved;              /* 0 */
+  int32_t ransac_flags;          /* 0     PNEC_HIP_RANSAC_* bits (ABI 7; `reserved` until ABI 6); an undefined bit:
+                                          PNEC_HIP_ERR_INVALID_ARGUMENT */
 } pnec_hip_pipeline_options;
 void pnec_hip_default_pipeline_options(pnec_hip_pipeline_options *opt);
 

@@ -184,6 +184,8 @@ void pnec_oracle_rot_to_cayley(const double R[9], double v[3]);
  * lambda_min composed with the reduced Cayley rotation).  A process-wide switch for test tooling; set it before, not
  * during, a batch call. */
 void pnec_oracle_set_eigensolver_scheme(int scheme);
+/* RANSAC: hypothesis h + 1 starts from the last scored model's rotation (opengv's adapter side effect [EXT]); default off */
+void pnec_oracle_set_ransac_chained_starts(int on);
 int pnec_oracle_get_eigensolver_scheme(void);
 /* scheme 2: Eigen's LevenbergMarquardtSpace::Status / nfev of the calling thread's last minimisation */
 int pnec_oracle_es_last_info(void);

@@ -284,6 +284,16 @@ def set_eigensolver_scheme(scheme: int) -> None:
     L.pnec_oracle_set_eigensolver_scheme(int(scheme))
 
 
+def set_ransac_chained_starts(on: bool) -> None:
+    """RANSAC hypothesis h + 1 starts from the last SCORED model's rotation + jitter (opengv's
+    EigensolverSacProblem::getSelectedDistancesToModel leaves the scored model in the adapter [EXT, recalled]);
+    off by default.  Process-wide switch, test tooling."""
+    L = lib()
+    L.pnec_oracle_set_ransac_chained_starts.argtypes = [C.c_int]
+    L.pnec_oracle_set_ransac_chained_starts.restype = None
+    L.pnec_oracle_set_ransac_chained_starts(int(bool(on)))
+
+
 def set_ransac_frozen_rules(on: bool) -> None:
     """RANSAC under scheme 0 with the round-3 rules: every hypothesis scored, 50 iterations for a hypothesis' minimisation
     (pnec_oracle_frontend.c); OFF by default"""

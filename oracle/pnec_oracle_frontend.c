@@ -265,6 +265,16 @@ void pnec_oracle_set_eigensolver_scheme(int scheme) { g_es_scheme = scheme; }
 static int g_ransac_frozen_rules = 0;
 void pnec_oracle_set_ransac_frozen_rules(int on) { g_ransac_frozen_rules = on; }
 int pnec_oracle_get_eigensolver_scheme(void) { return g_es_scheme; }
+/* RANSAC's chained starts [EXT, from memory, unpinned]: opengv's EigensolverSacProblem::getSelectedDistancesToModel writes
+ * the model it scores into the adapter (_adapter.sett12(model.translation); _adapter.setR12(model.rotation)) before it
+ * triangulates, and computeModelCoefficients starts every hypothesis from _adapter.getR12() + jitter -- so hypothesis
+ * h + 1 starts from the rotation of the last model SCORED (hypothesis h's, whether or not it became the best), not from
+ * the initial rotation (the call site: pnec.cc:235-252 hands the adapter the initial rotation once).  OFF by default: the
+ * device evaluates a round's sixteen hypotheses side by side from the initial rotation; ON restates the sequential
+ * dependence (the device: PNEC_HIP_RANSAC_CHAINED_STARTS, one hypothesis per round).  Statistical either way under
+ * opengv's rand(); the difference is which basin a contaminated sample's minimisation starts near. */
+static int g_ransac_chained_starts = 0;
+void pnec_oracle_set_ransac_chained_starts(int on) { g_ransac_chained_starts = on; }
 static int g_es_info; /* scheme 2: Eigen's status of the calling thread's last minimisation (5 = maxfev reached) */
 static int g_es_nfev;
 #pragma omp threadprivate(g_es_info, g_es_nfev)
@@ -682,6 +692,7 @@ int pnec_oracle_ransac_eigensolver(int64_t n, const double *bvs1, const double *
                                                                                               is scored, as opengv does) */
     for (int64_t i = 0; i < n && !cut_off; ++i)
       count += pnec_oracle_reprojection_score(bvs1 + 3 * i, bvs2 + 3 * i, R, t) < threshold;
+    if (g_ransac_chained_starts && !cut_off) pnec_oracle_rot_to_cayley(R, v0); /* the scored model stays in the adapter */
     if (count > best_count) {
       best_count = count;
       memcpy(best_R, R, sizeof(R));

@@ -54,8 +54,9 @@
  *    descent started up to 0.6 away, is returned (five times the work for nothing; tests/test_opengv_schemes.py shows
  *    it); it only makes sense for the 4x4 generalised problem it was written for.
  *
- *  Recalled and NOT reproduced (documented deviations of the RANSAC restatement in pnec_oracle_frontend.c, all inside
- *  the statistical noise of opengv's rand() draws): EigensolverSacProblem::getSelectedDistancesToModel writes the
+ *  Recalled, and reproduced behind a switch since round 6 (pnec_oracle_set_ransac_chained_starts in
+ *  pnec_oracle_frontend.c; the device: PNEC_HIP_RANSAC_CHAINED_STARTS; off by default -- the difference is inside the
+ *  statistical noise of opengv's rand() draws): EigensolverSacProblem::getSelectedDistancesToModel writes the
  *  scored model into the adapter (_adapter.sett12 / setR12) before triangulating, so the NEXT hypothesis' start is
  *  the last scored model's rotation + jitter, not the initial one.
  */

@@ -394,6 +394,12 @@ class Batch:
         ES_LM; include/pnec_hip.h pnec_hip_eigensolver_scheme).  solve_pipeline takes its own from the options."""
         capi.check(self._lib.pnec_hip_problem_set_eigensolver_scheme(self._h, int(scheme)))
 
+    def set_ransac_flags(self, flags: int) -> None:
+        """PNEC_HIP_RANSAC_* bits for the STAGE call ransac_eigensolver on this batch (capi.RANSAC_CHAINED_STARTS: every
+        hypothesis starts from the last scored model's rotation, opengv's adapter side effect [EXT]; one hypothesis per
+        round).  solve_pipeline takes its own from the options' ransac_flags."""
+        capi.check(self._lib.pnec_hip_problem_set_ransac_flags(self._h, int(flags)))
+
     def select(self, mask, view: bool = False) -> "Batch":
         """PNEC::InlierExtraction (pnec.cc:210-229): new Batch with the masked correspondences.
         view=True: into this batch's cached target (pnec_hip_problem_select_view: nothing allocated after the first

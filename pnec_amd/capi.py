@@ -12,11 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PNEC_HIP_LIB: load an alternative build of the same ABI (kernel A/B experiments only)
 LIB_PATH = os.environ.get("PNEC_HIP_LIB") or os.path.join(_HERE, "libpnec_hip.so")
 
-ABI_VERSION = 6  # PNEC_HIP_ABI_VERSION of include/pnec_hip.h this binding was written against
+ABI_VERSION = 7  # PNEC_HIP_ABI_VERSION of include/pnec_hip.h this binding was written against
 MODE_NEC, MODE_TARGET, MODE_HOST, MODE_SYM = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 # pnec_hip_eigensolver_scheme: which iteration stands in for opengv's eigenvalue minimisation (include/pnec_hip.h)
 ES_NEWTON, ES_DESCENT, ES_LM = 0, 1, 2
+# PNEC_HIP_RANSAC_* bits (pnec_hip_pipeline_options.ransac_flags, pnec_hip_problem_set_ransac_flags)
+RANSAC_CHAINED_STARTS = 1
 # pnec_hip_status
 OK, ERR_INVALID_ARGUMENT, ERR_HIP_RUNTIME, ERR_UNSUPPORTED, ERR_BUSY = 0, -1, -2, -3, -4
 TERM_NAMES = {
@@ -52,6 +54,8 @@ SYMBOLS = [
     "pnec_hip_problem_device",
     "pnec_hip_problem_set_eigensolver_scheme",
     "pnec_hip_problem_eigensolver_scheme",
+    "pnec_hip_problem_set_ransac_flags",
+    "pnec_hip_problem_ransac_flags",
     "pnec_hip_solve",
     "pnec_hip_select_best",
     "pnec_hip_cost_function",
@@ -138,7 +142,7 @@ class PipelineOptions(C.Structure):
         ("ransac_seed", C.c_uint64),
         ("solver", Options),
         ("eigensolver_scheme", C.c_int32),
-        ("reserved", C.c_int32),
+        ("ransac_flags", C.c_int32),
     ]
 
 
@@ -194,6 +198,8 @@ def lib() -> C.CDLL:
     L.pnec_hip_problem_device.argtypes = [_vp]
     L.pnec_hip_problem_set_eigensolver_scheme.argtypes = [_vp, C.c_int32]
     L.pnec_hip_problem_eigensolver_scheme.argtypes = [_vp]
+    L.pnec_hip_problem_set_ransac_flags.argtypes = [_vp, C.c_int32]
+    L.pnec_hip_problem_ransac_flags.argtypes = [_vp]
     L.pnec_hip_solve.argtypes = [_vp, _vp, _vp, C.c_int32, _vp, C.c_double, C.POINTER(Options),
                                  _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]
     L.pnec_hip_select_best.argtypes = [C.c_int64, C.c_int32, _vp, _vp, C.c_int, C.c_int, _vp]

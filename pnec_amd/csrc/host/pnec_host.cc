@@ -429,6 +429,7 @@ pnec_hip_pipeline_options ToPipeline(const Options &o) {
   p.regularization = o.regularization_;
   p.solver = optimization::SolverOptions().ToHip();
   p.eigensolver_scheme = o.eigensolver_scheme_;
+  p.ransac_flags = o.ransac_chained_starts_ ? PNEC_HIP_RANSAC_CHAINED_STARTS : 0;
   return p;
 }
 
@@ -488,6 +489,7 @@ SE3d PNEC::SolveImpl(const bearingVectors_t &bvs1, const bearingVectors_t &bvs2,
   pnec_hip_problem *stage = dev.prob.p;   // the batch the later stages run on (inliers under RANSAC)
   pnec_hip_problem *selected = nullptr;   // the handle's cached InlierExtraction target: nothing to destroy
   Check(pnec_hip_problem_set_eigensolver_scheme(dev.prob.p, options_.eigensolver_scheme_));
+  Check(pnec_hip_problem_set_ransac_flags(dev.prob.p, options_.ransac_chained_starts_ ? PNEC_HIP_RANSAC_CHAINED_STARTS : 0));
   // ES_solution = Eigensolver(bvs1, bvs2, initial_pose, inliers)
   inliers.clear();
   if (options_.use_ransac_) {
@@ -563,6 +565,7 @@ SE3d PNEC::Eigensolver(const bearingVectors_t &bvs1, const bearingVectors_t &bvs
     Check(pnec_hip_problem_fill(prob.p, 0, 1, bvs1[0].data(), bvs2[0].data(), nullptr, nullptr,
                                 PNEC_HIP_MEM_HOST, nullptr));
   Check(pnec_hip_problem_set_eigensolver_scheme(prob.p, options_.eigensolver_scheme_));
+  Check(pnec_hip_problem_set_ransac_flags(prob.p, options_.ransac_chained_starts_ ? PNEC_HIP_RANSAC_CHAINED_STARTS : 0));
   const Quaterniond q0(initial_pose.rotationMatrix());
   double q[4], t[3];
   if (options_.use_ransac_) {

@@ -207,6 +207,11 @@ struct Options {  // pnec_config.h:46-65, same names and defaults
   // This facade stands in for the reference's classes, so it defaults to the restatement believed to be what opengv runs
   // (2; 1.8x the cost of 0 on the whole chain) -- the C ABI's own default is 0.  INTEGRATION.md 6 has the evidence.
   int eigensolver_scheme_ = 2;
+  // NOT in the reference either: opengv's RANSAC starts hypothesis h + 1 from the last model it SCORED (a side effect of
+  // EigensolverSacProblem::getSelectedDistancesToModel on the adapter [EXT, recalled]) -- PNEC_HIP_RANSAC_CHAINED_STARTS.
+  // Off: a round's sixteen hypotheses run side by side from the initial rotation (inside the noise of opengv's rand());
+  // on: one hypothesis per round, ~3x the RANSAC stage.
+  bool ransac_chained_starts_ = false;
 };
 
 // One frame pair of a batch, in the reference's argument shapes.

@@ -42,7 +42,7 @@ hipError_t launch_solve_aos_mode_3(int, int, int, const SolveArgs &, hipStream_t
 hipError_t launch_ransac_eigensolver(const double *, const int64_t *, const int64_t *, const int32_t *, int64_t,
                                      const double *, unsigned long long, unsigned long long, int, int, double, double *, double *,
                                      uint8_t *, int32_t *, int32_t *, double *, int32_t *, hipStream_t, hipStream_t,
-                                     hipEvent_t, hipEvent_t, int, double *, const int64_t *, int32_t *, int64_t *, const int32_t *, int);
+                                     hipEvent_t, hipEvent_t, int, double *, const int64_t *, int32_t *, int64_t *, const int32_t *, int, int);
 hipError_t launch_ransac_order(const int32_t *, int64_t, int32_t *, hipStream_t);
 hipError_t frontend_work_counters(int, unsigned long long *, int *);
 hipError_t launch_select(int, const double *, const int64_t *, const int64_t *, const int32_t *, const uint8_t *,
@@ -99,6 +99,7 @@ struct pnec_hip_problem {
   int64_t front_pairs = 0;
   // which iteration the eigenvalue minimisations of the stage calls run (pnec_hip_problem_set_eigensolver_scheme)
   int es_scheme = 0;
+  int ransac_flags = 0;   // PNEC_HIP_RANSAC_*: what pnec_hip_ransac_eigensolver on this batch runs with
   // capacity-shaped batches (filled again and again): the host-space fill's AoS staging, kept and grown on demand
   double *d_fill = nullptr;
   int64_t fill_doubles = 0;
@@ -1817,6 +1818,14 @@ int pnec_hip_problem_set_eigensolver_scheme(pnec_hip_problem *p, int32_t scheme)
 }
 int pnec_hip_problem_eigensolver_scheme(const pnec_hip_problem *p) { return p ? p->es_scheme : 0; }
 
+int pnec_hip_problem_set_ransac_flags(pnec_hip_problem *p, int32_t flags) {
+  if (!p) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "problem is NULL");
+  if (flags & ~PNEC_HIP_RANSAC_CHAINED_STARTS) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "unknown RANSAC flag");
+  p->ransac_flags = flags;
+  return 0;
+}
+int pnec_hip_problem_ransac_flags(const pnec_hip_problem *p) { return p ? p->ransac_flags : 0; }
+
 int pnec_hip_nec_eigensolver(pnec_hip_problem *p, const double *init_q, double *out_q, double *out_t,
                              int space, void *stream) {
   return run_front_stage(p, false, init_q, nullptr, 0.0, 0, out_q, out_t, space, stream);
@@ -1879,7 +1888,8 @@ int pnec_hip_ransac_eigensolver(pnec_hip_problem *p, const double *init_q, uint6
                                            /*first_pair_id*/ 0ull, max_iterations, sample_size, threshold, d_oq, d_ot, d_mask, d_cnt, d_it,
                                            p->d_front, p->d_front_i, stream, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                                            nullptr, nullptr,
-                                           p->order_hint && p->order_pairs == P ? p->d_order : nullptr, p->es_scheme);
+                                           p->order_hint && p->order_pairs == P ? p->d_order : nullptr, p->es_scheme,
+                                           p->ransac_flags);
   if (e == hipSuccess && p->order_hint) {   // the next call's launch order from this call's counts
     e = launch_ransac_order(d_it, P, p->d_order, stream);
     p->order_pairs = P;

@@ -997,6 +997,8 @@ __device__ void pass_sums36(const double *base, int n, int stride, const double 
 // (sums36_kernel, or the RANSAC kernel's inlier pass), es_batch_kernel then minimises SIXTEEN pairs per
 // wavefront, one per quad, and the rest of the stage carries on from its result.  Per pair the arithmetic is
 // exactly what it was (same sums, same minimiser on the same lanes of a quad): the results do not change.
+constexpr int kStBuckets = 8;   // lists of the RANSAC stage's second launch (see ransac2_eigensolver_kernel, PHASE)
+static_assert(4 + kStBuckets <= kFrontCounterInts && 58 + kStBuckets / 2 <= kFrontDoublesPerPair, "front scratch layout");
 struct FrontScratch {
   double *G;        // [P,36] the sums of every pair
   double *v0;       // [P,3]  Cayley vector the minimisation starts from
@@ -1009,7 +1011,7 @@ struct FrontScratch {
   // the RANSAC stage's two launches (ransac2_eigensolver_kernel PHASE 1 / 2): the rule's state per pair lives in the
   // v_rounds region (free until the weighted stage), the list of pairs that go on and its length behind the ints
   double *st_k, *st_it, *st_best, *st_model;
-  int32_t *st_list, *st_count;
+  int32_t *st_list, *st_count;   // [kStBuckets, P], [kStBuckets]
   // the weighted stage's launch order (same ints, free by then): wo_order[b] = the pair block b of the weighted kernel
   // takes, wo_count[0 / 1] = pairs placed from the front / from the back so far
   int32_t *wo_order, *wo_count;
@@ -1031,9 +1033,11 @@ FrontScratch front_scratch(double *d, int32_t *i, int64_t P) {
   f.st_it = d + 44 * P;
   f.st_best = d + 45 * P;
   f.st_model = d + 46 * P;   // .. 58 P (of the 45 P the v_rounds region has)
-  f.st_list = i + 3 * P;
+  // kStBuckets lists of up to P pair indices each (a pair is listed in the bucket of the rounds its rule still asks for),
+  // 8 P ints = 4 P doubles behind the rule's state: 58 P .. 62 P of the 88 P doubles
+  f.st_list = reinterpret_cast<int32_t *>(d + 58 * P);
   int32_t *counters = i + (int64_t)kFrontIntsPerPair * P;
-  f.st_count = counters;     // (one int)
+  f.st_count = counters + 4; // (kStBuckets ints: counters[4 .. 12))
   f.wo_order = i + 3 * P;
   f.wo_count = counters + 2; // (two ints)
   return f;
@@ -1952,7 +1956,11 @@ struct RansacArgs {
   // two launches (PHASE 1 / 2 of ransac2_eigensolver_kernel): where the sequential rule of a pair stands after its first
   // round -- it, best count, k, the best model (R | t) -- and the list of the pairs that go on
   double *st_k, *st_it, *st_best, *st_model;   // [P], [P], [P], [P,12]
-  int32_t *st_list, *st_count;                 // [P], [1]
+  int32_t *st_list, *st_count;                 // [kStBuckets, P], [kStBuckets]
+  int st_buckets;                              // buckets in use (1: the list unordered -- A/B)
+  // PNEC_HIP_RANSAC_CHAINED_STARTS: every hypothesis starts from the rotation of the last model SCORED (+ jitter), as
+  // opengv's adapter side effect has it [EXT]: a sequential dependence, so a round is ONE hypothesis per pair
+  int chained;
   // two-pair form: blocks [0, n_double) take the pairs 2 b, 2 b + 1 (of the launch order), blocks from n_double on ONE
   // pair each, 2 n_double + (b - n_double): the launch's last wavefronts are short ones (see ransac_tail_singles)
   int64_t n_double;
@@ -2461,7 +2469,25 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  const int64_t n_listed = PHASE == 2 ? (int64_t)*a.st_count : 0;
+  // PHASE 2: the listed pairs in the order of the buckets, the one with the most rounds still asked for first
+  [[maybe_unused]] int st_n[kStBuckets];
+  int64_t n_listed = 0;
+  if constexpr (PHASE == 2) {
+#pragma unroll
+    for (int b = 0; b < kStBuckets; ++b) {
+      st_n[b] = a.st_count[b];
+      n_listed += st_n[b];
+    }
+  }
+  [[maybe_unused]] auto listed_pair = [&](int64_t e) -> int64_t {   // entry e of the concatenated lists (e < n_listed)
+    int64_t left = e;
+#pragma unroll
+    for (int b = kStBuckets - 1; b >= 0; --b) {
+      if (left < st_n[b]) return (int64_t)a.st_list[(int64_t)b * a.n_pairs + left];
+      left -= st_n[b];
+    }
+    return 0;
+  };
   for (int64_t work = (int64_t)blockIdx.x; PHASE != 2 || 2 * work < n_listed; work += (int64_t)gridDim.x) {
   // ---- the two pairs' wave-uniform state
   int64_t pair[2];
@@ -2477,7 +2503,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
     const int64_t blk = work;
     if constexpr (PHASE == 2) {
       exists[pp] = 2 * blk + pp < n_listed;
-      pair[pp] = exists[pp] ? (int64_t)a.st_list[2 * blk + pp] : 0;
+      pair[pp] = exists[pp] ? listed_pair(2 * blk + pp) : 0;
     } else {
       pair[pp] = blk < a.n_double ? 2 * blk + pp : a.n_double + blk;   // (= 2 n_double + (blk - n_double) for slot 0)
       exists[pp] = pair[pp] < a.n_pairs && (blk < a.n_double || pp == 0);
@@ -2530,7 +2556,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
     // The long pairs are the ones a launch ends with (a quarter of it is their tail): half as many rounds for them.
     // The finished pair waits in LDS for the kernel's end.  All of this is state shuffling at a round's boundary --
     // the round's code does not know; and since neither slot nor round enters a hypothesis' arithmetic: same bits.
-    if (!lent && go[0] != go[1]) {
+    if (!lent && go[0] != go[1] && !a.chained) {   // (chained starts: hypothesis it + 16 does not exist before it + 15's model)
       auto park = [&](auto dc) {  // the done (or absent) pair of slot D
         constexpr int D = decltype(dc)::value;
         if (lane == 0) {
@@ -2578,6 +2604,7 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
       // the first round evaluates all 16 hypotheses; a later round only those that can still be consumed (see the
       // one-pair kernel)
       needed[pp] = !go[pp] ? 0 : (it[pp] == 0 ? kHypPerRound : (int)fmin(ceil(k[pp] - (double)it[pp]), (double)kHypPerRound));
+      if (a.chained && needed[pp] > 1) needed[pp] = 1;   // the next hypothesis' start is this one's model
     }
     if (!go[0] && !go[1]) break;  // wave-uniform
     // ---- prepare the round's hypotheses: quad j samples hypothesis j of each pair that goes on.
@@ -2755,6 +2782,13 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
         if (it[pp] > a.max_iterations) { stop[pp] = true; break; }
       }
       PNEC_PHASE_END(kRpScore);
+      if (a.chained && needed[pp] > 0 && lds.models[0][kModelCapped] == 0.0) {
+        // the model just scored stays "in the adapter": the next hypothesis starts from its rotation (wave-uniform)
+        double Rl[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rl[i] = lds.models[0][i];
+        rot_to_cayley(Rl, v0[pp]);
+      }
       if (winner >= 0 && lane < 12) lds.best_model[pp][lane] = lds.models[winner][lane];
       lds_sync();
       if (lent) {
@@ -2802,7 +2836,10 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
           a.st_it[pq] = (double)it[pp];
           a.st_best[pq] = (double)best_count[pp];
           a.st_k[pq] = k[pp];
-          a.st_list[atomicAdd(a.st_count, 1)] = (int32_t)pq;
+          // (the bucket: how many more rounds of sixteen the rule asks for as it stands -- k only falls from here on)
+          const double more = ceil((k[pp] - (double)it[pp]) * (1.0 / kHypPerRound));
+          const int bucket = more >= (double)a.st_buckets ? a.st_buckets - 1 : (more <= 1.0 ? 0 : (int)more - 1);
+          a.st_list[(int64_t)bucket * a.n_pairs + atomicAdd(a.st_count + bucket, 1)] = (int32_t)pq;
         }
         continue;
       }
@@ -2822,6 +2859,10 @@ __global__ __launch_bounds__(kWave, PNEC_RANSAC_WAVES_PER_SIMD) void ransac2_eig
     for (int i = 0; i < 36; ++i) acc[i] = 0.0;
     int my_count = 0, my_first = 0x7fffffff;
     const int64_t aos0 = a.offsets[pair[pp]];
+    // (the loop reads every 64 correspondences where it uses them.  Measured and taken back in round 6: the first 512 from
+    // ONE batch of 48 loads, as the scoring does, and InlierExtraction six component planes at a time -- 204 against 202 us
+    // per frame, 2.70 against 2.66 ms per 20 000 pairs: the loads were not what this pass waits for, and the 96 registers of
+    // the batch cost fifteen more spilled ones)
     for (int idx = lane; idx < nn; idx += kWave) {
       const double f1[3] = {bs[idx], bs[(int64_t)st + idx], bs[(int64_t)2 * st + idx]};
       const double f2[3] = {bs[(int64_t)3 * st + idx], bs[(int64_t)4 * st + idx], bs[(int64_t)5 * st + idx]};
@@ -3072,7 +3113,8 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
                                      int32_t *scratch_i, hipStream_t stream, hipStream_t tail_stream,
                                      hipEvent_t tail_fork, hipEvent_t tail_done, int sel_nc, double *sel_data,
                                      const int64_t *sel_block, int32_t *sel_count, int64_t *sel_single_offsets,
-                                     const int32_t *order, int scheme) {
+                                     const int32_t *order, int scheme, int ransac_flags) {
+  // ransac_flags: PNEC_HIP_RANSAC_CHAINED_STARTS (include/pnec_hip.h)
   // order (optional): the pairs in launch order (ransac_order_kernel; honoured by the two-pair form)
   // tail_stream (optional): the eigensolver on the inliers (es_batch_kernel, which writes out_q / out_t) runs
   // there, forked from `stream` after the RANSAC kernel -- the caller goes on with work that only needs the
@@ -3102,6 +3144,7 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   a.sel_block = sel_block;
   a.sel_count = sel_count;
   a.sel_single_offsets = sel_single_offsets;
+  a.chained = (ransac_flags & PNEC_HIP_RANSAC_CHAINED_STARTS) ? 1 : 0;
   const char *tr = std::getenv("PNEC_HIP_TRACE_FRONT");
   if (tr && *tr) {
     const hipError_t e0 = hipMalloc(&a.trace, sizeof(unsigned long long) * kPhCount * (size_t)n_pairs);
@@ -3122,9 +3165,7 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   }();
   const bool two = forced_form == 1 ? false : (forced_form == 2 ? true : n_pairs >= 4096);
   a.order = two ? order : nullptr;
-  const int64_t singles = !two ? n_pairs : std::min<int64_t>(ransac_tail_singles(n_pairs), n_pairs) & ~(int64_t)1;  // (even: the rest pairs up)
-  a.n_double = (n_pairs - singles + 1) / 2;
-  const int64_t blocks = a.n_double + (n_pairs - std::min<int64_t>(2 * a.n_double, n_pairs));
+
   // The stage as TWO launches (first rounds, then the pairs that go on: the kernel's PHASE 1 / 2) is an A/B form, built only
   // with -DPNEC_RANSAC_TWO_LAUNCH_AB and then switched on by PNEC_RANSAC_LAUNCHES=2: bit-identical and, measured in round 5,
   // 8 % SLOWER at 10 % mismatches (1.72 -> 1.86 ms per 20 000 pairs; 14.9 -> 15.9 ms at 30 %) -- in one launch the slots
@@ -3136,9 +3177,18 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
     return ev && *ev ? std::atoi(ev) : 0;
   }();
   const bool split = !a.trace && forced_launches == 2;
+  static const int forced_buckets = [] {
+    const char *ev = std::getenv("PNEC_RANSAC_BUCKETS");
+    return ev && *ev ? std::max(1, std::min(kStBuckets, std::atoi(ev))) : kStBuckets;
+  }();
+  a.st_buckets = forced_buckets;
 #else
   constexpr bool split = false;
 #endif
+  // (two launches: the first rounds are all alike -- no tail to shorten with one-pair wavefronts)
+  const int64_t singles = !two ? n_pairs : (split ? 0 : std::min<int64_t>(ransac_tail_singles(n_pairs), n_pairs) & ~(int64_t)1);  // (even: the rest pairs up)
+  a.n_double = (n_pairs - singles + 1) / 2;
+  const int64_t blocks = a.n_double + (n_pairs - std::min<int64_t>(2 * a.n_double, n_pairs));
   a.st_k = a.scratch.st_k; a.st_it = a.scratch.st_it; a.st_best = a.scratch.st_best; a.st_model = a.scratch.st_model;
   a.st_list = a.scratch.st_list; a.st_count = a.scratch.st_count;
   const dim3 g1((unsigned)blocks), bl(kWave);
@@ -3150,7 +3200,7 @@ hipError_t launch_ransac_eigensolver(const double *data, const int64_t *block_of
   if (!split) {                                                                                               \
     hipLaunchKernelGGL((ransac2_eigensolver_kernel<S, 0>), g1, bl, 0, stream, a);                             \
   } else {                                                                                                    \
-    hipError_t em = hipMemsetAsync(a.st_count, 0, sizeof(int32_t), stream);                                   \
+    hipError_t em = hipMemsetAsync(a.st_count, 0, sizeof(int32_t) * kStBuckets, stream);                      \
     if (em != hipSuccess) return em;                                                                          \
     hipLaunchKernelGGL((ransac2_eigensolver_kernel<S, 1>), g1, bl, 0, stream, a);                             \
     hipLaunchKernelGGL((ransac2_eigensolver_kernel<S, 2>), g2, bl, 0, stream, a);                             \

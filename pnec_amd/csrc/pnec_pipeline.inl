@@ -140,7 +140,8 @@ static int pipeline_on(pnec_hip_problem *p, const double *d_iq, const double *d_
                                   fork ? p->fork_event : nullptr, fork ? p->side_done[0] : nullptr, p->nc,
                                   sv ? sv->d_data : nullptr, sv ? sv->d_block_offset : nullptr, sv ? sv->d_count : nullptr,
                                   sv && !sv_given && P == 1 ? sv->d_offsets : nullptr,
-                                  p->order_hint && p->order_pairs == P ? p->d_order : nullptr, o.eigensolver_scheme);
+                                  p->order_hint && p->order_pairs == P ? p->d_order : nullptr, o.eigensolver_scheme,
+                                  o.ransac_flags);
     if (e == hipSuccess && p->order_hint) {   // the next call's launch order from this call's counts (pnec_hip_problem_launch_order_hint)
       e = launch_ransac_order(p->d_hint_its, P, p->d_order, stream);
       p->order_pairs = P;
@@ -232,6 +233,7 @@ int pnec_hip_solve_pipeline(pnec_hip_problem *p, const double *init_q, const dou
     return fail(PNEC_HIP_ERR_UNSUPPORTED, "the PNEC chain needs a TARGET-mode problem (bearings + frame-2 covariances)");
   if (o.use_ransac && (o.max_ransac_iterations < 0 || o.ransac_sample_size < 1))
     return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "bad RANSAC parameters");
+  if (o.ransac_flags & ~PNEC_HIP_RANSAC_CHAINED_STARTS) return fail(PNEC_HIP_ERR_INVALID_ARGUMENT, "unknown RANSAC flag");
   if (o.use_ransac && o.ransac_sample_size > PNEC_HIP_MAX_RANSAC_SAMPLE)
     return fail(PNEC_HIP_ERR_UNSUPPORTED, "ransac sample_size > 16 is not built");
   const int64_t P = p->n_pairs;

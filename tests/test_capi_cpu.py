@@ -85,9 +85,10 @@ def test_argument_validation_without_device():
     assert L.pnec_hip_frame_capacity(None) == 0 and L.pnec_hip_frame_destroy(None) == 0
     po = capi.default_pipeline_options()
     assert (po.use_ransac, po.weighted_iterations, po.first_pair_id, po.ransac_seed) == (1, 10, 0, 1)
-    assert C.sizeof(capi.PipelineOptions) == 6 * 4 + 8 + 8 + 8 + 8 + C.sizeof(capi.Options) + 2 * 4   # first_pair_id where ABI 2 had reserved[2]; ABI 5: + eigensolver_scheme, reserved
+    assert C.sizeof(capi.PipelineOptions) == 6 * 4 + 8 + 8 + 8 + 8 + C.sizeof(capi.Options) + 2 * 4   # first_pair_id where ABI 2 had reserved[2]; ABI 5: + eigensolver_scheme, reserved (ABI 7: ransac_flags)
     assert po.eigensolver_scheme == capi.ES_NEWTON
     assert L.pnec_hip_problem_set_eigensolver_scheme(None, 1) == -1 and L.pnec_hip_problem_eigensolver_scheme(None) == 0
+    assert L.pnec_hip_problem_set_ransac_flags(None, 1) == -1 and L.pnec_hip_problem_ransac_flags(None) == 0
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
