@@ -126,7 +126,7 @@ def chain_stage_rooflines(counts, stage_ms, payload_bytes, inlier_payload_bytes,
 FRONT_KERNEL_SOURCES = ("pnec_frontend.hip", "pnec_es_schemes.inl", "pnec_device.hpp", "pnec_front_shared.hpp")
 # sha256 (front_sources_sha256) of the sources the FLOP_* table above was last derived from / cross-checked against
 # (tools/isa_front_regions.py); tests/test_bench_launch_cpu.py fails when the sources move on without it
-FRONT_FLOP_MODEL_STAMP = "421954b68fc87984d2338378f934f3fcbb4657f6c3074ce2756927c9f56e52fe"
+FRONT_FLOP_MODEL_STAMP = "27df01740a57074aa8fbcea9692d2fcf70cb7e05a0852e0a592793667e1aab93"
 
 
 def front_sources_sha256():

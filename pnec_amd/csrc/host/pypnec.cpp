@@ -207,7 +207,8 @@ double cost_function(arr bvs1, arr bvs2, arr covs, arr pose) {
 // :135-208): overload 0 = (bvs1, bvs2, covs, init), 1 = (+ inliers), 2 = (+ timing), 3 = (+ inliers,
 // timing).  Returns (pose 4x4, inliers or None, timing dict or None).
 py::tuple solve(arr bvs1, arr bvs2, arr covs, arr init_pose, int overload, bool use_ransac, bool use_nec,
-                bool use_ceres, int weighted_iterations, double regularization, int eigensolver_scheme) {
+                bool use_ceres, int weighted_iterations, double regularization, int eigensolver_scheme,
+                bool ransac_chained_starts) {
   const auto b1 = ToBearings(bvs1, "bvs1"), b2 = ToBearings(bvs2, "bvs2");
   const auto cv = ToCovariances(covs, "covs");
   const pnec::SE3d init = ToPose(init_pose);
@@ -218,6 +219,7 @@ py::tuple solve(arr bvs1, arr bvs2, arr covs, arr init_pose, int overload, bool 
   options.weighted_iterations_ = (size_t)weighted_iterations;
   options.regularization_ = regularization;
   options.eigensolver_scheme_ = eigensolver_scheme;
+  options.ransac_chained_starts_ = ransac_chained_starts;
   if (overload < 0 || overload > 3) throw std::invalid_argument("overload must be 0..3");
   pnec::SE3d pose;
   std::vector<int> inliers;
@@ -282,9 +284,9 @@ PYBIND11_MODULE(pypnec, m) {
   m.def("solve", &solve, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"), py::arg("init_pose"),
         py::arg("overload") = 1, py::arg("use_ransac") = true, py::arg("use_nec") = false,
         py::arg("use_ceres") = true, py::arg("weighted_iterations") = 10, py::arg("regularization") = 1e-13,
-        py::arg("eigensolver_scheme") = 2,
+        py::arg("eigensolver_scheme") = 2, py::arg("ransac_chained_starts") = false,
         "PNEC::Solve for one frame pair through one of its four overloads (eigensolver_scheme: which iteration stands in "
-        "for opengv's eigenvalue minimisation, include/pnec_hip.h)");
+        "for opengv's eigenvalue minimisation; ransac_chained_starts: PNEC_HIP_RANSAC_CHAINED_STARTS -- include/pnec_hip.h)");
   m.def("solve_batch", &solve_batch, py::arg("bvs1"), py::arg("bvs2"), py::arg("covs"), py::arg("init_poses"),
         py::arg("use_ransac") = true, py::arg("use_nec") = false, py::arg("use_ceres") = true,
         py::arg("weighted_iterations") = 10, py::arg("regularization") = 1e-13, py::arg("devices") = std::vector<int>{},

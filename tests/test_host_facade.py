@@ -275,6 +275,37 @@ def test_metric_helpers_of_the_facade_follow_the_reference_semantics(oracle):
 
 
 @pytest.mark.gpu
+def test_ransac_chained_starts_through_the_facade(oracle):
+    """Options::ransac_chained_starts_ (PNEC_HIP_RANSAC_CHAINED_STARTS [EXT]): the untimed overloads pass it in the chain's
+    options, the timed ones set it on the batch for the stage call -- same pose, same inliers; the inliers are the
+    checker's with its same switch, and not those of the side-by-side form's run (the switch does something)."""
+    import pypnec
+    g = sim.generate(1, 300, seed=411)
+    rng = np.random.default_rng(6)
+    b1, b2, cv = g.bvs1[0].numpy().copy(), g.bvs2[0].numpy().copy(), g.covs2[0].numpy().copy()
+    bad = rng.choice(300, 75, replace=False)
+    v = rng.normal(size=(75, 3))
+    b2[bad] = v / np.linalg.norm(v, axis=1, keepdims=True)
+    init = _pose4(g.init_R[0].numpy(), g.init_t[0].numpy())
+    T1, inl1, _ = pypnec.solve(b1, b2, cv, init, overload=1, ransac_chained_starts=True)
+    T3, inl3, _ = pypnec.solve(b1, b2, cv, init, overload=3, ransac_chained_starts=True)
+    T0, inl0, _ = pypnec.solve(b1, b2, cv, init, overload=1)
+    np.testing.assert_array_equal(T1, T3)
+    assert inl1 == inl3 and 150 < len(inl1) <= 225
+    oracle.set_eigensolver_scheme(2)
+    oracle.set_ransac_chained_starts(True)
+    try:
+        _, _, mo, its_on = oracle.ransac_eigensolver(b1, b2, init[:3, :3], seed=1, pair_id=0)
+        oracle.set_ransac_chained_starts(False)
+        _, _, mf, its_off = oracle.ransac_eigensolver(b1, b2, init[:3, :3], seed=1, pair_id=0)
+    finally:
+        oracle.set_ransac_chained_starts(False)
+        oracle.set_eigensolver_scheme(0)
+    assert inl1 == list(np.flatnonzero(mo)) and inl0 == list(np.flatnonzero(mf))
+    assert its_on != its_off or inl1 != inl0
+
+
+@pytest.mark.gpu
 def test_all_four_solve_overloads_agree_and_fill_the_timing_like_the_reference(oracle):
     """PNEC::Solve has four overloads (pnec.cc:69-75, :77-124, :126-134, :135-208): same pose from all,
     the inlier list from the two that take one, and a FrameTiming whose fields are written exactly where
